@@ -1,0 +1,3 @@
+// oracle shim header (test infrastructure): see cpu_cuda_shim.h
+#pragma once
+#include "cpu_cuda_shim.h"
