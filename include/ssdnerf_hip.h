@@ -1,0 +1,165 @@
+/* include/ssdnerf_hip.h -- C ABI of libssdnerf_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for SSDNeRF's volumetric-rendering hot path.  Every entry point takes plain
+ * DEVICE pointers, sizes and a HIP stream handle (void* == hipStream_t, NULL = default stream);
+ * no torch / ATen types cross this boundary.  Ownership follows the reference: the CALLER allocates
+ * every output; the library allocates nothing, holds no state and is re-entrant per stream.
+ *
+ * Return value: 0 on success, otherwise a negative SSDNERF_E_* code; ssdnerf_last_error() returns a
+ * thread-local human-readable message (the reference surfaces C++ exceptions as Python RuntimeError;
+ * the Python mirror in ssdnerf_amd/_cabi.py raises RuntimeError on any non-zero status).
+ * Unlike the reference (raymarching.cu launches on the legacy default stream and checks nothing),
+ * arguments are validated and hipGetLastError() is checked after every launch.
+ *
+ * Part 1 replaces, one for one, the 10 + 2 functions the reference binds with pybind11:
+ *     lib/ops/raymarching/src/bindings.cpp:5-18   (signatures: raymarching.h:7-18)
+ *     lib/ops/shencoder/src/bindings.cpp:5-8      (signatures: shencoder.h:9-12)
+ * Part 2 is the fused fast path that sits behind TriPlaneDecoder.point_decode /
+ * VolumeRenderer.forward / BaseNeRF.update_extra_state (same results, fewer HBM round trips).
+ *
+ * All floating-point tensors are fp32 unless a dtype argument says otherwise (the reference's Python
+ * wrappers force fp32 with custom_fwd(cast_inputs=torch.float32)).
+ */
+#ifndef SSDNERF_HIP_H
+#define SSDNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDNERF_OK 0
+#define SSDNERF_E_INVALID (-1)   /* bad argument (null pointer, size out of range, unsupported degree ...) */
+#define SSDNERF_E_LAUNCH (-2)    /* HIP reported an error at or after kernel launch */
+#define SSDNERF_E_WORKSPACE (-3) /* caller-provided workspace too small */
+
+#define SSDNERF_DTYPE_F32 0
+#define SSDNERF_DTYPE_F16 1
+
+const char* ssdnerf_last_error(void);
+/* ABI version: bumped whenever a signature below changes. */
+int ssdnerf_abi_version(void);
+
+/* ============================ Part 1: reference operator surface ============================ */
+
+/* replaces near_far_from_aabb (raymarching.h:7; kernel raymarching.cu:91-145).
+ * rays_o, rays_d [N,3]; aabb [6] = (xmin,ymin,zmin,xmax,ymax,zmax); nears, fars [N].
+ * A miss writes FLT_MAX to both. */
+int ssdnerf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                               float* nears, float* fars, void* stream);
+
+/* replaces sph_from_ray (raymarching.h:8; raymarching.cu:162-198). coords [N,2]. */
+int ssdnerf_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream);
+
+/* replaces morton3D / morton3D_invert (raymarching.h:9-10; raymarching.cu:214-254). coords [N,3] int32. */
+int ssdnerf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream);
+int ssdnerf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream);
+
+/* replaces packbits (raymarching.h:11; raymarching.cu:267-289). grid [8*N] of grid_dtype (the reference is
+ * templated on float/half); bitfield [N]; bit i of byte n = grid[8n+i] > density_thresh. */
+int ssdnerf_packbits(const void* grid, int grid_dtype, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream);
+
+/* replaces march_rays_train (raymarching.h:13; raymarching.cu:311-482).
+ * rays [N,3] int32 = (ray id, point offset, point count); counter [2] int32 is ACCUMULATED like the
+ * reference's atomicAdd: counter[0] += total points, counter[1] += N.  xyzs/dirs [M,3], deltas [M,2] = (dt, t).
+ * Difference by design: slots are assigned by an exclusive prefix sum in ray order (deterministic) instead of
+ * the reference's arrival-order atomicAdd; every ordering the reference can produce is a permutation of this
+ * one and compositing is order-independent.  Rays whose samples would overflow M are dropped exactly like
+ * raymarching.cu:415-416.  workspace: ssdnerf_march_rays_train_workspace(N) bytes. */
+size_t ssdnerf_march_rays_train_workspace(uint32_t N);
+int ssdnerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                             const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                             const float* noises, void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces composite_rays_train_forward / _backward (raymarching.h:14-15; raymarching.cu:502-698).
+ * forward writes weights_sum/depth [N], image [N,3] at index rays[n,0]; backward writes grad_sigmas [M],
+ * grad_rgbs [M,3] (caller zero-initialises, as the reference's Python does); grad wrt depth is not propagated. */
+int ssdnerf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                         uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth,
+                                         float* image, void* stream);
+int ssdnerf_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                          const float* rgbs, const float* deltas, const int32_t* rays,
+                                          const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                          float T_thresh, float* grad_sigmas, float* grad_rgbs, void* stream);
+
+/* replaces march_rays (raymarching.h:17; raymarching.cu:705-812): alive ray n writes <= n_step samples into
+ * slots [n*n_step, (n+1)*n_step); the caller zero-initialises xyzs/dirs/deltas (unused slots keep dt == 0). */
+int ssdnerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                       const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                       uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                       float* dirs, float* deltas, const float* noises, void* stream);
+
+/* replaces composite_rays (raymarching.h:18; raymarching.cu:825-913): in place on rays_alive (dead -> -1),
+ * rays_t, weights_sum, depth, image. */
+int ssdnerf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                           const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                           float* image, void* stream);
+
+/* replaces sh_encode_forward / sh_encode_backward (shencoder.h:9,12; shencoder.cu:27-383).
+ * inputs [B,D] with D == 3; C = degree in [1,8]; outputs [B,C*C]; dy_dx [B,3*C*C] when calc_grad_inputs.
+ * backward ACCUMULATES into grad_inputs [B,3] like the reference. */
+int ssdnerf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C,
+                              int calc_grad_inputs, float* dy_dx, void* stream);
+int ssdnerf_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
+                               const float* dy_dx, float* grad_inputs, void* stream);
+
+/* ================================ Part 2: fused fast path =================================== */
+
+/* Number of floats of the packed tiny-MLP parameter block consumed by the fused kernels (layout in
+ * DESIGN.md "Decoder parameter block"; built from the reference's state-dict by ssdnerf_amd/decoder.py). */
+#define SSDNERF_MLP_HIDDEN 64
+#define SSDNERF_MLP_FEATS 18
+#define SSDNERF_MLP_SH 16
+#define SSDNERF_MLP_REC 24 /* per hidden unit: W1[18], b1, w_sigma, Wc[3], pad */
+#define SSDNERF_MLP_PARAM_FLOATS (64 * 24 + 64 * 16 + 64 + 4)
+
+/* Triplane repack: code (S,3,Cch,Hp,Wp) NCHW (the reference's layout, triplane_decoder.py:125) of dtype
+ * code_dtype -> planes (S,3,Hp,Wp,8) channel-last, zero-padded to 8 channels, fp32 (32 B per texel) or
+ * fp16 (16 B per texel).  Cch <= 8.  One bilinear corner then is one (two) 16-byte load(s). */
+int ssdnerf_triplane_pack(const void* code, int code_dtype, uint32_t S, uint32_t Cch, uint32_t Hp, uint32_t Wp,
+                          void* planes, int planes_dtype, void* stream);
+
+/* Fused TriPlaneDecoder.point_decode (triplane_decoder.py:119-179) for ONE scene's packed planes:
+ * bilinear/border/align_corners=False gather of 3 planes -> 18 features -> base 18->64 -> sigma = exp(.)
+ * and rgb = sigmoid(color(silu(h + dir(SH4(d)))))*(1+2*sat)-sat.  xyzs, dirs [P,3]; sigmas [P]; rgbs [P,3]
+ * (rgbs and dirs may be NULL for density-only == point_density_decode). */
+int ssdnerf_point_decode(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                         const float* xyzs, const float* dirs, uint32_t P, float sigmoid_saturation, float* sigmas,
+                         float* rgbs, void* stream);
+
+/* Fused eval-branch render of VolumeRenderer.forward (base_volume_renderer.py:79-123) + the background blend
+ * of BaseNeRF.render (base_nerf.py:522-523) for ONE scene: AABB -> bitfield-guided march -> gather -> MLP ->
+ * composite entirely on chip.  rays_o/rays_d [N,3] in, image [N,3] (already blended with bg_color), depth [N],
+ * weights_sum [N] out; sample_counts [N] int32 (optional, may be NULL) receives the number of samples each ray
+ * took - the integer parity contract.  overflow_flag [1] int32 (optional) is incremented by every ray that reached
+ * the reference loop's sample cap (>= max_steps samples), where the reference's result depends on its global
+ * n_step schedule; callers re-render those scenes through the stepwise ops (never happens for bound=1 scenes
+ * unless a ray crosses 256 occupied steps). */
+int ssdnerf_render_rays_fused(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                              const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d,
+                              uint32_t N, float bound, float min_near, float dt_gamma, uint32_t max_steps, float T_thresh,
+                              float bg_color, float sigmoid_saturation, float* image, float* depth, float* weights_sum,
+                              int32_t* sample_counts, int32_t* overflow_flag, void* stream);
+
+/* Fused full-refresh branch of BaseNeRF.update_extra_state (base_nerf.py:328-351,377-387) for S scenes:
+ * for every cell of the H^3 grid (x-major order like custom_meshgrid) decode sigma at the jittered cell centre
+ * (jitter [H^3,3] uniform [0,1) shared by all scenes as in the reference, or NULL for no jitter) and fold it
+ * into density_grid [S,H^3] (Morton order, dtype grid_dtype): g = (g>=0) ? max(g*decay, sigma) : g.
+ * mean_out [1] fp32 (optional) receives mean(max(g,0)) over all S*H^3 cells (caller zero-initialises; it is
+ * accumulated with atomics), which the reference turns into the packbits threshold. */
+int ssdnerf_density_grid_update(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                uint32_t S, uint32_t grid_size, float bound, const float* jitter, float decay,
+                                void* density_grid, int grid_dtype, float* mean_out, void* stream);
+
+/* packbits with the threshold min(*mean, density_thresh) read ON DEVICE (removes the host sync of
+ * base_nerf.py:386-387). */
+int ssdnerf_packbits_dev_thresh(const void* grid, int grid_dtype, uint32_t N, const float* mean, float density_thresh,
+                                uint8_t* bitfield, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDNERF_HIP_H */

@@ -1,0 +1,167 @@
+// ssdnerf_amd/csrc/common.h -- shared host/device helpers for libssdnerf_hip.so (gfx950 only).
+//
+// Arithmetic contract: this library is compiled with -ffp-contract=off; a fused
+// multiply-add exists exactly where the source says __builtin_fmaf.  The marching arithmetic below
+// is fp32 IEEE with correctly rounded division (hipcc default), so that integer outputs (per-ray
+// sample counts, voxel indices, alive flags) are reproducible bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ssdnerf_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// error reporting
+// ------------------------------------------------------------------------------------------------
+extern thread_local char g_ssdnerf_err[512];
+static inline int ssdnerf_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_ssdnerf_err, sizeof(g_ssdnerf_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define SSD_REQUIRE(cond, ...) do { if (!(cond)) return ssdnerf_fail(SSDNERF_E_INVALID, __VA_ARGS__); } while (0)
+#define SSD_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); \
+    if (e__ != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); } while (0)
+
+static inline unsigned ssd_blocks(uint64_t work, unsigned threads) { return (unsigned)((work + threads - 1) / threads); }
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+#define SSD_DEV __device__ __forceinline__
+#define SSD_SQRT3 1.7320508075688772f
+
+SSD_DEV float ssd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+SSD_DEV float ssd_clamp(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
+SSD_DEV float ssd_sign1(float v) { return copysignf(1.0f, v); }
+
+// 10-bit-per-axis Morton code (what the reference's density grid is indexed by).
+SSD_DEV uint32_t ssd_spread3(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+SSD_DEV uint32_t ssd_morton(uint32_t x, uint32_t y, uint32_t z) { return ssd_spread3(x) | (ssd_spread3(y) << 1) | (ssd_spread3(z) << 2); }
+SSD_DEV uint32_t ssd_compact3(uint32_t v) {
+    v &= 0x49249249u;
+    v = (v | (v >> 2)) & 0xC30C30C3u;
+    v = (v | (v >> 4)) & 0x0F00F00Fu;
+    v = (v | (v >> 8)) & 0xFF0000FFu;
+    v = (v | (v >> 16)) & 0x0000FFFFu;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Density-grid guided marching: one "probe" at depth t and the empty-cell skip.
+// Restates the stepping rule of the reference (lib/ops/raymarching/src/raymarching.cu:359-399,
+// repeated at :427-480 and :755-810); see oracle/raymarching_oracle.c for the CPU statement of the
+// same contract.  MarchCfg holds everything that is uniform over a launch.
+// ------------------------------------------------------------------------------------------------
+struct MarchCfg {
+    float bound, dt_gamma, dt_min, dt_max, rH, Hf, H3f, Cf;
+    uint32_t H, C;
+    int h_pow2;  // H is a power of two: 0.5*(v)*H is exact in fp32, the double detour can be skipped bit-exactly
+    const uint8_t* grid;
+};
+
+static inline MarchCfg ssd_make_march_cfg(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid) {
+    MarchCfg c;
+    c.bound = bound; c.dt_gamma = dt_gamma;
+    c.dt_min = 2.0f * SSD_SQRT3 / (float)max_steps;
+    c.dt_max = 2.0f * SSD_SQRT3 * (float)(1u << (C - 1)) / (float)H;
+    c.H = H; c.C = C; c.Hf = (float)H; c.rH = 1.0f / (float)H; c.H3f = (float)(H * H * H); c.Cf = (float)C;
+    c.h_pow2 = (H & (H - 1)) == 0;
+    c.grid = grid;
+    return c;
+}
+
+struct RayGeom { float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz; };
+
+SSD_DEV RayGeom ssd_load_ray(const float* __restrict__ o, const float* __restrict__ d) {
+    RayGeom r;
+    r.ox = o[0]; r.oy = o[1]; r.oz = o[2];
+    r.dx = d[0]; r.dy = d[1]; r.dz = d[2];
+    r.rdx = 1.0f / r.dx; r.rdy = 1.0f / r.dy; r.rdz = 1.0f / r.dz;  // IEEE division (contract C4)
+    return r;
+}
+
+struct Probe { float x, y, z, dt, mip_bound; int nx, ny, nz; bool occ; };
+
+SSD_DEV int ssd_cell(const MarchCfg& c, float v /* x*rbound+1 */) {
+    float s;
+    if (c.h_pow2) s = (0.5f * v) * c.Hf;                    // exact: both factors are powers of two
+    else s = (float)(0.5 * (double)v * (double)c.H);        // reference promotes through double (raymarching.cu:374-376)
+    return (int)ssd_clamp(s, 0.0f, (float)(c.H - 1));
+}
+
+SSD_DEV Probe ssd_probe(const MarchCfg& c, const RayGeom& r, float t) {
+    Probe p;
+    p.x = ssd_clamp(ssd_fma(t, r.dx, r.ox), -c.bound, c.bound);
+    p.y = ssd_clamp(ssd_fma(t, r.dy, r.oy), -c.bound, c.bound);
+    p.z = ssd_clamp(ssd_fma(t, r.dz, r.oz), -c.bound, c.bound);
+    p.dt = ssd_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+    int level = 0;
+    if (c.C > 1) {  // cascade selection (raymarching.cu:42-54); with C == 1 both terms clamp to 0
+        int e1, e2;
+        (void)frexpf(fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))), &e1);
+        (void)frexpf((float)((double)(p.dt * c.Hf) * 0.5), &e2);
+        const int l1 = (int)fminf(c.Cf - 1.0f, fmaxf(0.0f, (float)e1));
+        const int l2 = (int)fminf(c.Cf - 1.0f, fmaxf(0.0f, (float)e2));
+        level = l1 > l2 ? l1 : l2;
+    }
+    p.mip_bound = fminf(ldexpf(1.0f, level), c.bound);
+    const float rb = 1.0f / p.mip_bound;
+    p.nx = ssd_cell(c, ssd_fma(p.x, rb, 1.0f));
+    p.ny = ssd_cell(c, ssd_fma(p.y, rb, 1.0f));
+    p.nz = ssd_cell(c, ssd_fma(p.z, rb, 1.0f));
+    const uint32_t idx = (uint32_t)ssd_fma((float)level, c.H3f, (float)ssd_morton((uint32_t)p.nx, (uint32_t)p.ny, (uint32_t)p.nz));
+    p.occ = (c.grid[idx >> 3] >> (idx & 7u)) & 1u;
+    return p;
+}
+
+// Advance t past the empty voxel the probe landed in: DDA distance to the next voxel face, then
+// fixed-size steps until that distance is covered (at least one step is always taken).
+SSD_DEV float ssd_skip_empty(const MarchCfg& c, const RayGeom& r, const Probe& p, float t) {
+    const float fx = ssd_fma(0.5f, ssd_sign1(r.dx), (float)p.nx + 0.5f);
+    const float fy = ssd_fma(0.5f, ssd_sign1(r.dy), (float)p.ny + 0.5f);
+    const float fz = ssd_fma(0.5f, ssd_sign1(r.dz), (float)p.nz + 0.5f);
+    const float tx = ssd_fma(ssd_fma(fx * c.rH, 2.0f, -1.0f), p.mip_bound, -p.x) * r.rdx;
+    const float ty = ssd_fma(ssd_fma(fy * c.rH, 2.0f, -1.0f), p.mip_bound, -p.y) * r.rdy;
+    const float tz = ssd_fma(ssd_fma(fz * c.rH, 2.0f, -1.0f), p.mip_bound, -p.z) * r.rdz;
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do {
+        t += ssd_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+    } while (t < tt);
+    return t;
+}
+
+// Slab test of one ray against the scene box.  Returns false on a miss (near = far = FLT_MAX).
+SSD_DEV bool ssd_near_far(const float* __restrict__ aabb, const RayGeom& r, float min_near, float& near_, float& far_) {
+    float lo = (aabb[0] - r.ox) * r.rdx, hi = (aabb[3] - r.ox) * r.rdx;
+    if (lo > hi) { const float s = lo; lo = hi; hi = s; }
+    float a = (aabb[1] - r.oy) * r.rdy, b = (aabb[4] - r.oy) * r.rdy;
+    if (a > b) { const float s = a; a = b; b = s; }
+    bool miss = (lo > b) || (a > hi);
+    if (!miss) {
+        if (a > lo) lo = a;
+        if (b < hi) hi = b;
+        a = (aabb[2] - r.oz) * r.rdz; b = (aabb[5] - r.oz) * r.rdz;
+        if (a > b) { const float s = a; a = b; b = s; }
+        miss = (lo > b) || (a > hi);
+        if (!miss) {
+            if (a > lo) lo = a;
+            if (b < hi) hi = b;
+        }
+    }
+    if (miss) { near_ = far_ = 3.402823466e+38f; return false; }
+    if (lo < min_near) lo = min_near;
+    near_ = lo; far_ = hi;
+    return true;
+}

@@ -1,0 +1,381 @@
+"""``VolumeRenderer`` and ``TriPlaneDecoder``: the reference's renderer types
+(lib/models/decoders/base_volume_renderer.py, lib/models/decoders/triplane_decoder.py) with the same constructor
+keywords, state-dict keys (``base_net.0.weight`` ...), ``forward`` signature and result dict - and the MI355X
+fast path behind them:
+
+* eval branch (``self.training == False``)  -> ONE fused HIP launch per scene
+  (``ssdnerf_render_rays_fused``: AABB + march + gather + MLP + composite on chip, on-device compaction)
+  instead of the reference's <=256-iteration host loop with a device->host sync per iteration.
+* ``point_decode`` / ``point_density_decode`` on packed sample lists -> one fused HIP decode per scene
+  (no grad) or an eager PyTorch-ROCm path (autograd; also the "reference-shaped eager" baseline B1).
+* train branch -> per-scene ``march_rays_train`` (deterministic prefix-sum packing) + decode +
+  ``batch_composite_rays_train`` (HIP forward/backward kernels).
+
+``render_mode='stepwise'`` runs the reference-shaped loop over the unfused operators instead (used by the
+parity tests and as the exact fallback when the fused kernel reports a ray at the global step cap).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _cabi as C
+from .activation import TruncExp
+from .raymarching import (batch_composite_rays_train, batch_near_far_from_aabb, composite_rays, march_rays,
+                          march_rays_train)
+from .registry import MODULES, build_module
+from .shencoder import SHEncoder
+
+MLP_PARAM_FLOATS = 64 * 24 + 64 * 16 + 64 + 4
+
+
+def _xavier_uniform_(m: nn.Linear):
+    nn.init.xavier_uniform_(m.weight, gain=1.0)
+    if m.bias is not None:
+        nn.init.constant_(m.bias, 0.0)
+
+
+def pack_triplanes(code: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """(S,3,C,H,W) NCHW code -> (S,3,H,W,8) channel-last zero-padded planes (fp32 or fp16) via the HIP repack kernel."""
+    assert code.dim() == 5 and code.size(1) == 3 and code.size(2) <= 8
+    code = code.contiguous()
+    if code.dtype not in (torch.float32, torch.float16):
+        code = code.float()
+    s, _, c, h, w = code.shape
+    planes = torch.empty(s, 3, h, w, 8, dtype=dtype, device=code.device)
+    C.check(C.lib().ssdnerf_triplane_pack(C.ptr(code), C.dtype_code(code), C.u32(s), C.u32(c), C.u32(h), C.u32(w), C.ptr(planes),
+                                          C.dtype_code(planes), C.stream()), "triplane_pack")
+    return planes
+
+
+def pack_mlp_params(sd: Dict[str, torch.Tensor], device) -> torch.Tensor:
+    """Reference state-dict tensors -> the packed parameter block of the fused kernels (layout: csrc/decode_core.h)."""
+    w1, b1 = sd["base_net.0.weight"].float(), sd["base_net.0.bias"].float()          # (64,18), (64)
+    ws, bs = sd["density_net.0.weight"].float(), sd["density_net.0.bias"].float()    # (1,64), (1)
+    wd, bd = sd["dir_net.0.weight"].float(), sd["dir_net.0.bias"].float()            # (64,16), (64)
+    wc, bc = sd["color_net.0.weight"].float(), sd["color_net.0.bias"].float()        # (3,64), (3)
+    rec = torch.zeros(64, 24, dtype=torch.float32, device=w1.device)
+    rec[:, :18] = w1
+    rec[:, 18] = b1
+    rec[:, 19] = ws[0]
+    rec[:, 20:23] = wc.t()
+    out = torch.cat([rec.reshape(-1), wd.reshape(-1), bd.reshape(-1), bs.reshape(-1), bc.reshape(-1)])
+    assert out.numel() == MLP_PARAM_FLOATS
+    return out.to(device).contiguous()
+
+
+class VolumeRenderer(nn.Module):
+    def __init__(self, bound=1, min_near=0.2, bg_radius=-1, max_steps=256, decoder_reg_loss=None, render_mode="fused",
+                 plane_dtype="float32"):
+        super().__init__()
+        self.bound = bound
+        self.min_near = min_near
+        self.bg_radius = bg_radius  # accepted and never consumed, like the reference (base_volume_renderer.py:23)
+        self.max_steps = max_steps
+        self.decoder_reg_loss = build_module(decoder_reg_loss) if decoder_reg_loss is not None else None
+        self.render_mode = render_mode
+        self.plane_dtype = getattr(torch, plane_dtype) if isinstance(plane_dtype, str) else plane_dtype
+        self.register_buffer("aabb", torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32))
+        self.last_render_stats: Dict[str, object] = {}
+
+    def point_decode(self, xyzs, dirs, code):
+        raise NotImplementedError
+
+    def point_density_decode(self, xyzs, code):
+        raise NotImplementedError
+
+    def loss(self):
+        assert self.decoder_reg_loss is None
+        return None
+
+    # -------------------------------------------------------------------------------------- forward
+    def forward(self, rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma=0, perturb=False, T_thresh=1e-4,
+                return_loss=False, bg_color=None):
+        """Same arguments/result dict as the reference (base_volume_renderer.py:41-133).  ``bg_color`` (extra, eval
+        branch only): when given, the returned ``image`` is ALREADY blended with the background and the dict carries
+        ``blended=True`` - this is what lets the fused kernel keep the blend on chip."""
+        num_scenes = len(rays_o)
+        assert num_scenes > 0
+        if isinstance(grid_size, int):
+            grid_size = [grid_size] * num_scenes
+        if isinstance(dt_gamma, (float, int)):
+            dt_gamma = [float(dt_gamma)] * num_scenes
+        elif isinstance(dt_gamma, torch.Tensor):
+            dt_gamma = [float(v) for v in dt_gamma.detach().reshape(-1).tolist()]
+
+        if self.training:
+            nears, fars = batch_near_far_from_aabb(rays_o, rays_d, self.aabb, self.min_near)
+            xyzs, dirs, deltas, rays = [], [], [], []
+            for s in range(num_scenes):
+                x, d, dl, r = march_rays_train(rays_o[s], rays_d[s], self.bound, density_bitfield[s], 1, grid_size[s], nears[s],
+                                               fars[s], perturb=perturb, align=128, force_all_rays=True, dt_gamma=dt_gamma[s],
+                                               max_steps=self.max_steps)
+                xyzs.append(x); dirs.append(d); deltas.append(dl); rays.append(r)
+            sigmas, rgbs, num_points = self.point_decode(xyzs, dirs, code)
+            weights_sum, depth, image = batch_composite_rays_train(sigmas, rgbs, deltas, rays, num_points, T_thresh)
+            results = dict(weights_sum=weights_sum, depth=depth, image=image)
+        elif self.render_mode == "fused" and self.fused_supported(code):
+            results = self._forward_eval_fused(rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color)
+        else:
+            results = self._forward_eval_stepwise(rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma, perturb, T_thresh)
+        if return_loss:
+            results.update(decoder_reg_loss=self.loss())
+        return results
+
+    def fused_supported(self, code) -> bool:
+        return False
+
+    def _forward_eval_stepwise(self, rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma, perturb, T_thresh):
+        """The reference's alive-ray loop, verbatim in structure, over the unfused HIP operators."""
+        nears, fars = batch_near_far_from_aabb(rays_o, rays_d, self.aabb, self.min_near)
+        device = rays_o[0].device
+        weights_sum, depth, image = [], [], []
+        history = []
+        for s in range(len(rays_o)):
+            o_s, d_s = rays_o[s], rays_d[s]
+            n = o_s.size(0)
+            ws = torch.zeros(n, dtype=torch.float32, device=device)
+            dp = torch.zeros(n, dtype=torch.float32, device=device)
+            im = torch.zeros(n, 3, dtype=torch.float32, device=device)
+            rays_alive = torch.arange(n, dtype=torch.int32, device=device)
+            rays_t = nears[s].clone()
+            step = 0
+            hist = []
+            while step < self.max_steps:
+                n_alive = rays_alive.size(0)
+                if n_alive == 0:
+                    break
+                n_step = min(max(n // n_alive, 1), 8)
+                xyzs, dirs, deltas = march_rays(n_alive, n_step, rays_alive, rays_t, o_s, d_s, self.bound, density_bitfield[s], 1,
+                                                grid_size[s], nears[s], fars[s], align=128, perturb=perturb, dt_gamma=dt_gamma[s],
+                                                max_steps=self.max_steps)
+                sigmas, rgbs, _ = self.point_decode([xyzs], [dirs], code[s][None])
+                composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, ws, dp, im, T_thresh)
+                hist.append((n_alive, n_step))
+                rays_alive = rays_alive[rays_alive >= 0]
+                step += n_step
+            weights_sum.append(ws); depth.append(dp); image.append(im)
+            history.append(hist)
+        self.last_render_stats = dict(mode="stepwise", iterations=history)
+        return dict(weights_sum=weights_sum, depth=depth, image=image)
+
+    def _forward_eval_fused(self, rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color):
+        raise NotImplementedError
+
+
+@MODULES.register_module()
+class TriPlaneDecoder(VolumeRenderer):
+    activation_dict = {"relu": nn.ReLU, "silu": nn.SiLU, "softplus": nn.Softplus, "trunc_exp": TruncExp}
+
+    def __init__(self, *args, interp_mode="bilinear", base_layers=[3 * 32, 128], density_layers=[128, 1],
+                 color_layers=[128, 128, 3], use_dir_enc=True, dir_layers=None, scene_base_size=None, scene_rand_dims=(0, 1),
+                 activation="silu", sigma_activation="trunc_exp", sigmoid_saturation=0.001, code_dropout=0.0, flip_z=False,
+                 **kwargs):
+        super().__init__(*args, **kwargs)
+        base_layers, density_layers, color_layers = list(base_layers), list(density_layers), list(color_layers)
+        self.interp_mode = interp_mode
+        self.in_chn = base_layers[0]
+        self.use_dir_enc = use_dir_enc
+        if scene_base_size is None:
+            self.scene_base = None
+        else:
+            rand_size = [1 for _ in scene_base_size]
+            for dim in scene_rand_dims:
+                rand_size[dim] = scene_base_size[dim]
+            self.scene_base = nn.Parameter(torch.randn(rand_size).expand(scene_base_size).clone())
+        self.dir_encoder = SHEncoder() if use_dir_enc else None
+        self.sigmoid_saturation = sigmoid_saturation
+        act = self.activation_dict[activation.lower()]
+        self._activation_name, self._sigma_activation_name = activation.lower(), sigma_activation.lower()
+
+        def mlp(layers, final=None):
+            mods = []
+            for i in range(len(layers) - 1):
+                mods.append(nn.Linear(layers[i], layers[i + 1]))
+                if i != len(layers) - 2:
+                    mods.append(act())
+            if final is not None:
+                mods.append(final)
+            return nn.Sequential(*mods)
+
+        self.base_net = mlp(base_layers)
+        self.base_activation = act()
+        self.density_net = mlp(density_layers, self.activation_dict[sigma_activation.lower()]())
+        self.dir_net = None
+        if use_dir_enc:
+            if dir_layers is not None:
+                self.dir_net = mlp(list(dir_layers))
+            else:
+                color_layers[0] = color_layers[0] + 16
+        self.color_net = mlp(color_layers, nn.Sigmoid())
+        self.code_dropout = nn.Dropout2d(code_dropout) if code_dropout > 0 else None
+        self.flip_z = flip_z
+        self._layer_cfg = (tuple(base_layers), tuple(density_layers), tuple(color_layers), tuple(dir_layers) if dir_layers else None)
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                _xavier_uniform_(m)
+        if self.dir_net is not None:
+            nn.init.constant_(self.dir_net[-1].weight, 0.0)
+            nn.init.constant_(self.dir_net[-1].bias, 0.0)
+
+    # ------------------------------------------------------------------------------ fused-path plumbing
+    def fused_supported(self, code=None) -> bool:
+        ok = (self._layer_cfg == ((18, 64), (64, 1), (64, 3), (16, 64)) and self.use_dir_enc and self.interp_mode == "bilinear"
+              and self._activation_name == "silu" and self._sigma_activation_name == "trunc_exp" and self.scene_base is None
+              and not self.flip_z and (self.code_dropout is None or not self.training))
+        if code is not None:
+            ok = ok and code.dim() == 5 and code.size(1) == 3 and code.size(2) == 6 and code.is_cuda
+        return ok
+
+    def packed_params(self) -> torch.Tensor:
+        ps = [self.base_net[0].weight, self.base_net[0].bias, self.density_net[0].weight, self.density_net[0].bias,
+              self.dir_net[0].weight, self.dir_net[0].bias, self.color_net[0].weight, self.color_net[0].bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._packed is None or key != self._packed_key:
+            sd = {"base_net.0.weight": ps[0].detach(), "base_net.0.bias": ps[1].detach(), "density_net.0.weight": ps[2].detach(),
+                  "density_net.0.bias": ps[3].detach(), "dir_net.0.weight": ps[4].detach(), "dir_net.0.bias": ps[5].detach(),
+                  "color_net.0.weight": ps[6].detach(), "color_net.0.bias": ps[7].detach()}
+            self._packed = pack_mlp_params(sd, ps[0].device)
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------------------ decode
+    def xyz_transform(self, xyz):
+        if self.flip_z:
+            xyz = torch.cat([xyz[..., :2], -xyz[..., 2:]], dim=-1)
+        xy, xz, yz = xyz[..., :2], xyz[..., ::2], xyz[..., 1:]
+        if xyz.dim() == 2:
+            return torch.stack([xy, xz, yz], dim=0).unsqueeze(1)
+        if xyz.dim() == 3:
+            s, p, _ = xyz.size()
+            return torch.stack([xy, xz, yz], dim=1).reshape(s * 3, 1, p, 2)
+        raise ValueError
+
+    def point_decode(self, xyzs, dirs, code, density_only=False):
+        """xyzs/dirs: per-scene lists of (P_s,3) (or a (S,P,3) tensor); code (S,3,C,h,w).  Returns sigmas (sum P), rgbs (sum P,3),
+        num_points (reference: triplane_decoder.py:119-179).  Uses the fused HIP decode when no gradient is required."""
+        need_grad = torch.is_grad_enabled() and (code.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not need_grad and self.fused_supported(code):
+            return self._point_decode_hip(xyzs, dirs, code, density_only)
+        return self.point_decode_eager(xyzs, dirs, code, density_only)
+
+    def _point_decode_hip(self, xyzs, dirs, code, density_only):
+        planes = pack_triplanes(code.detach(), self.plane_dtype)
+        params = self.packed_params()
+        if isinstance(xyzs, torch.Tensor):
+            xyzs = list(xyzs)
+            dirs = list(dirs) if dirs is not None else None
+        num_points = [int(x.size(-2)) for x in xyzs]
+        total = sum(num_points)
+        dev = code.device
+        sigmas = torch.empty(total, dtype=torch.float32, device=dev)
+        rgbs = None if density_only else torch.empty(total, 3, dtype=torch.float32, device=dev)
+        off = 0
+        _, _, hp, wp, _ = planes.shape
+        for s, x in enumerate(xyzs):
+            n = num_points[s]
+            if n == 0:
+                continue
+            x = x.reshape(-1, 3).float().contiguous()
+            d = None if density_only else dirs[s].reshape(-1, 3).float().contiguous()
+            C.check(C.lib().ssdnerf_point_decode(C.ptr(planes[s]), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(x),
+                                                 C.ptr(d), C.u32(n), C.f32(self.sigmoid_saturation), C.ptr(sigmas[off:off + n]),
+                                                 C.ptr(None if rgbs is None else rgbs[off:off + n]), C.stream()), "point_decode")
+            off += n
+        return sigmas, rgbs, num_points
+
+    def point_decode_eager(self, xyzs, dirs, code, density_only=False):
+        """PyTorch-ROCm eager statement of the reference decode (autograd-capable; baseline B1 of BASELINE.md)."""
+        num_scenes, _, n_channels, h, w = code.size()
+        if self.code_dropout is not None:
+            code = self.code_dropout(code.reshape(num_scenes * 3, n_channels, h, w)).reshape(num_scenes, 3, n_channels, h, w)
+        if self.scene_base is not None:
+            code = code + self.scene_base
+        if isinstance(xyzs, torch.Tensor):
+            assert xyzs.dim() == 3
+            num_points = xyzs.size(-2)
+            point_code = F.grid_sample(code.reshape(num_scenes * 3, -1, h, w), self.xyz_transform(xyzs), mode=self.interp_mode,
+                                       padding_mode="border", align_corners=False).reshape(num_scenes, 3, -1, num_points)
+            point_code = point_code.permute(0, 3, 2, 1).reshape(num_scenes * num_points, -1)
+            num_points = [num_points] * num_scenes
+        else:
+            num_points, pcs = [], []
+            for code_s, xyz_s in zip(code, xyzs):
+                n = xyz_s.size(-2)
+                pc = F.grid_sample(code_s, self.xyz_transform(xyz_s), mode=self.interp_mode, padding_mode="border",
+                                   align_corners=False).squeeze(-2)
+                pcs.append(pc.permute(2, 1, 0).reshape(n, -1))
+                num_points.append(n)
+            point_code = torch.cat(pcs, dim=0) if len(pcs) > 1 else pcs[0]
+        base_x = self.base_net(point_code)
+        base_x_act = self.base_activation(base_x)
+        sigmas = self.density_net(base_x_act).squeeze(-1)
+        if density_only:
+            return sigmas, None, num_points
+        if self.use_dir_enc:
+            dirs = torch.cat(list(dirs), dim=0) if num_scenes > 1 else dirs[0]
+            sh_enc = self.dir_encoder(dirs)
+            if self.dir_net is not None:
+                color_in = self.base_activation(base_x + self.dir_net(sh_enc))
+            else:
+                color_in = torch.cat([base_x_act, sh_enc], dim=-1)
+        else:
+            color_in = base_x_act
+        rgbs = self.color_net(color_in)
+        if self.sigmoid_saturation > 0:
+            rgbs = rgbs * (1 + self.sigmoid_saturation * 2) - self.sigmoid_saturation
+        return sigmas, rgbs, num_points
+
+    def point_density_decode(self, xyzs, code, **kwargs):
+        sigmas, _, num_points = self.point_decode(xyzs, None, code, density_only=True, **kwargs)
+        return sigmas, num_points
+
+    # ------------------------------------------------------------------------------ fused eval render
+    def _forward_eval_fused(self, rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color):
+        planes = pack_triplanes(code.detach(), self.plane_dtype)
+        out = self.render_packed(planes, rays_o, rays_d, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color, check_overflow=False)
+        if int(self.last_render_stats["overflow"].item()) != 0:   # one sync per batch (the reference: one per loop iteration)
+            # a ray reached the reference loop's global step cap, where the reference's answer depends on its n_step
+            # schedule: redo the batch through the reference-shaped stepwise path (exact by construction).
+            out = self._forward_eval_stepwise(rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma, False, T_thresh)
+            if bg_color is not None:
+                out["image"] = [im + float(bg_color) * (1 - ws.unsqueeze(-1)) for im, ws in zip(out["image"], out["weights_sum"])]
+                out["blended"] = True
+        return out
+
+    def render_packed(self, planes, rays_o, rays_d, density_bitfield, grid_size, dt_gamma, T_thresh=1e-4, bg_color=None,
+                      want_counts=False, check_overflow=True):
+        """Fused render of S scenes from already-packed planes (S,3,h,w,8).  rays_o/rays_d: (S,N,3) tensors or per-scene lists."""
+        params = self.packed_params()
+        num_scenes = len(rays_o)
+        dev = planes.device
+        _, _, hp, wp, _ = planes.shape
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        weights_sum, depth, image, counts = [], [], [], []
+        blend = 0.0 if bg_color is None else float(bg_color)
+        for s in range(num_scenes):
+            o = rays_o[s].reshape(-1, 3).float().contiguous()
+            d = rays_d[s].reshape(-1, 3).float().contiguous()
+            n = o.size(0)
+            im = torch.empty(n, 3, dtype=torch.float32, device=dev)
+            dp = torch.empty(n, dtype=torch.float32, device=dev)
+            ws = torch.empty(n, dtype=torch.float32, device=dev)
+            cn = torch.empty(n, dtype=torch.int32, device=dev) if want_counts else None
+            C.check(C.lib().ssdnerf_render_rays_fused(
+                C.ptr(planes[s]), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(density_bitfield[s]),
+                C.u32(grid_size[s]), C.ptr(o), C.ptr(d), C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(dt_gamma[s]),
+                C.u32(self.max_steps), C.f32(T_thresh), C.f32(blend), C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws),
+                C.ptr(cn), C.ptr(overflow), C.stream()), "render_rays_fused")
+            weights_sum.append(ws); depth.append(dp); image.append(im); counts.append(cn)
+        self.last_render_stats = dict(mode="fused", overflow=overflow, sample_counts=counts if want_counts else None)
+        if check_overflow and int(overflow.item()) != 0:
+            raise RuntimeError("render_rays_fused: a ray hit the max_steps cap; use render_mode='stepwise' for this batch")
+        return dict(weights_sum=weights_sum, depth=depth, image=image, blended=bg_color is not None)
