@@ -69,11 +69,11 @@ __global__ void __launch_bounds__(DEC_TPB) k_point_decode(const PT* __restrict__
 
 extern "C" int ssdnerf_point_decode(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params, const float* xyzs,
                                     const float* dirs, uint32_t n, float sigmoid_saturation, float* sigmas, float* rgbs, void* stream) {
+    if (n == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(planes && mlp_params && xyzs && sigmas, "point_decode: null pointer");
     SSD_REQUIRE((rgbs == nullptr) == (dirs == nullptr), "point_decode: rgbs and dirs must both be given or both be NULL");
     SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "point_decode: unsupported plane dtype");
     SSD_REQUIRE(Hp >= 1 && Wp >= 1, "point_decode: empty plane");
-    if (n == 0) return SSDNERF_OK;
     const PlaneGeom g = ssd_plane_geom(Hp, Wp);
     dim3 gr(ssd_blocks(n, DEC_TPB)), b(DEC_TPB);
     hipStream_t s = (hipStream_t)stream;
@@ -149,10 +149,10 @@ __global__ void __launch_bounds__(DEC_TPB) k_density_update(const PT* __restrict
 extern "C" int ssdnerf_density_grid_update(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params, uint32_t S,
                                            uint32_t grid_size, float bound, const float* jitter, float decay, void* density_grid, int grid_dtype,
                                            float* mean_out, void* stream) {
+    if (S == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(planes && mlp_params && density_grid, "density_grid_update: null pointer");
     SSD_REQUIRE((planes_dtype == 0 || planes_dtype == 1) && (grid_dtype == 0 || grid_dtype == 1), "density_grid_update: unsupported dtype");
     SSD_REQUIRE(grid_size >= 1 && grid_size <= 1024, "density_grid_update: grid_size out of range");
-    if (S == 0) return SSDNERF_OK;
     const PlaneGeom g = ssd_plane_geom(Hp, Wp);
     const uint32_t H3 = grid_size * grid_size * grid_size;
     const float centre = (float)((double)(grid_size - 1) / 2.0);

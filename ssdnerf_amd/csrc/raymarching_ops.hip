@@ -25,8 +25,8 @@ __global__ void k_near_far(const float* __restrict__ rays_o, const float* __rest
 
 extern "C" int ssdnerf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
                                           float* nears, float* fars, void* stream) {
+    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null pointer");
-    if (N == 0) return SSDNERF_OK;
     hipLaunchKernelGGL(k_near_far, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N, min_near, nears, fars);
     SSD_CHECK_LAUNCH("near_far_from_aabb");
     return SSDNERF_OK;
@@ -53,8 +53,8 @@ __global__ void k_sph_from_ray(const float* __restrict__ rays_o, const float* __
 }
 
 extern "C" int ssdnerf_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {
+    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null pointer");
-    if (N == 0) return SSDNERF_OK;
     hipLaunchKernelGGL(k_sph_from_ray, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, rays_o, rays_d, radius, N, coords);
     SSD_CHECK_LAUNCH("sph_from_ray");
     return SSDNERF_OK;
@@ -76,15 +76,15 @@ __global__ void k_morton3D_invert(const int32_t* __restrict__ indices, uint32_t 
 }
 
 extern "C" int ssdnerf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream) {
+    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(coords && indices, "morton3D: null pointer");
-    if (N == 0) return SSDNERF_OK;
     hipLaunchKernelGGL(k_morton3D, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, coords, N, indices);
     SSD_CHECK_LAUNCH("morton3D");
     return SSDNERF_OK;
 }
 extern "C" int ssdnerf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream) {
+    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(coords && indices, "morton3D_invert: null pointer");
-    if (N == 0) return SSDNERF_OK;
     hipLaunchKernelGGL(k_morton3D_invert, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, indices, N, coords);
     SSD_CHECK_LAUNCH("morton3D_invert");
     return SSDNERF_OK;
@@ -110,9 +110,9 @@ __global__ void k_packbits(const T* __restrict__ grid, uint32_t N, const float* 
 }
 
 static int packbits_impl(const void* grid, int grid_dtype, uint32_t N, const float* mean, float thresh, uint8_t* bitfield, void* stream) {
+    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(grid && bitfield, "packbits: null pointer");
     SSD_REQUIRE(grid_dtype == SSDNERF_DTYPE_F32 || grid_dtype == SSDNERF_DTYPE_F16, "packbits: unsupported grid dtype %d", grid_dtype);
-    if (N == 0) return SSDNERF_OK;
     dim3 g(ssd_blocks(N, TPB)), b(TPB);
     hipStream_t s = (hipStream_t)stream;
     if (grid_dtype == SSDNERF_DTYPE_F32) {
@@ -266,9 +266,9 @@ extern "C" int ssdnerf_march_rays_train(const float* rays_o, const float* rays_d
                                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                                         const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
                                         const float* noises, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises, "march_rays_train: null pointer");
     SSD_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays_train: bad C=%u H=%u max_steps=%u", C, H, max_steps);
-    if (N == 0) return SSDNERF_OK;
     if (!workspace || workspace_bytes < ssdnerf_march_rays_train_workspace(N))
         return ssdnerf_fail(SSDNERF_E_WORKSPACE, "march_rays_train: workspace %zu < %zu bytes", workspace_bytes, ssdnerf_march_rays_train_workspace(N));
     hipStream_t s = (hipStream_t)stream;
@@ -348,8 +348,8 @@ __global__ void k_composite_train_bwd(const float* __restrict__ grad_ws, const f
 extern "C" int ssdnerf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                                     uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth, float* image,
                                                     void* stream) {
+    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
-    if (N == 0) return SSDNERF_OK;
     hipLaunchKernelGGL(k_composite_train_fwd, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, M, N, T_thresh,
                        weights_sum, depth, image);
     SSD_CHECK_LAUNCH("composite_rays_train_forward");
@@ -433,9 +433,9 @@ extern "C" int ssdnerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32
                                   const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                                   const float* noises, void* stream) {
     (void)nears;
+    if (n_alive == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises, "march_rays: null pointer");
     SSD_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024 && max_steps >= 1 && n_step >= 1, "march_rays: bad C=%u H=%u max_steps=%u n_step=%u", C, H, max_steps, n_step);
-    if (n_alive == 0) return SSDNERF_OK;
     const MarchCfg c = ssd_make_march_cfg(bound, dt_gamma, max_steps, C, H, grid);
     hipLaunchKernelGGL(k_march_rays, dim3(ssd_blocks(n_alive, TPB)), dim3(TPB), 0, (hipStream_t)stream, c, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d,
                        fars, xyzs, dirs, deltas, noises);
@@ -445,9 +445,9 @@ extern "C" int ssdnerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32
 
 extern "C" int ssdnerf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t, const float* sigmas,
                                       const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {
+    if (n_alive == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "composite_rays: null pointer");
     SSD_REQUIRE(n_step >= 1, "composite_rays: n_step must be >= 1");
-    if (n_alive == 0) return SSDNERF_OK;
     hipLaunchKernelGGL(k_composite_rays, dim3(ssd_blocks(n_alive, TPB)), dim3(TPB), 0, (hipStream_t)stream, n_alive, n_step, T_thresh, rays_alive, rays_t,
                        sigmas, rgbs, deltas, weights_sum, depth, image);
     SSD_CHECK_LAUNCH("composite_rays");

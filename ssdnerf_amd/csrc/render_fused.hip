@@ -163,10 +163,10 @@ extern "C" int ssdnerf_render_rays_fused(const void* planes, int planes_dtype, u
                                          float bound, float min_near, float dt_gamma, uint32_t max_steps, float T_thresh, float bg_color,
                                          float sigmoid_saturation, float* image, float* depth, float* weights_sum, int32_t* sample_counts,
                                          int32_t* overflow_flag, void* stream) {
+    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(planes && mlp_params && bitfield && rays_o && rays_d && image && depth && weights_sum, "render_rays_fused: null pointer");
     SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "render_rays_fused: unsupported plane dtype");
     SSD_REQUIRE(grid_size >= 1 && grid_size <= 1024 && max_steps >= 1 && Hp >= 1 && Wp >= 1, "render_rays_fused: bad geometry");
-    if (N == 0) return SSDNERF_OK;
     RenderCfg c;
     c.m = ssd_make_march_cfg(bound, dt_gamma, max_steps, 1, grid_size, bitfield);  // cascades are hard-wired to 1 in the renderer (base_volume_renderer.py:113)
     c.g = ssd_plane_geom(Hp, Wp);

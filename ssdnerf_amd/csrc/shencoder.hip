@@ -47,11 +47,11 @@ static void launch_sh(const float* inputs, float* outputs, uint32_t B, uint32_t 
 
 extern "C" int ssdnerf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, int calc_grad_inputs,
                                          float* dy_dx, void* stream) {
+    if (B == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(inputs && outputs, "sh_encode_forward: null pointer");
     SSD_REQUIRE(D == 3, "sh_encode_forward: input dim must be 3 (got %u)", D);
     SSD_REQUIRE(C >= 1 && C <= 8, "sh_encode_forward: degree must be in [1, 8] (got %u)", C);
     SSD_REQUIRE(!calc_grad_inputs || dy_dx, "sh_encode_forward: dy_dx is null but calc_grad_inputs is set");
-    if (B == 0) return SSDNERF_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool g = calc_grad_inputs != 0;
     switch (C) {
@@ -85,10 +85,10 @@ __global__ void k_sh_backward(const float* __restrict__ grad, uint32_t B, uint32
 extern "C" int ssdnerf_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx,
                                           float* grad_inputs, void* stream) {
     (void)inputs;
+    if (B == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(grad && dy_dx && grad_inputs, "sh_encode_backward: null pointer");
     SSD_REQUIRE(D == 3, "sh_encode_backward: input dim must be 3 (got %u)", D);
     SSD_REQUIRE(C >= 1 && C <= 8, "sh_encode_backward: degree must be in [1, 8] (got %u)", C);
-    if (B == 0) return SSDNERF_OK;
     hipLaunchKernelGGL(k_sh_backward, dim3(ssd_blocks((uint64_t)B * D, SH_TPB)), dim3(SH_TPB), 0, (hipStream_t)stream, grad, B, D, C * C, dy_dx, grad_inputs);
     SSD_CHECK_LAUNCH("sh_encode_backward");
     return SSDNERF_OK;

@@ -312,7 +312,7 @@ class TriPlaneDecoder(VolumeRenderer):
                 n = xyz_s.size(-2)
                 pc = F.grid_sample(code_s, self.xyz_transform(xyz_s), mode=self.interp_mode, padding_mode="border",
                                    align_corners=False).squeeze(-2)
-                pcs.append(pc.permute(2, 1, 0).reshape(n, -1))
+                pcs.append(pc.permute(2, 1, 0).reshape(n, 3 * n_channels))
                 num_points.append(n)
             point_code = torch.cat(pcs, dim=0) if len(pcs) > 1 else pcs[0]
         base_x = self.base_net(point_code)

@@ -1,0 +1,92 @@
+"""Scene-level render entry points: the slice of ``BaseNeRF`` that sits on the hot path
+(reference: lib/models/autodecoders/base_nerf.py:494-533 ``render``, :551-553 output quantisation,
+lib/core/utils/nerf_utils.py:17-61 ``get_cam_rays``), host orchestration in Python on PyTorch-ROCm."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .decoders import TriPlaneDecoder, pack_triplanes
+
+
+def get_ray_directions(h: int, w: int, intrinsics: torch.Tensor, norm: bool = False, device=None) -> torch.Tensor:
+    """intrinsics (*,4) = [fx, fy, cx, cy] -> pixel-centre directions (*, h, w, 3) in camera space."""
+    batch = intrinsics.shape[:-1]
+    x = torch.linspace(0.5, w - 0.5, w, device=device)
+    y = torch.linspace(0.5, h - 0.5, h, device=device)
+    dx = ((x - intrinsics[..., 2:3]) / intrinsics[..., 0:1])[..., None, :].expand(*batch, h, w)
+    dy = ((y - intrinsics[..., 3:4]) / intrinsics[..., 1:2])[..., :, None].expand(*batch, h, w)
+    d = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)
+    return F.normalize(d, dim=-1) if norm else d
+
+
+def get_rays(directions: torch.Tensor, c2w: torch.Tensor, norm: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    rays_d = directions @ c2w[..., None, :3, :3].transpose(-1, -2)
+    rays_o = c2w[..., None, None, :3, 3].expand(rays_d.shape)
+    if norm:
+        rays_d = F.normalize(rays_d, dim=-1)
+    return rays_o, rays_d
+
+
+def get_cam_rays(c2w: torch.Tensor, intrinsics: torch.Tensor, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """c2w (S,V,4,4), intrinsics (S,V,4) -> rays_o, rays_d (S,V,h,w,3), directions normalised after rotation."""
+    directions = get_ray_directions(h, w, intrinsics, norm=False, device=intrinsics.device)
+    return get_rays(directions, c2w, norm=True)
+
+
+@torch.no_grad()
+def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch.Tensor, h: int, w: int, intrinsics: torch.Tensor,
+           poses: torch.Tensor, grid_size: int = 64, bg_color: float = 1.0, cfg: Optional[Dict] = None,
+           planes: Optional[torch.Tensor] = None, rays: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """``BaseNeRF.render``: (S,V) views of S scenes -> image (S,V,h,w,3) blended with ``bg_color``, depth (S,V,h,w).
+
+    ``planes`` / ``rays`` let callers that render the same scenes or cameras repeatedly keep the packed planes /
+    ray arrays resident instead of rebuilding them (they are pure functions of ``code`` / ``poses, intrinsics``)."""
+    cfg = cfg or {}
+    was_training = decoder.training
+    decoder.train(False)
+    dt_gamma_scale = cfg.get("dt_gamma_scale", 0.0)
+    dt_gamma = dt_gamma_scale * 2 / (intrinsics[..., 0] + intrinsics[..., 1]).mean(dim=-1)      # (S,)
+    if rays is None:
+        rays_o, rays_d = get_cam_rays(poses, intrinsics, h, w)
+    else:
+        rays_o, rays_d = rays
+    s, v = poses.shape[:2]
+    rays_o = rays_o.reshape(s, v * h * w, 3)
+    rays_d = rays_d.reshape(s, v * h * w, 3)
+    max_render_rays = cfg.get("max_render_rays", -1)
+    chunks_o = rays_o.split(max_render_rays, dim=1) if 0 < max_render_rays < rays_o.size(1) else [rays_o]
+    chunks_d = rays_d.split(max_render_rays, dim=1) if 0 < max_render_rays < rays_d.size(1) else [rays_d]
+    if planes is None and decoder.render_mode == "fused" and decoder.fused_supported(code):
+        planes = pack_triplanes(code, decoder.plane_dtype)
+    images, depths = [], []
+    gammas = [float(g) for g in dt_gamma.reshape(-1).tolist()]
+    for o, d in zip(chunks_o, chunks_d):
+        if planes is not None:
+            out = decoder.render_packed(planes, o, d, density_bitfield, [grid_size] * s, gammas, 1e-4, bg_color=bg_color,
+                                        check_overflow=False)
+            rgb = torch.stack(out["image"], dim=0)
+        else:
+            out = decoder(o, d, code, density_bitfield, grid_size, dt_gamma=gammas, perturb=False)
+            ws = torch.stack(out["weights_sum"], dim=0)
+            rgb = torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1))
+        images.append(rgb)
+        depths.append(torch.stack(out["depth"], dim=0))
+    image = (torch.cat(images, dim=1) if len(images) > 1 else images[0]).reshape(s, v, h, w, 3)
+    depth = (torch.cat(depths, dim=1) if len(depths) > 1 else depths[0]).reshape(s, v, h, w)
+    decoder.train(was_training)
+    return image, depth
+
+
+def quantize_u8(image: torch.Tensor) -> torch.Tensor:
+    """clamp [0,1] and round to k/255 as ``eval_and_viz`` does (base_nerf.py:551-553), kept as uint8 (what is all-gathered)."""
+    return torch.round(image.clamp(0, 1) * 255).to(torch.uint8)
+
+
+def eval_psnr(img1: torch.Tensor, img2: torch.Tensor, max_val: float = 1.0, eps: float = 1e-6) -> torch.Tensor:
+    """PSNR per batch element with the reference's epsilon (lib/core/evaluation/metrics.py:52-55)."""
+    import math
+    mse = (img1 - img2).square().flatten(1).mean(dim=-1)
+    return 10 * (2 * math.log10(max_val) - torch.log10(mse + eps))

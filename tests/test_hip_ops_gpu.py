@@ -84,7 +84,10 @@ def test_march_rays_train_bit_exact(orc, rm, C, H, dt_gamma, p):
     aabb = AABB * bound
     o, d = _rays(rng, 20000)
     o *= bound
-    bits = _bitfield(rng, C, H, p)
+    # Morton indices of a non power-of-two grid reach beyond H^3 (true of the reference too): size the bitfield for the
+    # enclosing power-of-two cube so the H=48 case exercises the double-precision cell path without reading out of bounds
+    Hb = 1 << (H - 1).bit_length()
+    bits = _bitfield(rng, C, Hb, p) if Hb != H else _bitfield(rng, C, H, p)
     nears, fars = orc.near_far_from_aabb(o, d, aabb, 0.2)
     noises = rng.random(o.shape[0]).astype(np.float32)
     X, D, L, R, cnt = orc.march_rays_train(o, d, bits, bound, dt_gamma, 256, C, H, nears, fars, noises)

@@ -62,7 +62,10 @@ def test_point_decode_matches_oracle(scene, decoder):
     np.testing.assert_allclose(rgb_e.cpu().numpy(), rgb0.numpy(), rtol=0, atol=5e-6)
     # empty and ragged inputs
     e = torch.zeros(0, 3).cuda()
-    s2, c2, n2 = decoder.point_decode([e, xyz[:77].cuda()], [e, dirs[:77].cuda()], code.expand(2, -1, -1, -1, -1).contiguous())
+    with torch.no_grad():
+        s2, c2, n2 = decoder.point_decode([e, xyz[:77].cuda()], [e, dirs[:77].cuda()], code.expand(2, -1, -1, -1, -1).contiguous())
+        s3, c3, n3 = decoder.point_decode_eager([e, xyz[:77].cuda()], [e, dirs[:77].cuda()], code.expand(2, -1, -1, -1, -1).contiguous())
+    assert n3 == [0, 77] and torch.allclose(s3, s2, rtol=1e-4, atol=1e-7)
     assert n2 == [0, 77] and s2.shape == (77,) and c2.shape == (77, 3)
 
 
