@@ -144,6 +144,16 @@ int ssdnerf_render_rays_fused(const void* planes, int planes_dtype, uint32_t Hp,
                               float bg_color, float sigmoid_saturation, float* image, float* depth, float* weights_sum,
                               int32_t* sample_counts, int32_t* overflow_flag, void* stream);
 
+/* Same, for S scenes in ONE launch (one tail instead of S): planes (S,3,Hp,Wp,8), bitfield (S, H^3/8), rays_o/rays_d (S,N,3),
+ * outputs (S,N,3) / (S,N) dense.  dt_gammas: optional DEVICE array [S] of per-scene cone angles (the reference pulls each
+ * one to the host with .item(), base_volume_renderer.py:112); NULL -> dt_gamma for every scene. */
+int ssdnerf_render_rays_fused_batch(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                    const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d,
+                                    uint32_t S, uint32_t N, float bound, float min_near, float dt_gamma, const float* dt_gammas,
+                                    uint32_t max_steps, float T_thresh, float bg_color, float sigmoid_saturation, float* image,
+                                    float* depth, float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag,
+                                    void* stream);
+
 /* Fused full-refresh branch of BaseNeRF.update_extra_state (base_nerf.py:328-351,377-387) for S scenes:
  * for every cell of the H^3 grid (x-major order like custom_meshgrid) decode sigma at the jittered cell centre
  * (jitter [H^3,3] uniform [0,1) shared by all scenes as in the reference, or NULL for no jitter) and fold it

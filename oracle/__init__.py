@@ -61,6 +61,13 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def set_threads(n: int) -> None:
+    """Cap the oracle's OpenMP team size (the GPU box has 256 host cores; the per-iteration work is small)."""
+    l = lib()
+    l.orc_set_threads.restype = None
+    l.orc_set_threads(ctypes.c_int(int(n)))
+
+
 def ref_lib(tag: str = "fma") -> Optional[ctypes.CDLL]:
     """The reference's kernels compiled for the CPU, or None when oracle/_ref was never built."""
     p = os.path.join(_HERE, "_ref", f"libssdnerf_ref_{tag}.so")

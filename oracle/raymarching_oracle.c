@@ -30,7 +30,20 @@
 #include <string.h>
 #include <float.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define ORC_SQRT3 1.7320508075688772f
+
+/* cap the OpenMP team (bench.py's cpu_baseline reports exactly this number as "cores") */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 static inline float orc_clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
 static inline float orc_sign1(float v) { return copysignf(1.0f, v); }
@@ -364,8 +377,8 @@ void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive
     }
 }
 
-/* composite_rays, inference (raymarching.cu:825-913): in place; T = 1 - sum(w) tested BEFORE...
- * no: computed before the update, compared after accumulating the sample (.cu:875-890).          */
+/* composite_rays, inference (raymarching.cu:825-913): in place.  T = 1 - sum(w) is read BEFORE the sample is
+ * added and compared with T_thresh AFTER it was accumulated (.cu:875-890).                        */
 void orc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
                         const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
                         float* image) {

@@ -23,7 +23,7 @@ EXPORTS = [
     "ssdnerf_morton3D_invert", "ssdnerf_packbits", "ssdnerf_march_rays_train_workspace", "ssdnerf_march_rays_train",
     "ssdnerf_composite_rays_train_forward", "ssdnerf_composite_rays_train_backward", "ssdnerf_march_rays", "ssdnerf_composite_rays",
     "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode",
-    "ssdnerf_render_rays_fused", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh",
+    "ssdnerf_render_rays_fused", "ssdnerf_render_rays_fused_batch", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh",
 ]
 
 

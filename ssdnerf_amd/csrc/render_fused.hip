@@ -38,6 +38,10 @@ struct RenderCfg {
     float aabb[6];
     float min_near, T_thresh, bg, sat;
     uint32_t N, cap;
+    // batch of scenes: blockIdx.y selects the scene; all per-scene arrays are dense with these strides
+    uint64_t plane_stride;     // elements between consecutive scenes' planes
+    uint64_t bitfield_stride;  // bytes between consecutive scenes' bitfields
+    const float* dt_gammas;    // [S] on device, or null -> m.dt_gamma for every scene
 };
 
 template <typename PT>
@@ -48,6 +52,16 @@ __global__ void __launch_bounds__(RF_TPB) k_render_fused(RenderCfg c, const PT* 
     __shared__ __attribute__((aligned(16))) float hd_lds[(RF_TPB / 64) * 64 * RF_HD_STRIDE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {   // select this workgroup's scene
+        const uint32_t scene = blockIdx.y;
+        planes += scene * c.plane_stride;
+        c.m.grid += scene * c.bitfield_stride;
+        if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
+        const uint64_t ray_off = (uint64_t)scene * c.N;
+        rays_o += 3 * ray_off; rays_d += 3 * ray_off;
+        image += 3 * ray_off; depth += ray_off; weights_sum += ray_off;
+        if (sample_counts) sample_counts += ray_off;
+    }
     float* hd_wave = hd_lds + wave * 64 * RF_HD_STRIDE;
     const float* hd_row = hd_wave + lane * RF_HD_STRIDE;
 
@@ -158,15 +172,16 @@ __global__ void __launch_bounds__(RF_TPB) k_render_fused(RenderCfg c, const PT* 
     }
 }
 
-extern "C" int ssdnerf_render_rays_fused(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
-                                         const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t N,
-                                         float bound, float min_near, float dt_gamma, uint32_t max_steps, float T_thresh, float bg_color,
-                                         float sigmoid_saturation, float* image, float* depth, float* weights_sum, int32_t* sample_counts,
-                                         int32_t* overflow_flag, void* stream) {
-    if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
+extern "C" int ssdnerf_render_rays_fused_batch(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                               const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S,
+                                               uint32_t N, float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps,
+                                               float T_thresh, float bg_color, float sigmoid_saturation, float* image, float* depth,
+                                               float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag, void* stream) {
+    if (N == 0 || S == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
     SSD_REQUIRE(planes && mlp_params && bitfield && rays_o && rays_d && image && depth && weights_sum, "render_rays_fused: null pointer");
     SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "render_rays_fused: unsupported plane dtype");
     SSD_REQUIRE(grid_size >= 1 && grid_size <= 1024 && max_steps >= 1 && Hp >= 1 && Wp >= 1, "render_rays_fused: bad geometry");
+    SSD_REQUIRE(S <= 65535, "render_rays_fused: at most 65535 scenes per launch");
     RenderCfg c;
     c.m = ssd_make_march_cfg(bound, dt_gamma, max_steps, 1, grid_size, bitfield);  // cascades are hard-wired to 1 in the renderer (base_volume_renderer.py:113)
     c.g = ssd_plane_geom(Hp, Wp);
@@ -174,11 +189,24 @@ extern "C" int ssdnerf_render_rays_fused(const void* planes, int planes_dtype, u
     c.aabb[3] = c.aabb[4] = c.aabb[5] = bound;
     c.min_near = min_near; c.T_thresh = T_thresh; c.bg = bg_color; c.sat = sigmoid_saturation;
     c.N = N; c.cap = max_steps;
+    c.plane_stride = (uint64_t)3 * Hp * Wp * 8;
+    c.bitfield_stride = ((uint64_t)grid_size * grid_size * grid_size) / 8;
+    c.dt_gammas = dt_gammas;
     const unsigned waves = ssd_blocks(N, RF_RAYS_PER_WAVE);
-    dim3 g(ssd_blocks(waves, RF_TPB / 64)), b(RF_TPB);
+    dim3 g(ssd_blocks(waves, RF_TPB / 64), S), b(RF_TPB);
     hipStream_t s = (hipStream_t)stream;
     if (planes_dtype == 0) hipLaunchKernelGGL((k_render_fused<float>), g, b, 0, s, c, (const float*)planes, mlp_params, rays_o, rays_d, image, depth, weights_sum, sample_counts, overflow_flag);
     else hipLaunchKernelGGL((k_render_fused<__half>), g, b, 0, s, c, (const __half*)planes, mlp_params, rays_o, rays_d, image, depth, weights_sum, sample_counts, overflow_flag);
     SSD_CHECK_LAUNCH("render_rays_fused");
     return SSDNERF_OK;
+}
+
+extern "C" int ssdnerf_render_rays_fused(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                         const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t N,
+                                         float bound, float min_near, float dt_gamma, uint32_t max_steps, float T_thresh, float bg_color,
+                                         float sigmoid_saturation, float* image, float* depth, float* weights_sum, int32_t* sample_counts,
+                                         int32_t* overflow_flag, void* stream) {
+    return ssdnerf_render_rays_fused_batch(planes, planes_dtype, Hp, Wp, mlp_params, bitfield, grid_size, rays_o, rays_d, 1, N, bound, min_near,
+                                           dt_gamma, nullptr, max_steps, T_thresh, bg_color, sigmoid_saturation, image, depth, weights_sum,
+                                           sample_counts, overflow_flag, stream);
 }

@@ -31,9 +31,24 @@ constexpr float dfact_odd(int m) {  // (2m-1)!!
     return (float)f;
 }
 
+// All constants are materialised at COMPILE time in one table (a plain call to the constexpr functions above from
+// device code is evaluated at run time - in fp64, with a 64-step Newton sqrt - unless forced into a constant expression).
+struct Tables {
+    float norm[64];   // norm[l*l + l + m] = c(l, m)
+    float dfact[9];   // (2m-1)!!
+};
+constexpr Tables make_tables() {
+    Tables t{};
+    for (int l = 0; l < 8; ++l)
+        for (int m = -l; m <= l; ++m) t.norm[l * l + l + m] = norm_const(l, m);
+    for (int m = 0; m < 9; ++m) t.dfact[m] = dfact_odd(m);
+    return t;
+}
+
 // Evaluates the C*C basis values (and optionally the three Jacobian rows) of one direction.
 template <int C, bool GRAD>
 SSD_DEV void eval(float x, float y, float z, float* __restrict__ out, float* __restrict__ gx, float* __restrict__ gy, float* __restrict__ gz) {
+    constexpr Tables T = make_tables();
     float A[C + 1], B[C + 1];
     A[0] = 1.0f; B[0] = 0.0f;
 #pragma unroll
@@ -48,7 +63,7 @@ SSD_DEV void eval(float x, float y, float z, float* __restrict__ out, float* __r
         for (int m = 0; m <= C; ++m) Q[l][m] = 0.0f;
 #pragma unroll
     for (int m = 0; m < C; ++m) {
-        Q[m][m] = dfact_odd(m);
+        Q[m][m] = T.dfact[m];
         if (m + 1 < C) Q[m + 1][m] = (float)(2 * m + 1) * z * Q[m][m];
 #pragma unroll
         for (int l = m + 2; l < C; ++l)
@@ -59,7 +74,7 @@ SSD_DEV void eval(float x, float y, float z, float* __restrict__ out, float* __r
 #pragma unroll
         for (int m = -l; m <= l; ++m) {
             const int am = m < 0 ? -m : m;
-            const float c = norm_const(l, m);
+            const float c = T.norm[l * l + l + m];
             const float xy = m >= 0 ? A[am] : B[am];
             const int idx = l * l + l + m;
             out[idx] = c * Q[l][am] * xy;

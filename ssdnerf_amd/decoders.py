@@ -353,28 +353,61 @@ class TriPlaneDecoder(VolumeRenderer):
 
     def render_packed(self, planes, rays_o, rays_d, density_bitfield, grid_size, dt_gamma, T_thresh=1e-4, bg_color=None,
                       want_counts=False, check_overflow=True):
-        """Fused render of S scenes from already-packed planes (S,3,h,w,8).  rays_o/rays_d: (S,N,3) tensors or per-scene lists."""
+        """Fused render of S scenes from already-packed planes (S,3,h,w,8).
+
+        rays_o/rays_d: a dense (S,N,3) tensor -> ONE launch for the whole batch (outputs are (S,N,3)/(S,N) tensors, indexable
+        per scene like the reference's lists); or per-scene lists of (N_s,3) -> one launch per scene.
+        dt_gamma: per-scene list of floats, or a DEVICE tensor (S,) (no host sync)."""
         params = self.packed_params()
         num_scenes = len(rays_o)
         dev = planes.device
         _, _, hp, wp, _ = planes.shape
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-        weights_sum, depth, image, counts = [], [], [], []
         blend = 0.0 if bg_color is None else float(bg_color)
-        for s in range(num_scenes):
-            o = rays_o[s].reshape(-1, 3).float().contiguous()
-            d = rays_d[s].reshape(-1, 3).float().contiguous()
-            n = o.size(0)
-            im = torch.empty(n, 3, dtype=torch.float32, device=dev)
-            dp = torch.empty(n, dtype=torch.float32, device=dev)
-            ws = torch.empty(n, dtype=torch.float32, device=dev)
-            cn = torch.empty(n, dtype=torch.int32, device=dev) if want_counts else None
-            C.check(C.lib().ssdnerf_render_rays_fused(
-                C.ptr(planes[s]), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(density_bitfield[s]),
-                C.u32(grid_size[s]), C.ptr(o), C.ptr(d), C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(dt_gamma[s]),
-                C.u32(self.max_steps), C.f32(T_thresh), C.f32(blend), C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws),
-                C.ptr(cn), C.ptr(overflow), C.stream()), "render_rays_fused")
-            weights_sum.append(ws); depth.append(dp); image.append(im); counts.append(cn)
+        gs = grid_size if isinstance(grid_size, int) else grid_size[0]
+        if not isinstance(grid_size, int):
+            assert all(g == gs for g in grid_size), "one grid size per batch"
+        dense = isinstance(rays_o, torch.Tensor) and rays_o.dim() == 3
+        if isinstance(dt_gamma, torch.Tensor):
+            dtg_dev, dtg_host = dt_gamma.float().contiguous(), None
+        else:
+            dtg_host = [float(g) for g in dt_gamma]
+            dtg_dev = None
+            if dense and not all(g == dtg_host[0] for g in dtg_host):
+                dtg_dev = torch.tensor(dtg_host, dtype=torch.float32, device=dev)
+        bits = density_bitfield if isinstance(density_bitfield, torch.Tensor) else torch.stack(list(density_bitfield), dim=0)
+        bits = bits.contiguous()
+        if dense:
+            o = rays_o.float().contiguous()
+            d = rays_d.float().contiguous()
+            n = o.size(1)
+            im = torch.empty(num_scenes, n, 3, dtype=torch.float32, device=dev)
+            dp = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
+            ws = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
+            cn = torch.empty(num_scenes, n, dtype=torch.int32, device=dev) if want_counts else None
+            C.check(C.lib().ssdnerf_render_rays_fused_batch(
+                C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(bits), C.u32(gs), C.ptr(o), C.ptr(d),
+                C.u32(num_scenes), C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(0.0 if dtg_host is None else dtg_host[0]),
+                C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(T_thresh), C.f32(blend), C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp),
+                C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.stream()), "render_rays_fused_batch")
+            weights_sum, depth, image, counts = ws, dp, im, cn
+        else:
+            weights_sum, depth, image, counts = [], [], [], []
+            for s in range(num_scenes):
+                o = rays_o[s].reshape(-1, 3).float().contiguous()
+                d = rays_d[s].reshape(-1, 3).float().contiguous()
+                n = o.size(0)
+                im = torch.empty(n, 3, dtype=torch.float32, device=dev)
+                dp = torch.empty(n, dtype=torch.float32, device=dev)
+                ws = torch.empty(n, dtype=torch.float32, device=dev)
+                cn = torch.empty(n, dtype=torch.int32, device=dev) if want_counts else None
+                g_s = float(dtg_dev[s]) if dtg_host is None else dtg_host[s]
+                C.check(C.lib().ssdnerf_render_rays_fused(
+                    C.ptr(planes[s]), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(bits[s]), C.u32(gs), C.ptr(o),
+                    C.ptr(d), C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(g_s), C.u32(self.max_steps), C.f32(T_thresh),
+                    C.f32(blend), C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.stream()),
+                    "render_rays_fused")
+                weights_sum.append(ws); depth.append(dp); image.append(im); counts.append(cn)
         self.last_render_stats = dict(mode="fused", overflow=overflow, sample_counts=counts if want_counts else None)
         if check_overflow and int(overflow.item()) != 0:
             raise RuntimeError("render_rays_fused: a ray hit the max_steps cap; use render_mode='stepwise' for this batch")

@@ -62,18 +62,20 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
     if planes is None and decoder.render_mode == "fused" and decoder.fused_supported(code):
         planes = pack_triplanes(code, decoder.plane_dtype)
     images, depths = [], []
-    gammas = [float(g) for g in dt_gamma.reshape(-1).tolist()]
+    gammas = None
     for o, d in zip(chunks_o, chunks_d):
         if planes is not None:
-            out = decoder.render_packed(planes, o, d, density_bitfield, [grid_size] * s, gammas, 1e-4, bg_color=bg_color,
+            # dt_gamma stays on the device (the reference calls .item() per scene, base_volume_renderer.py:112)
+            out = decoder.render_packed(planes, o, d, density_bitfield, grid_size, dt_gamma.reshape(-1), 1e-4, bg_color=bg_color,
                                         check_overflow=False)
-            rgb = torch.stack(out["image"], dim=0)
+            rgb = out["image"]                                    # already a dense (S,N,3) tensor: no stack copy
         else:
+            gammas = gammas or [float(g) for g in dt_gamma.reshape(-1).tolist()]
             out = decoder(o, d, code, density_bitfield, grid_size, dt_gamma=gammas, perturb=False)
             ws = torch.stack(out["weights_sum"], dim=0)
             rgb = torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1))
         images.append(rgb)
-        depths.append(torch.stack(out["depth"], dim=0))
+        depths.append(out["depth"] if isinstance(out["depth"], torch.Tensor) else torch.stack(out["depth"], dim=0))
     image = (torch.cat(images, dim=1) if len(images) > 1 else images[0]).reshape(s, v, h, w, 3)
     depth = (torch.cat(depths, dim=1) if len(depths) > 1 else depths[0]).reshape(s, v, h, w)
     decoder.train(was_training)
