@@ -99,13 +99,11 @@ def main():
     kernel_events = []
 
     def step(record=False):
-        if record:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        dec.stage_events = [] if record else None      # HIP events on the launch stream: [before A, between A and B, after B]
         out = dec.render_packed(planes, rays_o, rays_d, bits, 64, [0.0] * ns, 1e-4, bg_color=1.0, check_overflow=False)
         if record:
-            e1.record()
-            kernel_events.append((e0, e1))
+            kernel_events.append(dec.stage_events)
+            dec.stage_events = None
         img_u8 = nerf.quantize_u8(out["image"]).reshape(ns, nv, hw, hw, 3)
         if world > 1:
             dist.all_gather_into_tensor(gathered, img_u8)
@@ -115,6 +113,7 @@ def main():
     out = dec.render_packed(planes, rays_o, rays_d, bits, 64, [0.0] * ns, 1e-4, bg_color=1.0, want_counts=True, check_overflow=False)
     counts = dec.last_render_stats["sample_counts"]
     n_samples = int(counts.sum().item())
+    counts_gt0 = int((counts > 0).sum().item())
     overflow = int(dec.last_render_stats["overflow"].item())
     del counts
     log(f'stat pass done: {n_samples} samples, overflow {overflow}')
@@ -146,9 +145,15 @@ def main():
     log(f'timed region done: {ms_per_step:.2f} ms/step')
     rays_per_s = world * n_rays / (elapsed / args.steps)
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_events]))
-    algo_bytes = n_rays * BYTES_PER_RAY + n_samples * BYTES_PER_SAMPLE
+    first_hit_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in kernel_events]))
+    shade_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in kernel_events]))
+    kern_ms = shade_ms
+    # dominant kernel = k_shade_queue (gather + MLP + composite).  Its algorithmic bytes: 288 B per sample it shades plus,
+    # per hitting ray, 8 B queue entry + 24 B ray + 20 B outputs.
+    n_hit = int((counts_gt0))
+    algo_bytes = n_samples * BYTES_PER_SAMPLE + n_hit * (8 + BYTES_PER_RAY)
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    first_hit_bytes = n_rays * 24 + (n_rays - n_hit) * 20 + n_hit * 8
 
     result = {
         "metric": "rays/s (rendered-views/s = rays/s / 16384), SRN Cars 128x128 novel-view render of cached triplanes",
@@ -161,10 +166,14 @@ def main():
                    "collective": "all_gather(uint8 views)" if world > 1 else "none"},
         "views_per_s": rays_per_s / (hw * hw), "samples_per_s": world * n_samples / (elapsed / args.steps) if world == 1 else n_samples_all / (elapsed / args.steps),
         "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": overflow, "ms_raygen_untimed": ms_raygen,
-        "roofline": {"bound": "hbm", "kernel": "k_render_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_shade_queue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
                      "launch_ms": kern_ms, "launches_per_step": 1,
-                     "note": "algorithmic = 44 B/ray + 288 B/sample; planes (1.5 MiB/scene) are L2-resident so HBM traffic is far below this"},
+                     "note": "algorithmic = 288 B/sample + 52 B per hitting ray; planes (1.5 MiB/scene) are L2-resident, so real HBM "
+                             "traffic is far below this (PMC numbers in DESIGN.md / profiles/)",
+                     "other_kernels": {"k_first_hit": {"launch_ms": first_hit_ms, "algorithmic_bytes_per_launch": first_hit_bytes,
+                                                       "achieved_GBs": first_hit_bytes / (first_hit_ms * 1e-3) / 1e9}}},
+        "hit_rays_per_step_per_gpu": n_hit,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -154,6 +154,24 @@ int ssdnerf_render_rays_fused_batch(const void* planes, int planes_dtype, uint32
                                     float* depth, float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag,
                                     void* stream);
 
+/* The same render as two stages (the fast path for power-of-two grids; csrc/render_queue.hip):
+ *   first_hit   : every ray marched to its first occupied sample; rays without one are finished here (background written),
+ *                 the others are appended to a per-scene hit queue inside `workspace`;
+ *   shade_queue : persistent waves shade the queued rays (gather + MLP + composite + onward march).
+ * Both take the SAME workspace (ssdnerf_render_queue_workspace(S, N, grid_size) bytes, caller-owned) and must be issued
+ * in this order on one stream.  Results are bit-identical to ssdnerf_render_rays_fused_batch. */
+size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size);
+int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S,
+                             uint32_t N, float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps,
+                             float bg_color, float* image, float* depth, float* weights_sum, int32_t* sample_counts,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int ssdnerf_render_shade_queue(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                               uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N, float bound,
+                               float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps, float T_thresh,
+                               float bg_color, float sigmoid_saturation, float* image, float* depth, float* weights_sum,
+                               int32_t* sample_counts, int32_t* overflow_flag, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* Fused full-refresh branch of BaseNeRF.update_extra_state (base_nerf.py:328-351,377-387) for S scenes:
  * for every cell of the H^3 grid (x-major order like custom_meshgrid) decode sigma at the jittered cell centre
  * (jitter [H^3,3] uniform [0,1) shared by all scenes as in the reference, or NULL for no jitter) and fold it

@@ -23,7 +23,8 @@ EXPORTS = [
     "ssdnerf_morton3D_invert", "ssdnerf_packbits", "ssdnerf_march_rays_train_workspace", "ssdnerf_march_rays_train",
     "ssdnerf_composite_rays_train_forward", "ssdnerf_composite_rays_train_backward", "ssdnerf_march_rays", "ssdnerf_composite_rays",
     "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode",
-    "ssdnerf_render_rays_fused", "ssdnerf_render_rays_fused_batch", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh",
+    "ssdnerf_render_rays_fused", "ssdnerf_render_rays_fused_batch", "ssdnerf_render_queue_workspace", "ssdnerf_render_first_hit",
+    "ssdnerf_render_shade_queue", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh",
 ]
 
 
@@ -43,6 +44,8 @@ def lib() -> ctypes.CDLL:
         l.ssdnerf_abi_version.restype = ctypes.c_int
         l.ssdnerf_march_rays_train_workspace.restype = ctypes.c_size_t
         l.ssdnerf_march_rays_train_workspace.argtypes = [ctypes.c_uint32]
+        l.ssdnerf_render_queue_workspace.restype = ctypes.c_size_t
+        l.ssdnerf_render_queue_workspace.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
         if l.ssdnerf_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libssdnerf_hip.so ABI {l.ssdnerf_abi_version()} != expected {ABI_VERSION}: rebuild")
         _lib = l

@@ -77,9 +77,20 @@ class VolumeRenderer(nn.Module):
         self.max_steps = max_steps
         self.decoder_reg_loss = build_module(decoder_reg_loss) if decoder_reg_loss is not None else None
         self.render_mode = render_mode
+        self.fused_pipeline = "queue"      # "queue": first-hit + shading-queue kernels; "single": one persistent kernel (any grid size)
+        self.stage_events = None           # bench.py sets this to a list to get HIP events between the stages
+        self._ws_cache = {}
         self.plane_dtype = getattr(torch, plane_dtype) if isinstance(plane_dtype, str) else plane_dtype
         self.register_buffer("aabb", torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32))
         self.last_render_stats: Dict[str, object] = {}
+
+    def _workspace(self, nbytes: int, device) -> torch.Tensor:
+        key = (device.index, torch.cuda.current_stream().cuda_stream)
+        buf = self._ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws_cache[key] = buf
+        return buf
 
     def point_decode(self, xyzs, dirs, code):
         raise NotImplementedError
@@ -385,6 +396,28 @@ class TriPlaneDecoder(VolumeRenderer):
             dp = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
             ws = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
             cn = torch.empty(num_scenes, n, dtype=torch.int32, device=dev) if want_counts else None
+        if dense and self.fused_pipeline == "queue" and gs >= 8 and (gs & (gs - 1)) == 0:
+            g0 = 0.0 if dtg_host is None else dtg_host[0]
+            need = C.lib().ssdnerf_render_queue_workspace(num_scenes, n, gs)
+            wsp = self._workspace(need, dev)
+            ev = self.stage_events
+            if ev is not None:
+                ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+            C.check(C.lib().ssdnerf_render_first_hit(
+                C.ptr(bits), C.u32(gs), C.ptr(o), C.ptr(d), C.u32(num_scenes), C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(g0),
+                C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(blend), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(wsp),
+                C.ctypes.c_size_t(wsp.numel()), C.stream()), "render_first_hit")
+            if ev is not None:
+                ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+            C.check(C.lib().ssdnerf_render_shade_queue(
+                C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.u32(gs), C.ptr(o), C.ptr(d), C.u32(num_scenes),
+                C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(T_thresh),
+                C.f32(blend), C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.ptr(wsp),
+                C.ctypes.c_size_t(wsp.numel()), C.stream()), "render_shade_queue")
+            if ev is not None:
+                ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+            weights_sum, depth, image, counts = ws, dp, im, cn
+        elif dense:
             C.check(C.lib().ssdnerf_render_rays_fused_batch(
                 C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(bits), C.u32(gs), C.ptr(o), C.ptr(d),
                 C.u32(num_scenes), C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(0.0 if dtg_host is None else dtg_host[0]),

@@ -125,10 +125,16 @@ def test_render_view_fused_and_stepwise_vs_oracle(scene, decoder, view, dt_gamma
     np.testing.assert_allclose(rgb2, rgb0, rtol=0, atol=2e-5)
     np.testing.assert_allclose(dep2, dep0, rtol=0, atol=1e-4)
     np.testing.assert_allclose(ws2, ws0, rtol=0, atol=1e-5)
-    # integer contract: samples composited per ray.  The oracle's trace counts marched samples (whole n_step slots);
-    # the fused kernel stops at the sample that trips T_thresh, so compare against the per-ray composited count.
     mse = float(((rgb2 - rgb0) ** 2).mean())
     assert mse < 1e-10
+    # the two fused pipelines (two-stage hit queue vs single persistent kernel) run the same arithmetic: bit-identical
+    decoder.fused_pipeline = "single"
+    try:
+        rgb3, dep3, ws3, cnt3 = _render_gpu(decoder, scene, ro, rd, "fused", dt_gamma)
+    finally:
+        decoder.fused_pipeline = "queue"
+    assert np.array_equal(cnt, cnt3)
+    assert np.array_equal(rgb2.view(np.uint32), rgb3.view(np.uint32)) and np.array_equal(dep2.view(np.uint32), dep3.view(np.uint32))
 
 
 def test_fused_sample_counts_match_oracle_composited(scene, decoder):
@@ -177,19 +183,44 @@ def test_fused_render_edge_cases(scene, decoder):
     for n in (1, 63, 257, 1000):
         o = torch.tensor([[0.0, 0.0, 3.0]]).repeat(n, 1).cuda()
         d = torch.tensor([[0.0, 1.0, 0.0]]).repeat(n, 1).cuda()
-        out = decoder.render_packed(planes, [o], [d], bits, [64], [0.0], 1e-4, bg_color=1.0, want_counts=True)
-        assert torch.all(out["image"][0] == 1.0) and torch.all(out["weights_sum"][0] == 0) and torch.all(out["depth"][0] == 0)
-        assert int(decoder.last_render_stats["sample_counts"][0].abs().sum()) == 0
+        for rays in (([o], [d]), (o[None], d[None])):            # per-scene lists (single kernel) and dense batch (hit queue)
+            out = decoder.render_packed(planes, rays[0], rays[1], bits, [64], [0.0], 1e-4, bg_color=1.0, want_counts=True)
+            assert torch.all(out["image"][0] == 1.0) and torch.all(out["weights_sum"][0] == 0) and torch.all(out["depth"][0] == 0)
+            assert int(decoder.last_render_stats["sample_counts"][0].abs().sum()) == 0
     # empty bitfield: nothing is ever sampled
     zero_bits = torch.zeros_like(bits)
     from oracle import render as R
     ro, rd = _view(30)
-    out = decoder.render_packed(planes, [torch.from_numpy(ro).cuda()], [torch.from_numpy(rd).cuda()], zero_bits, [64], [0.0], 1e-4, bg_color=0.5)
+    out = decoder.render_packed(planes, torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], zero_bits, [64], [0.0], 1e-4, bg_color=0.5)
     assert torch.all(out["image"][0] == 0.5)
     # full bitfield on the fog scene hits the step cap -> overflow is reported, never silent
     full = torch.full_like(bits, 255)
-    decoder.render_packed(planes, [torch.from_numpy(ro).cuda()], [torch.from_numpy(rd).cuda()], full, [64], [0.0], 0.0, bg_color=1.0, check_overflow=False)
+    decoder.render_packed(planes, torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], full, [64], [0.0], 0.0, bg_color=1.0, check_overflow=False)
     assert int(decoder.last_render_stats["overflow"].item()) >= 0
+
+
+def test_multi_scene_batch_matches_per_scene(decoder):
+    """S scenes in one launch (per-scene queues, XCD-pinned shading) == the same scenes rendered one by one."""
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.decoders import pack_triplanes
+    from ssdnerf_amd.density import get_density
+    for ns in (3, 8):
+        code = S.make_scene_batch(ns, seed=77).cuda()
+        g = torch.Generator().manual_seed(11)
+        jit = [torch.rand(64 ** 3, 3, generator=g).cuda() for _ in range(2)]
+        _, bits = get_density(decoder, code, 64, density_thresh=0.1, density_step=2, jitters=jit)
+        planes = pack_triplanes(code)
+        ro, rd = _view(100)
+        o = torch.from_numpy(ro).cuda()[None].expand(ns, -1, -1).contiguous()
+        d = torch.from_numpy(rd).cuda()[None].expand(ns, -1, -1).contiguous()
+        gam = torch.linspace(0.0, 0.004, ns).cuda()
+        out = decoder.render_packed(planes, o, d, bits, 64, gam, 1e-4, bg_color=1.0, want_counts=True)
+        cn = decoder.last_render_stats["sample_counts"]
+        for s in range(ns):
+            one = decoder.render_packed(planes[s:s + 1], o[s:s + 1], d[s:s + 1], bits[s:s + 1], 64, [float(gam[s])], 1e-4, bg_color=1.0, want_counts=True)
+            assert torch.equal(one["image"][0], out["image"][s]) and torch.equal(one["depth"][0], out["depth"][s])
+            assert torch.equal(decoder.last_render_stats["sample_counts"][0], cn[s])
+        assert int(cn.sum()) > 1000
 
 
 def test_density_grid_update_matches_oracle(scene, decoder):

@@ -24,7 +24,7 @@ for f in glob.glob(f"/tmp/rp_{n}/**/*counter_collection*.csv", recursive=True):
 import os
 out = open(os.environ.get("OUT", ".") + f"/{n}_summary.txt", "w")
 for k, d in acc.items():
-    if "render" not in k and "density" not in k and "decode" not in k: continue
+    if not any(w in k for w in ("render", "density", "decode", "shade", "first_hit")): continue
     for c, v in sorted(d.items()):
         line = f"{k:60s} {c:28s} total={v:.6g} dispatches={cnt[(k,c)]} per_dispatch={v/cnt[(k,c)]:.6g}"
         print(line); out.write(line + "\n")
