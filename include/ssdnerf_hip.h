@@ -187,6 +187,12 @@ int ssdnerf_density_grid_update(const void* planes, int planes_dtype, uint32_t H
 int ssdnerf_packbits_dev_thresh(const void* grid, int grid_dtype, uint32_t N, const float* mean, float density_thresh,
                                 uint8_t* bitfield, void* stream);
 
+/* One DDIM step of the latent in V-parameterisation, eta = 0, no guidance (gaussian_diffusion.py:213,235,281-283):
+ *   x0 = clamp(sqrt_ab * x_t - sqrt_1mab * v, lo, hi);  eps = (x_t - sqrt_ab * x0) / sqrt_1mab;
+ *   x_prev = sqrt_ab_prev * x0 + dir_coef * eps,   dir_coef = sqrt(1 - ab_prev).      n elements (multiple of 4). */
+int ssdnerf_ddim_step_v(const float* x_t, const float* v, uint64_t n, float sqrt_ab, float sqrt_1mab, float sqrt_ab_prev,
+                        float dir_coef, float clip_lo, float clip_hi, float* x0_out, float* xprev_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,7 @@ class VolumeRenderer(nn.Module):
         self.decoder_reg_loss = build_module(decoder_reg_loss) if decoder_reg_loss is not None else None
         self.render_mode = render_mode
         self.fused_pipeline = "queue"      # "queue": first-hit + shading-queue kernels; "single": one persistent kernel (any grid size)
+        self.injected_noises = None        # optional (S,R) march jitter for the train branch (parity runs inject it; None -> torch.rand)
         self.stage_events = None           # bench.py sets this to a list to get HIP events between the stages
         self._ws_cache = {}
         self.plane_dtype = getattr(torch, plane_dtype) if isinstance(plane_dtype, str) else plane_dtype
@@ -123,7 +124,8 @@ class VolumeRenderer(nn.Module):
             for s in range(num_scenes):
                 x, d, dl, r = march_rays_train(rays_o[s], rays_d[s], self.bound, density_bitfield[s], 1, grid_size[s], nears[s],
                                                fars[s], perturb=perturb, align=128, force_all_rays=True, dt_gamma=dt_gamma[s],
-                                               max_steps=self.max_steps)
+                                               max_steps=self.max_steps,
+                                               noises=None if self.injected_noises is None else self.injected_noises[s])
                 xyzs.append(x); dirs.append(d); deltas.append(dl); rays.append(r)
             sigmas, rgbs, num_points = self.point_decode(xyzs, dirs, code)
             weights_sum, depth, image = batch_composite_rays_train(sigmas, rgbs, deltas, rays, num_points, T_thresh)

@@ -1,0 +1,247 @@
+"""``GaussianDiffusion``: noise schedules and the DDIM sampling loop over triplane latents, with the reference's
+rendering-loss guidance hook (reference: lib/models/diffusions/gaussian_diffusion.py:14-464).
+
+On the hot path: ``prepare_diffusion_vars`` (numpy float64 tables, :131-154),
+``pred_x_0`` (:180-240), ``p_sample_ddim`` (:264-293), ``p_sample_langevin`` (:242-262), ``ddim_sample`` (:295-331).
+The training loss, the DDPM ancestral sampler and the timestep samplers are out of scope; their config entries are
+accepted and ignored so that the reference's configs build unchanged.
+
+The per-step latent update (V-prediction -> x0, clamp, eps, x_prev) is one fused HIP kernel when no guidance closure is
+active (``ssdnerf_ddim_step_v``); the guided path keeps the reference's exact PyTorch expression order because autograd
+flows through it.
+"""
+from __future__ import annotations
+
+import math
+import sys
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _cabi as C
+from .registry import MODULES, build_module, get_module_device
+
+
+def _noise_like(x):
+    # mmgen's _get_noise_batch draws on the CPU and moves to the device
+    return torch.randn(x.shape, dtype=torch.float32).to(x.device)
+
+
+@MODULES.register_module()
+class GaussianDiffusion(nn.Module):
+    def __init__(self, denoising, ddpm_loss=None, betas_cfg=dict(type="cosine"), num_timesteps=1000, num_classes=0, sample_method="ddim",
+                 timestep_sampler=None, denoising_var_mode="FIXED_LARGE", denoising_mean_mode="V", train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_timesteps = num_timesteps
+        self.sample_method = sample_method
+        self._denoising_cfg = deepcopy(denoising)
+        self.denoising = build_module(denoising, default_args=dict(num_classes=num_classes, num_timesteps=num_timesteps))
+        self.denoising_var_mode = denoising_var_mode
+        self.denoising_mean_mode = denoising_mean_mode
+        self.betas_cfg = deepcopy(betas_cfg)
+        self.train_cfg = deepcopy(train_cfg) if train_cfg is not None else dict()
+        self.test_cfg = deepcopy(test_cfg) if test_cfg is not None else dict()
+        self.prepare_diffusion_vars()
+        # training-time objects: kept as plain config (out of scope), so that reference configs construct
+        self.sampler_cfg = deepcopy(timestep_sampler)
+        self.ddpm_loss_cfg = deepcopy(ddpm_loss)
+        self.use_fused_step = True
+
+    # ------------------------------------------------------------------------------------------ schedules
+    @staticmethod
+    def linear_beta_schedule(diffusion_timesteps, beta_0=1e-4, beta_T=2e-2):
+        scale = 1000 / diffusion_timesteps
+        return np.linspace(scale * beta_0, scale * beta_T, diffusion_timesteps, dtype=np.float64)
+
+    @staticmethod
+    def cosine_beta_schedule(diffusion_timesteps, max_beta=0.999, s=0.008):
+        def f(t, T, s):
+            return np.cos((t / T + s) / (1 + s) * np.pi / 2) ** 2
+        betas = []
+        for t in range(diffusion_timesteps):
+            betas.append(min(1 - f(t + 1, diffusion_timesteps, s) / f(t, diffusion_timesteps, s), max_beta))
+        return np.array(betas)
+
+    def get_betas(self):
+        cfg = dict(self.betas_cfg)
+        self.betas_schedule = cfg.pop("type")
+        if self.betas_schedule == "linear":
+            return self.linear_beta_schedule(self.num_timesteps, **cfg)
+        if self.betas_schedule == "cosine":
+            return self.cosine_beta_schedule(self.num_timesteps, **cfg)
+        if self.betas_schedule == "scaled_linear":
+            return np.linspace(cfg.get("beta_start", 0.0001) ** 0.5, cfg.get("beta_end", 0.02) ** 0.5, self.num_timesteps, dtype=np.float64) ** 2
+        raise AttributeError(f"Unknown method name {self.betas_schedule} for beta schedule.")
+
+    def prepare_diffusion_vars(self):
+        self.betas = self.get_betas()
+        self.alphas = 1.0 - self.betas
+        self.alphas_bar = np.cumprod(self.alphas, axis=0)
+        self.alphas_bar_prev = np.append(1.0, self.alphas_bar[:-1])
+        self.alphas_bar_next = np.append(self.alphas_bar[1:], 0.0)
+        self.sqrt_alphas_bar = np.sqrt(self.alphas_bar)
+        self.sqrt_one_minus_alphas_bar = np.sqrt(1.0 - self.alphas_bar)
+        self.log_one_minus_alphas_bar = np.log(1.0 - self.alphas_bar)
+        self.sqrt_recip_alplas_bar = np.sqrt(1.0 / self.alphas_bar)
+        self.sqrt_recipm1_alphas_bar = np.sqrt(1.0 / self.alphas_bar - 1)
+        self.tilde_betas_t = self.betas * (1 - self.alphas_bar_prev) / (1 - self.alphas_bar)
+        self.log_tilde_betas_t_clipped = np.log(np.append(self.tilde_betas_t[1], self.tilde_betas_t[1:]))
+        self.tilde_mu_t_coef1 = np.sqrt(self.alphas_bar_prev) / (1 - self.alphas_bar) * self.betas
+        self.tilde_mu_t_coef2 = np.sqrt(self.alphas) * (1 - self.alphas_bar_prev) / (1 - self.alphas_bar)
+
+    # ------------------------------------------------------------------------------------------ x0 prediction
+    def pred_x_0(self, x_t, t, grad_guide_fn=None, concat_cond=None, cfg=dict(), update_denoising_output=False):
+        clip_denoised = cfg.get("clip_denoised", True)
+        clip_range = cfg.get("clip_range", [-1, 1])
+        guidance_gain = cfg.get("guidance_gain", 1.0)
+        grad_through_unet = cfg.get("grad_through_unet", True)
+        snr_weight_power = cfg.get("snr_weight_power", 0.5)
+
+        num_batches = x_t.size(0)
+        t = torch.as_tensor(t).to(x_t.device)
+        if t.dim() == 0 or len(t) != num_batches:
+            t = t.expand(num_batches)
+        sqrt_alpha_bar_t = x_t.new_tensor(self.sqrt_alphas_bar)[t].reshape(-1, 1, 1, 1)
+        sqrt_one_minus_alpha_bar_t = x_t.new_tensor(self.sqrt_one_minus_alphas_bar)[t].reshape(-1, 1, 1, 1)
+
+        grad_enabled_prev = torch.is_grad_enabled()
+        if grad_guide_fn is not None and grad_through_unet:
+            x_t = x_t.detach().requires_grad_(True)    # the reference flips the flag on the (leaf) latent in place (:193-196)
+            torch.set_grad_enabled(True)
+
+        denoising_output = self.denoising(x_t, t, concat_cond=concat_cond)
+        mode = self.denoising_mean_mode.upper()
+        if mode == "EPS":
+            x_0_pred = (x_t - sqrt_one_minus_alpha_bar_t * denoising_output) / sqrt_alpha_bar_t
+        elif mode == "START_X":
+            x_0_pred = denoising_output
+        elif mode == "V":
+            x_0_pred = sqrt_alpha_bar_t * x_t - sqrt_one_minus_alpha_bar_t * denoising_output
+        else:
+            raise AttributeError(f"Unknown denoising mean output type [{self.denoising_mean_mode}].")
+
+        if grad_guide_fn is not None:
+            if clip_denoised:
+                x_0_pred = x_0_pred.clamp(*clip_range)
+            if grad_through_unet:
+                loss = grad_guide_fn(x_0_pred)
+                grad = torch.autograd.grad(loss, x_t)[0]
+            else:
+                x_0_pred.requires_grad = True
+                torch.set_grad_enabled(True)
+                loss = grad_guide_fn(x_0_pred)
+                grad = torch.autograd.grad(loss, x_0_pred)[0]
+            torch.set_grad_enabled(grad_enabled_prev)
+            x_0_pred.detach_()
+            x_0_pred -= grad * ((sqrt_one_minus_alpha_bar_t ** (2 - snr_weight_power * 2))
+                                * (sqrt_alpha_bar_t ** (snr_weight_power * 2 - 1)) * guidance_gain)
+        if clip_denoised:
+            x_0_pred = x_0_pred.clamp(*clip_range)
+
+        if update_denoising_output and grad_guide_fn is not None:
+            if mode == "EPS":
+                denoising_output = (x_t - x_0_pred * sqrt_alpha_bar_t) / sqrt_one_minus_alpha_bar_t
+            elif mode == "START_X":
+                denoising_output = x_0_pred
+            elif mode == "V":
+                denoising_output = (sqrt_alpha_bar_t * x_t - x_0_pred) / sqrt_one_minus_alpha_bar_t
+        return x_0_pred, denoising_output
+
+    # ------------------------------------------------------------------------------------------ samplers
+    def p_sample_langevin(self, x_t, t, noise=None, cfg=dict(), grad_guide_fn=None, **kwargs):
+        langevin_delta = cfg.get("langevin_delta", 0.1)
+        sigma = self.sqrt_one_minus_alphas_bar[int(t)]
+        x_0_pred, _ = self.pred_x_0(x_t, t, grad_guide_fn=grad_guide_fn, cfg=cfg, **kwargs)
+        eps_t_pred = (x_t - self.sqrt_alphas_bar[int(t)] * x_0_pred) / sigma
+        if noise is None:
+            noise = _noise_like(x_t)
+        return x_t - 0.5 * langevin_delta * sigma * eps_t_pred + math.sqrt(langevin_delta) * sigma * noise
+
+    def _fused_v_step_ok(self, x_t, cfg, grad_guide_fn, eta):
+        return (self.use_fused_step and grad_guide_fn is None and eta == 0 and self.denoising_mean_mode.upper() == "V"
+                and x_t.is_cuda and x_t.dtype == torch.float32 and cfg.get("clip_denoised", True))
+
+    def p_sample_ddim(self, x_t, t, t_prev, noise=None, cfg=dict(), grad_guide_fn=None, **kwargs):
+        eta = cfg.get("eta", 0)
+        t_i, tp_i = int(t), int(t_prev)
+        alpha_bar_t_prev = self.alphas_bar[tp_i] if tp_i >= 0 else self.alphas_bar_prev[0]
+        tilde_beta_t = self.tilde_betas_t[t_i]
+
+        if self._fused_v_step_ok(x_t, cfg, grad_guide_fn, eta):
+            # unguided V-prediction step: UNet forward, then ONE fused elementwise launch for
+            # x0 = clamp(a*x_t - b*v), eps = (x_t - a*x0)/b, x_prev = c*x0 + d*eps      (:213, :235, :281-283)
+            with torch.no_grad():
+                tt = torch.full((x_t.size(0),), t_i, dtype=torch.long, device=x_t.device)
+                v = self.denoising(x_t, tt, concat_cond=kwargs.get("concat_cond"))
+            clip_range = cfg.get("clip_range", [-1, 1])
+            x_t = x_t.contiguous()
+            v = v.float().contiguous()
+            x_prev, x_0_pred = torch.empty_like(x_t), torch.empty_like(x_t)
+            C.check(C.lib().ssdnerf_ddim_step_v(C.ptr(x_t), C.ptr(v), C.ctypes.c_uint64(x_t.numel()), C.f32(self.sqrt_alphas_bar[t_i]),
+                                                C.f32(self.sqrt_one_minus_alphas_bar[t_i]), C.f32(np.sqrt(alpha_bar_t_prev)),
+                                                C.f32(np.sqrt(1 - alpha_bar_t_prev - tilde_beta_t * (eta ** 2))), C.f32(clip_range[0]),
+                                                C.f32(clip_range[1]), C.ptr(x_0_pred), C.ptr(x_prev), C.stream()),
+                    "ddim_step_v")
+            return x_prev, x_0_pred
+
+        x_0_pred, _ = self.pred_x_0(x_t, t, grad_guide_fn=grad_guide_fn, cfg=cfg, **kwargs)
+        eps_t_pred = (x_t - self.sqrt_alphas_bar[t_i] * x_0_pred) / self.sqrt_one_minus_alphas_bar[t_i]
+        pred_sample_direction = np.sqrt(1 - alpha_bar_t_prev - tilde_beta_t * (eta ** 2)) * eps_t_pred
+        x_prev = np.sqrt(alpha_bar_t_prev) * x_0_pred + pred_sample_direction
+        if eta > 0:
+            if noise is None:
+                noise = _noise_like(x_t)
+            x_prev = x_prev + eta * np.sqrt(tilde_beta_t) * noise
+        return x_prev, x_0_pred
+
+    def ddim_timesteps(self, num_timesteps=None):
+        """arange(T-1, -1, -T/n).long(): 50 -> 999, 979, ..., 19; 75 -> 999, 985, 972, ..., 12   (:300-302)."""
+        n = self.test_cfg.get("num_timesteps", self.num_timesteps) if num_timesteps is None else num_timesteps
+        return torch.arange(start=self.num_timesteps - 1, end=-1, step=-(self.num_timesteps / n)).long()
+
+    def ddim_sample(self, noise, show_pbar=False, concat_cond=None, save_intermediates=False, **kwargs):
+        device = noise.device
+        x_t = noise
+        langevin_steps = self.test_cfg.get("langevin_steps", 0)
+        langevin_t_range = self.test_cfg.get("langevin_t_range", [0, 1000])
+        # timesteps stay on the HOST: the reference moves them to the device and then indexes numpy tables with them,
+        # which costs a device->host sync per table lookup (:275-283); the UNet gets a device copy inside pred_x_0.
+        timesteps = self.ddim_timesteps()
+        cond_step = 0
+        x_0_x_t_list = [] if save_intermediates else None
+        for step, t in enumerate(timesteps):
+            t_prev = timesteps[step + 1] if step + 1 < len(timesteps) else torch.tensor(-1)
+            tp_host = int(t_prev)
+            x_t, x_0_pred = self.p_sample_ddim(
+                x_t, t, t_prev,
+                concat_cond=concat_cond[:, cond_step % concat_cond.size(1)] if concat_cond is not None else None,
+                cfg=self.test_cfg, **kwargs)
+            cond_step += 1
+            if langevin_steps > 0 and langevin_t_range[0] < tp_host < langevin_t_range[1]:
+                for _ in range(langevin_steps):
+                    x_t = self.p_sample_langevin(
+                        x_t, t_prev, concat_cond=concat_cond[:, cond_step % concat_cond.size(1)] if concat_cond is not None else None,
+                        cfg=self.test_cfg, **kwargs)
+                    cond_step += 1
+            if x_0_x_t_list is not None:
+                x_0_x_t_list.append(x_0_pred)
+                x_0_x_t_list.append(x_t)
+        return x_0_x_t_list if save_intermediates else x_t
+
+    def sample_from_noise(self, noise, **kwargs):
+        name = f"{self.sample_method.lower()}_sample"
+        if not hasattr(self, name):
+            raise AttributeError(f"Cannot find sample method [{name}] correspond to [{self.sample_method}].")
+        return getattr(self, name)(noise=noise, **kwargs)
+
+    def forward_test(self, data, **kwargs):
+        assert data.dim() == 4
+        return self.sample_from_noise(data, **kwargs)
+
+    def forward(self, data, return_loss=False, **kwargs):
+        if return_loss:
+            raise NotImplementedError("diffusion training loss is outside the hot path (SURVEY.md section 2, rows 14-15)")
+        return self.forward_test(data, **kwargs)

@@ -1,0 +1,385 @@
+"""Model-level glue of the hot path: ``BaseNeRF`` / ``MultiSceneNeRF`` / ``DiffusionNeRF`` with the reference's
+constructor keywords (so ``configs/paper_cfgs/*.py`` build unchanged) and the test-time methods the north-star configs
+exercise:
+
+  render, get_density, update_extra_state, loss, ray_sample, load_scene / save_scene   (lib/models/autodecoders/base_nerf.py)
+  val_uncond, val_guide + grad_guide_fn, code_diff_pr[_inv], val_step                 (lib/models/autodecoders/diffusion_nerf.py)
+
+Training (``train_step``), ``val_optim`` / ``inverse_code``, the scene cache and the evaluation/visualisation code are
+out of scope (SURVEY.md sections 2 and 8(f)); calling them raises ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import math
+import os
+from copy import deepcopy
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nerf
+from .density import get_density as _get_density, update_density_grid
+from .registry import MODELS, MODULES, build_module, get_module_device
+
+
+# ---------------------------------------------------------------------------------------------- code activations
+@MODULES.register_module()
+class TanhCode(nn.Module):
+    def __init__(self, scale=1.0, eps=1e-5):
+        super().__init__()
+        self.scale = scale
+        self.eps = eps
+
+    def forward(self, code_, update_stats=False):
+        return code_.tanh() if self.scale == 1 else code_.tanh() * self.scale
+
+    def inverse(self, code):
+        c = code if self.scale == 1 else code / self.scale
+        return c.clamp(min=-1 + self.eps, max=1 - self.eps).atanh()
+
+
+@MODULES.register_module()
+class IdentityCode(nn.Module):
+    @staticmethod
+    def forward(code_, update_stats=False):
+        return code_
+
+    @staticmethod
+    def inverse(code):
+        return code
+
+
+@MODULES.register_module()
+class NormalizedTanhCode(nn.Module):
+    def __init__(self, mean=0.0, std=1.0, clip_range=1, eps=1e-5, momentum=0.001):
+        super().__init__()
+        self.mean, self.std, self.clip_range, self.momentum, self.eps = mean, std, clip_range, momentum, eps
+        self.register_buffer("running_mean", torch.tensor([0.0]))
+        self.register_buffer("running_var", torch.tensor([std ** 2]))
+
+    def forward(self, code_, update_stats=False):
+        # statistics are only updated during training (out of scope); test-time behaviour is the affine + tanh below
+        scale = (self.std / (self.running_var.sqrt() + self.eps)).to(code_.device)
+        return (code_ * scale + (self.mean - self.running_mean.to(code_.device) * scale)).div(self.clip_range).tanh().mul(self.clip_range)
+
+    def inverse(self, code):
+        scale = ((self.running_var.sqrt() + self.eps) / self.std).to(code.device)
+        return code.div(self.clip_range).clamp(min=-1 + self.eps, max=1 - self.eps).atanh().mul(self.clip_range * scale) + (
+            self.running_mean.to(code.device) - self.mean * scale)
+
+
+# ---------------------------------------------------------------------------------------------- losses on the guidance path
+@MODULES.register_module()
+class MSELoss(nn.Module):
+    """mmgen ``MSELoss``: ``loss_weight * mean((pred - target)^2)``."""
+
+    def __init__(self, loss_weight=1.0, reduction="mean", **kwargs):
+        super().__init__()
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, target, weight=None, **kwargs):
+        d = (pred - target).square()
+        if weight is not None:
+            d = d * weight
+        return d.mean() * self.loss_weight
+
+
+@MODULES.register_module()
+class RegLoss(nn.Module):
+    """``loss_weight * mean(|code|^power)`` (lib/models/losses/reg_loss.py)."""
+
+    def __init__(self, power=1, loss_weight=1.0):
+        super().__init__()
+        self.power, self.loss_weight = power, loss_weight
+
+    def forward(self, tensor, weight=None, avg_factor=None, **kwargs):
+        v = tensor.abs().mean() if self.power == 1 else (tensor.abs() ** self.power).mean()
+        return v * self.loss_weight
+
+
+class _ConfigOnly(nn.Module):
+    """Training-only config entries (losses / samplers / hooks): constructed so configs build, never executed."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.cfg = kwargs
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(f"{type(self).__name__} belongs to the training loop, which is outside the hot path")
+
+
+for _name in ("TVLoss", "L1LossMod", "DDPMMSELossMod", "SNRWeightedTimeStepSampler", "UniformTimeStepSampler"):
+    MODULES.register_module(name=_name, module=type(_name, (_ConfigOnly,), {}))
+
+
+# ---------------------------------------------------------------------------------------------- models
+class BaseNeRF(nn.Module):
+    def __init__(self, code_size=(3, 8, 64, 64), code_activation=dict(type="TanhCode", scale=1), grid_size=64,
+                 decoder=dict(type="TriPlaneDecoder"), decoder_use_ema=False, bg_color=1, pixel_loss=dict(type="MSELoss"), reg_loss=None,
+                 update_extra_interval=16, use_lpips_metric=True, init_from_mean=False, init_scale=1e-4, mean_ema_momentum=0.001,
+                 mean_scale=1.0, train_cfg=dict(), test_cfg=dict(), pretrained=None):
+        super().__init__()
+        self.code_size = tuple(code_size)
+        self.code_activation = build_module(code_activation)
+        self.grid_size = grid_size
+        self.decoder = build_module(decoder)
+        self.decoder_use_ema = decoder_use_ema
+        if self.decoder_use_ema:
+            self.decoder_ema = deepcopy(self.decoder)
+        self.bg_color = bg_color
+        self.pixel_loss = build_module(pixel_loss)
+        self.reg_loss = build_module(reg_loss) if reg_loss is not None else None
+        self.train_cfg = dict(train_cfg or {})
+        self.test_cfg = dict(test_cfg or {})
+        self.update_extra_interval = update_extra_interval
+        if init_from_mean:
+            self.register_buffer("init_code", torch.zeros(self.code_size))
+        else:
+            self.init_code = None
+        self.init_scale, self.mean_ema_momentum, self.mean_scale = init_scale, mean_ema_momentum, mean_scale
+        if pretrained is not None and os.path.isfile(pretrained):
+            sd = torch.load(pretrained, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+
+    # ---- scene wire format (base_nerf.py:143-170) -----------------------------------------------------------------
+    def load_scene(self, data, load_density=False):
+        device = get_module_device(self)
+        codes, grids, bits = [], [], []
+        for st in data["code"]:
+            p = st["param"]
+            codes.append(p["code"] if "code" in p else self.code_activation(p["code_"]))
+            if load_density:
+                grids.append(p["density_grid"])
+                bits.append(p["density_bitfield"])
+        code = torch.stack(codes, dim=0).to(device)
+        return (code, torch.stack(grids, dim=0).to(device) if load_density else None,
+                torch.stack(bits, dim=0).to(device) if load_density else None)
+
+    @staticmethod
+    def save_scene(save_dir, code, density_grid, density_bitfield, scene_name):
+        os.makedirs(save_dir, exist_ok=True)
+        for i, name in enumerate(scene_name):
+            torch.save(dict(scene_name=name, param=dict(code=code.data[i].cpu(), density_grid=density_grid.data[i].cpu(),
+                                                        density_bitfield=density_bitfield.data[i].cpu())),
+                       os.path.join(save_dir, name) + ".pth")
+
+    def get_init_density_grid(self, num_scenes, device=None):
+        return torch.zeros((num_scenes, self.grid_size ** 3), device=device, dtype=torch.float16)
+
+    def get_init_density_bitfield(self, num_scenes, device=None):
+        return torch.zeros((num_scenes, self.grid_size ** 3 // 8), device=device, dtype=torch.uint8)
+
+    # ---- density grid (base_nerf.py:318-401) ------------------------------------------------------------------------
+    def update_extra_state(self, decoder, code, density_grid, density_bitfield, iter_density, density_thresh=0.01, decay=0.9, S=128,
+                           jitter=None):
+        if iter_density >= 16:
+            raise NotImplementedError("the partial-update branch (base_nerf.py:353-376) is unreachable from the hot-path configs "
+                                      "(SURVEY.md Appendix B.12)")
+        with torch.no_grad():
+            update_density_grid(decoder, code, density_grid, density_bitfield, density_thresh=density_thresh, decay=decay, jitter=jitter,
+                                return_thresh=False)
+
+    def get_density(self, decoder, code, cfg=dict(), jitters=None):
+        return _get_density(decoder, code, self.grid_size, density_thresh=cfg.get("density_thresh", 0.01),
+                            density_step=cfg.get("density_step", 8), jitters=jitters)
+
+    # ---- guidance loss (base_nerf.py:231-261, 276-296) ---------------------------------------------------------------
+    @staticmethod
+    def ray_sample(cond_rays_o, cond_rays_d, cond_imgs, n_samples, sample_inds=None):
+        device = cond_rays_o.device
+        s, v, h, w, _ = cond_rays_o.size()
+        npix = v * h * w
+        rays_o, rays_d = cond_rays_o.reshape(s, npix, 3), cond_rays_d.reshape(s, npix, 3)
+        target = cond_imgs.reshape(s, npix, 3)
+        if npix > n_samples:
+            if sample_inds is None:
+                sample_inds = torch.stack([torch.randperm(npix, device=device)[:n_samples] for _ in range(s)], dim=0)
+            ar = torch.arange(s, device=device)[:, None]
+            rays_o, rays_d, target = rays_o[ar, sample_inds], rays_d[ar, sample_inds], target[ar, sample_inds]
+        return rays_o, rays_d, target
+
+    @staticmethod
+    def get_raybatch_inds(cond_imgs, n_inverse_rays):
+        device = cond_imgs.device
+        s, v, h, w, _ = cond_imgs.size()
+        npix = v * h * w
+        if npix > n_inverse_rays:
+            inds = torch.stack([torch.randperm(npix, device=device) for _ in range(s)], dim=0).split(n_inverse_rays, dim=1)
+            return inds, len(inds)
+        return None, None
+
+    def loss(self, decoder, code, density_bitfield, target_rgbs, rays_o, rays_d, dt_gamma=0.0, return_decoder_loss=False,
+             scale_num_ray=1.0, cfg=dict(), perturb=True, **kwargs):
+        outputs = decoder(rays_o, rays_d, code, density_bitfield, self.grid_size, dt_gamma=dt_gamma, perturb=perturb,
+                          return_loss=return_decoder_loss)
+        out_weights = outputs["weights_sum"]
+        out_rgbs = outputs["image"] + self.bg_color * (1 - out_weights.unsqueeze(-1))
+        scale = 1 - math.exp(-cfg["loss_coef"] * scale_num_ray) if "loss_coef" in cfg else 1
+        pixel_loss = self.pixel_loss(out_rgbs, target_rgbs, **kwargs) * (scale * 3)
+        loss = pixel_loss
+        loss_dict = dict(pixel_loss=pixel_loss)
+        if self.reg_loss is not None:
+            reg = self.reg_loss(code, **kwargs)
+            loss = loss + reg
+            loss_dict.update(reg_loss=reg)
+        return out_rgbs, loss, loss_dict
+
+    # ---- render (base_nerf.py:494-533) ---------------------------------------------------------------------------------
+    def render(self, decoder, code, density_bitfield, h, w, intrinsics, poses, cfg=dict()):
+        return nerf.render(decoder, code, density_bitfield, h, w, intrinsics, poses, grid_size=self.grid_size, bg_color=self.bg_color, cfg=cfg)
+
+    def train_step(self, *a, **k):
+        raise NotImplementedError("training is outside the hot path (SURVEY.md section 2)")
+
+    def inverse_code(self, *a, **k):
+        raise NotImplementedError("inverse_code / val_optim are SURVEY.md section 8(f) 'next'")
+
+
+@MODELS.register_module()
+class MultiSceneNeRF(BaseNeRF):
+    def __init__(self, *args, cache_size=0, cache_16bit=False, num_file_writers=0, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.cache_size, self.cache_16bit, self.num_file_writers = cache_size, cache_16bit, num_file_writers
+        self.cache = None   # the RAM/file scene cache belongs to training
+
+
+@MODELS.register_module()
+class DiffusionNeRF(MultiSceneNeRF):
+    def __init__(self, *args, diffusion=dict(type="GaussianDiffusion"), diffusion_use_ema=True, freeze_decoder=True, image_cond=False,
+                 code_permute=None, code_reshape=None, autocast_dtype=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        diffusion = dict(diffusion)
+        diffusion.update(train_cfg=self.train_cfg, test_cfg=self.test_cfg)
+        self.diffusion = build_module(diffusion)
+        self.diffusion_use_ema = diffusion_use_ema
+        if self.diffusion_use_ema:
+            self.diffusion_ema = deepcopy(self.diffusion)
+        self.freeze_decoder = freeze_decoder
+        if self.freeze_decoder:
+            self.decoder.requires_grad_(False)
+            if self.decoder_use_ema:
+                self.decoder_ema.requires_grad_(False)
+        self.image_cond = image_cond
+        self.code_permute = code_permute
+        self.code_reshape = code_reshape
+        self.code_reshape_inv = [self.code_size[a] for a in self.code_permute] if code_permute is not None else self.code_size
+        self.code_permute_inv = [self.code_permute.index(a) for a in range(len(self.code_permute))] if code_permute is not None else None
+        self.autocast_dtype = autocast_dtype
+
+    # (3,6,128,128) <-> (18,128,128) [or the tiled (6,128,384) layout via code_permute]   (diffusion_nerf.py:50-64)
+    def code_diff_pr(self, code):
+        x = code
+        if self.code_permute is not None:
+            x = x.permute([0] + [a + 1 for a in self.code_permute])
+        if self.code_reshape is not None:
+            x = x.reshape(code.size(0), *self.code_reshape)
+        return x
+
+    def code_diff_pr_inv(self, code_diff):
+        x = code_diff
+        if self.code_reshape is not None:
+            x = x.reshape(x.size(0), *self.code_reshape_inv)
+        if self.code_permute_inv is not None:
+            x = x.permute([0] + [a + 1 for a in self.code_permute_inv])
+        return x
+
+    def _autocast(self):
+        return torch.autocast(device_type="cuda", enabled=self.autocast_dtype is not None,
+                              dtype=getattr(torch, self.autocast_dtype) if self.autocast_dtype is not None else None)
+
+    # ---- unconditional sampling (diffusion_nerf.py:191-239) -----------------------------------------------------------
+    @torch.no_grad()
+    def val_uncond(self, data, show_pbar=False, density_jitters=None, **kwargs):
+        diffusion = self.diffusion_ema if self.diffusion_use_ema else self.diffusion
+        decoder = self.decoder_ema if self.decoder_use_ema else self.decoder
+        num_batches = len(data["scene_id"])
+        noise = data.get("noise", None)
+        if noise is None:
+            noise = torch.randn((num_batches, *self.code_size), device=get_module_device(self))
+        with self._autocast():
+            code_out = diffusion(self.code_diff_pr(noise), return_loss=False, show_pbar=show_pbar, **kwargs)
+        if self.test_cfg.get("n_inverse_steps", 0) > 0:
+            raise NotImplementedError("post-sampling code optimisation (n_inverse_steps > 0) is not used by the hot-path configs")
+        code = self.code_diff_pr_inv(code_out.float())
+        density_grid, density_bitfield = self.get_density(decoder, code, cfg=self.test_cfg, jitters=density_jitters)
+        return code, density_grid, density_bitfield
+
+    # ---- rendering-guided sampling (diffusion_nerf.py:241-311) --------------------------------------------------------
+    def val_guide(self, data, guide_noises=None, density_jitters=None, **kwargs):
+        """``guide_noises`` / ``density_jitters`` (extra): per-step injected march jitter (S,R) and grid jitter (H^3,3) lists,
+        replacing the reference's in-place ``torch.rand`` draws so that runs are reproducible across devices."""
+        device = get_module_device(self)
+        diffusion = self.diffusion_ema if self.diffusion_use_ema else self.diffusion
+        decoder = self.decoder_ema if self.decoder_use_ema else self.decoder
+        cond_imgs, cond_intrinsics, cond_poses = data["cond_imgs"], data["cond_intrinsics"], data["cond_poses"]
+        num_scenes, num_imgs, h, w, _ = cond_imgs.size()
+        cond_rays_o, cond_rays_d = nerf.get_cam_rays(cond_poses, cond_intrinsics, h, w)
+        dt_gamma_scale = self.test_cfg.get("dt_gamma_scale", 0.0)
+        dt_gamma = dt_gamma_scale / cond_intrinsics[..., :2].mean(dim=(-2, -1))
+        if self.image_cond:
+            raise NotImplementedError("image-conditioned UNets (concat_cond) are not part of the north-star configs")
+        decoder_training_prev = decoder.training
+        decoder.train(True)          # guidance uses the TRAIN branch of the renderer (diffusion_nerf.py:271-272)
+        req = [p.requires_grad for p in list(diffusion.parameters()) + list(decoder.parameters())]
+        for p in list(diffusion.parameters()) + list(decoder.parameters()):
+            p.requires_grad_(False)
+        try:
+            n_inverse_rays = self.test_cfg.get("n_inverse_rays", 4096)
+            raybatch_inds, num_raybatch = self.get_raybatch_inds(cond_imgs, n_inverse_rays)
+            density_grid = torch.zeros((num_scenes, self.grid_size ** 3), device=device)
+            density_bitfield = torch.zeros((num_scenes, self.grid_size ** 3 // 8), dtype=torch.uint8, device=device)
+            step_id = [0]
+
+            def grad_guide_fn(x_0_pred):
+                code_pred = self.code_diff_pr_inv(x_0_pred)
+                k = step_id[0]
+                self.update_extra_state(decoder, code_pred.detach().float(), density_grid, density_bitfield, 0,
+                                        density_thresh=self.test_cfg.get("density_thresh", 0.01),
+                                        jitter=None if density_jitters is None else density_jitters[k])
+                inds = raybatch_inds[k % num_raybatch] if raybatch_inds is not None else None
+                rays_o, rays_d, target_rgbs = self.ray_sample(cond_rays_o, cond_rays_d, cond_imgs, n_inverse_rays, sample_inds=inds)
+                if guide_noises is not None:
+                    decoder.injected_noises = guide_noises[k]
+                _, loss, _ = self.loss(decoder, code_pred, density_bitfield, target_rgbs, rays_o, rays_d, dt_gamma,
+                                       scale_num_ray=target_rgbs.size(1), cfg=self.test_cfg)
+                decoder.injected_noises = None
+                step_id[0] += 1
+                return loss * num_scenes
+
+            noise = data.get("noise", None)
+            if noise is None:
+                noise = torch.randn((num_scenes, *self.code_size), device=device)
+            with self._autocast():
+                code = diffusion(self.code_diff_pr(noise), return_loss=False, grad_guide_fn=grad_guide_fn, **kwargs)
+        finally:
+            for p, r in zip(list(diffusion.parameters()) + list(decoder.parameters()), req):
+                p.requires_grad_(r)
+            decoder.train(decoder_training_prev)
+        return self.code_diff_pr_inv(code.float()), density_grid, density_bitfield
+
+    def val_optim(self, *a, **k):
+        raise NotImplementedError("val_optim (fine-tuning after guidance) is SURVEY.md section 8(f) 'next'")
+
+    # ---- dispatch (diffusion_nerf.py:406-469), rendering only ----------------------------------------------------------
+    def val_step(self, data, **kwargs):
+        decoder = self.decoder_ema if self.decoder_use_ema else self.decoder
+        with torch.no_grad():
+            if "code" in data:
+                code, density_grid, density_bitfield = self.load_scene(data, load_density=True)
+            elif "cond_imgs" in data:
+                mode = self.test_cfg.get("cond_mode", "guide")
+                if mode not in ("guide", "guide_optim"):
+                    raise NotImplementedError(f"cond_mode={mode!r}: only the guidance half is on the hot path")
+                with torch.enable_grad():
+                    code, density_grid, density_bitfield = self.val_guide(data, **kwargs)
+            else:
+                code, density_grid, density_bitfield = self.val_uncond(data, **kwargs)
+            pred_imgs = None
+            if "test_poses" in data:
+                h, w = self.test_cfg.get("img_size", (128, 128))
+                image, depth = self.render(decoder, code, density_bitfield, h, w, data["test_intrinsics"], data["test_poses"], cfg=self.test_cfg)
+                pred_imgs = (torch.round(image.clamp(0, 1) * 255) / 255).permute(0, 1, 4, 2, 3)
+        return dict(log_vars=dict(), num_samples=code.size(0), pred_imgs=pred_imgs, code=code, density_grid=density_grid,
+                    density_bitfield=density_bitfield)

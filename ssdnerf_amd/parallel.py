@@ -1,0 +1,61 @@
+"""Scene-parallel multi-GPU helpers: one process per GPU, ``torch.distributed`` (backend ``nccl`` == RCCL on ROCm, over
+xGMI; ``gloo`` on CPU for tests).  The hot path shards by independent scenes: no collective inside
+render or DDIM, one all-gather of the rendered uint8 views per batch.
+
+``shard_scenes`` keeps the reference's partition (lib/datasets/samplers/distributed_sampler.py:27-40 and the code-cache
+split lib/models/autodecoders/multiscene_nerf.py:44-48: ``round(linspace(0, n, world + 1))``) so that the same scene lands
+on the same rank."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(num_scenes: int, world_size: int) -> np.ndarray:
+    return np.round(np.linspace(0, num_scenes, num=world_size + 1)).astype(np.int64)
+
+
+def shard_scenes(num_scenes: int, rank: int, world_size: int) -> range:
+    b = shard_bounds(num_scenes, world_size)
+    return range(int(b[rank]), int(b[rank + 1]))
+
+
+def all_gather_views(views_u8: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """(S_local, V, H, W, 3) uint8 on every rank -> (world * S_local, V, H, W, 3), rank-major.  Equal S_local per rank
+    (pad the last batch upstream); with xGMI's all-pairs links RCCL runs this as a direct one-hop gather."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return views_u8
+    world = dist.get_world_size(group)
+    views_u8 = views_u8.contiguous()
+    out = torch.empty((world * views_u8.size(0),) + tuple(views_u8.shape[1:]), dtype=views_u8.dtype, device=views_u8.device)
+    dist.all_gather_into_tensor(out, views_u8, group=group)
+    return out
+
+
+def all_gather_ragged_views(views_u8: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> List[torch.Tensor]:
+    """Variant for unequal per-rank scene counts (the tail of a scene list): gathers sizes first, pads to the maximum."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [views_u8]
+    world = dist.get_world_size(group)
+    n = torch.tensor([views_u8.size(0)], dtype=torch.int64, device=views_u8.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(views_u8.shape[1:]), dtype=views_u8.dtype, device=views_u8.device)
+    pad[: views_u8.size(0)] = views_u8
+    out = torch.empty((world * m,) + tuple(views_u8.shape[1:]), dtype=views_u8.dtype, device=views_u8.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return [out[r * m: r * m + sizes[r]] for r in range(world)]
+
+
+def reduce_mean(x: torch.Tensor) -> torch.Tensor:
+    """lib/core/utils/misc.py:34-40: all_reduce(SUM) of x / world."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return x
+    x = x.clone().div_(dist.get_world_size())
+    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    return x

@@ -1,0 +1,313 @@
+"""``DenoisingUnetMod`` and its blocks (reference: lib/models/architecture/ddpm/denoising.py:12-216,
+lib/models/architecture/ddpm/modules.py:12-129).
+
+The reference only *constructs* these blocks; their ``forward``s are inherited from mmgen 0.7.2, which is not
+vendored and not installable here.  The forwards below follow SURVEY.md Appendix A (the working spec: ADM-style
+residual blocks with scale-shift GroupNorm, per-head [q|k|v] channel order, nearest-neighbour upsampling, strided-conv
+downsampling, sinusoidal time embedding) and keep mmgen's module/attribute names so that released checkpoints'
+state-dict keys (``denoising.in_blocks.1.0.conv_1.2.weight`` ...) load unchanged.  **Unpinned**: there is no mmgen source
+on disk to check against.
+
+Compute: PyTorch-ROCm (MIOpen convolutions / rocBLAS GEMMs) in fp32 or under autocast.  Round 1 uses the library
+kernels; hand-written MFMA conv/attention kernels are the next step for this row.
+"""
+from __future__ import annotations
+
+import math
+from copy import deepcopy
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .registry import MODULES, build_module
+
+
+def _build_norm(norm_cfg, channels):
+    cfg = dict(norm_cfg)
+    typ = cfg.pop("type")
+    assert typ == "GN", f"only GroupNorm is used by the hot-path configs (got {typ})"
+    return nn.GroupNorm(cfg.pop("num_groups"), channels, **cfg)
+
+
+def _build_act(act_cfg):
+    cfg = dict(act_cfg)
+    typ = cfg.pop("type")
+    cfg.pop("inplace", None)
+    return {"SiLU": nn.SiLU, "ReLU": nn.ReLU, "GELU": nn.GELU}[typ]()
+
+
+class EmbedSequential(nn.Sequential):
+    """Passes the time embedding to the residual blocks and nothing to the others."""
+
+    def forward(self, x, y):
+        for layer in self:
+            x = layer(x, y) if isinstance(layer, DenoisingResBlockMod) else layer(x)
+        return x
+
+
+class TimeEmbedding(nn.Module):
+    def __init__(self, in_channels, embedding_channels, embedding_mode="sin", embedding_cfg=None, act_cfg=dict(type="SiLU", inplace=False)):
+        super().__init__()
+        assert embedding_mode.upper() == "SIN"
+        self.blocks = nn.Sequential(nn.Linear(in_channels, embedding_channels), _build_act(act_cfg),
+                                    nn.Linear(embedding_channels, embedding_channels))
+        cfg = dict(dim=in_channels)
+        if embedding_cfg is not None:
+            cfg.update(embedding_cfg)
+        self.dim = cfg["dim"]
+        self.max_period = cfg.get("max_period", 10000)
+
+    @staticmethod
+    def sinusodial_embedding(timesteps, dim, max_period=10000):
+        half = dim // 2
+        freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+        args = timesteps[:, None].float() * freqs[None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        if dim % 2:
+            emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+        return emb
+
+    def forward(self, t):
+        return self.blocks(self.sinusodial_embedding(t, self.dim, self.max_period))
+
+
+@MODULES.register_module()
+class NormWithEmbedding(nn.Module):
+    def __init__(self, in_channels, embedding_channels, norm_cfg=dict(type="GN", num_groups=32), act_cfg=dict(type="SiLU", inplace=False),
+                 use_scale_shift=True):
+        super().__init__()
+        self.use_scale_shift = use_scale_shift
+        self.norm = _build_norm(norm_cfg, in_channels)
+        out = in_channels * 2 if use_scale_shift else in_channels
+        self.embedding_layer = nn.Sequential(_build_act(act_cfg), nn.Linear(embedding_channels, out))
+
+    def forward(self, x, y):
+        e = self.embedding_layer(y)[:, :, None, None]
+        if self.use_scale_shift:
+            scale, shift = torch.chunk(e, 2, dim=1)
+            return self.norm(x) * (1 + scale) + shift
+        return self.norm(x + e)
+
+
+@MODULES.register_module()
+class DenoisingResBlockMod(nn.Module):
+    def __init__(self, in_channels, embedding_channels, use_scale_shift_norm, dropout, groups=1, out_channels=None,
+                 norm_cfg=dict(type="GN", num_groups=32), act_cfg=dict(type="SiLU", inplace=False), shortcut_kernel_size=1):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.conv_1 = nn.Sequential(_build_norm(norm_cfg, in_channels), _build_act(act_cfg),
+                                    nn.Conv2d(in_channels, out_channels, 3, padding=1, groups=groups))
+        self.norm_with_embedding = build_module(dict(type="NormWithEmbedding"), default_args=dict(
+            in_channels=out_channels, embedding_channels=embedding_channels, use_scale_shift=use_scale_shift_norm, norm_cfg=deepcopy(norm_cfg)))
+        conv_2 = [_build_act(act_cfg)]
+        if dropout > 0:
+            conv_2.append(nn.Dropout(dropout))
+        conv_2.append(nn.Conv2d(out_channels, out_channels, 3, padding=1, groups=groups))
+        self.conv_2 = nn.Sequential(*conv_2)
+        assert shortcut_kernel_size in (1, 3)
+        self.learnable_shortcut = out_channels != in_channels
+        if self.learnable_shortcut:
+            self.shortcut = nn.Conv2d(in_channels, out_channels, shortcut_kernel_size, padding=1 if shortcut_kernel_size == 3 else 0, groups=groups)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.constant_(self.conv_2[-1].weight, 0.0)          # mmgen zeroes the last conv of every residual branch
+        nn.init.constant_(self.conv_2[-1].bias, 0.0)
+
+    def forward(self, x, y):
+        s = self.shortcut(x) if self.learnable_shortcut else x
+        h = self.conv_1(x)
+        h = self.norm_with_embedding(h, y)
+        h = self.conv_2(h)
+        return h + s
+
+
+@MODULES.register_module()
+class MultiHeadAttentionMod(nn.Module):
+    def __init__(self, in_channels, num_heads=1, groups=1, norm_cfg=dict(type="GN", num_groups=32)):
+        super().__init__()
+        self.num_heads = num_heads
+        self.groups = groups
+        self.norm = _build_norm(norm_cfg, in_channels)
+        self.qkv = nn.Conv1d(in_channels, in_channels * 3, 1, groups=groups)
+        self.proj = nn.Conv1d(in_channels, in_channels, 1, groups=groups)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.constant_(self.proj.weight, 0.0)
+        nn.init.constant_(self.proj.bias, 0.0)
+
+    @staticmethod
+    def QKVAttention(qkv):
+        """qkv (B*heads, 3*c, T) with channel order [q | k | v] per head; softmax in fp32."""
+        ch = qkv.shape[1] // 3
+        q, k, v = torch.chunk(qkv, 3, dim=1)
+        scale = 1 / math.sqrt(math.sqrt(ch))
+        w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+        w = torch.softmax(w.float(), dim=-1).type(w.dtype)
+        return torch.einsum("bts,bcs->bct", w, v)
+
+    def forward(self, x):
+        b, c, *spatial = x.shape
+        x = x.reshape(b, c, -1)
+        t = x.size(-1)
+        qkv = self.qkv(self.norm(x))
+        qkv = qkv.reshape(b, self.groups, -1, t).transpose(1, 2).reshape(b * self.num_heads, -1, self.groups * t)   # modules.py:40-42
+        h = self.QKVAttention(qkv)
+        h = h.reshape(b, -1, self.groups, t).transpose(1, 2).reshape(b, -1, t)
+        h = self.proj(h)
+        return (h + x).reshape(b, c, *spatial)
+
+
+@MODULES.register_module()
+class DenoisingDownsampleMod(nn.Module):
+    def __init__(self, in_channels, groups=1, with_conv=True):
+        super().__init__()
+        self.downsample = nn.Conv2d(in_channels, in_channels, 3, 2, 1, groups=groups) if with_conv else nn.AvgPool2d(2, stride=2)
+
+    def forward(self, x):
+        return self.downsample(x)
+
+
+@MODULES.register_module()
+class DenoisingUpsampleMod(nn.Module):
+    def __init__(self, in_channels, groups=1, with_conv=True):
+        super().__init__()
+        self.with_conv = with_conv
+        if with_conv:
+            self.conv = nn.Conv2d(in_channels, in_channels, 3, 1, 1, groups=groups)
+
+    def forward(self, x):
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        return self.conv(x) if self.with_conv else x
+
+
+class _NormActConv(nn.Module):
+    """mmcv ``ConvModule(order=('norm','act','conv'))`` with its attribute names (``gn``, ``activate``, ``conv``)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding, groups, norm_cfg, act_cfg):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding, groups=groups, bias=True)
+        self.gn = _build_norm(norm_cfg, in_channels)
+        self.activate = _build_act(act_cfg)
+
+    def forward(self, x):
+        return self.conv(self.activate(self.gn(x)))
+
+
+@MODULES.register_module()
+class DenoisingUnetMod(nn.Module):
+    """Same constructor keywords and topology as the reference (denoising.py:15-187)."""
+
+    def __init__(self, image_size, in_channels=3, concat_cond_channels=0, base_channels=128, resblocks_per_downsample=3,
+                 num_timesteps=1000, use_rescale_timesteps=True, dropout=0, embedding_channels=-1, num_classes=0, channels_cfg=None,
+                 groups=1, norm_cfg=dict(type="GN", num_groups=32), act_cfg=dict(type="SiLU", inplace=False), shortcut_kernel_size=1,
+                 use_scale_shift_norm=False, num_heads=4, time_embedding_mode="sin", time_embedding_cfg=None,
+                 resblock_cfg=dict(type="DenoisingResBlockMod"), attention_cfg=dict(type="MultiHeadAttentionMod"), downsample_conv=True,
+                 upsample_conv=True, downsample_cfg=dict(type="DenoisingDownsampleMod"), upsample_cfg=dict(type="DenoisingUpsampleMod"),
+                 attention_res=[16, 8], pretrained=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_timesteps = num_timesteps
+        self.use_rescale_timesteps = use_rescale_timesteps
+        out_channels = in_channels
+        self.out_channels = out_channels
+        self.concat_cond_channels = concat_cond_channels
+        if isinstance(image_size, (list, tuple)):
+            assert len(image_size) == 2
+            image_size = list(image_size)
+        elif isinstance(image_size, int):
+            image_size = [image_size, image_size]
+        else:
+            raise TypeError("Only support `int` and `list[int]` for `image_size`.")
+        self.image_size = image_size
+        if not isinstance(channels_cfg, list):
+            raise ValueError(f"Only support list for `channels_cfg`, receive {type(channels_cfg)}")
+        self.channel_factor_list = channels_cfg
+        embedding_channels = base_channels * 4 if embedding_channels == -1 else embedding_channels
+        self.time_embedding = TimeEmbedding(base_channels, embedding_channels=embedding_channels, embedding_mode=time_embedding_mode,
+                                            embedding_cfg=time_embedding_cfg, act_cfg=act_cfg)
+        if self.num_classes != 0:
+            self.label_embedding = nn.Embedding(self.num_classes, embedding_channels)
+
+        res_cfg = deepcopy(resblock_cfg)
+        for k, v in dict(dropout=dropout, groups=groups, norm_cfg=norm_cfg, act_cfg=act_cfg, embedding_channels=embedding_channels,
+                         use_scale_shift_norm=use_scale_shift_norm, shortcut_kernel_size=shortcut_kernel_size).items():
+            res_cfg.setdefault(k, v)
+        attention_scale = [min(image_size) // int(res) for res in attention_res]
+        att_cfg = deepcopy(attention_cfg)
+        for k, v in dict(num_heads=num_heads, groups=groups, norm_cfg=norm_cfg).items():
+            att_cfg.setdefault(k, v)
+        down_cfg = deepcopy(downsample_cfg)
+        down_cfg.setdefault("groups", groups); down_cfg.setdefault("with_conv", downsample_conv)
+        up_cfg = deepcopy(upsample_cfg)
+        up_cfg.setdefault("groups", groups); up_cfg.setdefault("with_conv", upsample_conv)
+
+        scale = 1
+        self.in_blocks = nn.ModuleList([EmbedSequential(nn.Conv2d(in_channels + concat_cond_channels, base_channels, 3, 1, padding=1, groups=groups))])
+        self.in_channels_list = [base_channels]
+        in_ch = base_channels
+        for level, factor in enumerate(self.channel_factor_list):
+            in_ch = base_channels if level == 0 else base_channels * self.channel_factor_list[level - 1]
+            out_ch = base_channels * factor
+            for _ in range(resblocks_per_downsample):
+                layers = [build_module(res_cfg, {"in_channels": in_ch, "out_channels": out_ch})]
+                in_ch = out_ch
+                if scale in attention_scale:
+                    layers.append(build_module(att_cfg, {"in_channels": in_ch}))
+                self.in_channels_list.append(in_ch)
+                self.in_blocks.append(EmbedSequential(*layers))
+            if level != len(self.channel_factor_list) - 1:
+                self.in_blocks.append(EmbedSequential(build_module(down_cfg, {"in_channels": in_ch})))
+                self.in_channels_list.append(in_ch)
+                scale *= 2
+
+        self.mid_blocks = EmbedSequential(build_module(res_cfg, {"in_channels": in_ch}), build_module(att_cfg, {"in_channels": in_ch}),
+                                          build_module(res_cfg, {"in_channels": in_ch}))
+
+        skips = list(self.in_channels_list)
+        self.out_blocks = nn.ModuleList()
+        for level, factor in enumerate(self.channel_factor_list[::-1]):
+            for idx in range(resblocks_per_downsample + 1):
+                layers = [build_module(res_cfg, {"in_channels": in_ch + skips.pop(), "out_channels": base_channels * factor})]
+                in_ch = base_channels * factor
+                if scale in attention_scale:
+                    layers.append(build_module(att_cfg, {"in_channels": in_ch}))
+                if level != len(self.channel_factor_list) - 1 and idx == resblocks_per_downsample:
+                    layers.append(build_module(up_cfg, {"in_channels": in_ch}))
+                    scale //= 2
+                self.out_blocks.append(EmbedSequential(*layers))
+
+        self.out = _NormActConv(in_ch, out_channels, 3, 1, groups, norm_cfg, act_cfg)
+        self.init_weights(pretrained)
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            sd = torch.load(pretrained, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+            return
+        # mmgen: zero-init Conv2d named *conv_2* or (*out* and not *out_blocks*), and Conv1d named *proj*
+        for n, m in self.named_modules():
+            if isinstance(m, nn.Conv2d) and ("conv_2" in n or ("out" in n and "out_blocks" not in n)):
+                nn.init.constant_(m.weight, 0.0); nn.init.constant_(m.bias, 0.0)
+            if isinstance(m, nn.Conv1d) and "proj" in n:
+                nn.init.constant_(m.weight, 0.0); nn.init.constant_(m.bias, 0.0)
+
+    def forward(self, x_t, t, label=None, concat_cond=None, return_noise=False):
+        if self.use_rescale_timesteps:
+            t = t.float() * (1000.0 / self.num_timesteps)
+        embedding = self.time_embedding(t)
+        if label is not None:
+            embedding = self.label_embedding(label) + embedding
+        h, hs = x_t, []
+        if self.concat_cond_channels > 0:
+            h = torch.cat([h, concat_cond], dim=1)
+        for block in self.in_blocks:
+            h = block(h, embedding)
+            hs.append(h)
+        h = self.mid_blocks(h, embedding)
+        for block in self.out_blocks:
+            h = block(torch.cat([h, hs.pop()], dim=1), embedding)
+        return self.out(h)
