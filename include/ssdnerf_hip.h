@@ -172,6 +172,16 @@ int ssdnerf_render_shade_queue(const void* planes, int planes_dtype, uint32_t Hp
                                int32_t* sample_counts, int32_t* overflow_flag, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* Stage B with the 18->64 and 16->64 MLP layers on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) and wave-local LDS
+ * pools that turn long empty-space searches into full-width march passes (csrc/shade_mfma.hip).  Same arguments and
+ * workspace as ssdnerf_render_shade_queue; integer outputs identical, floats within fp32 rounding. */
+int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                    uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N,
+                                    float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps,
+                                    float T_thresh, float bg_color, float sigmoid_saturation, float* image, float* depth,
+                                    float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+
 /* Fused full-refresh branch of BaseNeRF.update_extra_state (base_nerf.py:328-351,377-387) for S scenes:
  * for every cell of the H^3 grid (x-major order like custom_meshgrid) decode sigma at the jittered cell centre
  * (jitter [H^3,3] uniform [0,1) shared by all scenes as in the reference, or NULL for no jitter) and fold it

@@ -24,7 +24,7 @@ EXPORTS = [
     "ssdnerf_composite_rays_train_forward", "ssdnerf_composite_rays_train_backward", "ssdnerf_march_rays", "ssdnerf_composite_rays",
     "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode",
     "ssdnerf_render_rays_fused", "ssdnerf_render_rays_fused_batch", "ssdnerf_render_queue_workspace", "ssdnerf_render_first_hit",
-    "ssdnerf_render_shade_queue", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh", "ssdnerf_ddim_step_v",
+    "ssdnerf_render_shade_queue", "ssdnerf_render_shade_queue_mfma", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh", "ssdnerf_ddim_step_v",
 ]
 
 

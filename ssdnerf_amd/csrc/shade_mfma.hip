@@ -1,0 +1,430 @@
+// ssdnerf_amd/csrc/shade_mfma.hip -- stage B of the fused renderer, MFMA form (the default shading kernel).
+//
+// Same contract as k_shade_queue (render_queue.hip): persistent waves shade the per-scene hit queues written by
+// k_first_hit.  Two changes, both driven by the r01 profiles (k_shade_queue was ISSUE-bound: ~5600 VALU instructions
+// per 64-sample iteration at ~50 % lane utilisation):
+//
+// 1. The two wide layers of the tiny MLP run on the matrix pipe in exact fp32:
+//        h      = W1 . [f ; 1]        64 x (18+1)   -> v_mfma_f32_32x32x2_f32, 10 k-steps x (2 M-tiles x 2 N-tiles)
+//        h_col  = h + Wd . [SH(d); 1] 64 x (16+1)   ->  9 k-steps, accumulated IN PLACE on top of h
+//    (biases ride along as a constant-1 input row, so the accumulator starts from the inline constant 0).
+//    One lane = one sample = one MFMA "column": lane l supplies the B operand of column l with ONE v_permlane32_swap per
+//    k-step for both 32-sample tiles, and after a second swap+add every lane ends up with the four outputs (sigma, r, g, b)
+//    of ITS OWN sample.  Weights live in 38 VGPRs as A operands (loaded once per wave) - no per-iteration scalar loads, and
+//    the per-ray LDS cache of the direction term disappears (it is recomputed on the otherwise idle matrix pipe).
+//    The 64->{1,3} output layer and the 128 SiLUs per sample stay on the VALU (4 outputs cannot fill an MFMA tile);
+//    output weights sit in 1 KiB of LDS and are read as broadcast ds_read_b128.
+//    f32-input MFMA is a k-ordered fp32 FMA chain (MI355X guide), i.e. the same arithmetic class as the VALU kernel.
+//
+// 2. A lane never searches more than SEARCH_PROBES empty voxels for its next sample.  A ray that needs a longer search
+//    (typically: it left the object and must cross the rest of the box) is parked - state and all - in a wave-local
+//    LDS pool; when 64 of them have collected (or nothing else is left) the wave runs a MARCH PASS in which every lane
+//    marches one parked ray to its next hit (-> "ready" pool, picked up by the next refill) or to the end of the box
+//    (-> finished).  Shading iterations therefore stay full, and marching runs at full lane utilisation too.
+//
+// Results are bit-identical in the integer outputs and within fp32 rounding of k_shade_queue for the floats (the MFMA
+// accumulates the same products in a different, fixed order); tests/test_render_gpu.py checks both against the oracle.
+#include "decode_core.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+static constexpr unsigned SM_TPB = 256;
+static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
+static constexpr unsigned SM_POOL = 128;           // entries per wave-local pool (two pools per wave)
+static constexpr unsigned SM_SEARCH_PROBES = 4;    // in-lane search budget after each sample
+
+struct FastMarchB {
+    float bound, dt_gamma, dt_min, dt_max, mip_bound, rb, half_H, two_rH, Hm1f;
+    uint32_t H, log2H;
+};
+struct ShadeCfg {
+    FastMarchB m;
+    PlaneGeom g;
+    float aabb[6];
+    float min_near, T_thresh, bg, sat;
+    uint32_t N, S, cap;
+    uint64_t plane_stride;
+    uint32_t bitfield_stride;
+    const float* dt_gammas;
+};
+
+struct ProbeB { float x, y, z, dt; int nx, ny, nz; bool occ; };
+
+SSD_DEV ProbeB sm_probe(const FastMarchB& m, const uint8_t* __restrict__ lin_bits, const RayGeom& r, float t) {
+    ProbeB p;
+    p.x = ssd_clamp(ssd_fma(t, r.dx, r.ox), -m.bound, m.bound);
+    p.y = ssd_clamp(ssd_fma(t, r.dy, r.oy), -m.bound, m.bound);
+    p.z = ssd_clamp(ssd_fma(t, r.dz, r.oz), -m.bound, m.bound);
+    p.dt = ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max);
+    p.nx = (int)ssd_clamp(ssd_fma(p.x, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
+    p.ny = (int)ssd_clamp(ssd_fma(p.y, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
+    p.nz = (int)ssd_clamp(ssd_fma(p.z, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
+    const uint32_t idx = (((uint32_t)p.nz << m.log2H) + (uint32_t)p.ny << m.log2H) + (uint32_t)p.nx;
+    p.occ = (lin_bits[idx >> 3] >> (idx & 7u)) & 1u;
+    return p;
+}
+SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, float sgx, float sgy, float sgz, float t) {
+    const float tx = ssd_fma(ssd_fma((float)p.nx + sgx, m.two_rH, -1.0f), m.mip_bound, -p.x) * r.rdx;
+    const float ty = ssd_fma(ssd_fma((float)p.ny + sgy, m.two_rH, -1.0f), m.mip_bound, -p.y) * r.rdy;
+    const float tz = ssd_fma(ssd_fma((float)p.nz + sgz, m.two_rH, -1.0f), m.mip_bound, -p.z) * r.rdz;
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do { t += ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max); } while (t < tt);
+    return t;
+}
+
+// v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.
+SSD_DEV void sm_swap(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+template <typename PT>
+__global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t slices_per_scene, const PT* __restrict__ planes,
+                                                           const float* __restrict__ P, const uint8_t* __restrict__ lin_bits,
+                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                           const uint2* __restrict__ queue, const uint32_t* __restrict__ queue_count,
+                                                           float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
+                                                           int32_t* __restrict__ sample_counts, int32_t* __restrict__ overflow_flag) {
+    // LDS: [0,1 KiB) output-layer weights per accumulator slot; then per wave two pools of SM_POOL x 8 dwords.
+    __shared__ __attribute__((aligned(16))) float lds[256 + (SM_TPB / 64) * 2 * SM_POOL * 8];
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- output weights: slot (mt, reg, half) <-> hidden row mt*32 + (reg&3) + 8*(reg>>2) + 4*half (32x32 MFMA C/D layout) ----
+    if (threadIdx.x < 64) {
+        const int mt = threadIdx.x >> 5, reg = (threadIdx.x >> 1) & 15, hf = threadIdx.x & 1;
+        const int row = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+        const float* rec = P + row * 24;
+        float4 w = make_float4(rec[19], rec[20], rec[21], rec[22]);   // w_sigma, Wc[0..2][row]
+        reinterpret_cast<float4*>(lds)[threadIdx.x] = w;
+    }
+    __syncthreads();
+    const float4* wout = reinterpret_cast<const float4*>(lds);      // index (mt*16 + reg)*2 + half
+    uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 256) + wave * 2 * SM_POOL * 8;
+    uint32_t* pool_ready = pool_search + SM_POOL * 8;
+
+    // ---- workgroup -> (scene, slice) with the scene pinned to one XCD when S is a multiple of 8 ----
+    const uint32_t b = blockIdx.x;
+    const uint32_t wg_per_scene = (slices_per_scene + (SM_TPB / 64) - 1) / (SM_TPB / 64);
+    uint32_t scene, wg;
+    if ((c.S & 7u) == 0) { const uint32_t xcd = b & 7u, j = b >> 3; scene = xcd + 8u * (j / wg_per_scene); wg = j % wg_per_scene; }
+    else { scene = b / wg_per_scene; wg = b % wg_per_scene; }
+    if (scene >= c.S) return;
+    const uint32_t count = queue_count[scene];
+    uint32_t next = __builtin_amdgcn_readfirstlane((wg * (SM_TPB / 64) + wave) * SM_SLICE);
+    if (next >= count) return;
+    const uint32_t end = min(next + SM_SLICE, count);
+    const uint64_t ray0 = (uint64_t)scene * c.N;
+    planes += scene * c.plane_stride;
+    lin_bits += (uint64_t)scene * c.bitfield_stride;
+    queue += ray0;
+    if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
+
+    // ---- A operands: lane l holds W[mt*32 + (l&31)][2s + (l>>5)] for every k-step s ----
+    float a1[2][10], a2[2][9];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 32 + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < 10; ++s) {
+            const int k = 2 * s + half;                       // W1 | b1 | 0
+            a1[mt][s] = k < 19 ? P[row * 24 + k] : 0.0f;      // rec[row][0..17] = W1, rec[row][18] = b1
+        }
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int k = 2 * s + half;                       // Wd | bd | 0
+            a2[mt][s] = k < 16 ? P[MLP_OFF_WD + row * 16 + k] : (k == 16 ? P[MLP_OFF_BD + row] : 0.0f);
+        }
+    }
+    const float b_const = half == 0 ? 1.0f : 0.0f;            // B operand of the (1, 0) bias/pad k-step, both tiles
+    const float b_sigma = P[MLP_OFF_TAIL + 0], bc0 = P[MLP_OFF_TAIL + 1], bc1 = P[MLP_OFF_TAIL + 2], bc2 = P[MLP_OFF_TAIL + 3];
+    const float sat_k = ssd_fma(c.sat, 2.0f, 1.0f);
+
+    // ---- lane state ----
+    int ray = -1;
+    RayGeom r = {};
+    float sgx = 0.f, sgy = 0.f, sgz = 0.f;
+    float t = 0.f, far_ = 0.f, ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    uint32_t cnt = 0;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sdt = 0.f;
+    float sh[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sh[i] = 0.f;
+    uint32_t sp_head = 0, sp_count = 0, rp_head = 0, rp_count = 0;    // wave-uniform pool cursors
+
+    auto write_out = [&](uint32_t rid, float ws_, float dep_, float cr_, float cg_, float cb_, uint32_t cnt_) {
+        const uint64_t gi = ray0 + rid;
+        const float bgk = c.bg * (1.0f - ws_);
+        image[3 * gi + 0] = cr_ + bgk;
+        image[3 * gi + 1] = cg_ + bgk;
+        image[3 * gi + 2] = cb_ + bgk;
+        depth[gi] = dep_;
+        weights_sum[gi] = ws_;
+        if (sample_counts) sample_counts[gi] = (int32_t)cnt_;
+    };
+    auto load_geometry = [&](uint32_t rid) {
+        const uint64_t gi = ray0 + rid;
+        r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
+        float near_;
+        ssd_near_far(c.aabb, r, c.min_near, near_, far_);
+        sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f); sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f); sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
+    };
+    auto begin_ray = [&]() {   // geometry is loaded and t points at an occupied probe
+        const ProbeB p = sm_probe(c.m, lin_bits, r, t);
+        sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
+        shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
+    };
+
+    for (;;) {
+        // ================= refill idle lanes: parked-and-found rays first, then the global hit queue =================
+        {
+            const uint64_t idle = __ballot(ray < 0);
+            if (idle != 0 && rp_count != 0) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t take = min((uint32_t)__popcll(idle), rp_count);
+                if (ray < 0 && rank < take) {
+                    const uint32_t* e = pool_ready + ((rp_head + rank) % SM_POOL) * 8;
+                    const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + 4);
+                    ray = (int)e0.x; t = __uint_as_float(e0.y); ws = __uint_as_float(e0.z); dep = __uint_as_float(e0.w);
+                    cr = __uint_as_float(e1.x); cg = __uint_as_float(e1.y); cb = __uint_as_float(e1.z); cnt = e1.w;
+                    load_geometry(e0.x);
+                    begin_ray();
+                }
+                rp_head = (rp_head + take) % SM_POOL;
+                rp_count -= take;
+            }
+        }
+        {
+            const uint64_t idle = __ballot(ray < 0);
+            if (idle != 0 && next < end) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t cand = next + rank;
+                if (ray < 0 && cand < end) {
+                    const uint2 e = queue[cand];
+                    ray = (int)e.x; t = __uint_as_float(e.y);
+                    ws = dep = cr = cg = cb = 0.f; cnt = 0;
+                    load_geometry(e.x);
+                    begin_ray();
+                }
+                next = __builtin_amdgcn_readfirstlane(min(next + (uint32_t)__popcll(idle), end));
+            }
+        }
+        const uint64_t live = __ballot(ray >= 0);
+
+        // ================= march pass: every lane takes one parked ray to its next hit or to the end of the box =================
+        if ((sp_count >= 64 || (live == 0 && sp_count != 0)) && rp_count <= SM_POOL - 64) {
+            const uint32_t n = min(sp_count, 64u);
+            bool found = false, mine = (uint32_t)lane < n;
+            uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+            if (mine) {
+                const uint32_t* e = pool_search + ((sp_head + lane) % SM_POOL) * 8;
+                e0 = *reinterpret_cast<const uint4*>(e); e1 = *reinterpret_cast<const uint4*>(e + 4);
+                const uint64_t gi = ray0 + e0.x;
+                const RayGeom q = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
+                float qn, qf;
+                ssd_near_far(c.aabb, q, c.min_near, qn, qf);
+                const float qx = ssd_fma(0.5f, ssd_sign1(q.dx), 0.5f), qy = ssd_fma(0.5f, ssd_sign1(q.dy), 0.5f), qz = ssd_fma(0.5f, ssd_sign1(q.dz), 0.5f);
+                float qt = __uint_as_float(e0.y);
+                while (qt < qf) {
+                    const ProbeB p = sm_probe(c.m, lin_bits, q, qt);
+                    if (p.occ) { found = true; break; }
+                    qt = sm_skip(c.m, q, p, qx, qy, qz, qt);
+                }
+                if (found) e0.y = __float_as_uint(qt);
+                else write_out(e0.x, __uint_as_float(e0.z), __uint_as_float(e0.w), __uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z), e1.w);
+            }
+            const uint64_t fm = __ballot(found);
+            if (found) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                uint32_t* e = pool_ready + ((rp_head + rp_count + rank) % SM_POOL) * 8;
+                *reinterpret_cast<uint4*>(e) = e0; *reinterpret_cast<uint4*>(e + 4) = e1;
+            }
+            rp_count += (uint32_t)__popcll(fm);
+            sp_head = (sp_head + n) % SM_POOL;
+            sp_count -= n;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            continue;   // refill from the ready pool before shading
+        }
+        if (live == 0) {
+            if (next >= end && sp_count == 0 && rp_count == 0) break;
+            continue;
+        }
+
+        // ================= shade: gather -> MFMA layers -> output layer -> composite =================
+        float f[18];
+        if (ray >= 0) ssd_gather18<PT>(planes, c.g, sx, sy, sz, f);
+        else {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) f[i] = 0.f;
+        }
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+        // layer 1: 9 feature k-steps + the (1,0) bias step
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            float b0 = f[2 * s], b1 = f[2 * s + 1];
+            sm_swap(b0, b1);          // b0 -> tile 0 operand (samples 0..31), b1 -> tile 1 operand (samples 32..63)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][s], b0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][s], b1, acc[mt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][9], b_const, acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][9], b_const, acc[mt][1], 0, 0, 0);
+        }
+        // density head on silu(h): partial dot products over this half's 32 hidden rows, for both tiles
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float w = wout[(mt * 16 + i) * 2 + half].x;
+                ps0 = ssd_fma(w, ssd_silu(acc[mt][0][i]), ps0);
+                ps1 = ssd_fma(w, ssd_silu(acc[mt][1][i]), ps1);
+            }
+        // direction term accumulated in place: 8 SH k-steps + the (1,0) bias step
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float b0 = sh[2 * s], b1 = sh[2 * s + 1];
+            sm_swap(b0, b1);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][s], b0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][s], b1, acc[mt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][8], b_const, acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][8], b_const, acc[mt][1], 0, 0, 0);
+        }
+        float pr0 = 0.f, pg0 = 0.f, pb0 = 0.f, pr1 = 0.f, pg1 = 0.f, pb1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 w = wout[(mt * 16 + i) * 2 + half];
+                const float c0 = ssd_silu(acc[mt][0][i]), c1 = ssd_silu(acc[mt][1][i]);
+                pr0 = ssd_fma(w.y, c0, pr0); pg0 = ssd_fma(w.z, c0, pg0); pb0 = ssd_fma(w.w, c0, pb0);
+                pr1 = ssd_fma(w.y, c1, pr1); pg1 = ssd_fma(w.z, c1, pg1); pb1 = ssd_fma(w.w, c1, pb1);
+            }
+        // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
+        sm_swap(ps0, ps1); sm_swap(pr0, pr1); sm_swap(pg0, pg1); sm_swap(pb0, pb1);
+        const float sigma = ssd_exp(ps0 + ps1 + b_sigma);
+        const float sr = ssd_fma(ssd_sigmoid(pr0 + pr1 + bc0), sat_k, -c.sat);
+        const float sg = ssd_fma(ssd_sigmoid(pg0 + pg1 + bc1), sat_k, -c.sat);
+        const float sb = ssd_fma(ssd_sigmoid(pb0 + pb1 + bc2), sat_k, -c.sat);
+
+        bool park = false;
+        if (ray >= 0) {
+            const float alpha = 1.0f - __expf(-sigma * sdt);
+            const float T = 1.0f - ws;
+            const float w = alpha * T;
+            ws += w;
+            dep = ssd_fma(w, t, dep);
+            cr = ssd_fma(w, sr, cr);
+            cg = ssd_fma(w, sg, cg);
+            cb = ssd_fma(w, sb, cb);
+            t += sdt;
+            ++cnt;
+            if (T < c.T_thresh) {
+                write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1;
+            } else {
+                uint32_t probes = 0;
+                for (;;) {
+                    if (!(t < far_)) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break; }
+                    if (cnt >= c.cap) {
+                        if (overflow_flag) atomicAdd(overflow_flag, 1);
+                        write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break;
+                    }
+                    if (probes == SM_SEARCH_PROBES) { park = true; break; }
+                    const ProbeB p = sm_probe(c.m, lin_bits, r, t);
+                    if (p.occ) { sx = p.x; sy = p.y; sz = p.z; sdt = p.dt; break; }
+                    t = sm_skip(c.m, r, p, sgx, sgy, sgz, t);
+                    ++probes;
+                }
+            }
+        }
+        // ---- park rays that need a long search (state -> LDS search pool) ----
+        const uint64_t pm = __ballot(park);
+        if (pm != 0) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+            const uint32_t room = SM_POOL - sp_count;
+            if (park && rank < room) {
+                uint32_t* e = pool_search + ((sp_head + sp_count + rank) % SM_POOL) * 8;
+                *reinterpret_cast<uint4*>(e) = make_uint4((uint32_t)ray, __float_as_uint(t), __float_as_uint(ws), __float_as_uint(dep));
+                *reinterpret_cast<uint4*>(e + 4) = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cb), cnt);
+                ray = -1;
+                park = false;
+            }
+            sp_count += min((uint32_t)__popcll(pm), room);
+            if (park) {   // pool full (cannot happen with the trigger above, kept as a guard): finish the search in the lane
+                for (;;) {
+                    if (!(t < far_)) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break; }
+                    const ProbeB p = sm_probe(c.m, lin_bits, r, t);
+                    if (p.occ) { sx = p.x; sy = p.y; sz = p.z; sdt = p.dt; break; }
+                    t = sm_skip(c.m, r, p, sgx, sgy, sgz, t);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size);   // render_queue.hip (same workspace layout)
+
+extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                               uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N, float bound,
+                                               float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps, float T_thresh,
+                                               float bg_color, float sigmoid_saturation, float* image, float* depth, float* weights_sum,
+                                               int32_t* sample_counts, int32_t* overflow_flag, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+    if (N == 0 || S == 0) return SSDNERF_OK;
+    SSD_REQUIRE(planes && mlp_params && rays_o && rays_d && image && depth && weights_sum && workspace, "render_shade_queue_mfma: null pointer");
+    SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "render_shade_queue_mfma: unsupported plane dtype");
+    SSD_REQUIRE(grid_size >= 8 && grid_size <= 512 && (grid_size & (grid_size - 1)) == 0, "render_shade_queue_mfma: grid_size must be a power of two in [8, 512]");
+    if (workspace_bytes < ssdnerf_render_queue_workspace(S, N, grid_size))
+        return ssdnerf_fail(SSDNERF_E_WORKSPACE, "render_shade_queue_mfma: workspace too small");
+    ShadeCfg c;
+    const MarchCfg mc = ssd_make_march_cfg(bound, dt_gamma, max_steps, 1, grid_size, nullptr);
+    c.m.bound = bound; c.m.dt_gamma = dt_gamma; c.m.dt_min = mc.dt_min; c.m.dt_max = mc.dt_max;
+    c.m.mip_bound = fminf(1.0f, bound); c.m.rb = 1.0f / c.m.mip_bound;
+    c.m.half_H = 0.5f * (float)grid_size; c.m.two_rH = 2.0f / (float)grid_size; c.m.Hm1f = (float)(grid_size - 1);
+    c.m.H = grid_size; c.m.log2H = (uint32_t)__builtin_ctz(grid_size);
+    c.g = ssd_plane_geom(Hp, Wp);
+    c.aabb[0] = c.aabb[1] = c.aabb[2] = -bound; c.aabb[3] = c.aabb[4] = c.aabb[5] = bound;
+    c.min_near = min_near; c.T_thresh = T_thresh; c.bg = bg_color; c.sat = sigmoid_saturation;
+    c.N = N; c.S = S; c.cap = max_steps;
+    c.plane_stride = (uint64_t)3 * Hp * Wp * 8;
+    c.bitfield_stride = (grid_size * grid_size * grid_size) / 8;
+    c.dt_gammas = dt_gammas;
+    // workspace carve (must match render_queue.hip)
+    const size_t counters = ((size_t)S * 4 + 255) / 256 * 256;
+    const size_t bits = ((size_t)S * c.bitfield_stride + 255) / 256 * 256;
+    const uint32_t* q_count = (const uint32_t*)workspace;
+    const uint8_t* lin_bits = (const uint8_t*)workspace + counters;
+    const uint2* queue = (const uint2*)((const uint8_t*)workspace + counters + bits);
+    const uint32_t slices = ssd_blocks(N, SM_SLICE);
+    const uint32_t wg_per_scene = ssd_blocks(slices, SM_TPB / 64);
+    dim3 g(S * wg_per_scene), b(SM_TPB);
+    hipStream_t s = (hipStream_t)stream;
+    if (planes_dtype == 0) hipLaunchKernelGGL((k_shade_mfma<float>), g, b, 0, s, c, slices, (const float*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag);
+    else hipLaunchKernelGGL((k_shade_mfma<__half>), g, b, 0, s, c, slices, (const __half*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag);
+    SSD_CHECK_LAUNCH("render_shade_queue_mfma");
+    return SSDNERF_OK;
+}

@@ -77,7 +77,7 @@ class VolumeRenderer(nn.Module):
         self.max_steps = max_steps
         self.decoder_reg_loss = build_module(decoder_reg_loss) if decoder_reg_loss is not None else None
         self.render_mode = render_mode
-        self.fused_pipeline = "queue"      # "queue": first-hit + shading-queue kernels; "single": one persistent kernel (any grid size)
+        self.fused_pipeline = "queue_mfma"  # "queue_mfma": first-hit + MFMA shading kernel; "queue": VALU shading kernel; "single": one persistent kernel (any grid size)
         self.injected_noises = None        # optional (S,R) march jitter for the train branch (parity runs inject it; None -> torch.rand)
         self.stage_events = None           # bench.py sets this to a list to get HIP events between the stages
         self._ws_cache = {}
@@ -398,7 +398,7 @@ class TriPlaneDecoder(VolumeRenderer):
             dp = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
             ws = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
             cn = torch.empty(num_scenes, n, dtype=torch.int32, device=dev) if want_counts else None
-        if dense and self.fused_pipeline == "queue" and gs >= 8 and (gs & (gs - 1)) == 0:
+        if dense and self.fused_pipeline in ("queue", "queue_mfma") and gs >= 8 and (gs & (gs - 1)) == 0:
             g0 = 0.0 if dtg_host is None else dtg_host[0]
             need = C.lib().ssdnerf_render_queue_workspace(num_scenes, n, gs)
             wsp = self._workspace(need, dev)
@@ -411,7 +411,8 @@ class TriPlaneDecoder(VolumeRenderer):
                 C.ctypes.c_size_t(wsp.numel()), C.stream()), "render_first_hit")
             if ev is not None:
                 ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
-            C.check(C.lib().ssdnerf_render_shade_queue(
+            shade = C.lib().ssdnerf_render_shade_queue_mfma if self.fused_pipeline == "queue_mfma" else C.lib().ssdnerf_render_shade_queue
+            C.check(shade(
                 C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.u32(gs), C.ptr(o), C.ptr(d), C.u32(num_scenes),
                 C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(T_thresh),
                 C.f32(blend), C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.ptr(wsp),

@@ -127,14 +127,22 @@ def test_render_view_fused_and_stepwise_vs_oracle(scene, decoder, view, dt_gamma
     np.testing.assert_allclose(ws2, ws0, rtol=0, atol=1e-5)
     mse = float(((rgb2 - rgb0) ** 2).mean())
     assert mse < 1e-10
-    # the two fused pipelines (two-stage hit queue vs single persistent kernel) run the same arithmetic: bit-identical
-    decoder.fused_pipeline = "single"
-    try:
-        rgb3, dep3, ws3, cnt3 = _render_gpu(decoder, scene, ro, rd, "fused", dt_gamma)
-    finally:
-        decoder.fused_pipeline = "queue"
-    assert np.array_equal(cnt, cnt3)
-    assert np.array_equal(rgb2.view(np.uint32), rgb3.view(np.uint32)) and np.array_equal(dep2.view(np.uint32), dep3.view(np.uint32))
+    # the two VALU pipelines (two-stage hit queue vs single persistent kernel) run the same arithmetic: bit-identical;
+    # the default MFMA shading kernel sums the same products in another fixed order: fp32-rounding close, same counts
+    # except on rays sitting at the T_thresh boundary
+    res = {}
+    for pipe in ("single", "queue"):
+        decoder.fused_pipeline = pipe
+        try:
+            res[pipe] = _render_gpu(decoder, scene, ro, rd, "fused", dt_gamma)
+        finally:
+            decoder.fused_pipeline = "queue_mfma"
+    assert np.array_equal(res["single"][3], res["queue"][3])
+    assert np.array_equal(res["single"][0].view(np.uint32), res["queue"][0].view(np.uint32))
+    assert np.array_equal(res["single"][1].view(np.uint32), res["queue"][1].view(np.uint32))
+    np.testing.assert_allclose(res["queue"][0], rgb0, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(rgb2, res["queue"][0], rtol=0, atol=1e-5)
+    assert int((cnt != res["queue"][3]).sum()) <= max(1, cnt.size // 2000)
 
 
 def test_fused_sample_counts_match_oracle_composited(scene, decoder):
