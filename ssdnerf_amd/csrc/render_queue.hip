@@ -308,9 +308,9 @@ static int rq_make_cfg(QueueCfg& c, uint32_t Hp, uint32_t Wp, uint32_t grid_size
     return SSDNERF_OK;
 }
 
-// workspace layout: [ S x u32 queue counters (padded to 256 B) | S x H^3/8 linear bitfields | S x N x uint2 queue ]
+// workspace layout: [ S x u32 queue counters, S x u32 slice tickets (padded to 256 B) | S x H^3/8 linear bitfields | S x N x uint2 queue ]
 extern "C" size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size) {
-    const size_t counters = ((size_t)S * 4 + 255) / 256 * 256;
+    const size_t counters = ((size_t)S * 8 + 255) / 256 * 256;
     const size_t bits = ((size_t)S * grid_size * grid_size * grid_size / 8 + 255) / 256 * 256;
     return counters + bits + (size_t)S * N * sizeof(uint2);
 }
@@ -318,7 +318,7 @@ extern "C" size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_
 struct RqWorkspace { uint32_t* counters; uint8_t* lin_bits; uint2* queue; };
 static RqWorkspace rq_carve(void* ws, uint32_t S, uint32_t grid_size) {
     RqWorkspace w;
-    const size_t counters = ((size_t)S * 4 + 255) / 256 * 256;
+    const size_t counters = ((size_t)S * 8 + 255) / 256 * 256;
     const size_t bits = ((size_t)S * grid_size * grid_size * grid_size / 8 + 255) / 256 * 256;
     w.counters = (uint32_t*)ws;
     w.lin_bits = (uint8_t*)ws + counters;
@@ -340,7 +340,7 @@ extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_s
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const RqWorkspace w = rq_carve(workspace, S, grid_size);
-    hipMemsetAsync(w.counters, 0, (size_t)S * 4, s);
+    hipMemsetAsync(w.counters, 0, (size_t)S * 8, s);   // hit counts + the shading kernel's slice tickets
     hipLaunchKernelGGL(k_bitfield_linearize, dim3(ssd_blocks(c.bitfield_stride, RQ_TPB), S), dim3(RQ_TPB), 0, s, bitfield, grid_size, c.m.log2H, c.bitfield_stride, w.lin_bits);
     hipLaunchKernelGGL(k_first_hit, dim3(ssd_blocks(N, RQ_TPB), S), dim3(RQ_TPB), 0, s, c, w.lin_bits, rays_o, rays_d, image, depth, weights_sum, sample_counts,
                        w.queue, w.counters);

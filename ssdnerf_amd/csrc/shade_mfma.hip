@@ -27,6 +27,21 @@
 #include "decode_core.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// SiLU of two values at once: the multiply / add / multiply around the two transcendentals are packed fp32 ops
+// (v_pk_mul_f32 / v_pk_add_f32 process two values per instruction at the plain VALU rate).
+SSD_DEV floatx2 sm_silu2(floatx2 h) {
+    const floatx2 a = h * floatx2{-1.4426950408889634f, -1.4426950408889634f};
+    floatx2 e;
+    e.x = __builtin_amdgcn_exp2f(a.x);
+    e.y = __builtin_amdgcn_exp2f(a.y);
+    const floatx2 d = e + floatx2{1.0f, 1.0f};
+    floatx2 rcp;
+    rcp.x = __builtin_amdgcn_rcpf(d.x);
+    rcp.y = __builtin_amdgcn_rcpf(d.y);
+    return h * rcp;
+}
 
 static constexpr unsigned SM_TPB = 256;
 static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
@@ -83,45 +98,47 @@ template <typename PT>
 __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t slices_per_scene, const PT* __restrict__ planes,
                                                            const float* __restrict__ P, const uint8_t* __restrict__ lin_bits,
                                                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                           const uint2* __restrict__ queue, const uint32_t* __restrict__ queue_count,
+                                                           const uint2* __restrict__ queue, uint32_t* __restrict__ queue_count,
                                                            float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
                                                            int32_t* __restrict__ sample_counts, int32_t* __restrict__ overflow_flag) {
     // LDS: [0,1 KiB) output-layer weights per accumulator slot; then per wave two pools of SM_POOL x 8 dwords.
-    __shared__ __attribute__((aligned(16))) float lds[256 + (SM_TPB / 64) * 2 * SM_POOL * 8];
+    // wout2: 64 entries x 8 floats; per (mt, pair p of adjacent accumulator registers, half): {ws_a, ws_b, wr_a, wr_b, wg_a, wg_b, wb_a, wb_b}
+    // sh  : per wave 64 lanes x 16 floats as [k/4][lane][k%4] (lane-contiguous 16-byte slots: conflict-free ds_read_b128)
+    __shared__ __attribute__((aligned(16))) float lds[512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + (SM_TPB / 64) * 1024];
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     // ---- output weights: slot (mt, reg, half) <-> hidden row mt*32 + (reg&3) + 8*(reg>>2) + 4*half (32x32 MFMA C/D layout) ----
     if (threadIdx.x < 64) {
-        const int mt = threadIdx.x >> 5, reg = (threadIdx.x >> 1) & 15, hf = threadIdx.x & 1;
-        const int row = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
-        const float* rec = P + row * 24;
-        float4 w = make_float4(rec[19], rec[20], rec[21], rec[22]);   // w_sigma, Wc[0..2][row]
-        reinterpret_cast<float4*>(lds)[threadIdx.x] = w;
+        const int mt = threadIdx.x >> 4, pr_ = (threadIdx.x >> 1) & 7, hf = threadIdx.x & 1;       // slot = (mt*8 + pair)*2 + half
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int reg = 2 * pr_ + e;
+            const int row = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+            const float* rec = P + row * 24;                         // rec[19] = w_sigma, rec[20..22] = Wc[0..2][row]
+            v[0 + e] = rec[19]; v[2 + e] = rec[20]; v[4 + e] = rec[21]; v[6 + e] = rec[22];
+        }
+        reinterpret_cast<float4*>(lds)[threadIdx.x * 2 + 0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(lds)[threadIdx.x * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
     }
     __syncthreads();
-    const float4* wout = reinterpret_cast<const float4*>(lds);      // index (mt*16 + reg)*2 + half
-    uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 256) + wave * 2 * SM_POOL * 8;
+    const float4* wout2 = reinterpret_cast<const float4*>(lds);     // index ((mt*8 + pair)*2 + half)*2 + {0: sigma|r, 1: g|b}
+    uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 512) + wave * 2 * SM_POOL * 8;
     uint32_t* pool_ready = pool_search + SM_POOL * 8;
+    float4* sh_lds = reinterpret_cast<float4*>(lds + 512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * 1024);   // [kq][lane]
 
-    // ---- workgroup -> (scene, slice) with the scene pinned to one XCD when S is a multiple of 8 ----
-    const uint32_t b = blockIdx.x;
-    const uint32_t wg_per_scene = (slices_per_scene + (SM_TPB / 64) - 1) / (SM_TPB / 64);
-    uint32_t scene, wg;
-    if ((c.S & 7u) == 0) { const uint32_t xcd = b & 7u, j = b >> 3; scene = xcd + 8u * (j / wg_per_scene); wg = j % wg_per_scene; }
-    else { scene = b / wg_per_scene; wg = b % wg_per_scene; }
-    if (scene >= c.S) return;
-    const uint32_t count = queue_count[scene];
-    uint32_t next = __builtin_amdgcn_readfirstlane((wg * (SM_TPB / 64) + wave) * SM_SLICE);
-    if (next >= count) return;
-    const uint32_t end = min(next + SM_SLICE, count);
-    const uint64_t ray0 = (uint64_t)scene * c.N;
-    planes += scene * c.plane_stride;
-    lin_bits += (uint64_t)scene * c.bitfield_stride;
-    queue += ray0;
-    if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
-
+    // ---- persistent grid: every wave pulls 512-ray slices of a scene's hit queue with one atomic ticket per slice.  Waves of
+    // XCD x (workgroups are dispatched round-robin over the 8 XCDs, b % 8) start on scene x so that the scene's 1.5 MiB of
+    // planes stay in that XCD's L2, and move on to the next scene when theirs has no slices left (work stealing: a wrong
+    // placement guess only costs L2 misses).  queue_count[0..S) = hits per scene, queue_count[S..2S) = slice tickets. ----
+    uint32_t* tickets = queue_count + c.S;
+    const uint32_t start_scene = (blockIdx.x & 7u) % c.S;
+    const PT* planes_base = planes;
+    const uint8_t* bits_base = lin_bits;
+    const uint2* queue_base = queue;
+    const float dt_gamma_default = c.m.dt_gamma;
     // ---- A operands: lane l holds W[mt*32 + (l&31)][2s + (l>>5)] for every k-step s ----
     float a1[2][10], a2[2][9];
 #pragma unroll
@@ -142,6 +159,18 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     const float b_sigma = P[MLP_OFF_TAIL + 0], bc0 = P[MLP_OFF_TAIL + 1], bc1 = P[MLP_OFF_TAIL + 2], bc2 = P[MLP_OFF_TAIL + 3];
     const float sat_k = ssd_fma(c.sat, 2.0f, 1.0f);
 
+  for (uint32_t sk = 0; sk < c.S; ++sk) {
+    const uint32_t scene = (start_scene + sk) % c.S;
+    const uint32_t count = queue_count[scene];
+    const uint32_t n_slices = (count + SM_SLICE - 1) / SM_SLICE;
+    const uint64_t ray0 = (uint64_t)scene * c.N;
+    planes = planes_base + scene * c.plane_stride;
+    lin_bits = bits_base + (uint64_t)scene * c.bitfield_stride;
+    queue = queue_base + ray0;
+    c.m.dt_gamma = c.dt_gammas ? c.dt_gammas[scene] : dt_gamma_default;
+    uint32_t next = 0, end = 0;
+    bool scene_done = n_slices == 0;
+
     // ---- lane state ----
     int ray = -1;
     RayGeom r = {};
@@ -149,9 +178,6 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     float t = 0.f, far_ = 0.f, ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
     uint32_t cnt = 0;
     float sx = 0.f, sy = 0.f, sz = 0.f, sdt = 0.f;
-    float sh[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sh[i] = 0.f;
     uint32_t sp_head = 0, sp_count = 0, rp_head = 0, rp_count = 0;    // wave-uniform pool cursors
 
     auto write_out = [&](uint32_t rid, float ws_, float dep_, float cr_, float cg_, float cb_, uint32_t cnt_) {
@@ -174,7 +200,10 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     auto begin_ray = [&]() {   // geometry is loaded and t points at an occupied probe
         const ProbeB p = sm_probe(c.m, lin_bits, r, t);
         sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
+        float sh[16];
         shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) sh_lds[kq * 64 + lane] = make_float4(sh[4 * kq], sh[4 * kq + 1], sh[4 * kq + 2], sh[4 * kq + 3]);
     };
 
     for (;;) {
@@ -195,6 +224,13 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
                 rp_head = (rp_head + take) % SM_POOL;
                 rp_count -= take;
             }
+        }
+        if (next >= end && !scene_done && __ballot(ray < 0) != 0) {      // current slice used up: take a ticket for the next one
+            uint32_t sl = 0;
+            if (lane == 0) sl = atomicAdd(tickets + scene, 1u);
+            sl = __builtin_amdgcn_readfirstlane(sl);
+            if (sl < n_slices) { next = sl * SM_SLICE; end = min(next + SM_SLICE, count); }
+            else scene_done = true;
         }
         {
             const uint64_t idle = __ballot(ray < 0);
@@ -250,7 +286,7 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
             continue;   // refill from the ready pool before shading
         }
         if (live == 0) {
-            if (next >= end && sp_count == 0 && rp_count == 0) break;
+            if (scene_done && sp_count == 0 && rp_count == 0) break;      // this scene is finished for this wave: go steal from the next one
             continue;
         }
 
@@ -285,16 +321,24 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
             acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][9], b_const, acc[mt][1], 0, 0, 0);
         }
         // density head on silu(h): partial dot products over this half's 32 hidden rows, for both tiles
-        float ps0 = 0.f, ps1 = 0.f;
+        // density head on silu(h): pairs of adjacent accumulator registers -> packed fp32 math, no register shuffling
+        floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float w = wout[(mt * 16 + i) * 2 + half].x;
-                ps0 = ssd_fma(w, ssd_silu(acc[mt][0][i]), ps0);
-                ps1 = ssd_fma(w, ssd_silu(acc[mt][1][i]), ps1);
+            for (int p2 = 0; p2 < 8; ++p2) {
+                const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
+                const floatx2 wS = {w.x, w.y};
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    ps_[nt] = __builtin_elementwise_fma(wS, sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]}), ps_[nt]);
             }
+        float ps0 = ps_[0].x + ps_[0].y, ps1 = ps_[1].x + ps_[1].y;
         // direction term accumulated in place: 8 SH k-steps + the (1,0) bias step
+        float4 shq[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) shq[kq] = sh_lds[kq * 64 + lane];
+        const float* sh = reinterpret_cast<const float*>(shq);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float b0 = sh[2 * s], b1 = sh[2 * s + 1];
@@ -310,16 +354,23 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
             acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][8], b_const, acc[mt][0], 0, 0, 0);
             acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][8], b_const, acc[mt][1], 0, 0, 0);
         }
-        float pr0 = 0.f, pg0 = 0.f, pb0 = 0.f, pr1 = 0.f, pg1 = 0.f, pb1 = 0.f;
+        floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float4 w = wout[(mt * 16 + i) * 2 + half];
-                const float c0 = ssd_silu(acc[mt][0][i]), c1 = ssd_silu(acc[mt][1][i]);
-                pr0 = ssd_fma(w.y, c0, pr0); pg0 = ssd_fma(w.z, c0, pg0); pb0 = ssd_fma(w.w, c0, pb0);
-                pr1 = ssd_fma(w.y, c1, pr1); pg1 = ssd_fma(w.z, c1, pg1); pb1 = ssd_fma(w.w, c1, pb1);
+            for (int p2 = 0; p2 < 8; ++p2) {
+                const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+                const floatx2 wR = {w0.z, w0.w}, wG = {w1.x, w1.y}, wB = {w1.z, w1.w};
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const floatx2 cc = sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]});
+                    pr_[nt] = __builtin_elementwise_fma(wR, cc, pr_[nt]);
+                    pg_[nt] = __builtin_elementwise_fma(wG, cc, pg_[nt]);
+                    pb_[nt] = __builtin_elementwise_fma(wB, cc, pb_[nt]);
+                }
             }
+        float pr0 = pr_[0].x + pr_[0].y, pr1 = pr_[1].x + pr_[1].y, pg0 = pg_[0].x + pg_[0].y, pg1 = pg_[1].x + pg_[1].y;
+        float pb0 = pb_[0].x + pb_[0].y, pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
         sm_swap(ps0, ps1); sm_swap(pr0, pr1); sm_swap(pg0, pg1); sm_swap(pb0, pb1);
         const float sigma = ssd_exp(ps0 + ps1 + b_sigma);
@@ -383,6 +434,7 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+  }   // scene loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,14 +466,20 @@ extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dt
     c.bitfield_stride = (grid_size * grid_size * grid_size) / 8;
     c.dt_gammas = dt_gammas;
     // workspace carve (must match render_queue.hip)
-    const size_t counters = ((size_t)S * 4 + 255) / 256 * 256;
+    const size_t counters = ((size_t)S * 8 + 255) / 256 * 256;
     const size_t bits = ((size_t)S * c.bitfield_stride + 255) / 256 * 256;
-    const uint32_t* q_count = (const uint32_t*)workspace;
+    uint32_t* q_count = (uint32_t*)workspace;
     const uint8_t* lin_bits = (const uint8_t*)workspace + counters;
     const uint2* queue = (const uint2*)((const uint8_t*)workspace + counters + bits);
-    const uint32_t slices = ssd_blocks(N, SM_SLICE);
-    const uint32_t wg_per_scene = ssd_blocks(slices, SM_TPB / 64);
-    dim3 g(S * wg_per_scene), b(SM_TPB);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const uint32_t slices = 0;   // (kept in the kernel signature; slices are ticketed dynamically)
+    dim3 g((unsigned)n_cu * 2u), b(SM_TPB);   // 2 workgroups x 4 waves per CU = the kernel's residency (<= 256 VGPRs, 50 KiB LDS)
     hipStream_t s = (hipStream_t)stream;
     if (planes_dtype == 0) hipLaunchKernelGGL((k_shade_mfma<float>), g, b, 0, s, c, slices, (const float*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag);
     else hipLaunchKernelGGL((k_shade_mfma<__half>), g, b, 0, s, c, slices, (const __half*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag);

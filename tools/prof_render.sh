@@ -34,6 +34,7 @@ export OUT
 pmc pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pmc pmc2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
 pmc pmc3 FETCH_SIZE
+pmc pmc6 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES
 pmc pmc4 WRITE_SIZE GRBM_GUI_ACTIVE
 pmc pmc5 TCC_HIT_sum TCC_MISS_sum
 head -30 $OUT/kt_kernel_stats.csv 2>/dev/null || ls $OUT
