@@ -47,6 +47,9 @@ static constexpr unsigned SM_TPB = 256;
 static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
 static constexpr unsigned SM_POOL = 128;           // entries per wave-local pool (two pools per wave)
 static constexpr unsigned SM_SEARCH_PROBES = 4;    // in-lane search budget after each sample
+#ifndef SM_REFILL_MIN
+#define SM_REFILL_MIN 1                            // refill only when this many lanes are idle (the divergent refill code then runs every few iterations instead of every iteration)
+#endif
 
 struct FastMarchB {
     float bound, dt_gamma, dt_min, dt_max, mip_bound, rb, half_H, two_rH, Hm1f;
@@ -104,7 +107,9 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     // LDS: [0,1 KiB) output-layer weights per accumulator slot; then per wave two pools of SM_POOL x 8 dwords.
     // wout2: 64 entries x 8 floats; per (mt, pair p of adjacent accumulator registers, half): {ws_a, ws_b, wr_a, wr_b, wg_a, wg_b, wb_a, wb_b}
     // sh  : per wave 64 lanes x 16 floats as [k/4][lane][k%4] (lane-contiguous 16-byte slots: conflict-free ds_read_b128)
-    __shared__ __attribute__((aligned(16))) float lds[512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + (SM_TPB / 64) * 1024];
+    // stage: per wave 64 PREPARED rays x 16 dwords {ray, t, far, dt | o | d | 1/d | sample xyz}: queue entries and ray geometry are fetched from
+    //        HBM 64 at a time by the whole wave (coalesced, full lane utilisation) instead of one lane at a time inside the divergent refill
+    __shared__ __attribute__((aligned(16))) float lds[512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + (SM_TPB / 64) * 1024 + (SM_TPB / 64) * 1024];
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -128,6 +133,7 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 512) + wave * 2 * SM_POOL * 8;
     uint32_t* pool_ready = pool_search + SM_POOL * 8;
     float4* sh_lds = reinterpret_cast<float4*>(lds + 512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * 1024);   // [kq][lane]
+    float4* stage = reinterpret_cast<float4*>(lds + 512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + (SM_TPB / 64) * 1024 + wave * 1024);   // [slot][4]
 
     // ---- persistent grid: every wave pulls 512-ray slices of a scene's hit queue with one atomic ticket per slice.  Waves of
     // XCD x (workgroups are dispatched round-robin over the 8 XCDs, b % 8) start on scene x so that the scene's 1.5 MiB of
@@ -179,6 +185,7 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     uint32_t cnt = 0;
     float sx = 0.f, sy = 0.f, sz = 0.f, sdt = 0.f;
     uint32_t sp_head = 0, sp_count = 0, rp_head = 0, rp_count = 0;    // wave-uniform pool cursors
+    uint32_t st_head = 0, st_count = 0;                                // staged (prepared) rays
 
     auto write_out = [&](uint32_t rid, float ws_, float dep_, float cr_, float cg_, float cb_, uint32_t cnt_) {
         const uint64_t gi = ray0 + rid;
@@ -208,8 +215,10 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
 
     for (;;) {
         // ================= refill idle lanes: parked-and-found rays first, then the global hit queue =================
-        {
-            const uint64_t idle = __ballot(ray < 0);
+        const uint64_t idle_now = __ballot(ray < 0);
+        const bool do_refill = (uint32_t)__popcll(idle_now) >= SM_REFILL_MIN || idle_now == ~0ull;
+        if (do_refill) {
+            const uint64_t idle = idle_now;
             if (idle != 0 && rp_count != 0) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t take = min((uint32_t)__popcll(idle), rp_count);
@@ -225,27 +234,57 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
                 rp_count -= take;
             }
         }
-        if (next >= end && !scene_done && __ballot(ray < 0) != 0) {      // current slice used up: take a ticket for the next one
-            uint32_t sl = 0;
-            if (lane == 0) sl = atomicAdd(tickets + scene, 1u);
-            sl = __builtin_amdgcn_readfirstlane(sl);
-            if (sl < n_slices) { next = sl * SM_SLICE; end = min(next + SM_SLICE, count); }
-            else scene_done = true;
-        }
-        {
+        // ---- from the staged rays (LDS); when the stage runs dry the whole wave prepares the next 64 queue entries ----
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
             const uint64_t idle = __ballot(ray < 0);
-            if (idle != 0 && next < end) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                const uint32_t cand = next + rank;
-                if (ray < 0 && cand < end) {
-                    const uint2 e = queue[cand];
-                    ray = (int)e.x; t = __uint_as_float(e.y);
-                    ws = dep = cr = cg = cb = 0.f; cnt = 0;
-                    load_geometry(e.x);
-                    begin_ray();
+            if (idle == 0) break;
+            if (st_count == 0) {
+                if (next >= end && !scene_done) {            // current slice used up: take a ticket for the next one
+                    uint32_t sl = 0;
+                    if (lane == 0) sl = atomicAdd(tickets + scene, 1u);
+                    sl = __builtin_amdgcn_readfirstlane(sl);
+                    if (sl < n_slices) { next = sl * SM_SLICE; end = min(next + SM_SLICE, count); }
+                    else scene_done = true;
                 }
-                next = __builtin_amdgcn_readfirstlane(min(next + (uint32_t)__popcll(idle), end));
+                if (next >= end) break;
+                const uint32_t n = min(end - next, 64u);
+                if ((uint32_t)lane < n) {                    // stage fill: one queue entry per lane, all lanes busy
+                    const uint2 e = queue[next + lane];
+                    const uint64_t gi = ray0 + e.x;
+                    const RayGeom q = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
+                    float qn, qf;
+                    ssd_near_far(c.aabb, q, c.min_near, qn, qf);
+                    const float qt = __uint_as_float(e.y);
+                    const ProbeB p = sm_probe(c.m, lin_bits, q, qt);      // the queued t is an occupied probe by construction
+                    float4* dst = stage + lane * 4;
+                    dst[0] = make_float4(__uint_as_float(e.x), qt, qf, p.dt);
+                    dst[1] = make_float4(q.ox, q.oy, q.oz, q.dx);
+                    dst[2] = make_float4(q.dy, q.dz, q.rdx, q.rdy);
+                    dst[3] = make_float4(q.rdz, p.x, p.y, p.z);
+                }
+                next = __builtin_amdgcn_readfirstlane(next + n);
+                st_head = 0; st_count = n;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t take = min((uint32_t)__popcll(idle), st_count);
+            if (ray < 0 && rank < take) {
+                const float4* src = stage + (st_head + rank) * 4;
+                const float4 g0 = src[0], g1 = src[1], g2 = src[2], g3 = src[3];
+                ray = (int)__float_as_uint(g0.x); t = g0.y; far_ = g0.z; sdt = g0.w;
+                r.ox = g1.x; r.oy = g1.y; r.oz = g1.z; r.dx = g1.w; r.dy = g2.x; r.dz = g2.y; r.rdx = g2.z; r.rdy = g2.w; r.rdz = g3.x;
+                sx = g3.y; sy = g3.z; sz = g3.w;
+                sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f); sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f); sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
+                ws = dep = cr = cg = cb = 0.f; cnt = 0;
+                float sh[16];
+                shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) sh_lds[kq * 64 + lane] = make_float4(sh[4 * kq], sh[4 * kq + 1], sh[4 * kq + 2], sh[4 * kq + 3]);
+            }
+            st_head += take; st_count -= take;
         }
         const uint64_t live = __ballot(ray >= 0);
 
@@ -286,7 +325,7 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
             continue;   // refill from the ready pool before shading
         }
         if (live == 0) {
-            if (scene_done && sp_count == 0 && rp_count == 0) break;      // this scene is finished for this wave: go steal from the next one
+            if (scene_done && next >= end && st_count == 0 && sp_count == 0 && rp_count == 0) break;      // this scene is finished for this wave: go steal from the next one
             continue;
         }
 
@@ -297,6 +336,14 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
         }
+        // Software-pipelined by sample tile so that (almost) every MFMA has independent VALU work to hide under, inside this
+        // wave: the f32 MFMA occupies the matrix pipe for 64 cycles, and an in-order wave that issues MFMAs back to back just
+        // waits (r01 counters: SQ_WAIT_INST_ANY = 2.4x the MFMA time, both waves of a SIMD colliding in their MFMA bursts).
+        //   A: layer-1 tile 0            (20 MFMA)
+        //   B: layer-1 tile 1            (20 MFMA)  ||  density head of tile 0   (16 SiLU pairs)
+        //   C: direction term tile 0     (18 MFMA)  ||  density head of tile 1
+        //   D: direction term tile 1     (18 MFMA)  ||  colour head of tile 0
+        //   E: colour head of tile 1
         floatx16 acc[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -304,71 +351,73 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
-        // layer 1: 9 feature k-steps + the (1,0) bias step
+        float fb0[10], fb1[10];                 // B operands of layer 1 for tile 0 / tile 1
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            float b0 = f[2 * s], b1 = f[2 * s + 1];
-            sm_swap(b0, b1);          // b0 -> tile 0 operand (samples 0..31), b1 -> tile 1 operand (samples 32..63)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][s], b0, acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][s], b1, acc[mt][1], 0, 0, 0);
-            }
+            fb0[s] = f[2 * s]; fb1[s] = f[2 * s + 1];
+            sm_swap(fb0[s], fb1[s]);
         }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][9], b_const, acc[mt][0], 0, 0, 0);
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][9], b_const, acc[mt][1], 0, 0, 0);
-        }
-        // density head on silu(h): partial dot products over this half's 32 hidden rows, for both tiles
-        // density head on silu(h): pairs of adjacent accumulator registers -> packed fp32 math, no register shuffling
+        fb0[9] = fb1[9] = b_const;
         floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+        floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+        auto density_pair = [&](int nt, int q) {     // q in [0,16): accumulator pair (mt = q / 8, registers 2*(q%8), 2*(q%8)+1)
+            const int mt = q >> 3, p2 = q & 7;
+            const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
+            const floatx2 wS = {w.x, w.y};
+            ps_[nt] = __builtin_elementwise_fma(wS, sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]}), ps_[nt]);
+        };
+        auto colour_pair = [&](int nt, int q) {
+            const int mt = q >> 3, p2 = q & 7;
+            const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+            const floatx2 wR = {w0.z, w0.w}, wG = {w1.x, w1.y}, wB = {w1.z, w1.w};
+            const floatx2 cc = sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]});
+            pr_[nt] = __builtin_elementwise_fma(wR, cc, pr_[nt]);
+            pg_[nt] = __builtin_elementwise_fma(wG, cc, pg_[nt]);
+            pb_[nt] = __builtin_elementwise_fma(wB, cc, pb_[nt]);
+        };
+        // ---- A
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int p2 = 0; p2 < 8; ++p2) {
-                const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
-                const floatx2 wS = {w.x, w.y};
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    ps_[nt] = __builtin_elementwise_fma(wS, sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]}), ps_[nt]);
-            }
-        float ps0 = ps_[0].x + ps_[0].y, ps1 = ps_[1].x + ps_[1].y;
-        // direction term accumulated in place: 8 SH k-steps + the (1,0) bias step
+        for (int s = 0; s < 10; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][s], fb0[s], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][s], fb0[s], acc[1][0], 0, 0, 0);
+        }
+        // SH operands (per-ray constants parked in LDS)
         float4 shq[4];
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) shq[kq] = sh_lds[kq * 64 + lane];
         const float* sh = reinterpret_cast<const float*>(shq);
+        float sb0[9], sb1[9];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            float b0 = sh[2 * s], b1 = sh[2 * s + 1];
-            sm_swap(b0, b1);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][s], b0, acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][s], b1, acc[mt][1], 0, 0, 0);
-            }
+            sb0[s] = sh[2 * s]; sb1[s] = sh[2 * s + 1];
+            sm_swap(sb0[s], sb1[s]);
         }
+        sb0[8] = sb1[8] = b_const;
+        // ---- B
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][8], b_const, acc[mt][0], 0, 0, 0);
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][8], b_const, acc[mt][1], 0, 0, 0);
+        for (int s = 0; s < 10; ++s) {
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][s], fb1[s], acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][s], fb1[s], acc[1][1], 0, 0, 0);
+            if (s < 8) { density_pair(0, 2 * s); density_pair(0, 2 * s + 1); }
         }
-        floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+        // ---- C
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int s = 0; s < 9; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][s], sb0[s], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][s], sb0[s], acc[1][0], 0, 0, 0);
+            if (s < 8) { density_pair(1, 2 * s); density_pair(1, 2 * s + 1); }
+        }
+        // ---- D
 #pragma unroll
-            for (int p2 = 0; p2 < 8; ++p2) {
-                const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
-                const floatx2 wR = {w0.z, w0.w}, wG = {w1.x, w1.y}, wB = {w1.z, w1.w};
+        for (int s = 0; s < 9; ++s) {
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][s], sb1[s], acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][s], sb1[s], acc[1][1], 0, 0, 0);
+            if (s < 8) { colour_pair(0, 2 * s); colour_pair(0, 2 * s + 1); }
+        }
+        // ---- E
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const floatx2 cc = sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]});
-                    pr_[nt] = __builtin_elementwise_fma(wR, cc, pr_[nt]);
-                    pg_[nt] = __builtin_elementwise_fma(wG, cc, pg_[nt]);
-                    pb_[nt] = __builtin_elementwise_fma(wB, cc, pb_[nt]);
-                }
-            }
+        for (int q = 0; q < 16; ++q) colour_pair(1, q);
+        float ps0 = ps_[0].x + ps_[0].y, ps1 = ps_[1].x + ps_[1].y;
         float pr0 = pr_[0].x + pr_[0].y, pr1 = pr_[1].x + pr_[1].y, pg0 = pg_[0].x + pg_[0].y, pg1 = pg_[1].x + pg_[1].y;
         float pb0 = pb_[0].x + pb_[0].y, pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
