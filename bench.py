@@ -155,6 +155,14 @@ def main():
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
     first_hit_bytes = n_rays * 24 + (n_rays - n_hit) * 20 + n_hit * 8
 
+    traffic = None          # HBM bytes per launch from the PMC counters: measured offline (separate rocprofv3 passes), valid for the default workload only
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        w = tj["workload"]
+        if (w["scenes"], w["views"], w["size"], w["variant"], w["plane_dtype"]) == (ns, nv, hw, args.variant, args.plane_dtype) and tj["kernel"] == "k_shade_mfma":
+            traffic = tj["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     result = {
         "metric": "rays/s (rendered-views/s = rays/s / 16384), SRN Cars 128x128 novel-view render of cached triplanes",
         "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -166,8 +174,8 @@ def main():
                    "collective": "all_gather(uint8 views)" if world > 1 else "none"},
         "views_per_s": rays_per_s / (hw * hw), "samples_per_s": world * n_samples / (elapsed / args.steps) if world == 1 else n_samples_all / (elapsed / args.steps),
         "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": overflow, "ms_raygen_untimed": ms_raygen,
-        "roofline": {"bound": "hbm", "kernel": "k_shade_queue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+        "roofline": {"bound": "hbm", "kernel": "k_shade_mfma", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                      "launch_ms": kern_ms, "launches_per_step": 1,
                      "note": "algorithmic = 288 B/sample + 52 B per hitting ray; planes (1.5 MiB/scene) are L2-resident, so real HBM "
                              "traffic is far below this (PMC numbers in DESIGN.md / profiles/)",
