@@ -142,7 +142,7 @@ def test_guidance_loss_and_gradient_match_oracle(model):
     finally:
         dec.injected_noises = None
         dec.train(False)
-    assert abs(float(loss) - float(loss0)) <= 2e-5 * max(1.0, abs(float(loss0)))
+    assert abs(float(loss.detach()) - float(loss0.detach())) <= 2e-5 * max(1.0, abs(float(loss0.detach())))
     g1 = g1[0].cpu()
     denom = float(g0.abs().max())
     assert denom > 0
