@@ -203,6 +203,44 @@ int ssdnerf_packbits_dev_thresh(const void* grid, int grid_dtype, uint32_t N, co
 int ssdnerf_ddim_step_v(const float* x_t, const float* v, uint64_t n, float sqrt_ab, float sqrt_1mab, float sqrt_ab_prev,
                         float dir_coef, float clip_lo, float clip_hi, float* x0_out, float* xprev_out, void* stream);
 
+/* ---- Part 3: denoising-UNet glue (lib/models/architecture/ddpm/modules.py:12-129, denoising.py:178-187) ------------------
+ * Activations are channel-last: x, y are [B][HW][C] of dtype 0 = fp32, 1 = fp16, 2 = bf16.
+ *
+ * y = act( GroupNorm_G(x + pre_bias) * gamma + beta  [ * (1 + scale[b]) + shift[b] ] ),  act = 0 none / 1 SiLU.
+ * pre_bias (nullable, fp32 [C]) is the bias of the convolution that produced x, folded in here so the producer needs no
+ * pass of its own.  scale_shift (nullable) is the NormWithEmbedding projection of the time embedding, fp32, row b at
+ * scale_shift + b * scale_shift_stride holding [scale[C] | shift[C]] (use_scale_shift_norm=True, modules.py:97-104);
+ * gamma/beta fp32 [C]; statistics in fp32/fp64 for every dtype.
+ * workspace: ssdnerf_group_norm_workspace(B, G) bytes, 8-byte aligned, fp64 [B][G][sum, sum of squares].
+ * workspace_state: 0 = the call zeroes it and computes the statistics; 1 = already zero (a caller running many norms zeroes
+ * one arena once); 2 = already holds the statistics of x (written by ssdnerf_conv2d_nhwc_bf16's gn_sums),
+ * only the normalisation pass runs (pre_bias must be NULL).  y may alias x. */
+size_t ssdnerf_group_norm_workspace(uint32_t B, uint32_t G);
+int ssdnerf_group_norm_nhwc(const void* x, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* pre_bias,
+                            const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride,
+                            float eps, int act, void* workspace, int workspace_state, void* y, void* stream);
+
+/* y = x + bias[c] + residual over [rows][C] channel-last data (bias fp32 [C] nullable, residual nullable, y may alias x):
+ * the epilogue of a bias-less convolution -- conv_2 of a residual block plus its skip connection (modules.py:51-110). */
+int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint64_t rows, uint32_t C, const float* bias, const void* residual,
+                               void* y, void* stream);
+
+/* The UNet's convolutions (modules.py:51-129; denoising.py:106-187) as an implicit GEMM on the bf16 matrix cores:
+ *   y[b][yo][xo][co] = sum_{kh,kw,ci} X[b][yo*stride+kh-pad][xo*stride+kw-pad][ci] * w[co][kh][kw][ci]  (+ bias[co]) (+ residual[b][yo][xo][co])
+ * x bf16 [B][H][W][Cin] channel-last; w bf16 [Cout][ksize][ksize][Cin] (= torch channels_last weight memory); pad = ksize/2;
+ * X = x, or with upsample != 0 the nearest-neighbour 2x upsampling of x, never materialised (DenoisingUpsampleMod);
+ * stride 2 = DenoisingDownsampleMod.  bias fp32 [Cout] (nullable), residual / y bf16 [B][Ho][Wo][Cout] (residual nullable,
+ * may alias y).  fp32 accumulation; bias and residual are added in fp32 before the single rounding to bf16.
+ * gn_sums (nullable): fp64 [B][gn_groups][2], pre-zeroed by the caller; receives sum and sum of squares of the rounded output
+ * per (sample, channel group) -- the statistics pass of the GroupNorm that follows (ssdnerf_group_norm_nhwc, workspace_state 2).
+ * Needs (Cout / gn_groups) % 4 == 0 and Ho*Wo a multiple of the M tile (128, or 64 for the smaller tiles).
+ * tile_hint: 0 = choose by problem size, 1 = 128x128, 2 = 64x128, 3 = 64x64 block tile.
+ * ssdnerf_conv2d_nhwc_bf16_supported() tells whether a layer fits (Cin % 64 == 0, Cout % 64 == 0, ksize 1|3, stride 1|2). */
+int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample);
+int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual, void* y, uint32_t B,
+                             uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride,
+                             uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

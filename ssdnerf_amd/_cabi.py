@@ -25,6 +25,8 @@ EXPORTS = [
     "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode",
     "ssdnerf_render_rays_fused", "ssdnerf_render_rays_fused_batch", "ssdnerf_render_queue_workspace", "ssdnerf_render_first_hit",
     "ssdnerf_render_shade_queue", "ssdnerf_render_shade_queue_mfma", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh", "ssdnerf_ddim_step_v",
+    "ssdnerf_group_norm_workspace", "ssdnerf_group_norm_nhwc", "ssdnerf_bias_residual_nhwc",
+    "ssdnerf_conv2d_nhwc_bf16_supported", "ssdnerf_conv2d_nhwc_bf16",
 ]
 
 
@@ -46,6 +48,8 @@ def lib() -> ctypes.CDLL:
         l.ssdnerf_march_rays_train_workspace.argtypes = [ctypes.c_uint32]
         l.ssdnerf_render_queue_workspace.restype = ctypes.c_size_t
         l.ssdnerf_render_queue_workspace.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        l.ssdnerf_group_norm_workspace.restype = ctypes.c_size_t
+        l.ssdnerf_group_norm_workspace.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         if l.ssdnerf_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libssdnerf_hip.so ABI {l.ssdnerf_abi_version()} != expected {ABI_VERSION}: rebuild")
         _lib = l

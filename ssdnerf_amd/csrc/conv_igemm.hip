@@ -1,0 +1,288 @@
+// ssdnerf_amd/csrc/conv_igemm.hip -- the denoising UNet's convolutions as an implicit GEMM on the bf16 matrix cores.
+//
+// Reference: every 3x3 / 1x1 / strided / post-upsample convolution of DenoisingUnetMod's residual, down- and up-sampling
+// blocks (lib/models/architecture/ddpm/modules.py:51-129; denoising.py:106-187 lays them out), 211.8 of the UNet's
+// 218 GFLOP per scene per DDIM step.  The reference runs them through cuDNN on NCHW tensors.
+//
+// Here, for channel-last bf16 activations x[B][H][W][Cin] and weights w[Cout][kh][kw][Cin] (torch's channels_last weight
+// memory, consumed in place):
+//     y[m][co] = sum_{tap, ci} x[pixel(m, tap)][ci] * w[co][tap][ci]   (+ bias[co]) (+ residual[m][co]),   m = (b, yo, xo)
+// is a GEMM with M = B*Ho*Wo, N = Cout, K = taps*Cin whose A rows are *gathered*: K-tile (tap, ci0) of output pixel m is
+// the 128 contiguous bytes x[pixel(m, tap)][ci0 .. ci0+64), or zeros where the tap falls into the padding.
+//
+//   * block = 4 waves (2 x 2), block tile (64*TM) x (64*TN), K-tile 64, `v_mfma_f32_32x32x16_bf16`, fp32 accumulators;
+//   * both operands go HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no ds_write pass), double buffered,
+//     one barrier per K-tile; padding taps read a 16-byte zero page instead of being predicated;
+//   * the LDS image of a tile row is its eight 16-byte chunks XOR-permuted by ((row >> 1) & 7) -- applied on the SOURCE
+//     address of the DMA (its LDS side is lane-linear) and again on the ds_read_b128 address -- which makes every one of
+//     ds_read_b128's 16-lane groups hit 16 distinct 16-byte bank slots (MI355X_MICROARCH.md, LDS table);
+//   * epilogue through LDS: accumulators -> fp32 tile -> rows of 8 channels per lane, + bias + residual in fp32, one
+//     rounding to bf16, 16-byte stores (a residual block's `conv_2 + bias + skip` costs no extra pass); optionally the
+//     per-(sample, group) sum / sum-of-squares of the *output* are accumulated for the GroupNorm that follows
+//     (fp64 atomics into the arena `ssdnerf_group_norm_nhwc` reads), which removes that norm's statistics pass;
+//   * stride 2 (DenoisingDownsampleMod) and "nearest-2x-upsample then 3x3" (DenoisingUpsampleMod, the upsampled tensor is
+//     never materialised) are index maps of the same gather;
+//   * consecutive M-tiles go to the same XCD so that the halo rows neighbouring tiles share are L2 hits.
+//
+// Bound: MFMA (dense bf16 peak ~2.5 PFLOP/s).  Arithmetic: bf16 products, fp32 accumulation in MFMA order.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __attribute__((aligned(16))) const uint32_t g_conv_zero_page[4] = {0, 0, 0, 0};
+
+struct ConvArgs {
+    const unsigned char* x;      // bf16 [B][H][W][Cin]
+    const unsigned char* w;      // bf16 [Cout][taps][Cin]
+    const float* bias;           // fp32 [Cout] or null
+    const unsigned char* res;    // bf16 [M][Cout] or null
+    unsigned char* y;            // bf16 [M][Cout]
+    double* gn_sums;             // fp64 [B][G][2] or null
+    uint32_t B, H, W, Cin, Cout; // input geometry
+    uint32_t Ho, Wo, M;          // output geometry, M = B*Ho*Wo
+    uint32_t ksize, stride, pad, upsample;
+    uint32_t G;                  // GroupNorm groups of the output (for gn_sums)
+    uint32_t m_tiles, n_tiles;
+};
+
+constexpr int CV_BK = 64;                  // bf16 elements per K-tile = 128 bytes per tile row
+constexpr int CV_ROWB = CV_BK * 2;
+
+SSD_DEV void cv_glds16(const void* gptr, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+SSD_DEV uint32_t cv_bf16_rne(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void k_conv_igemm_bf16(const ConvArgs a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int A_INST = BM / 32, B_INST = BN / 32;                        // global_load_lds instructions per wave per K-tile (8 rows each)
+    constexpr int STAGE = (BM + BN) * CV_ROWB;
+    constexpr int EPI = BM * BN * 4;
+    constexpr int LDS_BYTES = ((2 * STAGE > EPI) ? 2 * STAGE : EPI) + 512;   // + block partials of the fused GroupNorm statistics (ONE LDS object)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous range of tiles (M-major) ----------------
+    const uint32_t n_blocks = a.m_tiles * a.n_tiles;
+    uint32_t tile;
+    {
+        const uint32_t xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n_blocks >> 3, r = n_blocks & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const uint32_t m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
+
+    // ---- loader geometry: instruction i of this wave covers tile rows (wave*INST + i)*8 + (lane >> 3) ------------------------------
+    const uint32_t taps = a.ksize * a.ksize;
+    const uint32_t Hv = a.upsample ? a.H * 2 : a.H, Wv = a.upsample ? a.W * 2 : a.W;   // the (virtual) image the taps move over
+    int32_t a_y0[A_INST], a_x0[A_INST];
+    uint32_t a_img[A_INST], a_chunk[A_INST];
+    bool a_ok[A_INST];
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const uint32_t r = (wave * A_INST + i) * 8 + (lane >> 3);
+        const uint32_t m = m0 + r;
+        a_ok[i] = m < a.M;
+        const uint32_t mm = a_ok[i] ? m : 0;
+        const uint32_t b = mm / (a.Ho * a.Wo), rem = mm % (a.Ho * a.Wo);
+        a_y0[i] = (int32_t)((rem / a.Wo) * a.stride) - (int32_t)a.pad;
+        a_x0[i] = (int32_t)((rem % a.Wo) * a.stride) - (int32_t)a.pad;
+        a_img[i] = b * a.H * a.W;
+        a_chunk[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;                     // source-side swizzle
+    }
+    uint32_t b_off[B_INST];
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+        const uint32_t r = (wave * B_INST + i) * 8 + (lane >> 3);
+        b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+    }
+
+    uint64_t a_src[A_INST];                                                  // per-tap source of each A row (or the zero page)
+    bool a_zero[A_INST];
+    auto set_tap = [&](uint32_t tap) {
+        const int32_t kh = (int32_t)(tap / a.ksize), kw = (int32_t)(tap % a.ksize);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) {
+            const int32_t yv = a_y0[i] + kh, xv = a_x0[i] + kw;
+            const bool ok = a_ok[i] && yv >= 0 && xv >= 0 && yv < (int32_t)Hv && xv < (int32_t)Wv;
+            const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
+            const uint64_t off = ((uint64_t)(a_img[i] + yi * a.W + xi) * a.Cin) * 2 + a_chunk[i];
+            a_zero[i] = !ok;
+            a_src[i] = ok ? (uint64_t)a.x + off : (uint64_t)g_conv_zero_page;
+        }
+    };
+
+    auto issue = [&](uint32_t tap, uint32_t ci0, uint32_t buf) {
+        unsigned char* sa = lds + buf * STAGE;
+        unsigned char* sb = sa + BM * CV_ROWB;
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i)
+            cv_glds16((const void*)(a_src[i] + (a_zero[i] ? 0 : (uint64_t)ci0 * 2)), sa + (wave * A_INST + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < B_INST; ++i)
+            cv_glds16(a.w + b_off[i] + (uint64_t)(tap * a.Cin + ci0) * 2, sb + (wave * B_INST + i) * 1024);
+    };
+
+    // ---- reader geometry ---------------------------------------------------------------------------------------------------
+    const uint32_t rd_row = lane & 31;
+    const uint32_t rd_c0 = ((lane >> 5) ^ ((lane >> 1) & 7)) * 16;           // chunk of k-step 0; k-step s is ^ (s * 32)
+    const uint32_t a_rd = (wm * 32 * TM + rd_row) * CV_ROWB + rd_c0;
+    const uint32_t b_rd = BM * CV_ROWB + (wn * 32 * TN + rd_row) * CV_ROWB + rd_c0;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const uint32_t kc = a.Cin / CV_BK, KT = taps * kc;
+    uint32_t tap = 0, ci = 0;
+    set_tap(0);
+    issue(0, 0, 0);
+    __syncthreads();
+    for (uint32_t kt = 0; kt < KT; ++kt) {
+        const uint32_t buf = kt & 1;
+        if (kt + 1 < KT) {
+            if (++ci == kc) { ci = 0; ++tap; set_tap(tap); }
+            issue(tap, ci * CV_BK, buf ^ 1);
+        }
+        const unsigned char* st = lds + buf * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(st + ((a_rd + i * 32 * CV_ROWB) ^ (s * 32)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(st + ((b_rd + j * 32 * CV_ROWB) ^ (s * 32)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                                     // the next tile has landed and this one is free to be overwritten
+    }
+
+    // ---- epilogue: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> bf16 rows ----------------------------------------------
+    float* tile_f = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t row = wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const uint32_t col = wn * 32 * TN + j * 32 + (lane & 31);
+                tile_f[row * BN + col] = acc[i][j][e];
+            }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                                              // 8-channel chunks per row; 256 % CPR == 0, so a thread keeps its chunk column
+    float* red = reinterpret_cast<float*>(lds + EPI);                        // [CPR][2 halves][sum, sumsq] block partials for the GroupNorm statistics
+    if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
+    const uint32_t cc = tid % CPR, co = n0 + cc * 8;
+    float bias_v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
+    if (a.gn_sums) __syncthreads();
+#pragma unroll 2
+    for (uint32_t row = tid / CPR; row < (uint32_t)BM; row += 256 / CPR) {
+        const uint32_t m = m0 + row;
+        if (m >= a.M) break;
+        const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
+        float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += bias_v[k];
+        const size_t o = ((size_t)m * a.Cout + co) * 2;
+        if (a.res) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(a.res + o);
+            const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { f[2 * k] += __uint_as_float(rw[k] << 16); f[2 * k + 1] += __uint_as_float(rw[k] & 0xffff0000u); }
+        }
+        uint32_t pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
+        *reinterpret_cast<uint4*>(a.y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        if (a.gn_sums) {                                                     // statistics of what the next norm will read (the rounded values)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(pk[k] << 16), hi = __uint_as_float(pk[k] & 0xffff0000u);
+                gs[k >> 1] += lo + hi;
+                gq[k >> 1] = __builtin_fmaf(lo, lo, gq[k >> 1]);
+                gq[k >> 1] = __builtin_fmaf(hi, hi, gq[k >> 1]);
+            }
+        }
+    }
+    if (a.gn_sums) {                                                         // host guarantees: the tile lies in ONE sample, groups are multiples of 4 channels
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
+        __syncthreads();
+        if (tid < CPR * 2 && m0 < a.M) {
+            const uint32_t cpg = a.Cout / a.G, b = m0 / (a.Ho * a.Wo), g = (n0 + tid * 4) / cpg;
+            double* dst = a.gn_sums + ((size_t)b * a.G + g) * 2;
+            atomicAdd(dst, (double)red[tid * 2]);
+            atomicAdd(dst + 1, (double)red[tid * 2 + 1]);
+        }
+    }
+}
+
+template <int TM, int TN>
+int cv_launch(ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    a.m_tiles = (a.M + BM - 1) / BM;
+    a.n_tiles = a.Cout / BN;
+    hipLaunchKernelGGL((k_conv_igemm_bf16<TM, TN>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample) {
+    return (Cin % 64 == 0) && (Cout % 64 == 0) && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && !(upsample && stride != 1);
+}
+
+extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual, void* y, uint32_t B, uint32_t H, uint32_t W,
+                                        uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample, void* gn_sums, uint32_t gn_groups,
+                                        int tile_hint, void* stream) {
+    if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x && w && y, "conv2d_nhwc_bf16: null pointer");
+    SSD_REQUIRE(ssdnerf_conv2d_nhwc_bf16_supported(Cin, Cout, ksize, stride, upsample),
+                "conv2d_nhwc_bf16: needs Cin %% 64 == 0, Cout %% 64 == 0, ksize 1|3, stride 1|2 (no stride with upsample)");
+    SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0),
+                "conv2d_nhwc_bf16: fused GroupNorm statistics need groups of a multiple of 4 channels");
+    ConvArgs a;
+    a.x = (const unsigned char*)x; a.w = (const unsigned char*)w; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
+    a.gn_sums = (double*)gn_sums; a.G = gn_groups ? gn_groups : 1;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.ksize = ksize; a.stride = stride; a.pad = ksize / 2; a.upsample = upsample;
+    const uint32_t Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    a.Ho = (Hv + 2 * a.pad - ksize) / stride + 1;
+    a.Wo = (Wv + 2 * a.pad - ksize) / stride + 1;
+    SSD_REQUIRE((uint64_t)B * a.Ho * a.Wo < (1ull << 31) && (uint64_t)B * H * W * Cin * 2 < (1ull << 40), "conv2d_nhwc_bf16: tensor too large");
+    a.M = B * a.Ho * a.Wo;
+    // tile choice: the largest tile that still gives every CU (256) a block or two; tile_hint 1/2/3 forces 128x128 / 64x128 / 64x64
+    int choice = tile_hint;
+    if (choice < 1 || choice > 3) {
+        const uint64_t t128 = (uint64_t)((a.M + 127) / 128) * (Cout / 128);
+        const uint64_t t64 = (uint64_t)((a.M + 63) / 64) * (Cout / 128);
+        choice = (Cout % 128 == 0 && t128 >= 384) ? 1 : (Cout % 128 == 0 && t64 >= 256) ? 2 : 3;
+    }
+    if (choice != 3) SSD_REQUIRE(Cout % 128 == 0, "conv2d_nhwc_bf16: 128-wide tiles need Cout %% 128 == 0");
+    SSD_REQUIRE(!gn_sums || (a.Ho * a.Wo) % (choice == 1 ? 128 : 64) == 0, "conv2d_nhwc_bf16: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
+    hipStream_t st = (hipStream_t)stream;
+    if (choice == 1) cv_launch<2, 2>(a, st); else if (choice == 2) cv_launch<1, 2>(a, st); else cv_launch<1, 1>(a, st);
+    SSD_CHECK_LAUNCH("conv2d_nhwc_bf16");
+    return SSDNERF_OK;
+}

@@ -1,0 +1,239 @@
+// ssdnerf_amd/csrc/groupnorm.hip -- GroupNorm (+ optional per-sample scale/shift from the time embedding, + optional SiLU)
+// over channel-last activations, the memory-bound glue of the denoising UNet's residual and attention blocks.
+//
+// Reference: every DenoisingResBlockMod is  GN -> SiLU -> conv3x3 -> GN*(1+scale)+shift -> SiLU -> conv3x3  (+ shortcut)
+// (lib/models/architecture/ddpm/modules.py:51-110 builds the block, mmgen 0.7.2 supplies the forward),
+// every MultiHeadAttentionMod starts with a plain GN (modules.py:12-48) and the output head is GN -> SiLU -> conv
+// (lib/models/architecture/ddpm/denoising.py:178-187).  In eager PyTorch each of these is 4-7 kernels (moments, fused-params,
+// normalise, dtype casts, mul/add for scale-shift, SiLU) plus MIOpen's NCHW<->NHWC transposes around the neighbouring
+// convolution; at bf16 they cost more time than the convolutions themselves (tools/bench_unet.py).
+//
+// Here: activations stay NHWC ([B][H*W][C], the layout the MFMA convolution kernels consume), and the whole chain is
+//   k_gn_stats : one pass, per-(sample, group) sum and sum of squares (fp32 in-block, fp64 atomics across blocks)
+//   k_gn_apply : one pass, y = act(x * A[b][c] + B[b][c]) with A, B folded per block from (mean, rstd, gamma, beta, scale, shift)
+// = 2 reads + 1 write of the activation, 16-byte vector accesses, HBM-bound.  Statistics and the affine fold are fp32/fp64
+// whatever the storage type, so the bf16/fp16 paths are *more* accurate than the eager chain they replace.
+#include "common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace {
+
+enum { GN_F32 = 0, GN_F16 = 1, GN_BF16 = 2 };
+
+template <int DT> struct GnVec;                       // one 16-byte access
+template <> struct GnVec<GN_F32> {
+    static constexpr int V = 4;
+    __device__ static void load(const void* p, size_t idx, float* f) {
+        const float4 v = reinterpret_cast<const float4*>(p)[idx];
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
+    __device__ static void store(void* p, size_t idx, const float* f) { reinterpret_cast<float4*>(p)[idx] = make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct GnVec<GN_BF16> {
+    static constexpr int V = 8;
+    __device__ static void load(const void* p, size_t idx, float* f) {
+        const uint4 v = reinterpret_cast<const uint4*>(p)[idx];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static uint32_t rne(float x) {          // fp32 -> bf16 bits, round to nearest even (finite inputs)
+        const uint32_t u = __float_as_uint(x);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    __device__ static void store(void* p, size_t idx, const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = rne(f[2 * i]) | (rne(f[2 * i + 1]) << 16);
+        reinterpret_cast<uint4*>(p)[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct GnVec<GN_F16> {
+    static constexpr int V = 8;
+    __device__ static void load(const void* p, size_t idx, float* f) {
+        union { uint4 u; _Float16 h[8]; } v;
+        v.u = reinterpret_cast<const uint4*>(p)[idx];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v.h[i];
+    }
+    __device__ static void store(void* p, size_t idx, const float* f) {
+        union { uint4 u; _Float16 h[8]; } v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v.h[i] = (_Float16)f[i];
+        reinterpret_cast<uint4*>(p)[idx] = v.u;
+    }
+};
+
+constexpr int GN_TPB = 256;
+constexpr int GN_MAX_C = 2048;
+
+// grid (HW / rows_per_block, B).  Threads are laid out [row-in-flight][channel vector]; a thread keeps V running sums for
+// its fixed channel vector, the block folds them over the rows-in-flight through LDS (conflict-free: consecutive threads,
+// consecutive channels), then per group, then adds to the global fp64 sums.  pre_bias (nullable, fp32 [C]) is the bias of the
+// convolution that produced x, added on load so that the producer does not need a pass of its own for it.
+template <int DT>
+__global__ __launch_bounds__(GN_TPB) void k_gn_stats(const void* __restrict__ x, const float* __restrict__ pre_bias, uint32_t HW, uint32_t C, uint32_t G,
+                                                      uint32_t rows_per_block, double* __restrict__ sums) {
+    constexpr int V = GnVec<DT>::V;
+    __shared__ float part_s[GN_TPB * V], part_q[GN_TPB * V];              // [row-in-flight][C]  (rif * C <= 256 * V)
+    const uint32_t tpr = C / V, rif = GN_TPB / tpr;
+    const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
+    const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
+    if (lane_row < rif) {
+        float s[V], q[V], pb[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; pb[i] = pre_bias ? pre_bias[cv * V + i] : 0.f; }
+        const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+        for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
+            float f[V];
+            GnVec<DT>::load(x, base + (size_t)r * tpr, f);
+#pragma unroll
+            for (int i = 0; i < V; ++i) { const float v = f[i] + pb[i]; s[i] += v; q[i] = __builtin_fmaf(v, v, q[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) { part_s[lane_row * C + cv * V + i] = s[i]; part_q[lane_row * C + cv * V + i] = q[i]; }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < C; c += GN_TPB) {                   // fold the rows-in-flight, result in row 0
+        float s = 0.f, q = 0.f;
+        for (uint32_t r = 0; r < rif; ++r) { s += part_s[r * C + c]; q += part_q[r * C + c]; }
+        part_s[c] = s; part_q[c] = q;                                      // row 0 slot c is only read by this thread above
+    }
+    __syncthreads();
+    const uint32_t cpg = C / G;
+    for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
+        double ds = 0.0, dq = 0.0;
+        for (uint32_t i = 0; i < cpg; ++i) { ds += (double)part_s[g * cpg + i]; dq += (double)part_q[g * cpg + i]; }
+        atomicAdd(&sums[((size_t)b * G + g) * 2 + 0], ds);
+        atomicAdd(&sums[((size_t)b * G + g) * 2 + 1], dq);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x, const float* __restrict__ pre_bias, uint32_t HW, uint32_t C, uint32_t G,
+                                                      uint32_t rows_per_block, const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ scale_shift, uint32_t ss_stride, float eps,
+                                                      int act, void* __restrict__ y) {
+    constexpr int V = GnVec<DT>::V;
+    __shared__ float fa[GN_MAX_C], fb[GN_MAX_C];
+    const uint32_t tpr = C / V, rif = GN_TPB / tpr;
+    const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
+    const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
+    const uint32_t cpg = C / G;
+    const double inv_n = 1.0 / ((double)HW * (double)cpg);
+    for (uint32_t c = threadIdx.x; c < C; c += GN_TPB) {
+        const uint32_t g = c / cpg;
+        const double mean = sums[((size_t)b * G + g) * 2 + 0] * inv_n;
+        double var = sums[((size_t)b * G + g) * 2 + 1] * inv_n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float a = rstd * gamma[c];
+        float o = __builtin_fmaf((pre_bias ? pre_bias[c] : 0.f) - (float)mean, a, beta[c]);      // ((x + pb) - mean) * a + beta
+        if (scale_shift) {                             // NormWithEmbedding, use_scale_shift: norm(x) * (1 + scale) + shift
+            const float sc = 1.0f + scale_shift[(size_t)b * ss_stride + c], sh = scale_shift[(size_t)b * ss_stride + C + c];
+            a *= sc;
+            o = __builtin_fmaf(o, sc, sh);
+        }
+        fa[c] = a; fb[c] = o;
+    }
+    __syncthreads();
+    if (lane_row >= rif) return;
+    float a[V], o[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a[i] = fa[cv * V + i]; o[i] = fb[cv * V + i]; }
+    const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+    for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
+        float f[V];
+        GnVec<DT>::load(x, base + (size_t)r * tpr, f);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float v = __builtin_fmaf(f[i], a[i], o[i]);
+            if (act) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));        // SiLU
+            f[i] = v;
+        }
+        GnVec<DT>::store(y, base + (size_t)r * tpr, f);
+    }
+}
+
+// y = x + bias[c] + residual  (either addend optional): the epilogue of a bias-less convolution -- conv_2 of a residual block
+// plus its skip (modules.py:51-110), or a plain bias add for the stand-alone convolutions.
+template <int DT>
+__global__ __launch_bounds__(GN_TPB) void k_bias_residual(const void* __restrict__ x, const float* __restrict__ bias, const void* __restrict__ residual,
+                                                           uint64_t n_vec, uint32_t tpr, void* __restrict__ y) {
+    constexpr int V = GnVec<DT>::V;
+    const uint64_t stride = (uint64_t)gridDim.x * GN_TPB;
+    for (uint64_t i = (uint64_t)blockIdx.x * GN_TPB + threadIdx.x; i < n_vec; i += stride) {
+        float f[V], r[V];
+        GnVec<DT>::load(x, i, f);
+        const uint32_t cv = (uint32_t)(i % tpr);
+        if (bias) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) f[k] += bias[cv * V + k];
+        }
+        if (residual) {
+            GnVec<DT>::load(residual, i, r);
+#pragma unroll
+            for (int k = 0; k < V; ++k) f[k] += r[k];
+        }
+        GnVec<DT>::store(y, i, f);
+    }
+}
+
+uint32_t gn_rows_per_block(uint32_t B, uint32_t HW, uint32_t min_blocks, uint32_t min_rows) {
+    uint32_t rows = HW;                                 // largest power-of-two split of HW that still leaves >= min_blocks blocks
+    while (rows > min_rows && (rows % 2 == 0) && (uint64_t)B * (HW / rows) < min_blocks) rows /= 2;
+    return rows;
+}
+
+}  // namespace
+
+extern "C" size_t ssdnerf_group_norm_workspace(uint32_t B, uint32_t G) { return (size_t)B * G * 2 * sizeof(double); }
+
+extern "C" int ssdnerf_group_norm_nhwc(const void* x, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* pre_bias, const float* gamma,
+                                       const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act, void* workspace,
+                                       int workspace_state, void* y, void* stream) {
+    if (B == 0 || HW == 0 || C == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x && y && gamma && beta && workspace, "group_norm_nhwc: null pointer");
+    SSD_REQUIRE(dtype == GN_F32 || dtype == GN_F16 || dtype == GN_BF16, "group_norm_nhwc: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    const uint32_t V = dtype == GN_F32 ? 4 : 8;
+    SSD_REQUIRE(G > 0 && C % G == 0, "group_norm_nhwc: channels must be divisible by groups");
+    SSD_REQUIRE(!scale_shift || scale_shift_stride >= 2 * C, "group_norm_nhwc: scale_shift_stride must be >= 2*C");
+    SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t rows_s = gn_rows_per_block(B, HW, 1024, 64), rows_a = gn_rows_per_block(B, HW, 2048, 16);
+    const dim3 grid_s(HW / rows_s, B), grid_a(HW / rows_a, B), block(GN_TPB);
+    SSD_REQUIRE(workspace_state >= 0 && workspace_state <= 2 && !(workspace_state == 2 && pre_bias), "group_norm_nhwc: bad workspace_state");
+    const bool stats_ready = workspace_state == 2;
+    if (workspace_state == 0 && hipMemsetAsync(workspace, 0, ssdnerf_group_norm_workspace(B, G), st) != hipSuccess)
+        return ssdnerf_fail(SSDNERF_E_LAUNCH, "group_norm_nhwc: memset failed");
+    double* sums = (double*)workspace;
+#define SSD_GN_LAUNCH(DT)                                                                                                                    \
+    if (!stats_ready) hipLaunchKernelGGL(k_gn_stats<DT>, grid_s, block, 0, st, x, pre_bias, HW, C, G, rows_s, sums);                                            \
+    hipLaunchKernelGGL(k_gn_apply<DT>, grid_a, block, 0, st, x, pre_bias, HW, C, G, rows_a, (const double*)sums, gamma, beta, scale_shift,    \
+                       scale_shift_stride, eps, act, y);
+    if (dtype == GN_F32) { SSD_GN_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_GN_LAUNCH(GN_F16) } else { SSD_GN_LAUNCH(GN_BF16) }
+#undef SSD_GN_LAUNCH
+    SSD_CHECK_LAUNCH("group_norm_nhwc");
+    return SSDNERF_OK;
+}
+
+extern "C" int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint64_t rows, uint32_t C, const float* bias, const void* residual, void* y,
+                                          void* stream) {
+    if (rows == 0 || C == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x && y, "bias_residual_nhwc: null pointer");
+    SSD_REQUIRE(dtype == GN_F32 || dtype == GN_F16 || dtype == GN_BF16, "bias_residual_nhwc: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    const uint32_t V = dtype == GN_F32 ? 4 : 8;
+    SSD_REQUIRE(C % V == 0, "bias_residual_nhwc: channel count must be a multiple of the 16-byte vector");
+    const uint64_t n_vec = rows * (C / V);
+    const unsigned blocks = (unsigned)((n_vec + GN_TPB - 1) / GN_TPB < 8192 ? (n_vec + GN_TPB - 1) / GN_TPB : 8192);
+    hipStream_t st = (hipStream_t)stream;
+#define SSD_BR_LAUNCH(DT) hipLaunchKernelGGL(k_bias_residual<DT>, dim3(blocks), dim3(GN_TPB), 0, st, x, bias, residual, n_vec, C / V, y);
+    if (dtype == GN_F32) { SSD_BR_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_BR_LAUNCH(GN_F16) } else { SSD_BR_LAUNCH(GN_BF16) }
+#undef SSD_BR_LAUNCH
+    SSD_CHECK_LAUNCH("bias_residual_nhwc");
+    return SSDNERF_OK;
+}

@@ -14,6 +14,7 @@ kernels; hand-written MFMA conv/attention kernels are the next step for this row
 from __future__ import annotations
 
 import math
+import os
 from copy import deepcopy
 from typing import List, Optional
 
@@ -295,7 +296,24 @@ class DenoisingUnetMod(nn.Module):
             if isinstance(m, nn.Conv1d) and "proj" in n:
                 nn.init.constant_(m.weight, 0.0); nn.init.constant_(m.bias, 0.0)
 
+    #: inference (no-grad, GPU) calls run through ``unet_fast.FastUnet`` (fused GroupNorm HIP kernels, channel-last
+    #: activations, hipGraph replay); set to False (or SSDNERF_UNET_FAST=0) to force the eager module forward.
+    fast_inference = os.environ.get("SSDNERF_UNET_FAST", "1") != "0"
+
+    def _fast_executor(self, dtype):
+        from .unet_fast import FastUnet
+        cache = self.__dict__.setdefault("_fast_cache", {})
+        ex = cache.get(dtype)
+        if ex is None:
+            ex = cache[dtype] = FastUnet(self, dtype=dtype)
+        return ex
+
     def forward(self, x_t, t, label=None, concat_cond=None, return_noise=False):
+        if (self.fast_inference and x_t.is_cuda and not torch.is_grad_enabled() and not self.training and label is None
+                and self.concat_cond_channels == 0 and self.num_classes == 0):
+            dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+            with torch.autocast("cuda", enabled=False):
+                return self._fast_executor(dtype)(x_t.float(), t)
         if self.use_rescale_timesteps:
             t = t.float() * (1000.0 / self.num_timesteps)
         embedding = self.time_embedding(t)

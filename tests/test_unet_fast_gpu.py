@@ -1,0 +1,182 @@
+"""GPU checks of the UNet inference executor: the fused GroupNorm HIP kernel against torch's fp32 group_norm, and the whole
+executor (channel-last, hipGraph replay) against the eager module forward."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ssdnerf_amd  # noqa: F401
+from ssdnerf_amd import unet_fast
+from ssdnerf_amd.registry import MODULES
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_gn(x_nchw, groups, gamma, beta, ss, eps, act):
+    y = F.group_norm(x_nchw.float(), groups, gamma, beta, eps)
+    if ss is not None:
+        c = x_nchw.size(1)
+        y = y * (1 + ss[:, :c, None, None]) + ss[:, c:, None, None]
+    return F.silu(y) if act else y
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("C,H", [(128, 32), (256, 16), (384, 16), (512, 8), (768, 8), (1024, 8), (64, 4)])
+def test_group_norm_kernel(dtype, tol, C, H):
+    g = torch.Generator().manual_seed(C + H)
+    B = 3
+    x = (torch.randn(B, C, H, H, generator=g) * 1.7 + 0.4).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    gamma, beta = (torch.randn(C, generator=g) * 0.5 + 1).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    big = (torch.randn(B, 5 * C, generator=g) * 0.4).cuda()                 # the per-block slice is a strided view, as in the executor
+    ws = torch.empty(B * 64 * 2, dtype=torch.float64, device="cuda")
+    for ss, act in ((None, True), (big[:, C:3 * C], True), (None, False)):
+        y = unet_fast.group_norm_nhwc(x, 32, gamma, beta, ss, 1e-5, act, ws)
+        assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+        want = _ref_gn(x, 32, gamma, beta, ss, 1e-5, act)
+        err = (y.float() - want).abs().max().item()
+        assert err <= tol * max(1.0, want.abs().max().item()), (C, H, dtype, act, err)
+    # conv bias folded into the norm, pre-zeroed workspace
+    pb = (torch.randn(C, generator=g) * 0.5).cuda()
+    ws.zero_()
+    y = unet_fast.group_norm_nhwc(x, 32, gamma, beta, big[:, C:3 * C], 1e-5, True, ws, pre_bias=pb, workspace_is_zero=True)
+    want = _ref_gn(x.float() + pb[None, :, None, None], 32, gamma, beta, big[:, C:3 * C], 1e-5, True)
+    assert (y.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    # residual epilogue
+    r = torch.randn(B, C, H, H, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    want = x.float() + pb[None, :, None, None] + r.float()
+    got = unet_fast.bias_residual_nhwc(x.clone(memory_format=torch.channels_last), pb, r)
+    assert (got.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    # (B, T, C) entry used by attention
+    xt = x.permute(0, 2, 3, 1).reshape(B, H * H, C)
+    yt = unet_fast.group_norm_nhwc(xt, 32, gamma, beta, None, 1e-5, False, ws)
+    want = _ref_gn(x, 32, gamma, beta, None, 1e-5, False).permute(0, 2, 3, 1).reshape(B, H * H, C)
+    assert (yt.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+
+
+def test_group_norm_rejects_bad_shapes():
+    x = torch.randn(1, 36, 4, 4, device="cuda").contiguous(memory_format=torch.channels_last)      # 36 % 32 != 0
+    ws = torch.empty(128, dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError):
+        unet_fast.group_norm_nhwc(x, 32, torch.ones(36, device="cuda"), torch.zeros(36, device="cuda"), None, 1e-5, False, ws)
+    with pytest.raises(RuntimeError):
+        unet_fast.group_norm_nhwc(torch.randn(1, 64, 4, 4, device="cuda"), 32, torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"), None, 1e-5,
+                                  False, ws)                                                       # not channels_last
+
+
+def _unet(seed=0, **kw):
+    cfg = dict(type="DenoisingUnetMod", image_size=32, in_channels=18, base_channels=64, channels_cfg=[1, 2, 2], resblocks_per_downsample=2, dropout=0.0,
+               use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4, attention_res=[16, 8])
+    cfg.update(kw)
+    net = MODULES.build(cfg).cuda().eval()
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * 0.04).cuda())
+    return net
+
+
+def test_executor_fp32_matches_eager_and_replays():
+    net = _unet()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for i in range(3):                                                    # first call captures, later calls replay the hipGraph
+            x = torch.randn(4, 18, 32, 32, generator=g).cuda()
+            t = torch.randint(0, 1000, (4,), generator=g).cuda()
+            net.fast_inference = False
+            want = net(x, t)
+            net.fast_inference = True
+            got = net(x, t)
+            assert got.dtype == torch.float32 and got.shape == want.shape
+            err = (got - want).abs().max().item()
+            assert err <= 2e-3 * max(1.0, want.abs().max().item()), (i, err)
+    assert len(net._fast_cache[torch.float32]._graphs) == 1
+
+
+def test_executor_bf16_close_to_fp32():
+    net = _unet(seed=1)
+    x = torch.randn(2, 18, 32, 32, generator=torch.Generator().manual_seed(4)).cuda()
+    t = torch.tensor([999, 19]).cuda()
+    with torch.no_grad():
+        net.fast_inference = False
+        want = net(x, t)
+        net.fast_inference = True
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got = net(x, t)
+    assert got.dtype == torch.float32
+    rel = (got - want).norm() / want.norm()
+    assert rel < 3e-2, rel
+
+
+def test_guided_path_stays_on_autograd():
+    net = _unet(seed=2)
+    x = torch.randn(1, 18, 32, 32).cuda().requires_grad_(True)
+    y = net(x, torch.tensor([10]).cuda())                                   # grad enabled -> eager module path
+    y.square().mean().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+# ------------------------------------------------------------------------------------------------ implicit-GEMM convolution
+def _conv_ref(x, w, bias, residual, stride, upsample):
+    xf = x.float()
+    if upsample:
+        xf = F.interpolate(xf, scale_factor=2, mode="nearest")
+    y = F.conv2d(xf, w.float(), bias, stride, w.size(-1) // 2)
+    return y if residual is None else y + residual.float()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, upsample, tile_hint
+    (2, 16, 16, 64, 64, 3, 1, False, 3),
+    (2, 16, 16, 64, 128, 3, 1, False, 2),
+    (2, 16, 16, 128, 128, 3, 1, False, 1),
+    (1, 5, 7, 64, 64, 3, 1, False, 0),         # ragged M (35 rows), every border case
+    (3, 9, 6, 128, 256, 1, 1, False, 0),       # 1x1 shortcut
+    (2, 16, 16, 128, 128, 3, 2, False, 0),     # DenoisingDownsampleMod
+    (2, 8, 8, 128, 128, 3, 1, True, 0),        # DenoisingUpsampleMod (upsample fused into the gather)
+    (2, 32, 32, 384, 256, 3, 1, False, 0),     # the concat widths of the decoder half
+    (8, 8, 8, 1024, 512, 3, 1, False, 0),
+    (1, 64, 64, 128, 128, 3, 1, False, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,upsample,hint", CONV_CASES)
+def test_conv_igemm_matches_fp32_reference(B, H, W, Cin, Cout, k, stride, upsample, hint):
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin + k)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(Cout, generator=g).cuda()
+    want_plain = _conv_ref(x, w, None, None, stride, upsample)
+    got = unet_fast.conv2d_nhwc_bf16(x, w, None, None, stride, upsample, tile_hint=hint)
+    assert got.shape == want_plain.shape and got.is_contiguous(memory_format=torch.channels_last)
+    # bf16 inputs are exact in the fp32 reference; the only differences are accumulation order and the final rounding to bf16
+    assert (got.float() - want_plain).abs().max().item() <= 2e-2 * max(1.0, want_plain.abs().max().item())
+    assert ((got.float() - want_plain).norm() / want_plain.norm()).item() < 4e-3
+    res = torch.randn(want_plain.shape, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    want = _conv_ref(x, w, bias, res, stride, upsample)
+    got = unet_fast.conv2d_nhwc_bf16(x, w, bias, res, stride, upsample, tile_hint=hint)
+    assert ((got.float() - want).norm() / want.norm()).item() < 4e-3
+
+
+@pytest.mark.parametrize("C,hint,H", [(128, 1, 16), (256, 2, 8), (384 * 2, 3, 8), (512, 0, 32)])
+def test_conv_igemm_fused_groupnorm_statistics(C, hint, H):
+    g = torch.Generator().manual_seed(C)
+    B, G = 2, 32
+    x = torch.randn(B, 64, H, H, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, 64, 3, 3, generator=g) / 24).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(C, generator=g).cuda()
+    sums = torch.zeros(B, G, 2, dtype=torch.float64, device="cuda")
+    y = unet_fast.conv2d_nhwc_bf16(x, w, bias, None, gn_sums=sums, gn_groups=G, tile_hint=hint)
+    yf = y.double().reshape(B, G, C // G, H * H)
+    assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sums[..., 1], yf.square().sum((2, 3)), rtol=1e-5, atol=1e-3)
+    # and the norm that consumes them
+    gamma, beta = torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda()
+    out = unet_fast.group_norm_nhwc(y, G, gamma, beta, None, 1e-5, True, sums, stats_ready=True)
+    want = F.silu(F.group_norm(y.float(), G, gamma, beta, 1e-5))
+    assert (out.float() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+
+
+def test_conv_igemm_rejects_unsupported():
+    x = torch.randn(1, 18, 8, 8).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 18, 3, 3).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    with pytest.raises(RuntimeError):
+        unet_fast.conv2d_nhwc_bf16(x, w)
