@@ -233,13 +233,20 @@ int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint64_t rows, uint32_t
  * may alias y).  fp32 accumulation; bias and residual are added in fp32 before the single rounding to bf16.
  * gn_sums (nullable): fp64 [B][gn_groups][2], pre-zeroed by the caller; receives sum and sum of squares of the rounded output
  * per (sample, channel group) -- the statistics pass of the GroupNorm that follows (ssdnerf_group_norm_nhwc, workspace_state 2).
- * Needs (Cout / gn_groups) % 4 == 0 and Ho*Wo a multiple of the M tile (128, or 64 for the smaller tiles).
- * tile_hint: 0 = choose by problem size, 1 = 128x128, 2 = 64x128, 3 = 64x64 block tile.
+ * Needs (Cout / gn_groups) % 4 == 0 and Ho*Wo a multiple of the M tile (256 / 128 / 64).
+ * tile_hint: 0 = choose by problem size, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 block tile.
+ * splitk_ws (nullable): fp32 scratch of splitk_ws_bytes >= B*Ho*Wo*Cout*4 that is ALL ZERO on entry and is left all zero on
+ * return; when given (and gn_sums is NULL) layers with too few output tiles to fill the chip are cut along K (splits_hint: 0 =
+ * choose, n = force n ranges) and reduced through it.
  * ssdnerf_conv2d_nhwc_bf16_supported() tells whether a layer fits (Cin % 64 == 0, Cout % 64 == 0, ksize 1|3, stride 1|2). */
 int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample);
+/* The decomposition ssdnerf_conv2d_nhwc_bf16 will use for M = B*Ho*Wo output pixels: tile choice (1..3) | splits << 8. */
+int ssdnerf_conv2d_nhwc_bf16_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int may_split,
+                                  int splits_hint);
 int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual, void* y, uint32_t B,
                              uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride,
-                             uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint, void* stream);
+                             uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint, void* splitk_ws,
+                             size_t splitk_ws_bytes, int splits_hint, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,9 +10,11 @@
 // is a GEMM with M = B*Ho*Wo, N = Cout, K = taps*Cin whose A rows are *gathered*: K-tile (tap, ci0) of output pixel m is
 // the 128 contiguous bytes x[pixel(m, tap)][ci0 .. ci0+64), or zeros where the tap falls into the padding.
 //
-//   * block = 4 waves (2 x 2), block tile (64*TM) x (64*TN), K-tile 64, `v_mfma_f32_32x32x16_bf16`, fp32 accumulators;
-//   * both operands go HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no ds_write pass), double buffered,
-//     one barrier per K-tile; padding taps read a 16-byte zero page instead of being predicated;
+//   * block = 4 waves (2 x 2) with a 64x64 / 64x128 / 128x128 tile, or 8 waves (4 x 2) with a 256x128 tile (large layers: the
+//     bigger the tile, the fewer L2->LDS bytes per FLOP); K-tile 64, `v_mfma_f32_32x32x16_bf16`, fp32 accumulators;
+//   * both operands go HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no ds_write pass) through a 2-stage
+//     (128x128 tile, two blocks per CU) to 4-stage (64x64 tile) ring with counted `s_waitcnt vmcnt(N)` and one raw barrier
+//     per K-tile; padding taps read a 16-byte zero page instead of being predicated;
 //   * the LDS image of a tile row is its eight 16-byte chunks XOR-permuted by ((row >> 1) & 7) -- applied on the SOURCE
 //     address of the DMA (its LDS side is lane-linear) and again on the ds_read_b128 address -- which makes every one of
 //     ds_read_b128's 16-lane groups hit 16 distinct 16-byte bank slots (MI355X_MICROARCH.md, LDS table);
@@ -41,6 +43,8 @@ struct ConvArgs {
     const unsigned char* res;    // bf16 [M][Cout] or null
     unsigned char* y;            // bf16 [M][Cout]
     double* gn_sums;             // fp64 [B][G][2] or null
+    float* splitk_ws;            // fp32 [M][Cout], zero on entry (split-K partial sums), or null
+    uint32_t splits;             // K is cut into `splits` ranges of K-tiles, one block each
     uint32_t B, H, W, Cin, Cout; // input geometry
     uint32_t Ho, Wo, M;          // output geometry, M = B*Ho*Wo
     uint32_t ksize, stride, pad, upsample;
@@ -60,24 +64,36 @@ SSD_DEV uint32_t cv_bf16_rne(float x) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void k_conv_igemm_bf16(const ConvArgs a) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int A_INST = BM / 32, B_INST = BN / 32;                        // global_load_lds instructions per wave per K-tile (8 rows each)
+template <int N> SSD_DEV void cv_wait_tiles_and_barrier() {
+    // this wave's DMA of the tile about to be read has landed (N younger loads may stay in flight), its own LDS reads of the previous
+    // tile have returned; after the barrier that holds for every wave, so the buffer of the previous tile may be refilled
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// TM x TN MFMA tiles (32 x 32) per wave, WM x WN waves per block, NS staging buffers.
+template <int TM, int TN, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs a) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;                // global_load_lds instructions per wave per K-tile (8 rows each)
     constexpr int STAGE = (BM + BN) * CV_ROWB;
-    constexpr int EPI = BM * BN * 4;
-    constexpr int LDS_BYTES = ((2 * STAGE > EPI) ? 2 * STAGE : EPI) + 512;   // + block partials of the fused GroupNorm statistics (ONE LDS object)
+    constexpr int EP_ROWS = BM < 128 ? BM : 128;                             // the epilogue goes through LDS in passes of EP_ROWS rows
+    constexpr int EPI = EP_ROWS * BN * 4;
+    constexpr int LPT = A_INST + B_INST;                                     // DMA instructions per wave per K-tile
+    constexpr int LDS_BYTES = ((NS * STAGE > EPI) ? NS * STAGE : EPI) + 512;   // + block partials of the fused GroupNorm statistics (ONE LDS object)
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && EP_ROWS % (32 * TM) == 0, "tile / wave grid mismatch");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t wm = wave >> 1, wn = wave & 1;
+    const uint32_t wm = wave / WN, wn = wave % WN;
 
     // ---- XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous range of tiles (M-major) ----------------
-    const uint32_t n_blocks = a.m_tiles * a.n_tiles;
-    uint32_t tile;
+    const uint32_t n_blocks = a.m_tiles * a.n_tiles * a.splits;
+    uint32_t tile, split;
     {
         const uint32_t xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n_blocks >> 3, r = n_blocks & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const uint32_t lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile = lin / a.splits; split = lin % a.splits;                       // a tile's K ranges run side by side on one XCD
     }
     const uint32_t m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
 
@@ -146,47 +162,63 @@ __global__ __launch_bounds__(256) void k_conv_igemm_bf16(const ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const uint32_t kc = a.Cin / CV_BK, KT = taps * kc;
-    uint32_t tap = 0, ci = 0;
-    set_tap(0);
-    issue(0, 0, 0);
-    __syncthreads();
+    const uint32_t kc = a.Cin / CV_BK, KT_all = taps * kc;
+    const uint32_t kt_begin = (uint32_t)((uint64_t)split * KT_all / a.splits), KT = (uint32_t)((uint64_t)(split + 1) * KT_all / a.splits) - kt_begin;
+    // NS-stage pipeline, one barrier per K-tile: tiles kt+1 .. kt+NS-2 stay in flight while tile kt is multiplied
+    uint32_t tap = kt_begin / kc, ci = kt_begin % kc, issued = 0;
+    set_tap(tap);
+    auto issue_next = [&]() {
+        if (issued) { if (++ci == kc) { ci = 0; ++tap; set_tap(tap); } }
+        issue(tap, ci * CV_BK, issued % NS);
+        ++issued;
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (issued < KT) issue_next();
     for (uint32_t kt = 0; kt < KT; ++kt) {
-        const uint32_t buf = kt & 1;
-        if (kt + 1 < KT) {
-            if (++ci == kc) { ci = 0; ++tap; set_tap(tap); }
-            issue(tap, ci * CV_BK, buf ^ 1);
-        }
-        const unsigned char* st = lds + buf * STAGE;
+        const uint32_t in_flight = issued - (kt + 1);                        // tiles younger than kt already issued (0 .. NS-2)
+        if (NS >= 4 && in_flight >= 2) cv_wait_tiles_and_barrier<2 * LPT>();
+        else if (NS >= 3 && in_flight == 1) cv_wait_tiles_and_barrier<1 * LPT>();
+        else cv_wait_tiles_and_barrier<0>();
+        if (issued < KT) issue_next();                                       // refills the buffer tile kt-1 was read from
+        const unsigned char* st = lds + (kt % NS) * STAGE;
+        // all of the K-tile's fragments are requested before the first MFMA: the LDS latency is paid once per tile, not per k-step
+        bf16x8 fa[4][TM], fb[4][TN];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(st + ((a_rd + i * 32 * CV_ROWB) ^ (s * 32)));
+            for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(st + ((a_rd + i * 32 * CV_ROWB) ^ (s * 32)));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(st + ((b_rd + j * 32 * CV_ROWB) ^ (s * 32)));
+            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(st + ((b_rd + j * 32 * CV_ROWB) ^ (s * 32)));
+        }
+        __builtin_amdgcn_sched_barrier(0);                                   // keep the reads clustered ahead of the MFMAs (the scheduler would re-serialise them)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();                                                     // the next tile has landed and this one is free to be overwritten
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                                         // every wave is done with the staging buffers (the epilogue reuses them)
+
+    // ---- split-K: add this block's partial sums to the fp32 workspace; k_conv_splitk_finish turns it into the output ------------------
+    if (a.splits > 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const uint32_t col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
+                    if (m < a.M) unsafeAtomicAdd(a.splitk_ws + (size_t)m * a.Cout + col, acc[i][j][e]);
+                }
+        return;
     }
 
-    // ---- epilogue: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> bf16 rows ----------------------------------------------
+    // ---- epilogue: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> bf16 rows, EP_ROWS rows per pass ---------------------------
     float* tile_f = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t row = wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const uint32_t col = wn * 32 * TN + j * 32 + (lane & 31);
-                tile_f[row * BN + col] = acc[i][j][e];
-            }
-    __syncthreads();
-    constexpr int CPR = BN / 8;                                              // 8-channel chunks per row; 256 % CPR == 0, so a thread keeps its chunk column
+    constexpr int CPR = BN / 8;                                              // 8-channel chunks per row; NT % CPR == 0, so a thread keeps its chunk column
     float* red = reinterpret_cast<float*>(lds + EPI);                        // [CPR][2 halves][sum, sumsq] block partials for the GroupNorm statistics
     if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
     const uint32_t cc = tid % CPR, co = n0 + cc * 8;
@@ -194,34 +226,50 @@ __global__ __launch_bounds__(256) void k_conv_igemm_bf16(const ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
     float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
-    if (a.gn_sums) __syncthreads();
-#pragma unroll 2
-    for (uint32_t row = tid / CPR; row < (uint32_t)BM; row += 256 / CPR) {
-        const uint32_t m = m0 + row;
-        if (m >= a.M) break;
-        const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8);
-        const float4 v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
-        float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] += bias_v[k];
-        const size_t o = ((size_t)m * a.Cout + co) * 2;
-        if (a.res) {
-            const uint4 rv = *reinterpret_cast<const uint4*>(a.res + o);
-            const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+        if (pass) __syncthreads();                                           // the previous pass has been read out
+        if ((wm * 32 * TM) / EP_ROWS == (uint32_t)pass) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { f[2 * k] += __uint_as_float(rw[k] << 16); f[2 * k + 1] += __uint_as_float(rw[k] & 0xffff0000u); }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t row = (wm * 32 * TM) % EP_ROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const uint32_t col = wn * 32 * TN + j * 32 + (lane & 31);
+                        tile_f[row * BN + col] = acc[i][j][e];
+                    }
         }
-        uint32_t pk[4];
+        __syncthreads();
+#pragma unroll 2
+        for (uint32_t row = tid / CPR; row < (uint32_t)EP_ROWS; row += NT / CPR) {
+            const uint32_t m = m0 + pass * EP_ROWS + row;
+            if (m >= a.M) break;
+            const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
+            float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
-        *reinterpret_cast<uint4*>(a.y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        if (a.gn_sums) {                                                     // statistics of what the next norm will read (the rounded values)
+            for (int k = 0; k < 8; ++k) f[k] += bias_v[k];
+            const size_t o = ((size_t)m * a.Cout + co) * 2;
+            if (a.res) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + o);
+                const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float lo = __uint_as_float(pk[k] << 16), hi = __uint_as_float(pk[k] & 0xffff0000u);
-                gs[k >> 1] += lo + hi;
-                gq[k >> 1] = __builtin_fmaf(lo, lo, gq[k >> 1]);
-                gq[k >> 1] = __builtin_fmaf(hi, hi, gq[k >> 1]);
+                for (int k = 0; k < 4; ++k) { f[2 * k] += __uint_as_float(rw[k] << 16); f[2 * k + 1] += __uint_as_float(rw[k] & 0xffff0000u); }
+            }
+            uint32_t pk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
+            *reinterpret_cast<uint4*>(a.y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (a.gn_sums) {                                                 // statistics of what the next norm will read (the rounded values)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(pk[k] << 16), hi = __uint_as_float(pk[k] & 0xffff0000u);
+                    gs[k >> 1] += lo + hi;
+                    gq[k >> 1] = __builtin_fmaf(lo, lo, gq[k >> 1]);
+                    gq[k >> 1] = __builtin_fmaf(hi, hi, gq[k >> 1]);
+                }
             }
         }
     }
@@ -238,16 +286,76 @@ __global__ __launch_bounds__(256) void k_conv_igemm_bf16(const ConvArgs a) {
     }
 }
 
-template <int TM, int TN>
+// y = bf16(ws + bias + residual), and ws goes back to zero for the next split-K convolution.
+__global__ __launch_bounds__(256) void k_conv_splitk_finish(float* __restrict__ ws, const float* __restrict__ bias, const unsigned char* __restrict__ res,
+                                                            unsigned char* __restrict__ y, uint64_t n_chunks, uint32_t cpr) {
+    const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_chunks) return;
+    float4* p = reinterpret_cast<float4*>(ws + q * 8);
+    const float4 v0 = p[0], v1 = p[1];
+    p[0] = make_float4(0.f, 0.f, 0.f, 0.f); p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const uint32_t co = (uint32_t)(q % cpr) * 8;
+    if (bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += bias[co + k];
+    }
+    if (res) {
+        const uint4 rv = *reinterpret_cast<const uint4*>(res + q * 16);
+        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[2 * k] += __uint_as_float(rw[k] << 16); f[2 * k + 1] += __uint_as_float(rw[k] & 0xffff0000u); }
+    }
+    uint32_t pk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
+    *reinterpret_cast<uint4*>(y + q * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+template <int TM, int TN, int WM, int WN, int NS>
 int cv_launch(ConvArgs& a, hipStream_t st) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     a.m_tiles = (a.M + BM - 1) / BM;
     a.n_tiles = a.Cout / BN;
-    hipLaunchKernelGGL((k_conv_igemm_bf16<TM, TN>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_igemm_bf16<TM, TN, WM, WN, NS>), dim3(a.m_tiles * a.n_tiles * a.splits), dim3(64 * WM * WN), 0, st, a);
     return 0;
 }
 
 }  // namespace
+
+// tile choice: the largest tile that still gives every CU (256) a block; tile_hint 1/2/3/4 forces 128x128 / 64x128 / 64x64 / 256x128
+// (the bigger the tile the fewer L2->LDS bytes per FLOP, which is what bounds the large layers).
+// split-K: a layer with too few output tiles to occupy the chip (each block then pays a full memory round trip per K-tile with
+// nothing to hide it) is cut along K into `splits` blocks per tile that accumulate into the caller's zeroed fp32 workspace.
+static void cv_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, bool may_split, int splits_hint, int* choice_out, uint32_t* splits_out) {
+    int choice = tile_hint;
+    if (choice < 1 || choice > 4) {
+        const uint64_t t256 = (uint64_t)((M + 255) / 256) * (Cout / 128);
+        const uint64_t t128 = (uint64_t)((M + 127) / 128) * (Cout / 128);
+        const uint64_t t64 = (uint64_t)((M + 63) / 64) * (Cout / 128);
+        (void)t256;   // 256x128 (8 waves, hint 4) measures no faster than 128x128 at 2 blocks/CU: the loop is bound by DMA issue slots per MFMA, not by L2 bytes
+        choice = (Cout % 128 != 0) ? 3 : (t128 >= 384) ? 1 : (t64 >= 256) ? 2 : 3;
+    }
+    const uint32_t bm = choice == 4 ? 256 : choice == 1 ? 128 : 64;
+    const uint32_t tiles = ((M + bm - 1) / bm) * (Cout / (choice == 3 ? 64 : 128));
+    const uint32_t KT = ksize * ksize * (Cin / 64);
+    uint32_t splits = 1;
+    if (may_split) {
+        if (splits_hint > 0) splits = (uint32_t)splits_hint;
+        else if (tiles < 512 && (uint64_t)M * Cout <= (1u << 20)) splits = (1024 + tiles - 1) / tiles;   // larger outputs: the fp32 atomics cost more than they buy
+        if (splits > 16) splits = 16;
+        if (splits > KT / 2) splits = KT / 2 ? KT / 2 : 1;                   // at least two K-tiles per block
+    }
+    *choice_out = choice; *splits_out = splits;
+}
+
+// Returns tile choice (1..3) | splits << 8 for a layer with M = B*Ho*Wo output pixels: lets the host know whether the epilogue
+// can carry GroupNorm statistics (only unsplit layers) before it decides what to ask for.
+extern "C" int ssdnerf_conv2d_nhwc_bf16_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int may_split, int splits_hint) {
+    int choice; uint32_t splits;
+    cv_plan(M, Cin, Cout, ksize, tile_hint, may_split != 0, splits_hint, &choice, &splits);
+    return choice | (int)(splits << 8);
+}
 
 extern "C" int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample) {
     return (Cin % 64 == 0) && (Cout % 64 == 0) && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && !(upsample && stride != 1);
@@ -255,7 +363,7 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, u
 
 extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual, void* y, uint32_t B, uint32_t H, uint32_t W,
                                         uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample, void* gn_sums, uint32_t gn_groups,
-                                        int tile_hint, void* stream) {
+                                        int tile_hint, void* splitk_ws, size_t splitk_ws_bytes, int splits_hint, void* stream) {
     if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
     SSD_REQUIRE(x && w && y, "conv2d_nhwc_bf16: null pointer");
     SSD_REQUIRE(ssdnerf_conv2d_nhwc_bf16_supported(Cin, Cout, ksize, stride, upsample),
@@ -272,17 +380,17 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const floa
     a.Wo = (Wv + 2 * a.pad - ksize) / stride + 1;
     SSD_REQUIRE((uint64_t)B * a.Ho * a.Wo < (1ull << 31) && (uint64_t)B * H * W * Cin * 2 < (1ull << 40), "conv2d_nhwc_bf16: tensor too large");
     a.M = B * a.Ho * a.Wo;
-    // tile choice: the largest tile that still gives every CU (256) a block or two; tile_hint 1/2/3 forces 128x128 / 64x128 / 64x64
-    int choice = tile_hint;
-    if (choice < 1 || choice > 3) {
-        const uint64_t t128 = (uint64_t)((a.M + 127) / 128) * (Cout / 128);
-        const uint64_t t64 = (uint64_t)((a.M + 63) / 64) * (Cout / 128);
-        choice = (Cout % 128 == 0 && t128 >= 384) ? 1 : (Cout % 128 == 0 && t64 >= 256) ? 2 : 3;
-    }
+    int choice; uint32_t splits;
+    cv_plan(a.M, Cin, Cout, ksize, tile_hint, splitk_ws && !gn_sums && splitk_ws_bytes >= (size_t)a.M * Cout * 4, splits_hint, &choice, &splits);
     if (choice != 3) SSD_REQUIRE(Cout % 128 == 0, "conv2d_nhwc_bf16: 128-wide tiles need Cout %% 128 == 0");
-    SSD_REQUIRE(!gn_sums || (a.Ho * a.Wo) % (choice == 1 ? 128 : 64) == 0, "conv2d_nhwc_bf16: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
+    SSD_REQUIRE(!gn_sums || (a.Ho * a.Wo) % (choice == 4 ? 256 : choice == 1 ? 128 : 64) == 0, "conv2d_nhwc_bf16: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
+    a.splits = splits; a.splitk_ws = (float*)splitk_ws;
     hipStream_t st = (hipStream_t)stream;
-    if (choice == 1) cv_launch<2, 2>(a, st); else if (choice == 2) cv_launch<1, 2>(a, st); else cv_launch<1, 1>(a, st);
+    if (choice == 4) cv_launch<2, 2, 4, 2, 3>(a, st); else if (choice == 1) cv_launch<2, 2, 2, 2, 2>(a, st); else if (choice == 2) cv_launch<1, 2, 2, 2, 3>(a, st); else cv_launch<1, 1, 2, 2, 4>(a, st);
+    if (splits > 1) {
+        const uint64_t n_chunks = (uint64_t)a.M * (Cout / 8);
+        hipLaunchKernelGGL(k_conv_splitk_finish, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, a.splitk_ws, bias, a.res, a.y, n_chunks, Cout / 8);
+    }
     SSD_CHECK_LAUNCH("conv2d_nhwc_bf16");
     return SSDNERF_OK;
 }

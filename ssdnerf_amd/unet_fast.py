@@ -71,9 +71,11 @@ def bias_residual_nhwc(x: torch.Tensor, bias: Optional[torch.Tensor], residual: 
 
 
 def conv2d_nhwc_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, stride: int = 1,
-                     upsample: bool = False, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0, tile_hint: int = 0) -> torch.Tensor:
+                     upsample: bool = False, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0, tile_hint: int = 0,
+                     splitk_ws: Optional[torch.Tensor] = None, splits_hint: int = 0) -> torch.Tensor:
     """Hand-written implicit-GEMM convolution (csrc/conv_igemm.hip).  ``x`` (B, Cin, H, W) bf16 channels_last, ``w`` (Cout, Cin, k, k) bf16
-    channels_last, ``bias`` fp32, ``residual`` like the output.  ``upsample``: convolve the nearest-2x upsampling of x without building it."""
+    channels_last, ``bias`` fp32, ``residual`` like the output.  ``upsample``: convolve the nearest-2x upsampling of x without building it.
+    ``splitk_ws``: all-zero fp32 scratch (left all zero) that lets small layers be cut along K."""
     if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
         raise RuntimeError("conv2d_nhwc_bf16: bf16 tensors only")
     if not x.is_contiguous(memory_format=torch.channels_last) or not w.is_contiguous(memory_format=torch.channels_last):
@@ -89,7 +91,9 @@ def conv2d_nhwc_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or not residual.is_contiguous(memory_format=torch.channels_last)):
         raise RuntimeError("conv2d_nhwc_bf16: residual must match the output's shape, dtype and layout")
     C.check(C.lib().ssdnerf_conv2d_nhwc_bf16(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(residual), C.ptr(y), C.u32(B), C.u32(H), C.u32(W), C.u32(Cin), C.u32(Cout),
-                                              C.u32(k), C.u32(stride), C.u32(int(upsample)), C.ptr(gn_sums), C.u32(gn_groups), int(tile_hint), C.stream()),
+                                              C.u32(k), C.u32(stride), C.u32(int(upsample)), C.ptr(gn_sums), C.u32(gn_groups), int(tile_hint), C.ptr(splitk_ws),
+                                              ctypes.c_size_t(0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size()), int(splits_hint),
+                                              C.stream()),
             "conv2d_nhwc_bf16")
     return y
 
@@ -98,6 +102,7 @@ class _Conv:
     """A convolution split into its bias-less GEMM part (``mm``) and an fp32 bias that the *consumer* folds in: the following
     GroupNorm (``pre_bias``) or the residual epilogue -- the library convolution would spend a pass of its own on it."""
     __slots__ = ("w", "bias", "stride", "padding", "fold", "own")
+    SPLITK_BYTES = 16 << 20
 
     def __init__(self, conv: torch.nn.Conv2d, dtype):
         assert conv.groups == 1
@@ -111,8 +116,10 @@ class _Conv:
                         and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and tuple(conv.dilation) == (1, 1)
                         and C.lib().ssdnerf_conv2d_nhwc_bf16_supported(conv.in_channels, conv.out_channels, k[0], conv.stride[0], 0))
 
+    splitk_ws: Optional[torch.Tensor] = None        # shared all-zero fp32 scratch for the small layers' split-K (set by the executor)
+
     def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0):
-        return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups)
+        return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups, splitk_ws=_Conv.splitk_ws)
 
     def mm(self, x):
         return F.conv2d(x, self.w, None, self.stride, self.padding)
@@ -209,6 +216,8 @@ class FastUnet:
         self.out_ops = [seq(b) for b in net.out_blocks]
         self.head = (_GN(net.out.gn), _Conv(net.out.conv, dt))
         self.emb_w, self.emb_b = torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous()
+        if dt == torch.bfloat16 and self.device.type == "cuda" and _Conv.splitk_ws is None:
+            _Conv.splitk_ws = torch.zeros(_Conv.SPLITK_BYTES // 4, dtype=torch.float32, device=self.device)
         self._ws, self._ws_by_batch = None, {}
 
     # ------------------------------------------------------------------------------------------------ blocks
@@ -230,7 +239,11 @@ class FastUnet:
         if not conv.own:
             return False
         hw = x.size(2) * x.size(3) * (4 if upsample else 1) // (conv.stride[0] * conv.stride[1])
-        return hw % 128 == 0 and (conv.w.size(0) // gn.groups) % 4 == 0     # csrc/conv_igemm.hip: tile inside one sample, 4-channel half chunks
+        cout, cin, k = conv.w.size(0), conv.w.size(1), conv.w.size(2)
+        plan = C.lib().ssdnerf_conv2d_nhwc_bf16_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, int(_Conv.splitk_ws is not None), 0)
+        if plan >> 8 != 1:
+            return False                                                    # a split-K layer: its finishing pass does not carry statistics
+        return hw % 128 == 0 and (cout // gn.groups) % 4 == 0               # csrc/conv_igemm.hip: tile inside one sample, 4-channel half chunks
 
     def _res(self, x, stats, op, ss_all):
         _, gn1, conv1, gn2, (off, n), conv2, shortcut, out_bias = op

@@ -135,6 +135,9 @@ CONV_CASES = [
     (2, 32, 32, 384, 256, 3, 1, False, 0),     # the concat widths of the decoder half
     (8, 8, 8, 1024, 512, 3, 1, False, 0),
     (1, 64, 64, 128, 128, 3, 1, False, 1),
+    (1, 32, 32, 128, 128, 3, 1, False, 4),     # 256x128 tile, 8 waves
+    (3, 10, 10, 64, 256, 3, 1, False, 4),      # ... with a ragged last tile
+    (1, 16, 16, 128, 256, 3, 1, True, 4),
 ]
 
 
@@ -156,7 +159,7 @@ def test_conv_igemm_matches_fp32_reference(B, H, W, Cin, Cout, k, stride, upsamp
     assert ((got.float() - want).norm() / want.norm()).item() < 4e-3
 
 
-@pytest.mark.parametrize("C,hint,H", [(128, 1, 16), (256, 2, 8), (384 * 2, 3, 8), (512, 0, 32)])
+@pytest.mark.parametrize("C,hint,H", [(128, 1, 16), (256, 2, 8), (384 * 2, 3, 8), (512, 0, 32), (128, 4, 16), (256, 4, 32)])
 def test_conv_igemm_fused_groupnorm_statistics(C, hint, H):
     g = torch.Generator().manual_seed(C)
     B, G = 2, 32
@@ -173,6 +176,21 @@ def test_conv_igemm_fused_groupnorm_statistics(C, hint, H):
     out = unet_fast.group_norm_nhwc(y, G, gamma, beta, None, 1e-5, True, sums, stats_ready=True)
     want = F.silu(F.group_norm(y.float(), G, gamma, beta, 1e-5))
     assert (out.float() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,splits", [(8, 8, 512, 512, 3, 0), (2, 16, 1024, 512, 3, 5), (4, 8, 256, 512, 1, 2), (1, 5, 128, 64, 3, 3)])
+def test_conv_igemm_split_k(B, H, Cin, Cout, k, splits):
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn(B, Cin, H, H, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, Cout, H, H, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    ws = torch.zeros(B * H * H * Cout, dtype=torch.float32, device="cuda")
+    want = _conv_ref(x, w, bias, res, 1, False)
+    for _ in range(2):                                                        # second call: the workspace must have been left all zero
+        got = unet_fast.conv2d_nhwc_bf16(x, w, bias, res, splitk_ws=ws, splits_hint=splits)
+        assert ((got.float() - want).norm() / want.norm()).item() < 4e-3
+        assert ws.abs().max().item() == 0.0
 
 
 def test_conv_igemm_rejects_unsupported():

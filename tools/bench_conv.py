@@ -8,9 +8,10 @@ import torch.nn.functional as F
 from ssdnerf_amd import unet_fast
 
 ap = argparse.ArgumentParser(); ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--hints", default="0,1,2,3"); ap.add_argument("--no-lib", action="store_true")
+ap.add_argument("--hints", default="0,1,2,3,4"); ap.add_argument("--no-lib", action="store_true")
 a = ap.parse_args()
 B = a.scenes
+WS = torch.zeros(4 << 20, dtype=torch.float32, device="cuda")     # split-K scratch (all zero between calls)
 # (H, Cin, Cout, k, stride, upsample, count) -- the layer census of DenoisingUnetMod(base 128, mult [1,2,2,4,4], 2 blocks/level, 128x128)
 LAYERS = [
     (128, 128, 128, 3, 1, 0, 8), (128, 256, 128, 3, 1, 0, 2), (128, 256, 128, 1, 1, 0, 2), (128, 384, 128, 3, 1, 0, 1), (128, 384, 128, 1, 1, 0, 1),
@@ -53,8 +54,8 @@ for (H, Cin, Cout, k, stride, up, count) in LAYERS:
     best = None
     per_hint = {}
     for h in [int(v) for v in a.hints.split(",")]:
-        if h in (1, 2) and Cout % 128: continue
-        t = timeit(lambda: unet_fast.conv2d_nhwc_bf16(x, w, bias, None, stride, bool(up), tile_hint=h))
+        if h in (1, 2, 4) and Cout % 128: continue
+        t = timeit(lambda: unet_fast.conv2d_nhwc_bf16(x, w, bias, None, stride, bool(up), tile_hint=h, splitk_ws=WS))
         per_hint[h] = round(t, 1)
         if h != 0 and (best is None or t < best[1]): best = (h, t)
     t_own = per_hint.get(0, best[1] if best else float("nan"))
