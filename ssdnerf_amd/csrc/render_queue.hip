@@ -26,6 +26,7 @@
 
 static constexpr unsigned RQ_TPB = 256;
 static constexpr unsigned RQ_SLICE = 256;        // hit-queue entries per shading wave
+static constexpr unsigned RQ_COARSE_MAX_BYTES = 4096; // coarse occupancy ((H/2)^3 bits) staged in LDS by k_first_hit: H <= 64
 static constexpr unsigned RQ_HD_STRIDE = 68;     // floats per LDS row of the per-ray direction term (64 + 4 pad)
 
 struct FastMarch {
@@ -97,8 +98,43 @@ __global__ void k_bitfield_linearize(const uint8_t* __restrict__ morton_bits, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// Conservative coarse occupancy: one bit per block of 2^3 cells, set if ANY cell of the block dilated by RQ_COARSE_DILATE cells is
+// occupied.  k_first_hit walks it with points RQ_COARSE_STEP cells apart: if every point lands in a clear block, no cell within one
+// cell of the ray is occupied, so the exact march would test nothing but empty cells and need not run at all (see k_first_hit).
+static constexpr int RQ_COARSE_DILATE = 2;
+static constexpr float RQ_COARSE_STEP = 1.9f;     // in cells: every point of the ray is within 0.95 cell of a test point
+
+__global__ void __launch_bounds__(RQ_TPB) k_bitfield_coarsen(const uint8_t* __restrict__ lin_bits_all, uint32_t H, uint32_t log2H, uint32_t bytes_per_scene,
+                                                              uint8_t* __restrict__ coarse_all) {
+    const uint32_t Hc = H >> 1, log2Hc = log2H - 1;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;               // coarse cell, x fastest
+    const uint8_t* lin = lin_bits_all + (uint64_t)blockIdx.y * bytes_per_scene;
+    bool occ = false;
+    if (i < Hc * Hc * Hc) {
+        const int cx = (int)(i & (Hc - 1)), cy = (int)((i >> log2Hc) & (Hc - 1)), cz = (int)(i >> (2 * log2Hc));
+        const int x0 = max(2 * cx - RQ_COARSE_DILATE, 0), x1 = min(2 * cx + 1 + RQ_COARSE_DILATE, (int)H - 1);
+        for (int z = max(2 * cz - RQ_COARSE_DILATE, 0); z <= min(2 * cz + 1 + RQ_COARSE_DILATE, (int)H - 1); ++z)
+            for (int y = max(2 * cy - RQ_COARSE_DILATE, 0); y <= min(2 * cy + 1 + RQ_COARSE_DILATE, (int)H - 1); ++y)
+                for (int x = x0; x <= x1; ++x) {
+                    const uint32_t idx = ((((uint32_t)z << log2H) + (uint32_t)y) << log2H) + (uint32_t)x;
+                    occ |= (lin[idx >> 3] >> (idx & 7u)) & 1u;
+                }
+    }
+    const uint64_t word = __ballot(occ);                                     // 64 consecutive coarse cells = 8 bytes of the coarse bitfield
+    if ((threadIdx.x & 63) == 0 && i < Hc * Hc * Hc)
+        *reinterpret_cast<uint64_t*>(coarse_all + (uint64_t)blockIdx.y * (Hc * Hc * Hc / 8) + (i >> 3)) = word;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stage A: first occupied sample of every ray.
-__global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t* __restrict__ lin_bits, const float* __restrict__ rays_o,
+//
+// Empty-space pre-test (exact by construction): the reference's march only ever tests the cell that contains a point o + t d of the
+// ray (t in [near, far)), in fp32, i.e. a cell within one cell of the true segment.  Before marching, the lane samples the segment every
+// RQ_COARSE_STEP cells and looks each sample up in the dilated coarse bitfield; if all samples are clear, every cell the march could
+// test is empty, the ray has zero samples whatever its stepping sequence, and the background is written at once.  Otherwise the exact
+// march runs from `near` as before -- the pre-test never moves a ray along, so the stepping sequence of a marched ray is untouched.
+__global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t* __restrict__ lin_bits, const uint8_t* __restrict__ coarse_bits,
+                                                       const float* __restrict__ rays_o,
                                                        const float* __restrict__ rays_d, float* __restrict__ image, float* __restrict__ depth,
                                                        float* __restrict__ weights_sum, int32_t* __restrict__ sample_counts,
                                                        uint2* __restrict__ queue, uint32_t* __restrict__ queue_count) {
@@ -107,6 +143,15 @@ __global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t*
     const uint64_t gi = (uint64_t)scene * c.N + n;
     lin_bits += (uint64_t)scene * c.bitfield_stride;
     if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
+    // this scene's coarse bitfield -> LDS ((H/2)^3 bits; 4 KiB for H = 64)
+    __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
+    const uint32_t Hc = c.m.H >> 1, log2Hc = c.m.log2H - 1, coarse_bytes = (Hc * Hc * Hc) >> 3;
+    const bool use_coarse = coarse_bits != nullptr && coarse_bytes <= RQ_COARSE_MAX_BYTES && coarse_bytes % 16 == 0;
+    if (use_coarse) {
+        const uint4* src = reinterpret_cast<const uint4*>(coarse_bits + (uint64_t)scene * coarse_bytes);
+        for (uint32_t i = threadIdx.x; i < coarse_bytes / 16; i += RQ_TPB) reinterpret_cast<uint4*>(coarse_lds)[i] = src[i];
+        __syncthreads();
+    }
     bool hit = false;
     float t = 0.f;
     if (n < c.N) {
@@ -114,6 +159,22 @@ __global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t*
         float far_;
         ssd_near_far(c.aabb, r, c.min_near, t, far_);
         const float sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f), sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f), sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
+        if (use_coarse && t < far_) {
+            const float len = sqrtf(ssd_fma(r.dx, r.dx, ssd_fma(r.dy, r.dy, r.dz * r.dz)));
+            const float step_t = (RQ_COARSE_STEP * c.m.two_rH * c.m.mip_bound) / fmaxf(len, 1e-20f);   // RQ_COARSE_STEP cells of world length, in t
+            const float quarter_H = 0.5f * c.m.half_H, Hcm1 = (float)(Hc - 1);
+            bool any = false;
+            for (float tc = t; ; tc += step_t) {                             // test points from near to (at least) far
+                const float u = fminf(tc, far_);
+                const int bx = (int)ssd_clamp(ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f) * quarter_H, 0.0f, Hcm1);
+                const int by = (int)ssd_clamp(ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f) * quarter_H, 0.0f, Hcm1);
+                const int bz = (int)ssd_clamp(ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f) * quarter_H, 0.0f, Hcm1);
+                const uint32_t ci = ((((uint32_t)bz << log2Hc) + (uint32_t)by) << log2Hc) + (uint32_t)bx;
+                any |= (coarse_lds[ci >> 3] >> (ci & 7u)) & 1u;
+                if (any || !(tc < far_)) break;
+            }
+            if (!any) t = far_;                                              // nothing within a cell of this ray: skip the march
+        }
         while (t < far_) {
             const FastProbe p = rq_probe(c.m, lin_bits, r, t);
             if (p.occ) { hit = true; break; }
@@ -309,20 +370,26 @@ static int rq_make_cfg(QueueCfg& c, uint32_t Hp, uint32_t Wp, uint32_t grid_size
 }
 
 // workspace layout: [ S x u32 queue counters, S x u32 slice tickets (padded to 256 B) | S x H^3/8 linear bitfields | S x N x uint2 queue ]
+static size_t rq_coarse_bytes(uint32_t S, uint32_t grid_size) {
+    const size_t hc = grid_size / 2;
+    return ((size_t)S * (hc * hc * hc / 8) + 255) / 256 * 256;
+}
+
 extern "C" size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size) {
     const size_t counters = ((size_t)S * 8 + 255) / 256 * 256;
     const size_t bits = ((size_t)S * grid_size * grid_size * grid_size / 8 + 255) / 256 * 256;
-    return counters + bits + (size_t)S * N * sizeof(uint2);
+    return counters + bits + rq_coarse_bytes(S, grid_size) + (size_t)S * N * sizeof(uint2);
 }
 
-struct RqWorkspace { uint32_t* counters; uint8_t* lin_bits; uint2* queue; };
+struct RqWorkspace { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; };
 static RqWorkspace rq_carve(void* ws, uint32_t S, uint32_t grid_size) {
     RqWorkspace w;
     const size_t counters = ((size_t)S * 8 + 255) / 256 * 256;
     const size_t bits = ((size_t)S * grid_size * grid_size * grid_size / 8 + 255) / 256 * 256;
     w.counters = (uint32_t*)ws;
     w.lin_bits = (uint8_t*)ws + counters;
-    w.queue = (uint2*)((uint8_t*)ws + counters + bits);
+    w.coarse = (uint8_t*)ws + counters + bits;
+    w.queue = (uint2*)((uint8_t*)ws + counters + bits + rq_coarse_bytes(S, grid_size));
     return w;
 }
 
@@ -342,8 +409,12 @@ extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_s
     const RqWorkspace w = rq_carve(workspace, S, grid_size);
     hipMemsetAsync(w.counters, 0, (size_t)S * 8, s);   // hit counts + the shading kernel's slice tickets
     hipLaunchKernelGGL(k_bitfield_linearize, dim3(ssd_blocks(c.bitfield_stride, RQ_TPB), S), dim3(RQ_TPB), 0, s, bitfield, grid_size, c.m.log2H, c.bitfield_stride, w.lin_bits);
-    hipLaunchKernelGGL(k_first_hit, dim3(ssd_blocks(N, RQ_TPB), S), dim3(RQ_TPB), 0, s, c, w.lin_bits, rays_o, rays_d, image, depth, weights_sum, sample_counts,
-                       w.queue, w.counters);
+    const uint32_t hc = grid_size / 2;
+    const bool coarse_ok = grid_size >= 16 && (hc * hc * hc / 8) <= RQ_COARSE_MAX_BYTES && bound <= 1.0f && getenv("SSDNERF_NO_COARSE") == nullptr;
+    if (coarse_ok)
+        hipLaunchKernelGGL(k_bitfield_coarsen, dim3(ssd_blocks(hc * hc * hc, RQ_TPB), S), dim3(RQ_TPB), 0, s, w.lin_bits, grid_size, c.m.log2H, c.bitfield_stride, w.coarse);
+    hipLaunchKernelGGL(k_first_hit, dim3(ssd_blocks(N, RQ_TPB), S), dim3(RQ_TPB), 0, s, c, w.lin_bits, coarse_ok ? w.coarse : (const uint8_t*)nullptr, rays_o, rays_d, image,
+                       depth, weights_sum, sample_counts, w.queue, w.counters);
     SSD_CHECK_LAUNCH("render_first_hit");
     return SSDNERF_OK;
 }

@@ -519,7 +519,8 @@ extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dt
     const size_t bits = ((size_t)S * c.bitfield_stride + 255) / 256 * 256;
     uint32_t* q_count = (uint32_t*)workspace;
     const uint8_t* lin_bits = (const uint8_t*)workspace + counters;
-    const uint2* queue = (const uint2*)((const uint8_t*)workspace + counters + bits);
+    const size_t hc = grid_size / 2, coarse = ((size_t)S * (hc * hc * hc / 8) + 255) / 256 * 256;   // k_first_hit's coarse occupancy
+    const uint2* queue = (const uint2*)((const uint8_t*)workspace + counters + bits + coarse);
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;

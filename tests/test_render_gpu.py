@@ -248,3 +248,17 @@ def test_density_grid_update_matches_oracle(scene, decoder):
         flips = int(np.unpackbits(bits1[0].cpu().numpy() ^ b0).sum())
         assert flips <= 4, flips                                  # cells within float noise of the threshold
         assert abs(float(th1) - th0) <= 1e-6 + 1e-3 * th0
+
+
+@pytest.mark.parametrize("view,dt_gamma", [(64, 0.0), (17, 0.0038095), (230, 0.0)])
+def test_coarse_empty_space_pretest_changes_nothing(scene, decoder, view, dt_gamma, monkeypatch):
+    """k_first_hit's conservative coarse-occupancy pre-test only removes marches that cannot find a sample: every output, including the
+    per-ray sample counts, is bit-identical with the pre-test switched off (SSDNERF_NO_COARSE=1)."""
+    ro, rd = _view(view)
+    with_pretest = _render_gpu(decoder, scene, ro, rd, "fused", dt_gamma)
+    monkeypatch.setenv("SSDNERF_NO_COARSE", "1")
+    without = _render_gpu(decoder, scene, ro, rd, "fused", dt_gamma)
+    monkeypatch.delenv("SSDNERF_NO_COARSE")
+    assert (without[3] == 0).sum() > 1000 and (without[3] > 0).sum() > 1000          # both kinds of rays are present
+    for a, b in zip(with_pretest, without):
+        assert np.array_equal(np.asarray(a).view(np.uint32) if np.asarray(a).dtype == np.float32 else np.asarray(a), np.asarray(b).view(np.uint32) if np.asarray(b).dtype == np.float32 else np.asarray(b))
