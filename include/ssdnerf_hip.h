@@ -248,6 +248,12 @@ int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, co
                              uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint, void* splitk_ws,
                              size_t splitk_ws_bytes, int splits_hint, void* stream);
 
+/* Self-attention of MultiHeadAttentionMod (modules.py:12-48; mmgen QKVAttention) over the qkv projection of a channel-last
+ * activation: qkv bf16 [B][T][3*heads*ch] with the reference's channel order [head][q | k | v][ch], out bf16 [B][T][heads*ch]
+ * (channel = head*ch + i):  out = softmax(q k^T / sqrt(ch)) v  per (sample, head), softmax statistics and accumulation in fp32,
+ * probabilities rounded to bf16 before the PV product (as the reference's `.type(weight.dtype)`).  ch in {64, 128}, T % 32 == 0. */
+int ssdnerf_attention_qkv_bf16(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -407,7 +407,7 @@ extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_s
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const RqWorkspace w = rq_carve(workspace, S, grid_size);
-    hipMemsetAsync(w.counters, 0, (size_t)S * 8, s);   // hit counts + the shading kernel's slice tickets
+    if (hipMemsetAsync(w.counters, 0, (size_t)S * 8, s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "render_first_hit: memset failed");   // hit counts + slice tickets
     hipLaunchKernelGGL(k_bitfield_linearize, dim3(ssd_blocks(c.bitfield_stride, RQ_TPB), S), dim3(RQ_TPB), 0, s, bitfield, grid_size, c.m.log2H, c.bitfield_stride, w.lin_bits);
     const uint32_t hc = grid_size / 2;
     const bool coarse_ok = grid_size >= 16 && (hc * hc * hc / 8) <= RQ_COARSE_MAX_BYTES && bound <= 1.0f && getenv("SSDNERF_NO_COARSE") == nullptr;

@@ -98,6 +98,18 @@ def conv2d_nhwc_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def attention_qkv_bf16(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """Hand-written MFMA flash attention (csrc/attention.hip).  ``qkv`` (B, T, 3C) bf16 contiguous, per-head channel order [q | k | v];
+    returns (B, T, C) bf16."""
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous():
+        raise RuntimeError("attention_qkv_bf16: contiguous bf16 input only")
+    out = torch.empty((B, T, Cc), dtype=torch.bfloat16, device=qkv.device)
+    C.check(C.lib().ssdnerf_attention_qkv_bf16(C.ptr(qkv), C.ptr(out), C.u32(B), C.u32(T), C.u32(heads), C.u32(Cc // heads), C.stream()), "attention_qkv_bf16")
+    return out
+
+
 class _Conv:
     """A convolution split into its bias-less GEMM part (``mm``) and an fp32 bias that the *consumer* folds in: the following
     GroupNorm (``pre_bias``) or the residual epilogue -- the library convolution would spend a pass of its own on it."""
@@ -266,9 +278,12 @@ class FastUnet:
         T, ch = H * W, Cc // heads
         xt = x.permute(0, 2, 3, 1).reshape(B, T, Cc)                       # a view: channels_last storage is already [B][T][C]
         qkv = F.linear(self._gn(xt, gn, None, False, stats=stats), wqkv, bqkv)           # (B, T, 3C), channel = head*3ch + {q,k,v}*ch + i
-        q, k, v = qkv.view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)       # each (B, heads, T, ch)
-        h = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch))
-        h = F.linear(h.permute(0, 2, 1, 3).reshape(B, T, Cc), wproj, bproj).add_(xt)
+        if qkv.dtype == torch.bfloat16 and qkv.is_cuda and ch in (64, 128) and T % 32 == 0:
+            a = attention_qkv_bf16(qkv, heads)                                # hand-written MFMA flash attention, (B, T, C)
+        else:
+            q, k, v = qkv.view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)   # each (B, heads, T, ch)
+            a = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(B, T, Cc)
+        h = F.linear(a, wproj, bproj).add_(xt)
         return h.view(B, H, W, Cc).permute(0, 3, 1, 2)                      # back to a channels_last (B, C, H, W) view
 
     def _run(self, ops, h, ss_all, stats=None):

@@ -198,3 +198,32 @@ def test_conv_igemm_rejects_unsupported():
     w = torch.randn(64, 18, 3, 3).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
     with pytest.raises(RuntimeError):
         unet_fast.conv2d_nhwc_bf16(x, w)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 1024, 4, 64), (3, 256, 4, 128), (2, 64, 4, 128), (1, 96, 2, 64), (1, 160, 1, 128)])
+def test_attention_kernel_matches_fp32_reference(B, T, heads, ch):
+    g = torch.Generator().manual_seed(T + ch)
+    C = heads * ch
+    qkv = (torch.randn(B, T, 3 * C, generator=g) * 1.3).cuda().bfloat16()
+    got = unet_fast.attention_qkv_bf16(qkv, heads).float()
+    q, k, v = qkv.float().view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)            # (B, heads, T, ch), reference channel order [head][q|k|v][ch]
+    w = torch.softmax(q @ k.transpose(-1, -2) / ch ** 0.5, dim=-1)
+    want = (w @ v).permute(0, 2, 1, 3).reshape(B, T, C)
+    err = (got - want).abs().max().item()
+    assert err <= 2e-2 * max(1.0, want.abs().max().item()), err                       # bf16 probabilities + bf16 output rounding
+    assert ((got - want).norm() / want.norm()).item() < 6e-3
+
+
+def test_attention_kernel_peaked_softmax():
+    """Large logits: the online max/rescale path (rows whose max moves from key block to key block)."""
+    g = torch.Generator().manual_seed(7)
+    B, T, heads, ch = 1, 256, 2, 64
+    qkv = torch.randn(B, T, 3 * heads * ch, generator=g).cuda()
+    qkv[..., :ch] *= 6.0                                                               # head 0 queries: sharp attention
+    qkv = qkv.bfloat16()
+    got = unet_fast.attention_qkv_bf16(qkv, heads).float()
+    q, k, v = qkv.float().view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)
+    want = (torch.softmax(q @ k.transpose(-1, -2) / ch ** 0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, T, heads * ch)
+    assert torch.isfinite(got).all()
+    assert ((got - want).norm() / want.norm()).item() < 8e-3
