@@ -203,6 +203,12 @@ int ssdnerf_packbits_dev_thresh(const void* grid, int grid_dtype, uint32_t N, co
 int ssdnerf_ddim_step_v(const float* x_t, const float* v, uint64_t n, float sqrt_ab, float sqrt_1mab, float sqrt_ab_prev,
                         float dir_coef, float clip_lo, float clip_hi, float* x0_out, float* xprev_out, void* stream);
 
+/* Camera rays of n_views pinhole views (get_cam_rays, lib/core/utils/nerf_utils.py:17-61): c2w [n_views][4][4] row-major,
+ * intrinsics [n_views][4] = {fx, fy, cx, cy}; rays_o, rays_d [n_views][h][w][3]: pixel-centre (x + 0.5) directions rotated by
+ * c2w[:3,:3] and L2-normalised, origins c2w[:3,3] broadcast. */
+int ssdnerf_cam_rays(const float* c2w, const float* intrinsics, uint32_t n_views, uint32_t h, uint32_t w, float* rays_o,
+                     float* rays_d, void* stream);
+
 /* ---- Part 3: denoising-UNet glue (lib/models/architecture/ddpm/modules.py:12-129, denoising.py:178-187) ------------------
  * Activations are channel-last: x, y are [B][HW][C] of dtype 0 = fp32, 1 = fp16, 2 = bf16.
  *

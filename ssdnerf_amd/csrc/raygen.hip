@@ -1,0 +1,42 @@
+// ssdnerf_amd/csrc/raygen.hip -- camera rays for whole batches of views (reference: get_ray_directions / get_rays / get_cam_rays,
+// lib/core/utils/nerf_utils.py:17-38,41-54,57-61).
+//
+// The reference builds the ray arrays with ~10 eager tensor ops (linspace, broadcasted subtract/divide, stack, batched matmul,
+// normalise, expand) that each stream the (S,V,H,W,3) arrays through HBM; for the bench's 8 x 251 views that chain takes ~220 ms
+// on an MI355X, 17x the render it feeds.  Here it is one pass: a lane owns a pixel, the view's pose and intrinsics are wave-uniform
+// scalar loads, 24 bytes are written per ray.
+//     d_cam = ((x + 0.5 - cx) / fx, (y + 0.5 - cy) / fy, 1)      pixel-centre pinhole direction (IEEE divisions, as the reference)
+//     d     = R d_cam,  rays_d = d / max(|d|, 1e-12)              rotate by c2w[:3,:3], L2-normalise (F.normalize's eps)
+//     rays_o = c2w[:3, 3]
+// HBM-bound: 24 B written per ray.
+#include "common.h"
+
+__global__ void __launch_bounds__(256) k_cam_rays(const float* __restrict__ c2w, const float* __restrict__ intrinsics, uint32_t h, uint32_t w,
+                                                   float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const uint32_t view = blockIdx.y, hw = h * w;
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= hw) return;
+    const float* M = c2w + (size_t)view * 16;
+    const float* K = intrinsics + (size_t)view * 4;
+    const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const float px = (float)(pix % w) + 0.5f, py = (float)(pix / w) + 0.5f;
+    const float dx = (px - cx) / fx, dy = (py - cy) / fy;
+    // rays_d = d_cam @ R^T: component k = dx R[k][0] + dy R[k][1] + R[k][2]
+    const float vx = ssd_fma(dx, M[0], ssd_fma(dy, M[1], M[2]));
+    const float vy = ssd_fma(dx, M[4], ssd_fma(dy, M[5], M[6]));
+    const float vz = ssd_fma(dx, M[8], ssd_fma(dy, M[9], M[10]));
+    const float inv = 1.0f / fmaxf(sqrtf(ssd_fma(vx, vx, ssd_fma(vy, vy, vz * vz))), 1e-12f);
+    const size_t o = ((size_t)view * hw + pix) * 3;
+    rays_d[o + 0] = vx * inv; rays_d[o + 1] = vy * inv; rays_d[o + 2] = vz * inv;
+    rays_o[o + 0] = M[3]; rays_o[o + 1] = M[7]; rays_o[o + 2] = M[11];
+}
+
+extern "C" int ssdnerf_cam_rays(const float* c2w, const float* intrinsics, uint32_t n_views, uint32_t h, uint32_t w, float* rays_o, float* rays_d,
+                                void* stream) {
+    if (n_views == 0 || h == 0 || w == 0) return SSDNERF_OK;
+    SSD_REQUIRE(c2w && intrinsics && rays_o && rays_d, "cam_rays: null pointer");
+    SSD_REQUIRE(n_views <= 65535, "cam_rays: at most 65535 views per launch");
+    hipLaunchKernelGGL(k_cam_rays, dim3(ssd_blocks((uint64_t)h * w, 256), n_views), dim3(256), 0, (hipStream_t)stream, c2w, intrinsics, h, w, rays_o, rays_d);
+    SSD_CHECK_LAUNCH("cam_rays");
+    return SSDNERF_OK;
+}

@@ -262,3 +262,21 @@ def test_coarse_empty_space_pretest_changes_nothing(scene, decoder, view, dt_gam
     assert (without[3] == 0).sum() > 1000 and (without[3] > 0).sum() > 1000          # both kinds of rays are present
     for a, b in zip(with_pretest, without):
         assert np.array_equal(np.asarray(a).view(np.uint32) if np.asarray(a).dtype == np.float32 else np.asarray(a), np.asarray(b).view(np.uint32) if np.asarray(b).dtype == np.float32 else np.asarray(b))
+
+
+def test_cam_rays_kernel_matches_tensor_op_form():
+    """ssdnerf_cam_rays (one HIP pass) against the reference-shaped tensor ops on the CPU, and against the golden fixture the reference's own
+    get_cam_rays produced (tests/golden/cam_rays_64.npz)."""
+    import os
+    from ssdnerf_amd import nerf, synthetic as S
+    poses = S.spiral_poses(7)[None].expand(2, -1, -1, -1).contiguous()
+    intr = S.cars_intrinsics(48, 40)[None, None].expand(2, 7, -1).contiguous()
+    o_cpu, d_cpu = nerf.get_cam_rays(poses, intr, 40, 48)
+    o_gpu, d_gpu = nerf.get_cam_rays(poses.cuda(), intr.cuda(), 40, 48)
+    assert o_gpu.shape == (2, 7, 40, 48, 3)
+    assert torch.equal(o_gpu.cpu(), o_cpu.contiguous())
+    assert (d_gpu.cpu() - d_cpu).abs().max().item() <= 3e-7                          # a few ulp: summation order / FMA of the 3x3 rotation
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "cam_rays_64.npz"))
+    ro, rd = nerf.get_cam_rays(torch.from_numpy(f["pose"]).cuda(), torch.from_numpy(f["intrinsics"]).cuda(), 64, 64)     # 1 scene, 1 view, 64x64
+    assert np.abs(rd.cpu().numpy().reshape(f["rays_d"].shape) - f["rays_d"]).max() <= 3e-7
+    assert np.array_equal(ro.cpu().numpy().reshape(f["rays_o"].shape), f["rays_o"])
