@@ -212,7 +212,9 @@ int ssdnerf_cam_rays(const float* c2w, const float* intrinsics, uint32_t n_views
 /* ---- Part 3: denoising-UNet glue (lib/models/architecture/ddpm/modules.py:12-129, denoising.py:178-187) ------------------
  * Activations are channel-last: x, y are [B][HW][C] of dtype 0 = fp32, 1 = fp16, 2 = bf16.
  *
- * y = act( GroupNorm_G(x + pre_bias) * gamma + beta  [ * (1 + scale[b]) + shift[b] ] ),  act = 0 none / 1 SiLU.
+ * y = act( GroupNorm_G(X + pre_bias) * gamma + beta  [ * (1 + scale[b]) + shift[b] ] ),  act = 0 none / 1 SiLU,
+ * where X = x, or -- with x2 != NULL -- the channel concatenation [x (C1 channels) | x2 (C - C1 channels)] of two tensors, which
+ * is never materialised (the decoder half's `torch.cat([h, skip], dim=1)`, denoising.py:209-213).
  * pre_bias (nullable, fp32 [C]) is the bias of the convolution that produced x, folded in here so the producer needs no
  * pass of its own.  scale_shift (nullable) is the NormWithEmbedding projection of the time embedding, fp32, row b at
  * scale_shift + b * scale_shift_stride holding [scale[C] | shift[C]] (use_scale_shift_norm=True, modules.py:97-104);
@@ -222,35 +224,38 @@ int ssdnerf_cam_rays(const float* c2w, const float* intrinsics, uint32_t n_views
  * one arena once); 2 = already holds the statistics of x (written by ssdnerf_conv2d_nhwc_bf16's gn_sums),
  * only the normalisation pass runs (pre_bias must be NULL).  y may alias x. */
 size_t ssdnerf_group_norm_workspace(uint32_t B, uint32_t G);
-int ssdnerf_group_norm_nhwc(const void* x, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* pre_bias,
+int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C1, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* pre_bias,
                             const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride,
                             float eps, int act, void* workspace, int workspace_state, void* y, void* stream);
 
-/* y = x + bias[c] + residual over [rows][C] channel-last data (bias fp32 [C] nullable, residual nullable, y may alias x):
- * the epilogue of a bias-less convolution -- conv_2 of a residual block plus its skip connection (modules.py:51-110). */
-int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint64_t rows, uint32_t C, const float* bias, const void* residual,
-                               void* y, void* stream);
+/* y = x + bias[c] + residual over [B][HW][C] channel-last data (bias fp32 [C] nullable, residual nullable, y may alias x):
+ * the epilogue of a bias-less convolution (modules.py:51-110) or the `h + x` closing an attention block (modules.py:47).
+ * gn_sums (nullable, fp64 [B][gn_groups][2], pre-zeroed) receives the GroupNorm sums of y for the norm that follows. */
+int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint32_t B, uint32_t HW, uint32_t C, const float* bias,
+                               const void* residual, void* y, void* gn_sums, uint32_t gn_groups, void* stream);
 
 /* The UNet's convolutions (modules.py:51-129; denoising.py:106-187) as an implicit GEMM on the bf16 matrix cores:
  *   y[b][yo][xo][co] = sum_{kh,kw,ci} X[b][yo*stride+kh-pad][xo*stride+kw-pad][ci] * w[co][kh][kw][ci]  (+ bias[co]) (+ residual[b][yo][xo][co])
- * x bf16 [B][H][W][Cin] channel-last; w bf16 [Cout][ksize][ksize][Cin] (= torch channels_last weight memory); pad = ksize/2;
+ * x bf16 [B][H][W][Cin] channel-last -- or, with x2 != NULL, the never-materialised channel concatenation of x [..][Cin1] and
+ * x2 [..][Cin - Cin1] (Cin1 % 64 == 0); w bf16 [Cout][ksize][ksize][Cin] (= torch channels_last weight memory); pad = ksize/2;
  * X = x, or with upsample != 0 the nearest-neighbour 2x upsampling of x, never materialised (DenoisingUpsampleMod);
  * stride 2 = DenoisingDownsampleMod.  bias fp32 [Cout] (nullable), residual / y bf16 [B][Ho][Wo][Cout] (residual nullable,
  * may alias y).  fp32 accumulation; bias and residual are added in fp32 before the single rounding to bf16.
  * gn_sums (nullable): fp64 [B][gn_groups][2], pre-zeroed by the caller; receives sum and sum of squares of the rounded output
  * per (sample, channel group) -- the statistics pass of the GroupNorm that follows (ssdnerf_group_norm_nhwc, workspace_state 2).
- * Needs (Cout / gn_groups) % 4 == 0 and Ho*Wo a multiple of the M tile (256 / 128 / 64).
+ * Needs (Cout / gn_groups) % 4 == 0 and, for layers that are not cut along K, Ho*Wo a multiple of the M tile (256 / 128 / 64).
  * tile_hint: 0 = choose by problem size, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 block tile.
  * splitk_ws (nullable): fp32 scratch of splitk_ws_bytes >= B*Ho*Wo*Cout*4 that is ALL ZERO on entry and is left all zero on
- * return; when given (and gn_sums is NULL) layers with too few output tiles to fill the chip are cut along K (splits_hint: 0 =
+ * return; when given, layers with too few output tiles to fill the chip are cut along K (splits_hint: 0 =
  * choose, n = force n ranges) and reduced through it.
  * ssdnerf_conv2d_nhwc_bf16_supported() tells whether a layer fits (Cin % 64 == 0, Cout % 64 == 0, ksize 1|3, stride 1|2). */
 int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample);
 /* The decomposition ssdnerf_conv2d_nhwc_bf16 will use for M = B*Ho*Wo output pixels: tile choice (1..3) | splits << 8. */
 int ssdnerf_conv2d_nhwc_bf16_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int may_split,
                                   int splits_hint);
-int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual, void* y, uint32_t B,
-                             uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride,
+int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t Cin1, const void* w, const float* bias,
+                             const void* residual, void* y, uint32_t B, uint32_t H, uint32_t W, uint32_t Cin,
+                             uint32_t Cout, uint32_t ksize, uint32_t stride,
                              uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint, void* splitk_ws,
                              size_t splitk_ws_bytes, int splits_hint, void* stream);
 

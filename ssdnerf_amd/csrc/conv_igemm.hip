@@ -37,7 +37,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __attribute__((aligned(16))) const uint32_t g_conv_zero_page[4] = {0, 0, 0, 0};
 
 struct ConvArgs {
-    const unsigned char* x;      // bf16 [B][H][W][Cin]
+    const unsigned char* x;      // bf16 [B][H][W][Cin1]   (Cin1 = Cin unless x2 is given)
+    const unsigned char* x2;     // bf16 [B][H][W][Cin - Cin1] or null: the input is the never-materialised concatenation [x | x2]
+    uint32_t Cin1;
     const unsigned char* w;      // bf16 [Cout][taps][Cin]
     const float* bias;           // fp32 [Cout] or null
     const unsigned char* res;    // bf16 [M][Cout] or null
@@ -122,8 +124,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
         b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
     }
 
-    uint64_t a_src[A_INST];                                                  // per-tap source of each A row (or the zero page)
+    uint64_t a_src[A_INST], a_src2[A_INST];                                  // per-tap source of each A row in x / x2 (or the zero page)
     bool a_zero[A_INST];
+    const uint32_t Cin2 = a.Cin - a.Cin1;
     auto set_tap = [&](uint32_t tap) {
         const int32_t kh = (int32_t)(tap / a.ksize), kw = (int32_t)(tap % a.ksize);
 #pragma unroll
@@ -131,18 +134,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
             const int32_t yv = a_y0[i] + kh, xv = a_x0[i] + kw;
             const bool ok = a_ok[i] && yv >= 0 && xv >= 0 && yv < (int32_t)Hv && xv < (int32_t)Wv;
             const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
-            const uint64_t off = ((uint64_t)(a_img[i] + yi * a.W + xi) * a.Cin) * 2 + a_chunk[i];
+            const uint64_t pix = (uint64_t)(a_img[i] + yi * a.W + xi);
             a_zero[i] = !ok;
-            a_src[i] = ok ? (uint64_t)a.x + off : (uint64_t)g_conv_zero_page;
+            a_src[i] = ok ? (uint64_t)a.x + pix * a.Cin1 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
+            a_src2[i] = (ok && a.x2) ? (uint64_t)a.x2 + pix * Cin2 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
         }
     };
 
     auto issue = [&](uint32_t tap, uint32_t ci0, uint32_t buf) {
         unsigned char* sa = lds + buf * STAGE;
         unsigned char* sb = sa + BM * CV_ROWB;
+        const bool second = ci0 >= a.Cin1;                                   // K-tiles never straddle the two tensors (Cin1 % 64 == 0)
+        const uint64_t coff = (uint64_t)(second ? ci0 - a.Cin1 : ci0) * 2;
 #pragma unroll
         for (int i = 0; i < A_INST; ++i)
-            cv_glds16((const void*)(a_src[i] + (a_zero[i] ? 0 : (uint64_t)ci0 * 2)), sa + (wave * A_INST + i) * 1024);
+            cv_glds16((const void*)((second ? a_src2[i] : a_src[i]) + (a_zero[i] ? 0 : coff)), sa + (wave * A_INST + i) * 1024);
 #pragma unroll
         for (int i = 0; i < B_INST; ++i)
             cv_glds16(a.w + b_off[i] + (uint64_t)(tap * a.Cin + ci0) * 2, sb + (wave * B_INST + i) * 1024);
@@ -277,39 +283,74 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
 #pragma unroll
         for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
         __syncthreads();
-        if (tid < CPR * 2 && m0 < a.M) {
-            const uint32_t cpg = a.Cout / a.G, b = m0 / (a.Ho * a.Wo), g = (n0 + tid * 4) / cpg;
-            double* dst = a.gn_sums + ((size_t)b * a.G + g) * 2;
-            atomicAdd(dst, (double)red[tid * 2]);
-            atomicAdd(dst + 1, (double)red[tid * 2 + 1]);
+        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;   // groups this tile touches (BN and cpg are multiples of 4)
+        if (tid < ng && m0 < a.M) {
+            // half chunks of group g0 + tid inside this tile: global half-chunk index range [g*hpg, (g+1)*hpg) minus the tile's first, n0/4
+            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
+            float ss = 0.f, qq = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
+            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
+            atomicAdd(dst, (double)ss);
+            atomicAdd(dst + 1, (double)qq);
         }
     }
 }
 
-// y = bf16(ws + bias + residual), and ws goes back to zero for the next split-K convolution.
+// y = bf16(ws + bias + residual), ws goes back to zero for the next split-K convolution, and (optionally) the GroupNorm sums of y are
+// accumulated for the norm that follows.  grid (row slabs, B); 256 threads = (256 / cpr) rows x cpr 8-channel chunks.
 __global__ __launch_bounds__(256) void k_conv_splitk_finish(float* __restrict__ ws, const float* __restrict__ bias, const unsigned char* __restrict__ res,
-                                                            unsigned char* __restrict__ y, uint64_t n_chunks, uint32_t cpr) {
-    const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= n_chunks) return;
-    float4* p = reinterpret_cast<float4*>(ws + q * 8);
-    const float4 v0 = p[0], v1 = p[1];
-    p[0] = make_float4(0.f, 0.f, 0.f, 0.f); p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    const uint32_t co = (uint32_t)(q % cpr) * 8;
-    if (bias) {
+                                                            unsigned char* __restrict__ y, uint32_t HW, uint32_t cpr, uint32_t rows_per_block,
+                                                            double* __restrict__ gn_sums, uint32_t G) {
+    __shared__ float red[512];                                               // [cpr][2 halves][sum, sumsq], cpr <= 64... sized for Cout <= 1024
+    const uint32_t tid = threadIdx.x, cc = tid % cpr, rstep = 256 / cpr, b = blockIdx.y;      // threads past rstep * cpr idle (cpr not a divisor of 256)
+    const uint32_t Cout = cpr * 8, co = cc * 8;
+    if (gn_sums) { for (uint32_t i = tid; i < cpr * 4; i += 256) red[i] = 0.f; __syncthreads(); }
+    float bv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] += bias[co + k];
+    for (int k = 0; k < 8; ++k) bv[k] = bias ? bias[co + k] : 0.f;
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
+    const uint32_t row_end = (tid / cpr < rstep) ? min((blockIdx.x + 1) * rows_per_block, HW) : 0u;
+    for (uint32_t row = blockIdx.x * rows_per_block + tid / cpr; row < row_end; row += rstep) {
+        const size_t q = ((size_t)b * HW + row) * cpr + cc;
+        float4* p = reinterpret_cast<float4*>(ws + q * 8);
+        const float4 v0 = p[0], v1 = p[1];
+        p[0] = make_float4(0.f, 0.f, 0.f, 0.f); p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += bv[k];
+        if (res) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(res + q * 16);
+            const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { f[2 * k] += __uint_as_float(rw[k] << 16); f[2 * k + 1] += __uint_as_float(rw[k] & 0xffff0000u); }
+        }
+        uint32_t pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
+        *reinterpret_cast<uint4*>(y + q * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        if (gn_sums) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(pk[k] << 16), hi = __uint_as_float(pk[k] & 0xffff0000u);
+                gs[k >> 1] += lo + hi;
+                gq[k >> 1] = __builtin_fmaf(lo, lo, gq[k >> 1]);
+                gq[k >> 1] = __builtin_fmaf(hi, hi, gq[k >> 1]);
+            }
+        }
     }
-    if (res) {
-        const uint4 rv = *reinterpret_cast<const uint4*>(res + q * 16);
-        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    if (gn_sums) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { f[2 * k] += __uint_as_float(rw[k] << 16); f[2 * k + 1] += __uint_as_float(rw[k] & 0xffff0000u); }
+        for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
+        __syncthreads();
+        const uint32_t hpg = (Cout / G) / 4;                                 // 4-channel half chunks per group: one pair of atomics per group and block
+        for (uint32_t g = tid; g < G; g += 256) {
+            float ss = 0.f, qq = 0.f;
+            for (uint32_t i = g * hpg; i < (g + 1) * hpg; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
+            double* dst = gn_sums + ((size_t)b * G + g) * 2;
+            atomicAdd(dst, (double)ss);
+            atomicAdd(dst + 1, (double)qq);
+        }
     }
-    uint32_t pk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
-    *reinterpret_cast<uint4*>(y + q * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
 
 template <int TM, int TN, int WM, int WN, int NS>
@@ -361,8 +402,8 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, u
     return (Cin % 64 == 0) && (Cout % 64 == 0) && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && !(upsample && stride != 1);
 }
 
-extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual, void* y, uint32_t B, uint32_t H, uint32_t W,
-                                        uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample, void* gn_sums, uint32_t gn_groups,
+extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t Cin1, const void* w, const float* bias, const void* residual, void* y, uint32_t B,
+                                        uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample, void* gn_sums, uint32_t gn_groups,
                                         int tile_hint, void* splitk_ws, size_t splitk_ws_bytes, int splits_hint, void* stream) {
     if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
     SSD_REQUIRE(x && w && y, "conv2d_nhwc_bf16: null pointer");
@@ -370,7 +411,10 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const floa
                 "conv2d_nhwc_bf16: needs Cin %% 64 == 0, Cout %% 64 == 0, ksize 1|3, stride 1|2 (no stride with upsample)");
     SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0),
                 "conv2d_nhwc_bf16: fused GroupNorm statistics need groups of a multiple of 4 channels");
+    if (!x2) Cin1 = Cin;
+    SSD_REQUIRE(Cin1 <= Cin && Cin1 % 64 == 0 && (x2 || Cin1 == Cin), "conv2d_nhwc_bf16: the first input's channel count must be a multiple of 64 and <= Cin");
     ConvArgs a;
+    a.x2 = (const unsigned char*)x2; a.Cin1 = Cin1;
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
     a.gn_sums = (double*)gn_sums; a.G = gn_groups ? gn_groups : 1;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -381,15 +425,19 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* w, const floa
     SSD_REQUIRE((uint64_t)B * a.Ho * a.Wo < (1ull << 31) && (uint64_t)B * H * W * Cin * 2 < (1ull << 40), "conv2d_nhwc_bf16: tensor too large");
     a.M = B * a.Ho * a.Wo;
     int choice; uint32_t splits;
-    cv_plan(a.M, Cin, Cout, ksize, tile_hint, splitk_ws && !gn_sums && splitk_ws_bytes >= (size_t)a.M * Cout * 4, splits_hint, &choice, &splits);
+    cv_plan(a.M, Cin, Cout, ksize, tile_hint, splitk_ws && splitk_ws_bytes >= (size_t)a.M * Cout * 4 && Cout <= 1024, splits_hint, &choice, &splits);
     if (choice != 3) SSD_REQUIRE(Cout % 128 == 0, "conv2d_nhwc_bf16: 128-wide tiles need Cout %% 128 == 0");
-    SSD_REQUIRE(!gn_sums || (a.Ho * a.Wo) % (choice == 4 ? 256 : choice == 1 ? 128 : 64) == 0, "conv2d_nhwc_bf16: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
+    SSD_REQUIRE(!gn_sums || splits > 1 || (a.Ho * a.Wo) % (choice == 4 ? 256 : choice == 1 ? 128 : 64) == 0, "conv2d_nhwc_bf16: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
     a.splits = splits; a.splitk_ws = (float*)splitk_ws;
+    double* stats = a.gn_sums;
+    if (splits > 1) a.gn_sums = nullptr;                                     // a split layer's statistics are taken by the finishing pass
     hipStream_t st = (hipStream_t)stream;
     if (choice == 4) cv_launch<2, 2, 4, 2, 3>(a, st); else if (choice == 1) cv_launch<2, 2, 2, 2, 2>(a, st); else if (choice == 2) cv_launch<1, 2, 2, 2, 3>(a, st); else cv_launch<1, 1, 2, 2, 4>(a, st);
     if (splits > 1) {
-        const uint64_t n_chunks = (uint64_t)a.M * (Cout / 8);
-        hipLaunchKernelGGL(k_conv_splitk_finish, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, a.splitk_ws, bias, a.res, a.y, n_chunks, Cout / 8);
+        const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
+        uint32_t rows = HWo;                                                 // rows per block: >= one pass of the rows in flight, ~1024 blocks
+        while (rows > rstep && rows % 2 == 0 && (uint64_t)B * (HWo / rows) < 1024) rows /= 2;
+        hipLaunchKernelGGL(k_conv_splitk_finish, dim3((HWo + rows - 1) / rows, B), dim3(256), 0, st, a.splitk_ws, bias, a.res, a.y, HWo, cpr, rows, stats, a.G);
     }
     SSD_CHECK_LAUNCH("conv2d_nhwc_bf16");
     return SSDNERF_OK;

@@ -29,6 +29,7 @@ template <> struct GnVec<GN_F32> {
         f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
     }
     __device__ static void store(void* p, size_t idx, const float* f) { reinterpret_cast<float4*>(p)[idx] = make_float4(f[0], f[1], f[2], f[3]); }
+    __device__ static float round(float x) { return x; }               // value as it reads back from storage
 };
 template <> struct GnVec<GN_BF16> {
     static constexpr int V = 8;
@@ -51,6 +52,7 @@ template <> struct GnVec<GN_BF16> {
         for (int i = 0; i < 4; ++i) w[i] = rne(f[2 * i]) | (rne(f[2 * i + 1]) << 16);
         reinterpret_cast<uint4*>(p)[idx] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    __device__ static float round(float x) { return __uint_as_float(rne(x) << 16); }
 };
 template <> struct GnVec<GN_F16> {
     static constexpr int V = 8;
@@ -66,6 +68,7 @@ template <> struct GnVec<GN_F16> {
         for (int i = 0; i < 8; ++i) v.h[i] = (_Float16)f[i];
         reinterpret_cast<uint4*>(p)[idx] = v.u;
     }
+    __device__ static float round(float x) { return (float)(_Float16)x; }
 };
 
 constexpr int GN_TPB = 256;
@@ -75,22 +78,28 @@ constexpr int GN_MAX_C = 2048;
 // its fixed channel vector, the block folds them over the rows-in-flight through LDS (conflict-free: consecutive threads,
 // consecutive channels), then per group, then adds to the global fp64 sums.  pre_bias (nullable, fp32 [C]) is the bias of the
 // convolution that produced x, added on load so that the producer does not need a pass of its own for it.
+// x may be the channel concatenation [x | x2] of two tensors (C1 channels from x, C - C1 from x2) that is never materialised: the
+// skip connections of the UNet's decoder half (denoising.py:209-213 `torch.cat([h, hs.pop()], dim=1)`).
 template <int DT>
-__global__ __launch_bounds__(GN_TPB) void k_gn_stats(const void* __restrict__ x, const float* __restrict__ pre_bias, uint32_t HW, uint32_t C, uint32_t G,
-                                                      uint32_t rows_per_block, double* __restrict__ sums) {
+__global__ __launch_bounds__(GN_TPB) void k_gn_stats(const void* __restrict__ x, const void* __restrict__ x2, uint32_t C1, const float* __restrict__ pre_bias,
+                                                      uint32_t HW, uint32_t C, uint32_t G, uint32_t rows_per_block, double* __restrict__ sums) {
     constexpr int V = GnVec<DT>::V;
     __shared__ float part_s[GN_TPB * V], part_q[GN_TPB * V];              // [row-in-flight][C]  (rif * C <= 256 * V)
     const uint32_t tpr = C / V, rif = GN_TPB / tpr;
     const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
     const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
+    const uint32_t tpr1 = C1 / V;
+    const bool second = cv >= tpr1;
+    const void* src = second ? x2 : x;
+    const uint32_t stpr = second ? tpr - tpr1 : tpr1, scv = second ? cv - tpr1 : cv;
     if (lane_row < rif) {
         float s[V], q[V], pb[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; pb[i] = pre_bias ? pre_bias[cv * V + i] : 0.f; }
-        const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+        const size_t base = ((size_t)b * HW + row0) * stpr + scv;
         for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
             float f[V];
-            GnVec<DT>::load(x, base + (size_t)r * tpr, f);
+            GnVec<DT>::load(src, base + (size_t)r * stpr, f);
 #pragma unroll
             for (int i = 0; i < V; ++i) { const float v = f[i] + pb[i]; s[i] += v; q[i] = __builtin_fmaf(v, v, q[i]); }
         }
@@ -114,8 +123,8 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_stats(const void* __restrict__ x,
 }
 
 template <int DT>
-__global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x, const float* __restrict__ pre_bias, uint32_t HW, uint32_t C, uint32_t G,
-                                                      uint32_t rows_per_block, const double* __restrict__ sums, const float* __restrict__ gamma,
+__global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x, const void* __restrict__ x2, uint32_t C1, const float* __restrict__ pre_bias,
+                                                      uint32_t HW, uint32_t C, uint32_t G, uint32_t rows_per_block, const double* __restrict__ sums, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ scale_shift, uint32_t ss_stride, float eps,
                                                       int act, void* __restrict__ y) {
     constexpr int V = GnVec<DT>::V;
@@ -145,10 +154,15 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x,
     float a[V], o[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { a[i] = fa[cv * V + i]; o[i] = fb[cv * V + i]; }
+    const uint32_t tpr1 = C1 / V;
+    const bool second = cv >= tpr1;
+    const void* src = second ? x2 : x;
+    const uint32_t stpr = second ? tpr - tpr1 : tpr1, scv = second ? cv - tpr1 : cv;
+    const size_t sbase = ((size_t)b * HW + row0) * stpr + scv;
     const size_t base = ((size_t)b * HW + row0) * tpr + cv;
     for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
         float f[V];
-        GnVec<DT>::load(x, base + (size_t)r * tpr, f);
+        GnVec<DT>::load(src, sbase + (size_t)r * stpr, f);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float v = __builtin_fmaf(f[i], a[i], o[i]);
@@ -160,26 +174,60 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x,
 }
 
 // y = x + bias[c] + residual  (either addend optional): the epilogue of a bias-less convolution -- conv_2 of a residual block
-// plus its skip (modules.py:51-110), or a plain bias add for the stand-alone convolutions.
+// plus its skip (modules.py:51-110) -- or the `h + x` that closes an attention block; optionally accumulates the GroupNorm sums
+// of y (per sample and group) for the norm that reads y next.  grid (row slabs, B); a thread keeps one channel vector.
 template <int DT>
 __global__ __launch_bounds__(GN_TPB) void k_bias_residual(const void* __restrict__ x, const float* __restrict__ bias, const void* __restrict__ residual,
-                                                           uint64_t n_vec, uint32_t tpr, void* __restrict__ y) {
+                                                           uint32_t HW, uint32_t C, uint32_t rows_per_block, void* __restrict__ y, double* __restrict__ sums,
+                                                           uint32_t G) {
     constexpr int V = GnVec<DT>::V;
-    const uint64_t stride = (uint64_t)gridDim.x * GN_TPB;
-    for (uint64_t i = (uint64_t)blockIdx.x * GN_TPB + threadIdx.x; i < n_vec; i += stride) {
-        float f[V], r[V];
-        GnVec<DT>::load(x, i, f);
-        const uint32_t cv = (uint32_t)(i % tpr);
-        if (bias) {
+    __shared__ float part_s[GN_TPB * V], part_q[GN_TPB * V];
+    const uint32_t tpr = C / V, rif = GN_TPB / tpr;
+    const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
+    const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
+    float s[V], q[V];
 #pragma unroll
-            for (int k = 0; k < V; ++k) f[k] += bias[cv * V + k];
-        }
-        if (residual) {
-            GnVec<DT>::load(residual, i, r);
+    for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    if (lane_row < rif) {
+        float bv[V];
 #pragma unroll
-            for (int k = 0; k < V; ++k) f[k] += r[k];
+        for (int i = 0; i < V; ++i) bv[i] = bias ? bias[cv * V + i] : 0.f;
+        const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+        for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
+            float f[V], rr[V];
+            GnVec<DT>::load(x, base + (size_t)r * tpr, f);
+#pragma unroll
+            for (int i = 0; i < V; ++i) f[i] += bv[i];
+            if (residual) {
+                GnVec<DT>::load(residual, base + (size_t)r * tpr, rr);
+#pragma unroll
+                for (int i = 0; i < V; ++i) f[i] += rr[i];
+            }
+            GnVec<DT>::store(y, base + (size_t)r * tpr, f);
+            if (sums) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) { const float v = GnVec<DT>::round(f[i]); s[i] += v; q[i] = __builtin_fmaf(v, v, q[i]); }   // what the next norm will read
+            }
         }
-        GnVec<DT>::store(y, i, f);
+    }
+    if (!sums) return;
+    if (lane_row < rif) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) { part_s[lane_row * C + cv * V + i] = s[i]; part_q[lane_row * C + cv * V + i] = q[i]; }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < C; c += GN_TPB) {
+        float ss = 0.f, qq = 0.f;
+        for (uint32_t r = 0; r < rif; ++r) { ss += part_s[r * C + c]; qq += part_q[r * C + c]; }
+        part_s[c] = ss; part_q[c] = qq;
+    }
+    __syncthreads();
+    const uint32_t cpg = C / G;
+    for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
+        double ds = 0.0, dq = 0.0;
+        for (uint32_t i = 0; i < cpg; ++i) { ds += (double)part_s[g * cpg + i]; dq += (double)part_q[g * cpg + i]; }
+        atomicAdd(&sums[((size_t)b * G + g) * 2 + 0], ds);
+        atomicAdd(&sums[((size_t)b * G + g) * 2 + 1], dq);
     }
 }
 
@@ -193,7 +241,7 @@ uint32_t gn_rows_per_block(uint32_t B, uint32_t HW, uint32_t min_blocks, uint32_
 
 extern "C" size_t ssdnerf_group_norm_workspace(uint32_t B, uint32_t G) { return (size_t)B * G * 2 * sizeof(double); }
 
-extern "C" int ssdnerf_group_norm_nhwc(const void* x, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* pre_bias, const float* gamma,
+extern "C" int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C1, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* pre_bias, const float* gamma,
                                        const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act, void* workspace,
                                        int workspace_state, void* y, void* stream) {
     if (B == 0 || HW == 0 || C == 0) return SSDNERF_OK;
@@ -203,6 +251,8 @@ extern "C" int ssdnerf_group_norm_nhwc(const void* x, int dtype, uint32_t B, uin
     SSD_REQUIRE(G > 0 && C % G == 0, "group_norm_nhwc: channels must be divisible by groups");
     SSD_REQUIRE(!scale_shift || scale_shift_stride >= 2 * C, "group_norm_nhwc: scale_shift_stride must be >= 2*C");
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
+    if (!x2) C1 = C;
+    SSD_REQUIRE(C1 <= C && C1 % V == 0 && (x2 || C1 == C), "group_norm_nhwc: the first tensor's channel count must be a multiple of the 16-byte vector and <= C");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t rows_s = gn_rows_per_block(B, HW, 1024, 64), rows_a = gn_rows_per_block(B, HW, 2048, 16);
     const dim3 grid_s(HW / rows_s, B), grid_a(HW / rows_a, B), block(GN_TPB);
@@ -212,8 +262,8 @@ extern "C" int ssdnerf_group_norm_nhwc(const void* x, int dtype, uint32_t B, uin
         return ssdnerf_fail(SSDNERF_E_LAUNCH, "group_norm_nhwc: memset failed");
     double* sums = (double*)workspace;
 #define SSD_GN_LAUNCH(DT)                                                                                                                    \
-    if (!stats_ready) hipLaunchKernelGGL(k_gn_stats<DT>, grid_s, block, 0, st, x, pre_bias, HW, C, G, rows_s, sums);                                            \
-    hipLaunchKernelGGL(k_gn_apply<DT>, grid_a, block, 0, st, x, pre_bias, HW, C, G, rows_a, (const double*)sums, gamma, beta, scale_shift,    \
+    if (!stats_ready) hipLaunchKernelGGL(k_gn_stats<DT>, grid_s, block, 0, st, x, x2, C1, pre_bias, HW, C, G, rows_s, sums);                                            \
+    hipLaunchKernelGGL(k_gn_apply<DT>, grid_a, block, 0, st, x, x2, C1, pre_bias, HW, C, G, rows_a, (const double*)sums, gamma, beta, scale_shift,    \
                        scale_shift_stride, eps, act, y);
     if (dtype == GN_F32) { SSD_GN_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_GN_LAUNCH(GN_F16) } else { SSD_GN_LAUNCH(GN_BF16) }
 #undef SSD_GN_LAUNCH
@@ -221,17 +271,18 @@ extern "C" int ssdnerf_group_norm_nhwc(const void* x, int dtype, uint32_t B, uin
     return SSDNERF_OK;
 }
 
-extern "C" int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint64_t rows, uint32_t C, const float* bias, const void* residual, void* y,
-                                          void* stream) {
-    if (rows == 0 || C == 0) return SSDNERF_OK;
+extern "C" int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint32_t B, uint32_t HW, uint32_t C, const float* bias, const void* residual, void* y,
+                                          void* gn_sums, uint32_t gn_groups, void* stream) {
+    if (B == 0 || HW == 0 || C == 0) return SSDNERF_OK;
     SSD_REQUIRE(x && y, "bias_residual_nhwc: null pointer");
     SSD_REQUIRE(dtype == GN_F32 || dtype == GN_F16 || dtype == GN_BF16, "bias_residual_nhwc: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
     const uint32_t V = dtype == GN_F32 ? 4 : 8;
-    SSD_REQUIRE(C % V == 0, "bias_residual_nhwc: channel count must be a multiple of the 16-byte vector");
-    const uint64_t n_vec = rows * (C / V);
-    const unsigned blocks = (unsigned)((n_vec + GN_TPB - 1) / GN_TPB < 8192 ? (n_vec + GN_TPB - 1) / GN_TPB : 8192);
+    SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "bias_residual_nhwc: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
+    SSD_REQUIRE(!gn_sums || (gn_groups > 0 && C % gn_groups == 0), "bias_residual_nhwc: channels must be divisible by groups");
+    const uint32_t rows = gn_rows_per_block(B, HW, 2048, 16);
     hipStream_t st = (hipStream_t)stream;
-#define SSD_BR_LAUNCH(DT) hipLaunchKernelGGL(k_bias_residual<DT>, dim3(blocks), dim3(GN_TPB), 0, st, x, bias, residual, n_vec, C / V, y);
+    const dim3 grid(HW / rows, B), block(GN_TPB);
+#define SSD_BR_LAUNCH(DT) hipLaunchKernelGGL(k_bias_residual<DT>, grid, block, 0, st, x, bias, residual, HW, C, rows, y, (double*)gn_sums, gn_groups ? gn_groups : 1u);
     if (dtype == GN_F32) { SSD_BR_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_BR_LAUNCH(GN_F16) } else { SSD_BR_LAUNCH(GN_BF16) }
 #undef SSD_BR_LAUNCH
     SSD_CHECK_LAUNCH("bias_residual_nhwc");

@@ -29,8 +29,22 @@
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
-// SiLU of two values at once: the multiply / add / multiply around the two transcendentals are packed fp32 ops
-// (v_pk_mul_f32 / v_pk_add_f32 process two values per instruction at the plain VALU rate).
+// SiLU of two values at once.  Default: the multiply / add / multiply around the two transcendentals are packed fp32 ops
+// (v_pk_mul_f32 / v_pk_add_f32 process two values per instruction).  -DSM_SCALAR_VALU issues plain v_mul/v_add/v_fma instead
+// (inline asm, so that the SLP vectoriser cannot re-pack them): packed f32 ops issued beside MFMAs cost extra cycles on gfx950
+// (MI355X guide, "price of one filler beside MFMAs"), and phases B-D of the shading loop run VALU work under MFMAs on purpose.
+#ifdef SM_SCALAR_VALU
+SSD_DEV float sm_vmul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+SSD_DEV float sm_vadd(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+SSD_DEV float sm_vfma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+SSD_DEV floatx2 sm_silu2(floatx2 h) {
+    floatx2 o;
+    o.x = sm_vmul(h.x, __builtin_amdgcn_rcpf(sm_vadd(__builtin_amdgcn_exp2f(sm_vmul(h.x, -1.4426950408889634f)), 1.0f)));
+    o.y = sm_vmul(h.y, __builtin_amdgcn_rcpf(sm_vadd(__builtin_amdgcn_exp2f(sm_vmul(h.y, -1.4426950408889634f)), 1.0f)));
+    return o;
+}
+SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return floatx2{sm_vfma(w.x, v.x, acc.x), sm_vfma(w.y, v.y, acc.y)}; }
+#else
 SSD_DEV floatx2 sm_silu2(floatx2 h) {
     const floatx2 a = h * floatx2{-1.4426950408889634f, -1.4426950408889634f};
     floatx2 e;
@@ -42,6 +56,8 @@ SSD_DEV floatx2 sm_silu2(floatx2 h) {
     rcp.y = __builtin_amdgcn_rcpf(d.y);
     return h * rcp;
 }
+SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_elementwise_fma(w, v, acc); }
+#endif
 
 static constexpr unsigned SM_TPB = 256;
 static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
@@ -364,16 +380,16 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
             const int mt = q >> 3, p2 = q & 7;
             const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
             const floatx2 wS = {w.x, w.y};
-            ps_[nt] = __builtin_elementwise_fma(wS, sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]}), ps_[nt]);
+            ps_[nt] = sm_fma2(wS, sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]}), ps_[nt]);
         };
         auto colour_pair = [&](int nt, int q) {
             const int mt = q >> 3, p2 = q & 7;
             const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
             const floatx2 wR = {w0.z, w0.w}, wG = {w1.x, w1.y}, wB = {w1.z, w1.w};
             const floatx2 cc = sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]});
-            pr_[nt] = __builtin_elementwise_fma(wR, cc, pr_[nt]);
-            pg_[nt] = __builtin_elementwise_fma(wG, cc, pg_[nt]);
-            pb_[nt] = __builtin_elementwise_fma(wB, cc, pb_[nt]);
+            pr_[nt] = sm_fma2(wR, cc, pr_[nt]);
+            pg_[nt] = sm_fma2(wG, cc, pg_[nt]);
+            pb_[nt] = sm_fma2(wB, cc, pb_[nt]);
         };
         // ---- A
 #pragma unroll

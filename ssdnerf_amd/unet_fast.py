@@ -33,54 +33,78 @@ _GN_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 def group_norm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, scale_shift: Optional[torch.Tensor], eps: float,
                     act: bool, workspace: torch.Tensor, out: Optional[torch.Tensor] = None, pre_bias: Optional[torch.Tensor] = None,
-                    workspace_is_zero: bool = False, stats_ready: bool = False) -> torch.Tensor:
+                    workspace_is_zero: bool = False, stats_ready: bool = False, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x``: (B, C, H, W) tensor in channels_last memory format, or (B, T, C) contiguous.  ``scale_shift``: fp32 view (B, 2C) whose
     rows may be strided.  ``pre_bias``: fp32 (C,) added to x before the norm.  ``stats_ready``: ``workspace`` already holds the sums
-    (written by the producing convolution's epilogue).  Returns a tensor of the same shape/strides."""
+    (written by the producing convolution's epilogue).  ``x2``: normalise the channel concatenation [x | x2] without building it
+    (4-D only).  Returns a tensor of the input's shape/strides (of the concatenation's shape with ``x2``)."""
     if x.dim() == 4:
-        B, Cc, H, W = x.shape
+        B, C1, H, W = x.shape
         HW = H * W
         if not x.is_contiguous(memory_format=torch.channels_last):
             raise RuntimeError("group_norm_nhwc: 4-D input must be channels_last")
+        Cc = C1
+        if x2 is not None:
+            if x2.dim() != 4 or x2.shape[0] != B or x2.shape[2:] != x.shape[2:] or x2.dtype != x.dtype or not x2.is_contiguous(memory_format=torch.channels_last):
+                raise RuntimeError("group_norm_nhwc: x2 must match x in batch, spatial size, dtype and layout")
+            Cc = C1 + x2.shape[1]
     else:
         B, HW, Cc = x.shape
-        if not x.is_contiguous():
-            raise RuntimeError("group_norm_nhwc: 3-D input must be contiguous (B, T, C)")
-    y = torch.empty_like(x) if out is None else out
+        C1 = Cc
+        if x2 is not None or not x.is_contiguous():
+            raise RuntimeError("group_norm_nhwc: 3-D input must be a single contiguous (B, T, C) tensor")
+    if out is not None:
+        y = out
+    elif x2 is None:
+        y = torch.empty_like(x)
+    else:
+        y = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     ss_stride = 0
     if scale_shift is not None:
         assert scale_shift.dtype == torch.float32 and scale_shift.shape == (B, 2 * Cc) and scale_shift.stride(1) == 1
         ss_stride = scale_shift.stride(0)
-    C.check(C.lib().ssdnerf_group_norm_nhwc(C.ptr(x), _GN_DTYPE[x.dtype], C.u32(B), C.u32(HW), C.u32(Cc), C.u32(groups), C.ptr(pre_bias), C.ptr(gamma),
+    C.check(C.lib().ssdnerf_group_norm_nhwc(C.ptr(x), C.ptr(x2), C.u32(C1), _GN_DTYPE[x.dtype], C.u32(B), C.u32(HW), C.u32(Cc), C.u32(groups), C.ptr(pre_bias), C.ptr(gamma),
                                              C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)), C.ptr(workspace),
                                              2 if stats_ready else int(bool(workspace_is_zero)), C.ptr(y), C.stream()),
             "group_norm_nhwc")
     return y
 
 
-def bias_residual_nhwc(x: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor]) -> torch.Tensor:
-    """In place ``x += bias[c] + residual`` for a channels_last (B, C, H, W) tensor (fp32 bias, residual of x's dtype and layout)."""
-    if not x.is_contiguous(memory_format=torch.channels_last):
-        raise RuntimeError("bias_residual_nhwc: input must be channels_last")
-    if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or not residual.is_contiguous(memory_format=torch.channels_last)):
-        raise RuntimeError("bias_residual_nhwc: residual must match the input's shape, dtype and layout")
-    B, Cc, H, W = x.shape
-    C.check(C.lib().ssdnerf_bias_residual_nhwc(C.ptr(x), _GN_DTYPE[x.dtype], ctypes.c_uint64(B * H * W), C.u32(Cc), C.ptr(bias), C.ptr(residual), C.ptr(x),
-                                                C.stream()), "bias_residual_nhwc")
+def bias_residual_nhwc(x: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor], gn_sums: Optional[torch.Tensor] = None,
+                       gn_groups: int = 0) -> torch.Tensor:
+    """In place ``x += bias[c] + residual`` for a channels_last (B, C, H, W) or contiguous (B, T, C) tensor (fp32 bias, residual of x's
+    dtype and layout); ``gn_sums`` (zeroed fp64 (B, groups, 2)) receives the GroupNorm sums of the result."""
+    if x.dim() == 4:
+        B, Cc, H, W = x.shape
+        HW = H * W
+        ok = x.is_contiguous(memory_format=torch.channels_last) and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))
+    else:
+        B, HW, Cc = x.shape
+        ok = x.is_contiguous() and (residual is None or residual.is_contiguous())
+    if not ok or (residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype)):
+        raise RuntimeError("bias_residual_nhwc: input (and residual) must be channel-last with matching shape and dtype")
+    C.check(C.lib().ssdnerf_bias_residual_nhwc(C.ptr(x), _GN_DTYPE[x.dtype], C.u32(B), C.u32(HW), C.u32(Cc), C.ptr(bias), C.ptr(residual), C.ptr(x),
+                                                C.ptr(gn_sums), C.u32(gn_groups), C.stream()), "bias_residual_nhwc")
     return x
 
 
 def conv2d_nhwc_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, stride: int = 1,
                      upsample: bool = False, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0, tile_hint: int = 0,
-                     splitk_ws: Optional[torch.Tensor] = None, splits_hint: int = 0) -> torch.Tensor:
+                     splitk_ws: Optional[torch.Tensor] = None, splits_hint: int = 0, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Hand-written implicit-GEMM convolution (csrc/conv_igemm.hip).  ``x`` (B, Cin, H, W) bf16 channels_last, ``w`` (Cout, Cin, k, k) bf16
     channels_last, ``bias`` fp32, ``residual`` like the output.  ``upsample``: convolve the nearest-2x upsampling of x without building it.
-    ``splitk_ws``: all-zero fp32 scratch (left all zero) that lets small layers be cut along K."""
+    ``splitk_ws``: all-zero fp32 scratch (left all zero) that lets small layers be cut along K.  ``x2``: convolve the channel
+    concatenation [x | x2] without building it."""
     if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
         raise RuntimeError("conv2d_nhwc_bf16: bf16 tensors only")
     if not x.is_contiguous(memory_format=torch.channels_last) or not w.is_contiguous(memory_format=torch.channels_last):
         raise RuntimeError("conv2d_nhwc_bf16: input and weight must be channels_last")
-    B, Cin, H, W = x.shape
+    B, Cin1, H, W = x.shape
+    Cin = Cin1
+    if x2 is not None:
+        if x2.dtype != torch.bfloat16 or not x2.is_contiguous(memory_format=torch.channels_last) or x2.shape[0] != B or x2.shape[2:] != x.shape[2:]:
+            raise RuntimeError("conv2d_nhwc_bf16: x2 must match x in batch, spatial size, dtype and layout")
+        Cin = Cin1 + x2.shape[1]
     Cout, Cin_w, k, k2 = w.shape
     if Cin_w != Cin or k != k2:
         raise RuntimeError("conv2d_nhwc_bf16: weight shape does not match the input")
@@ -90,7 +114,7 @@ def conv2d_nhwc_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     y = torch.empty((B, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or not residual.is_contiguous(memory_format=torch.channels_last)):
         raise RuntimeError("conv2d_nhwc_bf16: residual must match the output's shape, dtype and layout")
-    C.check(C.lib().ssdnerf_conv2d_nhwc_bf16(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(residual), C.ptr(y), C.u32(B), C.u32(H), C.u32(W), C.u32(Cin), C.u32(Cout),
+    C.check(C.lib().ssdnerf_conv2d_nhwc_bf16(C.ptr(x), C.ptr(x2), C.u32(Cin1), C.ptr(w), C.ptr(bias), C.ptr(residual), C.ptr(y), C.u32(B), C.u32(H), C.u32(W), C.u32(Cin), C.u32(Cout),
                                               C.u32(k), C.u32(stride), C.u32(int(upsample)), C.ptr(gn_sums), C.u32(gn_groups), int(tile_hint), C.ptr(splitk_ws),
                                               ctypes.c_size_t(0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size()), int(splits_hint),
                                               C.stream()),
@@ -130,8 +154,8 @@ class _Conv:
 
     splitk_ws: Optional[torch.Tensor] = None        # shared all-zero fp32 scratch for the small layers' split-K (set by the executor)
 
-    def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0):
-        return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups, splitk_ws=_Conv.splitk_ws)
+    def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0, x2=None):
+        return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups, splitk_ws=_Conv.splitk_ws, x2=x2)
 
     def mm(self, x):
         return F.conv2d(x, self.w, None, self.stride, self.padding)
@@ -242,30 +266,37 @@ class FastUnet:
         assert ws.numel() == n, "GroupNorm statistics arena exhausted"
         return ws
 
-    def _gn(self, x, gn: _GN, ss, act, pre_bias=None, stats=None):
+    def _gn(self, x, gn: _GN, ss, act, pre_bias=None, stats=None, x2=None):
         if stats is not None:
-            return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, stats, stats_ready=True)
-        return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, self._stats_slice(x.size(0)), pre_bias=pre_bias, workspace_is_zero=True)
+            return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, stats, stats_ready=True, x2=x2)
+        return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, self._stats_slice(x.size(0)), pre_bias=pre_bias, workspace_is_zero=True,
+                               x2=x2)
 
     def _can_fuse_stats(self, conv: _Conv, x, gn: _GN, upsample=False):
         if not conv.own:
             return False
         hw = x.size(2) * x.size(3) * (4 if upsample else 1) // (conv.stride[0] * conv.stride[1])
         cout, cin, k = conv.w.size(0), conv.w.size(1), conv.w.size(2)
+        if (cout // gn.groups) % 4 != 0:
+            return False                                                    # csrc/conv_igemm.hip: statistics per 4-channel half chunk
         plan = C.lib().ssdnerf_conv2d_nhwc_bf16_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, int(_Conv.splitk_ws is not None), 0)
         if plan >> 8 != 1:
-            return False                                                    # a split-K layer: its finishing pass does not carry statistics
-        return hw % 128 == 0 and (cout // gn.groups) % 4 == 0               # csrc/conv_igemm.hip: tile inside one sample, 4-channel half chunks
+            return True                                                     # a split-K layer: its finishing pass takes the statistics
+        return hw % 128 == 0                                                # unsplit: the M tile must lie inside one sample
 
-    def _res(self, x, stats, op, ss_all):
+    def _res(self, x, stats, op, ss_all, x2=None):
+        """One residual block.  ``x2``: the block's input is the concatenation [x | x2] (decoder half) and is never built."""
         _, gn1, conv1, gn2, (off, n), conv2, shortcut, out_bias = op
-        g1 = self._gn(x, gn1, None, True, stats=stats)
         ss = ss_all[:, off:off + n]
-        if conv1.own and conv2.own and (shortcut is None or shortcut.own):
+        own = conv1.own and conv2.own and (shortcut is None or shortcut.own)
+        if x2 is not None and not (own and shortcut is not None and x.size(1) % 64 == 0):
+            x, x2, stats = torch.cat([x, x2], dim=1).contiguous(memory_format=torch.channels_last), None, None
+        g1 = self._gn(x, gn1, None, True, stats=stats, x2=x2)
+        if own:
             st1 = self._stats_slice(x.size(0)) if self._can_fuse_stats(conv1, g1, gn2) else None
             h = conv1.igemm(g1, conv1.bias, gn_sums=st1, gn_groups=gn2.groups)             # conv + bias (+ statistics for gn2)
             g2 = self._gn(h, gn2, ss, True, stats=st1)
-            skip = shortcut.igemm(x) if shortcut is not None else x                         # the shortcut's bias rides in out_bias
+            skip = shortcut.igemm(x, x2=x2) if shortcut is not None else x                  # the shortcut's bias rides in out_bias
             st2 = self._stats_slice(x.size(0)) if self._can_fuse_stats(conv2, g2, gn1) else None
             return conv2.igemm(g2, out_bias, skip, gn_sums=st2, gn_groups=gn1.groups), st2  # conv + bias + skip (+ statistics for the next norm)
         h = conv1.mm(g1)
@@ -283,16 +314,18 @@ class FastUnet:
         else:
             q, k, v = qkv.view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)   # each (B, heads, T, ch)
             a = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(B, T, Cc)
-        h = F.linear(a, wproj, bproj).add_(xt)
-        return h.view(B, H, W, Cc).permute(0, 3, 1, 2)                      # back to a channels_last (B, C, H, W) view
+        st = self._stats_slice(B)                                            # h + x, and the sums the next block's norm needs, in one pass
+        h = bias_residual_nhwc(F.linear(a, wproj, bproj), None, xt, gn_sums=st, gn_groups=gn.groups)
+        return h.view(B, H, W, Cc).permute(0, 3, 1, 2), st                  # back to a channels_last (B, C, H, W) view
 
-    def _run(self, ops, h, ss_all, stats=None):
+    def _run(self, ops, h, ss_all, stats=None, x2=None):
         for op in ops:
             kind = op[0]
             if kind == "res":
-                h, stats = self._res(h, stats, op, ss_all)
+                h, stats = self._res(h, stats, op, ss_all, x2=x2)
+                x2 = None
             elif kind == "att":
-                h, stats = self._att(h, stats, op), None
+                h, stats = self._att(h, stats, op)
             elif kind == "conv":
                 h, stats = op[1](h), None
             elif kind == "up":
@@ -330,7 +363,8 @@ class FastUnet:
             hs.append(h)
         h, stats = self._run(self.mid_ops, h, ss_all, stats)
         for ops in self.out_ops:
-            h, stats = self._run(ops, torch.cat([h, hs.pop()], dim=1).contiguous(memory_format=torch.channels_last), ss_all)
+            assert ops[0][0] == "res"
+            h, stats = self._run(ops, h, ss_all, x2=hs.pop())                # torch.cat([h, skip]) happens inside the block's kernels
         gn, conv = self.head
         out = conv(self._gn(h, gn, None, True, stats=stats))
         return out.float().contiguous()                                     # NCHW fp32, what the DDIM update consumes

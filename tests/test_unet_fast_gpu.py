@@ -227,3 +227,48 @@ def test_attention_kernel_peaked_softmax():
     want = (torch.softmax(q @ k.transpose(-1, -2) / ch ** 0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, T, heads * ch)
     assert torch.isfinite(got).all()
     assert ((got - want).norm() / want.norm()).item() < 8e-3
+
+
+# ------------------------------------------------------------------------------------------------ fused skip concatenation / statistics
+@pytest.mark.parametrize("C1,C2,H", [(256, 128, 16), (512, 512, 8), (128, 128, 32)])
+def test_concat_is_fused_into_norm_and_shortcut(C1, C2, H):
+    """GroupNorm and the 1x1 shortcut convolution over torch.cat([h, skip], 1) without building the concatenation."""
+    g = torch.Generator().manual_seed(C1 + C2)
+    B, C = 2, C1 + C2
+    a = torch.randn(B, C1, H, H, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    b = (torch.randn(B, C2, H, H, generator=g) * 2 + 1).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    cat = torch.cat([a, b], dim=1).contiguous(memory_format=torch.channels_last)
+    gamma, beta = torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda()
+    ws = torch.zeros(B * 64 * 2, dtype=torch.float64, device="cuda")
+    y2 = unet_fast.group_norm_nhwc(a, 32, gamma, beta, None, 1e-5, True, ws, x2=b)
+    ws1 = torch.zeros_like(ws)
+    y1 = unet_fast.group_norm_nhwc(cat, 32, gamma, beta, None, 1e-5, True, ws1)
+    assert y2.shape == cat.shape and torch.equal(y1, y2)                    # same arithmetic, bit-identical
+    w = (torch.randn(128, C, 1, 1, generator=g) / C ** 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    assert torch.equal(unet_fast.conv2d_nhwc_bf16(a, w, x2=b), unet_fast.conv2d_nhwc_bf16(cat, w))
+    w3 = (torch.randn(128, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    assert torch.equal(unet_fast.conv2d_nhwc_bf16(a, w3, x2=b), unet_fast.conv2d_nhwc_bf16(cat, w3))
+
+
+def test_statistics_from_split_k_and_residual_add():
+    g = torch.Generator().manual_seed(5)
+    B, C, H, G = 2, 512, 8, 32
+    x = torch.randn(B, 512, H, H, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, 512, 3, 3, generator=g) / 68).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    res = torch.randn(B, C, H, H, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(C, generator=g).cuda()
+    scratch = torch.zeros(B * H * H * C, dtype=torch.float32, device="cuda")
+    sums = torch.zeros(B, G, 2, dtype=torch.float64, device="cuda")
+    y = unet_fast.conv2d_nhwc_bf16(x, w, bias, res, gn_sums=sums, gn_groups=G, splitk_ws=scratch, splits_hint=6)
+    yf = y.double().reshape(B, G, C // G, H * H)
+    assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-5, atol=1e-3) and torch.allclose(sums[..., 1], yf.square().sum((2, 3)), rtol=1e-5, atol=1e-3)
+    assert scratch.abs().max().item() == 0.0
+    # the attention block's closing  h + x  on (B, T, C), with the sums for the next norm
+    h = torch.randn(B, H * H, C, generator=g).cuda().bfloat16()
+    xt = torch.randn(B, H * H, C, generator=g).cuda().bfloat16()
+    sums.zero_()
+    want = (h.float() + xt.float()).bfloat16()
+    got = unet_fast.bias_residual_nhwc(h.clone(), None, xt, gn_sums=sums, gn_groups=G)
+    assert torch.equal(got, want)
+    wf = want.double().reshape(B, H * H, G, C // G)
+    assert torch.allclose(sums[..., 0], wf.sum((1, 3)), rtol=1e-6, atol=1e-3) and torch.allclose(sums[..., 1], wf.square().sum((1, 3)), rtol=1e-6, atol=1e-3)

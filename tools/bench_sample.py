@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""tools/bench_sample.py -- unconditional sampling end to end on one MI355X (BASELINE.json configs[3]-style workload per GPU):
+noise -> 50-step DDIM over the triplane latents (cars UNet, 122 M parameters) -> density grids -> V novel views per scene.
+Prints one JSON line with scenes/s and the split DDIM / density / render.  Random weights, synthetic decoder: timing only."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ssdnerf_amd  # noqa
+from ssdnerf_amd.registry import MODELS
+from ssdnerf_amd import synthetic as S
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--views", type=int, default=251); ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16"]); ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--eager-unet", action="store_true", help="module forward instead of the inference executor (the baseline this repo started from)")
+a = ap.parse_args()
+cfg = dict(type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64,
+           diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"),
+                          denoising=dict(type="DenoisingUnetMod", image_size=128, in_channels=18, base_channels=128, channels_cfg=[1, 2, 2, 4, 4],
+                                         resblocks_per_downsample=2, dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True,
+                                         num_heads=4, attention_res=[32, 16, 8]),
+                          timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5), denoising_mean_mode="V",
+                          ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="constant", log_cfgs=None, weight_scale=4.0)),
+           decoder=dict(type="TriPlaneDecoder", interp_mode="bilinear", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3],
+                        use_dir_enc=True, dir_layers=[16, 64], activation="silu", sigma_activation="trunc_exp", sigmoid_saturation=0.001, max_steps=256),
+           decoder_use_ema=True, freeze_decoder=False, bg_color=1, pixel_loss=dict(type="MSELoss", loss_weight=20.0),
+           reg_loss=dict(type="RegLoss", power=2, loss_weight=3e-3), cache_size=0,
+           autocast_dtype=dict(fp32=None, bf16="bfloat16", fp16="float16")[a.dtype],
+           test_cfg=dict(img_size=(128, 128), num_timesteps=a.steps, clip_range=[-2, 2], density_thresh=0.1))
+try:
+    model = MODELS.build(cfg)
+except Exception:                                   # option names differ between config generations: fall back to the minimal diffusion dict
+    cfg["diffusion"] = dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"), denoising=cfg["diffusion"]["denoising"], denoising_mean_mode="V")
+    model = MODELS.build(cfg)
+g = torch.Generator().manual_seed(0)
+with torch.no_grad():
+    for p in model.diffusion_ema.parameters():
+        p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+model.decoder_ema.load_state_dict(S.make_decoder_params(), strict=False)
+model = model.cuda().eval()
+model.diffusion_ema.denoising.fast_inference = not a.eager_unet
+ns, nv = a.scenes, a.views
+poses = S.spiral_poses(nv).cuda()[None].expand(ns, -1, -1, -1).contiguous()
+intr = S.cars_intrinsics(128, 128).cuda()[None, None].expand(ns, nv, -1).contiguous()
+jit = [torch.rand(64 ** 3, 3, generator=g).cuda() for _ in range(8)]
+
+
+def ev():
+    e = torch.cuda.Event(enable_timing=True); e.record(); return e
+
+
+res = []
+for rep in range(a.reps + 1):                       # rep 0 = warm-up (graph capture, MIOpen/hipBLASLt kernel selection)
+    noise = torch.randn(ns, 3, 6, 128, 128, generator=g).cuda()
+    torch.cuda.synchronize(); t0 = time.perf_counter(); e0 = ev()
+    with torch.no_grad():
+        diffusion = model.diffusion_ema
+        with model._autocast():
+            code_out = diffusion(model.code_diff_pr(noise), return_loss=False)
+        e1 = ev()
+        code = model.code_diff_pr_inv(code_out.float())
+        grid, bits = model.get_density(model.decoder_ema, code, cfg=model.test_cfg, jitters=jit)
+        e2 = ev()
+        image, depth = model.render(model.decoder_ema, code, bits, 128, 128, intr, poses, cfg=model.test_cfg)
+        e3 = ev()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if rep:
+        res.append(dict(total_s=dt, ddim_ms=e0.elapsed_time(e1), density_ms=e1.elapsed_time(e2), render_ms=e2.elapsed_time(e3)))
+best = min(res, key=lambda r: r["total_s"])
+print(json.dumps(dict(metric="scenes/s, unconditional sampling + render", value=ns / best["total_s"], unit="scenes/s", scenes=ns, views_per_scene=nv, ddim_steps=a.steps,
+                      unet_dtype=a.dtype, unet_path="eager module" if a.eager_unet else "inference executor", **{k: round(v, 2) for k, v in best.items()},
+                      ms_per_ddim_step=round(best["ddim_ms"] / a.steps, 3), image_finite=bool(torch.isfinite(image).all()))))
