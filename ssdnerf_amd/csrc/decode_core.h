@@ -58,7 +58,9 @@ SSD_DEV void ssd_grid_coord(float u, float size_f, uint32_t size, uint32_t& i0, 
 }
 
 // f[c*3 + p] = bilinear sample of channel c of plane p; planes (xy, xz, yz), first coordinate on the width axis.
-template <typename PT>
+// PLANE_BY_PLANE: a scheduling barrier after each plane keeps at most one plane's texels (4 x 8 registers) in flight instead of all
+// three (96 registers) -- for kernels that trade memory-level parallelism per wave for a third wave per SIMD.
+template <typename PT, bool PLANE_BY_PLANE = false>
 SSD_DEV void ssd_gather18(const PT* __restrict__ planes, const PlaneGeom& g, float x, float y, float z, float f[18]) {
     const float us[3] = {x, x, y};
     const float vs[3] = {y, z, z};
@@ -79,6 +81,7 @@ SSD_DEV void ssd_gather18(const PT* __restrict__ planes, const PlaneGeom& g, flo
 #pragma unroll
         for (int c = 0; c < 6; ++c)
             f[c * 3 + p] = ssd_fma(t11[c], w11, ssd_fma(t10[c], w10, ssd_fma(t01[c], w01, t00[c] * w00)));
+        if (PLANE_BY_PLANE) __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -61,8 +61,22 @@ SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_el
 
 static constexpr unsigned SM_TPB = 256;
 static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
-static constexpr unsigned SM_POOL = 128;           // entries per wave-local pool (two pools per wave)
 static constexpr unsigned SM_SEARCH_PROBES = 4;    // in-lane search budget after each sample
+// Two residencies of the same kernel (template parameter WPS = waves per SIMD):
+//   WPS 2: weights as MFMA A operands in 38 VGPRs, both 32-sample tiles in flight (64 accumulator registers), 253 VGPRs, 66 KiB LDS per block.
+//   WPS 3: weights as A operands read from LDS right before each MFMA, the two tiles shaded one after the other (32 accumulator registers),
+//          B operands built in place; <= 168 VGPRs and <= 53 KiB LDS per block, so THREE waves share a SIMD: the r01 counters showed the
+//          2-wave form waiting (SQ_WAIT_INST_ANY ~ 43 % of wave time) with both pipes half idle -- a third wave is what fills those gaps.
+template <int WPS> struct SmGeo {
+    static constexpr unsigned POOL = WPS == 3 ? 64 : 128;      // entries per wave-local pool (two pools per wave)
+    static constexpr unsigned MARCH_W = POOL / 2;              // rays advanced by one march pass
+    static constexpr unsigned STAGE = WPS == 3 ? 32 : 64;      // prepared rays per wave
+    static constexpr unsigned WLDS = WPS == 3 ? (2 * 10 + 2 * 9) * 64 : 0;   // floats of A-operand weights in LDS
+    static constexpr unsigned LDS_FLOATS = 512 + WLDS + (SM_TPB / 64) * (2 * POOL * 8 + 1024 + STAGE * 16);
+};
+#ifndef SM_DEFAULT_WPS
+#define SM_DEFAULT_WPS 3                           // measured r01: 9.42 ms vs 9.66 ms (WPS 2) on the bench scene, 28.1 vs 29.2 ms on the fog scene
+#endif
 #ifndef SM_REFILL_MIN
 #define SM_REFILL_MIN 1                            // refill only when this many lanes are idle (the divergent refill code then runs every few iterations instead of every iteration)
 #endif
@@ -113,8 +127,8 @@ SSD_DEV void sm_swap(float& a, float& b) {
     b = __uint_as_float(r[1]);
 }
 
-template <typename PT>
-__global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t slices_per_scene, const PT* __restrict__ planes,
+template <typename PT, int WPS>
+__global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t slices_per_scene, const PT* __restrict__ planes,
                                                            const float* __restrict__ P, const uint8_t* __restrict__ lin_bits,
                                                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                            const uint2* __restrict__ queue, uint32_t* __restrict__ queue_count,
@@ -125,7 +139,8 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     // sh  : per wave 64 lanes x 16 floats as [k/4][lane][k%4] (lane-contiguous 16-byte slots: conflict-free ds_read_b128)
     // stage: per wave 64 PREPARED rays x 16 dwords {ray, t, far, dt | o | d | 1/d | sample xyz}: queue entries and ray geometry are fetched from
     //        HBM 64 at a time by the whole wave (coalesced, full lane utilisation) instead of one lane at a time inside the divergent refill
-    __shared__ __attribute__((aligned(16))) float lds[512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + (SM_TPB / 64) * 1024 + (SM_TPB / 64) * 1024];
+    constexpr unsigned SM_POOL = SmGeo<WPS>::POOL, SM_MARCH_W = SmGeo<WPS>::MARCH_W, SM_STAGE = SmGeo<WPS>::STAGE, SM_WLDS = SmGeo<WPS>::WLDS;
+    __shared__ __attribute__((aligned(16))) float lds[SmGeo<WPS>::LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -146,10 +161,11 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     }
     __syncthreads();
     const float4* wout2 = reinterpret_cast<const float4*>(lds);     // index ((mt*8 + pair)*2 + half)*2 + {0: sigma|r, 1: g|b}
-    uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 512) + wave * 2 * SM_POOL * 8;
+    float* w_lds = lds + 512;                                       // WPS 3: A operands [layer-1: mt][s][lane] then [dir: mt][s][lane]
+    uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 512 + SM_WLDS) + wave * 2 * SM_POOL * 8;
     uint32_t* pool_ready = pool_search + SM_POOL * 8;
-    float4* sh_lds = reinterpret_cast<float4*>(lds + 512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * 1024);   // [kq][lane]
-    float4* stage = reinterpret_cast<float4*>(lds + 512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + (SM_TPB / 64) * 1024 + wave * 1024);   // [slot][4]
+    float4* sh_lds = reinterpret_cast<float4*>(lds + 512 + SM_WLDS + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * 1024);   // [kq][lane]
+    float4* stage = reinterpret_cast<float4*>(lds + 512 + SM_WLDS + (SM_TPB / 64) * (2 * SM_POOL * 8 + 1024) + wave * SM_STAGE * 16);   // [slot][4]
 
     // ---- persistent grid: every wave pulls 512-ray slices of a scene's hit queue with one atomic ticket per slice.  Waves of
     // XCD x (workgroups are dispatched round-robin over the 8 XCDs, b % 8) start on scene x so that the scene's 1.5 MiB of
@@ -163,19 +179,33 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
     const float dt_gamma_default = c.m.dt_gamma;
     // ---- A operands: lane l holds W[mt*32 + (l&31)][2s + (l>>5)] for every k-step s ----
     float a1[2][10], a2[2][9];
+    if (WPS == 2 || wave == 0) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int row = mt * 32 + (lane & 31);
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = mt * 32 + (lane & 31);
 #pragma unroll
-        for (int s = 0; s < 10; ++s) {
-            const int k = 2 * s + half;                       // W1 | b1 | 0
-            a1[mt][s] = k < 19 ? P[row * 24 + k] : 0.0f;      // rec[row][0..17] = W1, rec[row][18] = b1
+            for (int s = 0; s < 10; ++s) {
+                const int k = 2 * s + half;                       // W1 | b1 | 0
+                a1[mt][s] = k < 19 ? P[row * 24 + k] : 0.0f;      // rec[row][0..17] = W1, rec[row][18] = b1
+            }
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const int k = 2 * s + half;                       // Wd | bd | 0
+                a2[mt][s] = k < 16 ? P[MLP_OFF_WD + row * 16 + k] : (k == 16 ? P[MLP_OFF_BD + row] : 0.0f);
+            }
         }
+    }
+    if constexpr (WPS == 3) {                                 // park the A operands in LDS (one copy per block), lane-contiguous: conflict-free ds_read_b32
+        if (wave == 0) {
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            const int k = 2 * s + half;                       // Wd | bd | 0
-            a2[mt][s] = k < 16 ? P[MLP_OFF_WD + row * 16 + k] : (k == 16 ? P[MLP_OFF_BD + row] : 0.0f);
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int s = 0; s < 10; ++s) w_lds[(mt * 10 + s) * 64 + lane] = a1[mt][s];
+#pragma unroll
+                for (int s = 0; s < 9; ++s) w_lds[1280 + (mt * 9 + s) * 64 + lane] = a2[mt][s];
+            }
         }
+        __syncthreads();
     }
     const float b_const = half == 0 ? 1.0f : 0.0f;            // B operand of the (1, 0) bias/pad k-step, both tiles
     const float b_sigma = P[MLP_OFF_TAIL + 0], bc0 = P[MLP_OFF_TAIL + 1], bc1 = P[MLP_OFF_TAIL + 2], bc2 = P[MLP_OFF_TAIL + 3];
@@ -225,8 +255,13 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
         sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
         float sh[16];
         shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
+        if constexpr (WPS == 3) {                      // operand form [k][sample]: the dir-term MFMAs read their B operands straight from LDS
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) sh_lds[kq * 64 + lane] = make_float4(sh[4 * kq], sh[4 * kq + 1], sh[4 * kq + 2], sh[4 * kq + 3]);
+            for (int k = 0; k < 16; ++k) reinterpret_cast<float*>(sh_lds)[k * 64 + lane] = sh[k];
+        } else {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) sh_lds[kq * 64 + lane] = make_float4(sh[4 * kq], sh[4 * kq + 1], sh[4 * kq + 2], sh[4 * kq + 3]);
+        }
     };
 
     for (;;) {
@@ -264,7 +299,7 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
                     else scene_done = true;
                 }
                 if (next >= end) break;
-                const uint32_t n = min(end - next, 64u);
+                const uint32_t n = min(end - next, SM_STAGE);
                 if ((uint32_t)lane < n) {                    // stage fill: one queue entry per lane, all lanes busy
                     const uint2 e = queue[next + lane];
                     const uint64_t gi = ray0 + e.x;
@@ -297,16 +332,21 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
                 ws = dep = cr = cg = cb = 0.f; cnt = 0;
                 float sh[16];
                 shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
+                if constexpr (WPS == 3) {
 #pragma unroll
-                for (int kq = 0; kq < 4; ++kq) sh_lds[kq * 64 + lane] = make_float4(sh[4 * kq], sh[4 * kq + 1], sh[4 * kq + 2], sh[4 * kq + 3]);
+                    for (int k = 0; k < 16; ++k) reinterpret_cast<float*>(sh_lds)[k * 64 + lane] = sh[k];
+                } else {
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) sh_lds[kq * 64 + lane] = make_float4(sh[4 * kq], sh[4 * kq + 1], sh[4 * kq + 2], sh[4 * kq + 3]);
+                }
             }
             st_head += take; st_count -= take;
         }
         const uint64_t live = __ballot(ray >= 0);
 
         // ================= march pass: every lane takes one parked ray to its next hit or to the end of the box =================
-        if ((sp_count >= 64 || (live == 0 && sp_count != 0)) && rp_count <= SM_POOL - 64) {
-            const uint32_t n = min(sp_count, 64u);
+        if ((sp_count >= SM_MARCH_W || (live == 0 && sp_count != 0)) && rp_count <= SM_POOL - SM_MARCH_W) {
+            const uint32_t n = min(sp_count, SM_MARCH_W);
             bool found = false, mine = (uint32_t)lane < n;
             uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
             if (mine) {
@@ -347,7 +387,7 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
 
         // ================= shade: gather -> MFMA layers -> output layer -> composite =================
         float f[18];
-        if (ray >= 0) ssd_gather18<PT>(planes, c.g, sx, sy, sz, f);
+        if (ray >= 0) ssd_gather18<PT, WPS == 3>(planes, c.g, sx, sy, sz, f);
         else {
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
@@ -360,82 +400,138 @@ __global__ void __launch_bounds__(SM_TPB, 2) k_shade_mfma(ShadeCfg c, uint32_t s
         //   C: direction term tile 0     (18 MFMA)  ||  density head of tile 1
         //   D: direction term tile 1     (18 MFMA)  ||  colour head of tile 0
         //   E: colour head of tile 1
-        floatx16 acc[2][2];
+        float ps0, ps1, pr0, pr1, pg0, pg1, pb0, pb1;            // per tile: this lane half's share of (sigma, r, g, b) pre-activations
+        if constexpr (WPS == 3) {
+            // ---- three waves per SIMD: the tiles are shaded one after the other, A operands come from LDS, B operands are built in place ----
+            // after the swaps f[2s] feeds tile 0 (the samples of lanes 0-31) and f[2s+1] tile 1, k-step s; the SH operands sit in LDS in that form
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int s = 0; s < 9; ++s) sm_swap(f[2 * s], f[2 * s + 1]);
+            const float* sh_op = reinterpret_cast<const float*>(sh_lds) + half * 64 + (lane & 31);   // + (2s)*64 + nt*32: SH_{2s+half} of sample nt*32 + (lane & 31)
+            float res[2][4];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt) {
+                // the A operands are the same for both tiles; the laundered lane offset keeps the compiler from loading them once and holding
+                // all 38 of them in registers across the two tiles (which is exactly the register budget this variant exists to avoid)
+                uint32_t wl = (uint32_t)lane;
+                asm volatile("" : "+v"(wl));
+                const float* wA = w_lds + wl;
+                floatx16 acc[2];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
-        float fb0[10], fb1[10];                 // B operands of layer 1 for tile 0 / tile 1
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            fb0[s] = f[2 * s]; fb1[s] = f[2 * s + 1];
-            sm_swap(fb0[s], fb1[s]);
+                    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 10; ++s) {                              // h = W1 [f; 1]
+                    const float bop = s < 9 ? f[2 * s + nt] : b_const;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[(0 * 10 + s) * 64], bop, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[(1 * 10 + s) * 64], bop, acc[1], 0, 0, 0);
+                }
+                floatx2 ps = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {                              // density head on silu(h)
+                    const int mt = q >> 3, p2 = q & 7;
+                    const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
+                    ps = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]}), ps);
+                    if (q & 1) __builtin_amdgcn_sched_barrier(0);           // two pairs at a time: the scheduler otherwise batches all 32 exp/rcp and spills their results
+                }
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {                               // h += Wd [SH(d); 1], in place
+                    const float bop = s < 8 ? sh_op[2 * s * 64 + nt * 32] : b_const;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[1280 + (0 * 9 + s) * 64], bop, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[1280 + (1 * 9 + s) * 64], bop, acc[1], 0, 0, 0);
+                }
+                floatx2 pr = {0.f, 0.f}, pg = {0.f, 0.f}, pb = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {                              // colour head on silu(h + hd)
+                    const int mt = q >> 3, p2 = q & 7;
+                    const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+                    const floatx2 cc = sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]});
+                    pr = sm_fma2(floatx2{w0.z, w0.w}, cc, pr);
+                    pg = sm_fma2(floatx2{w1.x, w1.y}, cc, pg);
+                    pb = sm_fma2(floatx2{w1.z, w1.w}, cc, pb);
+                    if (q & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                res[nt][0] = ps.x + ps.y; res[nt][1] = pr.x + pr.y; res[nt][2] = pg.x + pg.y; res[nt][3] = pb.x + pb.y;
+            }
+            ps0 = res[0][0]; ps1 = res[1][0]; pr0 = res[0][1]; pr1 = res[1][1]; pg0 = res[0][2]; pg1 = res[1][2]; pb0 = res[0][3]; pb1 = res[1][3];
+        } else {
+            floatx16 acc[2][2];
+    #pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+    #pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+            float fb0[10], fb1[10];                 // B operands of layer 1 for tile 0 / tile 1
+    #pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                fb0[s] = f[2 * s]; fb1[s] = f[2 * s + 1];
+                sm_swap(fb0[s], fb1[s]);
+            }
+            fb0[9] = fb1[9] = b_const;
+            floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+            floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+            auto density_pair = [&](int nt, int q) {     // q in [0,16): accumulator pair (mt = q / 8, registers 2*(q%8), 2*(q%8)+1)
+                const int mt = q >> 3, p2 = q & 7;
+                const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
+                const floatx2 wS = {w.x, w.y};
+                ps_[nt] = sm_fma2(wS, sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]}), ps_[nt]);
+            };
+            auto colour_pair = [&](int nt, int q) {
+                const int mt = q >> 3, p2 = q & 7;
+                const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+                const floatx2 wR = {w0.z, w0.w}, wG = {w1.x, w1.y}, wB = {w1.z, w1.w};
+                const floatx2 cc = sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]});
+                pr_[nt] = sm_fma2(wR, cc, pr_[nt]);
+                pg_[nt] = sm_fma2(wG, cc, pg_[nt]);
+                pb_[nt] = sm_fma2(wB, cc, pb_[nt]);
+            };
+            // ---- A
+    #pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][s], fb0[s], acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][s], fb0[s], acc[1][0], 0, 0, 0);
+            }
+            // SH operands (per-ray constants parked in LDS)
+            float4 shq[4];
+    #pragma unroll
+            for (int kq = 0; kq < 4; ++kq) shq[kq] = sh_lds[kq * 64 + lane];
+            const float* sh = reinterpret_cast<const float*>(shq);
+            float sb0[9], sb1[9];
+    #pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                sb0[s] = sh[2 * s]; sb1[s] = sh[2 * s + 1];
+                sm_swap(sb0[s], sb1[s]);
+            }
+            sb0[8] = sb1[8] = b_const;
+            // ---- B
+    #pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][s], fb1[s], acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][s], fb1[s], acc[1][1], 0, 0, 0);
+                if (s < 8) { density_pair(0, 2 * s); density_pair(0, 2 * s + 1); }
+            }
+            // ---- C
+    #pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][s], sb0[s], acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][s], sb0[s], acc[1][0], 0, 0, 0);
+                if (s < 8) { density_pair(1, 2 * s); density_pair(1, 2 * s + 1); }
+            }
+            // ---- D
+    #pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][s], sb1[s], acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][s], sb1[s], acc[1][1], 0, 0, 0);
+                if (s < 8) { colour_pair(0, 2 * s); colour_pair(0, 2 * s + 1); }
+            }
+            // ---- E
+    #pragma unroll
+            for (int q = 0; q < 16; ++q) colour_pair(1, q);
+            ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y;
+            pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y; pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y;
+            pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         }
-        fb0[9] = fb1[9] = b_const;
-        floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
-        floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
-        auto density_pair = [&](int nt, int q) {     // q in [0,16): accumulator pair (mt = q / 8, registers 2*(q%8), 2*(q%8)+1)
-            const int mt = q >> 3, p2 = q & 7;
-            const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
-            const floatx2 wS = {w.x, w.y};
-            ps_[nt] = sm_fma2(wS, sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]}), ps_[nt]);
-        };
-        auto colour_pair = [&](int nt, int q) {
-            const int mt = q >> 3, p2 = q & 7;
-            const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
-            const floatx2 wR = {w0.z, w0.w}, wG = {w1.x, w1.y}, wB = {w1.z, w1.w};
-            const floatx2 cc = sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]});
-            pr_[nt] = sm_fma2(wR, cc, pr_[nt]);
-            pg_[nt] = sm_fma2(wG, cc, pg_[nt]);
-            pb_[nt] = sm_fma2(wB, cc, pb_[nt]);
-        };
-        // ---- A
-#pragma unroll
-        for (int s = 0; s < 10; ++s) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][s], fb0[s], acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][s], fb0[s], acc[1][0], 0, 0, 0);
-        }
-        // SH operands (per-ray constants parked in LDS)
-        float4 shq[4];
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) shq[kq] = sh_lds[kq * 64 + lane];
-        const float* sh = reinterpret_cast<const float*>(shq);
-        float sb0[9], sb1[9];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            sb0[s] = sh[2 * s]; sb1[s] = sh[2 * s + 1];
-            sm_swap(sb0[s], sb1[s]);
-        }
-        sb0[8] = sb1[8] = b_const;
-        // ---- B
-#pragma unroll
-        for (int s = 0; s < 10; ++s) {
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][s], fb1[s], acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][s], fb1[s], acc[1][1], 0, 0, 0);
-            if (s < 8) { density_pair(0, 2 * s); density_pair(0, 2 * s + 1); }
-        }
-        // ---- C
-#pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][s], sb0[s], acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][s], sb0[s], acc[1][0], 0, 0, 0);
-            if (s < 8) { density_pair(1, 2 * s); density_pair(1, 2 * s + 1); }
-        }
-        // ---- D
-#pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][s], sb1[s], acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][s], sb1[s], acc[1][1], 0, 0, 0);
-            if (s < 8) { colour_pair(0, 2 * s); colour_pair(0, 2 * s + 1); }
-        }
-        // ---- E
-#pragma unroll
-        for (int q = 0; q < 16; ++q) colour_pair(1, q);
-        float ps0 = ps_[0].x + ps_[0].y, ps1 = ps_[1].x + ps_[1].y;
-        float pr0 = pr_[0].x + pr_[0].y, pr1 = pr_[1].x + pr_[1].y, pg0 = pg_[0].x + pg_[0].y, pg1 = pg_[1].x + pg_[1].y;
-        float pb0 = pb_[0].x + pb_[0].y, pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
         sm_swap(ps0, ps1); sm_swap(pr0, pr1); sm_swap(pg0, pg1); sm_swap(pb0, pb1);
         const float sigma = ssd_exp(ps0 + ps1 + b_sigma);
@@ -545,10 +641,18 @@ extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dt
         if (n_cu <= 0) n_cu = 256;
     }
     const uint32_t slices = 0;   // (kept in the kernel signature; slices are ticketed dynamically)
-    dim3 g((unsigned)n_cu * 2u), b(SM_TPB);   // 2 workgroups x 4 waves per CU = the kernel's residency (<= 256 VGPRs, 50 KiB LDS)
+    // residency: WPS workgroups x 4 waves per CU, persistent.  SSDNERF_SHADE_WPS=2|3 picks the variant (default below).
+    static int wps = 0;
+    if (wps == 0) {
+        const char* e = getenv("SSDNERF_SHADE_WPS");
+        wps = (e && e[0] == '2') ? 2 : (e && e[0] == '3') ? 3 : SM_DEFAULT_WPS;
+    }
+    dim3 g((unsigned)n_cu * (unsigned)wps), b(SM_TPB);
     hipStream_t s = (hipStream_t)stream;
-    if (planes_dtype == 0) hipLaunchKernelGGL((k_shade_mfma<float>), g, b, 0, s, c, slices, (const float*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag);
-    else hipLaunchKernelGGL((k_shade_mfma<__half>), g, b, 0, s, c, slices, (const __half*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag);
+#define SM_LAUNCH(PT, W) hipLaunchKernelGGL((k_shade_mfma<PT, W>), g, b, 0, s, c, slices, (const PT*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag)
+    if (planes_dtype == 0) { if (wps == 3) SM_LAUNCH(float, 3); else SM_LAUNCH(float, 2); }
+    else { if (wps == 3) SM_LAUNCH(__half, 3); else SM_LAUNCH(__half, 2); }
+#undef SM_LAUNCH
     SSD_CHECK_LAUNCH("render_shade_queue_mfma");
     return SSDNERF_OK;
 }

@@ -36,7 +36,7 @@ def test_cam_rays_match_reference():
     for fn in (R.get_cam_rays, nerf.get_cam_rays):
         ro, rd = fn(pose, intr, 64, 64)
         np.testing.assert_allclose(ro.reshape(1, -1, 3).numpy(), f["rays_o"], rtol=0, atol=0)
-        np.testing.assert_allclose(rd.reshape(1, -1, 3).numpy(), f["rays_d"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(rd.reshape(1, -1, 3).numpy(), f["rays_d"], rtol=0, atol=3e-7)      # the 3x3 rotation is a BLAS call: a few ulp between hosts
 
 
 def test_oracle_decode_matches_reference(scene):
