@@ -62,20 +62,46 @@ SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_el
 static constexpr unsigned SM_TPB = 256;
 static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
 static constexpr unsigned SM_SEARCH_PROBES = 4;    // in-lane search budget after each sample
-// Two residencies of the same kernel (template parameter WPS = waves per SIMD):
-//   WPS 2: weights as MFMA A operands in 38 VGPRs, both 32-sample tiles in flight (64 accumulator registers), 253 VGPRs, 66 KiB LDS per block.
-//   WPS 3: weights as A operands read from LDS right before each MFMA, the two tiles shaded one after the other (32 accumulator registers),
+// Variants of the same kernel (template parameter VAR):
+//   VAR 2: weights as MFMA A operands in 38 VGPRs, both 32-sample tiles in flight (64 accumulator registers), 253 VGPRs, 66 KiB LDS per block.
+//   VAR 3: weights as A operands read from LDS right before each MFMA, the two tiles shaded one after the other (32 accumulator registers),
 //          B operands built in place; <= 168 VGPRs and <= 53 KiB LDS per block, so THREE waves share a SIMD: the r01 counters showed the
 //          2-wave form waiting (SQ_WAIT_INST_ANY ~ 43 % of wave time) with both pipes half idle -- a third wave is what fills those gaps.
-template <int WPS> struct SmGeo {
-    static constexpr unsigned POOL = WPS == 3 ? 64 : 128;      // entries per wave-local pool (two pools per wave)
+//   VAR 4: the two wide layers on the REAL matrix cores (v_mfma_f32_32x32x16_bf16) with every fp32 operand split exactly into three
+//          bf16 terms (x = hi + mid + lo, 8 + 8 + 8 significand bits) and the six products whose weight is >= 2^-16 accumulated in
+//          fp32: the same accuracy class as the fp32 chain (dropped terms <= 2^-24 relative), but -- unlike the f32-input MFMA, which
+//          executes on the VALU's own FMA lanes and therefore cannot overlap with VALU work at all (tools/ubench/mfma_valu_overlap.hip:
+//          2 MFMA + 32 v_fma take 126 ns = 59 + 70 with f32 MFMA, 77 ns with bf16 MFMA) -- it runs beside the SiLU / gather / marching VALU
+//          stream.  Two waves per SIMD, weights as 96 VGPRs of pre-split A operands, tiles shaded in sequence, SH operands pre-split in LDS.
+template <int VAR> struct SmGeo {
+    static constexpr int WPS = VAR == 3 ? 3 : 2;
+    static constexpr unsigned POOL = VAR == 3 ? 64 : 128;      // entries per wave-local pool (two pools per wave)
     static constexpr unsigned MARCH_W = POOL / 2;              // rays advanced by one march pass
-    static constexpr unsigned STAGE = WPS == 3 ? 32 : 64;      // prepared rays per wave
-    static constexpr unsigned WLDS = WPS == 3 ? (2 * 10 + 2 * 9) * 64 : 0;   // floats of A-operand weights in LDS
-    static constexpr unsigned LDS_FLOATS = 512 + WLDS + (SM_TPB / 64) * (2 * POOL * 8 + 1024 + STAGE * 16);
+    static constexpr unsigned STAGE = VAR == 3 ? 32 : 64;      // prepared rays per wave
+    static constexpr unsigned WLDS = VAR == 3 ? (2 * 10 + 2 * 9) * 64 : 0;   // floats of A-operand weights in LDS
+    static constexpr unsigned SHF = VAR == 4 ? 1536 : 1024;    // floats of per-ray SH operands per wave (VAR 4: three bf16 terms x 64 rays x 16)
+    static constexpr unsigned LDS_FLOATS = 512 + WLDS + (SM_TPB / 64) * (2 * POOL * 8 + SHF + STAGE * 16);
 };
-#ifndef SM_DEFAULT_WPS
-#define SM_DEFAULT_WPS 3                           // measured r01: 9.42 ms vs 9.66 ms (WPS 2) on the bench scene, 28.1 vs 29.2 ms on the fog scene
+
+typedef __bf16 sm_bf16x8 __attribute__((ext_vector_type(8)));
+// x == hi + mid + lo exactly, each term a bf16 value (returned as fp32 bit patterns whose low 16 bits are zero)
+SSD_DEV void sm_split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hi);                  // exact: the low 16 significand bits
+    mid = __float_as_uint(r1) & 0xffff0000u;
+    lo = __float_as_uint(r1 - __uint_as_float(mid));           // exact, at most 8 significant bits
+}
+SSD_DEV uint32_t sm_pack2(uint32_t even, uint32_t odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }   // {bf16(even), bf16(odd)}
+SSD_DEV sm_bf16x8 sm_op(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint4 u = make_uint4(a, b, c, d);
+    return *reinterpret_cast<const sm_bf16x8*>(&u);
+}
+SSD_DEV void sm_swap_u(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+#ifndef SM_DEFAULT_VARIANT
+#define SM_DEFAULT_VARIANT 4                       // measured r01 (bench scene / fog scene): variant 2 9.66 / 29.2 ms, 3 9.36 / 28.1 ms, 4 8.10 / 26.0 ms
 #endif
 #ifndef SM_REFILL_MIN
 #define SM_REFILL_MIN 1                            // refill only when this many lanes are idle (the divergent refill code then runs every few iterations instead of every iteration)
@@ -127,8 +153,8 @@ SSD_DEV void sm_swap(float& a, float& b) {
     b = __uint_as_float(r[1]);
 }
 
-template <typename PT, int WPS>
-__global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t slices_per_scene, const PT* __restrict__ planes,
+template <typename PT, int VAR>
+__global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg c, uint32_t slices_per_scene, const PT* __restrict__ planes,
                                                            const float* __restrict__ P, const uint8_t* __restrict__ lin_bits,
                                                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                            const uint2* __restrict__ queue, uint32_t* __restrict__ queue_count,
@@ -139,8 +165,9 @@ __global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t
     // sh  : per wave 64 lanes x 16 floats as [k/4][lane][k%4] (lane-contiguous 16-byte slots: conflict-free ds_read_b128)
     // stage: per wave 64 PREPARED rays x 16 dwords {ray, t, far, dt | o | d | 1/d | sample xyz}: queue entries and ray geometry are fetched from
     //        HBM 64 at a time by the whole wave (coalesced, full lane utilisation) instead of one lane at a time inside the divergent refill
-    constexpr unsigned SM_POOL = SmGeo<WPS>::POOL, SM_MARCH_W = SmGeo<WPS>::MARCH_W, SM_STAGE = SmGeo<WPS>::STAGE, SM_WLDS = SmGeo<WPS>::WLDS;
-    __shared__ __attribute__((aligned(16))) float lds[SmGeo<WPS>::LDS_FLOATS];
+    constexpr int WPS = SmGeo<VAR>::WPS;
+    constexpr unsigned SM_POOL = SmGeo<VAR>::POOL, SM_MARCH_W = SmGeo<VAR>::MARCH_W, SM_STAGE = SmGeo<VAR>::STAGE, SM_WLDS = SmGeo<VAR>::WLDS, SM_SHF = SmGeo<VAR>::SHF;
+    __shared__ __attribute__((aligned(16))) float lds[SmGeo<VAR>::LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -164,8 +191,8 @@ __global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t
     float* w_lds = lds + 512;                                       // WPS 3: A operands [layer-1: mt][s][lane] then [dir: mt][s][lane]
     uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 512 + SM_WLDS) + wave * 2 * SM_POOL * 8;
     uint32_t* pool_ready = pool_search + SM_POOL * 8;
-    float4* sh_lds = reinterpret_cast<float4*>(lds + 512 + SM_WLDS + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * 1024);   // [kq][lane]
-    float4* stage = reinterpret_cast<float4*>(lds + 512 + SM_WLDS + (SM_TPB / 64) * (2 * SM_POOL * 8 + 1024) + wave * SM_STAGE * 16);   // [slot][4]
+    float4* sh_lds = reinterpret_cast<float4*>(lds + 512 + SM_WLDS + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * SM_SHF);   // [kq][lane]  (VAR 4: [term][sample][2 x 16 B])
+    float4* stage = reinterpret_cast<float4*>(lds + 512 + SM_WLDS + (SM_TPB / 64) * (2 * SM_POOL * 8 + SM_SHF) + wave * SM_STAGE * 16);   // [slot][4]
 
     // ---- persistent grid: every wave pulls 512-ray slices of a scene's hit queue with one atomic ticket per slice.  Waves of
     // XCD x (workgroups are dispatched round-robin over the 8 XCDs, b % 8) start on scene x so that the scene's 1.5 MiB of
@@ -178,8 +205,33 @@ __global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t
     const uint2* queue_base = queue;
     const float dt_gamma_default = c.m.dt_gamma;
     // ---- A operands: lane l holds W[mt*32 + (l&31)][2s + (l>>5)] for every k-step s ----
+    // VAR 4: pre-split A operands.  wa1[mt][ks][term] / wa2[mt][ks][term]: lane l holds the 8 bf16 terms of W[mt*32 + (l&31)][16 ks + 8 (l>>5) + e]
+    sm_bf16x8 wa1[2][2][3], wa2[2][2][3];
+    if constexpr (VAR == 4) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = mt * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint32_t t1[3][8], t2[3][8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * ks + 8 * half + e;
+                    const float w1 = k < 19 ? P[row * 24 + k] : 0.0f;                                                        // W1 | b1 | 0
+                    const float w2 = k < 16 ? P[MLP_OFF_WD + row * 16 + k] : (k == 16 ? P[MLP_OFF_BD + row] : 0.0f);           // Wd | bd | 0
+                    sm_split3(w1, t1[0][e], t1[1][e], t1[2][e]);
+                    sm_split3(w2, t2[0][e], t2[1][e], t2[2][e]);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    wa1[mt][ks][t] = sm_op(sm_pack2(t1[t][0], t1[t][1]), sm_pack2(t1[t][2], t1[t][3]), sm_pack2(t1[t][4], t1[t][5]), sm_pack2(t1[t][6], t1[t][7]));
+                    wa2[mt][ks][t] = sm_op(sm_pack2(t2[t][0], t2[t][1]), sm_pack2(t2[t][2], t2[t][3]), sm_pack2(t2[t][4], t2[t][5]), sm_pack2(t2[t][6], t2[t][7]));
+                }
+            }
+        }
+    }
     float a1[2][10], a2[2][9];
-    if (WPS == 2 || wave == 0) {
+    if (VAR == 2 || (VAR == 3 && wave == 0)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int row = mt * 32 + (lane & 31);
@@ -195,7 +247,7 @@ __global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t
             }
         }
     }
-    if constexpr (WPS == 3) {                                 // park the A operands in LDS (one copy per block), lane-contiguous: conflict-free ds_read_b32
+    if constexpr (VAR == 3) {                                 // park the A operands in LDS (one copy per block), lane-contiguous: conflict-free ds_read_b32
         if (wave == 0) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -255,7 +307,17 @@ __global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t
         sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
         float sh[16];
         shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
-        if constexpr (WPS == 3) {                      // operand form [k][sample]: the dir-term MFMAs read their B operands straight from LDS
+        if constexpr (VAR == 4) {                      // three bf16 terms per value, in MFMA B-operand form: [term][sample][k 0-7 | k 8-15]
+            uint32_t tm[3][16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sm_split3(sh[k], tm[0][k], tm[1][k], tm[2][k]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                uint4* dst = reinterpret_cast<uint4*>(sh_lds) + t * 128 + lane * 2;
+                dst[0] = make_uint4(sm_pack2(tm[t][0], tm[t][1]), sm_pack2(tm[t][2], tm[t][3]), sm_pack2(tm[t][4], tm[t][5]), sm_pack2(tm[t][6], tm[t][7]));
+                dst[1] = make_uint4(sm_pack2(tm[t][8], tm[t][9]), sm_pack2(tm[t][10], tm[t][11]), sm_pack2(tm[t][12], tm[t][13]), sm_pack2(tm[t][14], tm[t][15]));
+            }
+        } else if constexpr (VAR == 3) {               // operand form [k][sample]: the dir-term MFMAs read their B operands straight from LDS
 #pragma unroll
             for (int k = 0; k < 16; ++k) reinterpret_cast<float*>(sh_lds)[k * 64 + lane] = sh[k];
         } else {
@@ -332,7 +394,17 @@ __global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t
                 ws = dep = cr = cg = cb = 0.f; cnt = 0;
                 float sh[16];
                 shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
-                if constexpr (WPS == 3) {
+                if constexpr (VAR == 4) {
+                    uint32_t tm[3][16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sm_split3(sh[k], tm[0][k], tm[1][k], tm[2][k]);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        uint4* dst = reinterpret_cast<uint4*>(sh_lds) + t * 128 + lane * 2;
+                        dst[0] = make_uint4(sm_pack2(tm[t][0], tm[t][1]), sm_pack2(tm[t][2], tm[t][3]), sm_pack2(tm[t][4], tm[t][5]), sm_pack2(tm[t][6], tm[t][7]));
+                        dst[1] = make_uint4(sm_pack2(tm[t][8], tm[t][9]), sm_pack2(tm[t][10], tm[t][11]), sm_pack2(tm[t][12], tm[t][13]), sm_pack2(tm[t][14], tm[t][15]));
+                    }
+                } else if constexpr (VAR == 3) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) reinterpret_cast<float*>(sh_lds)[k * 64 + lane] = sh[k];
                 } else {
@@ -387,7 +459,7 @@ __global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t
 
         // ================= shade: gather -> MFMA layers -> output layer -> composite =================
         float f[18];
-        if (ray >= 0) ssd_gather18<PT, WPS == 3>(planes, c.g, sx, sy, sz, f);
+        if (ray >= 0) ssd_gather18<PT, VAR != 2>(planes, c.g, sx, sy, sz, f);
         else {
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
@@ -401,7 +473,88 @@ __global__ void __launch_bounds__(SM_TPB, WPS) k_shade_mfma(ShadeCfg c, uint32_t
         //   D: direction term tile 1     (18 MFMA)  ||  colour head of tile 0
         //   E: colour head of tile 1
         float ps0, ps1, pr0, pr1, pg0, pg1, pb0, pb1;            // per tile: this lane half's share of (sigma, r, g, b) pre-activations
-        if constexpr (WPS == 3) {
+        if constexpr (VAR == 4) {
+            // ---- bf16 x 3 on the matrix cores.  Split every feature into three bf16 terms, pack feature pairs, and trade halves so that
+            // T[t][0..3] is tile 0's k-step-0 operand (features 0-15 of the samples of lanes 0-31) and T[t][4..7] tile 1's; T[t][8] / Z[t]
+            // carry features 16, 17 for k-step 1 (their other k slots are the bias row and zeros)
+            uint32_t T[3][9], Z[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int p2 = 0; p2 < 9; ++p2) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                sm_split3(f[2 * p2], h0, m0, l0);
+                sm_split3(f[2 * p2 + 1], h1, m1, l1);
+                T[0][p2] = sm_pack2(h0, h1); T[1][p2] = sm_pack2(m0, m1); T[2][p2] = sm_pack2(l0, l1);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sm_swap_u(T[t][k], T[t][4 + k]);
+                sm_swap_u(T[t][8], Z[t]);
+            }
+            const uint32_t bias_pair = half == 0 ? 0x00003F80u : 0u;          // {bf16(1.0), 0}: the bias row of k-step 1 (k = 18 resp. 16), lane half 0 only
+            const sm_bf16x8 b_bias = sm_op(bias_pair, 0u, 0u, 0u);            // dir layer, k-step 1: [1, 0, ...]
+            float res[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                floatx16 acc[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+                sm_bf16x8 b0[3], b1[3];                                      // B operands of k-step 0 / 1, terms hi, mid, lo
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    b0[t] = sm_op(T[t][4 * nt], T[t][4 * nt + 1], T[t][4 * nt + 2], T[t][4 * nt + 3]);
+                    b1[t] = sm_op(nt == 0 ? T[t][8] : Z[t], t == 0 ? bias_pair : 0u, 0u, 0u);
+                }
+                // h = W1 [f; 1]: products (weight term i) x (feature term j), i + j <= 2, smallest first
+#pragma unroll
+                for (int pr_i = 0; pr_i < 6; ++pr_i) {
+                    constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};
+                    const int i = TI[pr_i], j = TJ[pr_i];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0[j], acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][1][i], b1[j], acc[mt], 0, 0, 0);
+                    }
+                }
+                floatx2 ps = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {                              // density head on silu(h)
+                    const int mt = q >> 3, p2 = q & 7;
+                    const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
+                    ps = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]}), ps);
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // four pairs at a time (see VAR 3)
+                }
+                // h += Wd [SH(d); 1]: SH operands pre-split per ray in LDS, [term][sample][k 0-7 | k 8-15]
+                sm_bf16x8 sb[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) sb[t] = *reinterpret_cast<const sm_bf16x8*>(reinterpret_cast<const uint4*>(sh_lds) + t * 128 + (nt * 32 + (lane & 31)) * 2 + half);
+#pragma unroll
+                for (int pr_i = 0; pr_i < 6; ++pr_i) {
+                    constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};
+                    const int i = TI[pr_i], j = TJ[pr_i];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][0][i], sb[j], acc[mt], 0, 0, 0);
+                        if (j == 0) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][1][i], b_bias, acc[mt], 0, 0, 0);   // + bd (exactly: 1.0 has one term)
+                    }
+                }
+                floatx2 pr = {0.f, 0.f}, pg = {0.f, 0.f}, pb = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {                              // colour head on silu(h + hd)
+                    const int mt = q >> 3, p2 = q & 7;
+                    const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+                    const floatx2 cc = sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]});
+                    pr = sm_fma2(floatx2{w0.z, w0.w}, cc, pr);
+                    pg = sm_fma2(floatx2{w1.x, w1.y}, cc, pg);
+                    pb = sm_fma2(floatx2{w1.z, w1.w}, cc, pb);
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                res[nt][0] = ps.x + ps.y; res[nt][1] = pr.x + pr.y; res[nt][2] = pg.x + pg.y; res[nt][3] = pb.x + pb.y;
+            }
+            ps0 = res[0][0]; ps1 = res[1][0]; pr0 = res[0][1]; pr1 = res[1][1]; pg0 = res[0][2]; pg1 = res[1][2]; pb0 = res[0][3]; pb1 = res[1][3];
+        } else if constexpr (VAR == 3) {
             // ---- three waves per SIMD: the tiles are shaded one after the other, A operands come from LDS, B operands are built in place ----
             // after the swaps f[2s] feeds tile 0 (the samples of lanes 0-31) and f[2s+1] tile 1, k-step s; the SH operands sit in LDS in that form
 #pragma unroll
@@ -642,16 +795,16 @@ extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dt
     }
     const uint32_t slices = 0;   // (kept in the kernel signature; slices are ticketed dynamically)
     // residency: WPS workgroups x 4 waves per CU, persistent.  SSDNERF_SHADE_WPS=2|3 picks the variant (default below).
-    static int wps = 0;
-    if (wps == 0) {
-        const char* e = getenv("SSDNERF_SHADE_WPS");
-        wps = (e && e[0] == '2') ? 2 : (e && e[0] == '3') ? 3 : SM_DEFAULT_WPS;
+    static int var = 0;                                  // 2: f32 MFMA, 2 waves/SIMD; 3: f32 MFMA, 3 waves/SIMD; 4: bf16 x 3 on the matrix cores
+    if (var == 0) {
+        const char* e = getenv("SSDNERF_SHADE_VARIANT");
+        var = (e && e[0] >= '2' && e[0] <= '4') ? e[0] - '0' : SM_DEFAULT_VARIANT;
     }
-    dim3 g((unsigned)n_cu * (unsigned)wps), b(SM_TPB);
+    dim3 g((unsigned)n_cu * (var == 3 ? 3u : 2u)), b(SM_TPB);
     hipStream_t s = (hipStream_t)stream;
-#define SM_LAUNCH(PT, W) hipLaunchKernelGGL((k_shade_mfma<PT, W>), g, b, 0, s, c, slices, (const PT*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag)
-    if (planes_dtype == 0) { if (wps == 3) SM_LAUNCH(float, 3); else SM_LAUNCH(float, 2); }
-    else { if (wps == 3) SM_LAUNCH(__half, 3); else SM_LAUNCH(__half, 2); }
+#define SM_LAUNCH(PT, V) hipLaunchKernelGGL((k_shade_mfma<PT, V>), g, b, 0, s, c, slices, (const PT*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag)
+    if (planes_dtype == 0) { if (var == 4) SM_LAUNCH(float, 4); else if (var == 3) SM_LAUNCH(float, 3); else SM_LAUNCH(float, 2); }
+    else { if (var == 4) SM_LAUNCH(__half, 4); else if (var == 3) SM_LAUNCH(__half, 3); else SM_LAUNCH(__half, 2); }
 #undef SM_LAUNCH
     SSD_CHECK_LAUNCH("render_shade_queue_mfma");
     return SSDNERF_OK;
