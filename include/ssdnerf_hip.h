@@ -209,6 +209,9 @@ int ssdnerf_ddim_step_v(const float* x_t, const float* v, uint64_t n, float sqrt
 int ssdnerf_cam_rays(const float* c2w, const float* intrinsics, uint32_t n_views, uint32_t h, uint32_t w, float* rays_o,
                      float* rays_d, void* stream);
 
+/* y[i] = uint8(round_half_even(clamp(x[i], 0, 1) * 255)): the output quantisation of eval_and_viz (base_nerf.py:551-553). */
+int ssdnerf_quantize_u8(const float* x, uint64_t n, uint8_t* y, void* stream);
+
 /* ---- Part 3: denoising-UNet glue (lib/models/architecture/ddpm/modules.py:12-129, denoising.py:178-187) ------------------
  * Activations are channel-last: x, y are [B][HW][C] of dtype 0 = fp32, 1 = fp16, 2 = bf16.
  *

@@ -40,3 +40,30 @@ extern "C" int ssdnerf_cam_rays(const float* c2w, const float* intrinsics, uint3
     SSD_CHECK_LAUNCH("cam_rays");
     return SSDNERF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Output quantisation of eval_and_viz (lib/models/autodecoders/base_nerf.py:551-553): clamp to [0, 1], scale by 255, round half to even
+// (torch.round), store as uint8 -- the form the views are all-gathered and written in.  One pass: 16 B read, 4 B written per lane.
+__global__ void __launch_bounds__(256) k_quantize_u8(const float* __restrict__ x, uint64_t n, uint8_t* __restrict__ y) {
+    const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const uint32_t a = (uint32_t)rintf(fminf(fmaxf(v.x, 0.f), 1.f) * 255.f), b = (uint32_t)rintf(fminf(fmaxf(v.y, 0.f), 1.f) * 255.f);
+        const uint32_t c = (uint32_t)rintf(fminf(fmaxf(v.z, 0.f), 1.f) * 255.f), d = (uint32_t)rintf(fminf(fmaxf(v.w, 0.f), 1.f) * 255.f);
+        reinterpret_cast<uint32_t*>(y)[i] = a | (b << 8) | (c << 16) | (d << 24);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const uint64_t i = n4 * 4 + threadIdx.x;
+        y[i] = (uint8_t)rintf(fminf(fmaxf(x[i], 0.f), 1.f) * 255.f);
+    }
+}
+
+extern "C" int ssdnerf_quantize_u8(const float* x, uint64_t n, uint8_t* y, void* stream) {
+    if (n == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x && y, "quantize_u8: null pointer");
+    const uint64_t n4 = n / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 + 1 : 4096);
+    hipLaunchKernelGGL(k_quantize_u8, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    SSD_CHECK_LAUNCH("quantize_u8");
+    return SSDNERF_OK;
+}

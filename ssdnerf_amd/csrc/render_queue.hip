@@ -98,23 +98,30 @@ __global__ void k_bitfield_linearize(const uint8_t* __restrict__ morton_bits, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// Conservative coarse occupancy: one bit per block of 2^3 cells, set if ANY cell of the block dilated by RQ_COARSE_DILATE cells is
-// occupied.  k_first_hit walks it with points RQ_COARSE_STEP cells apart: if every point lands in a clear block, no cell within one
+// Conservative coarse occupancy: one bit per block of B^3 cells (B = 2^RQ_COARSE_LOG2B), set if ANY cell of the block dilated by B/2 cells
+// is occupied.  k_first_hit walks it with points RQ_COARSE_STEP = B - 0.1 cells apart: every point q of the segment is then within
+// (B - 0.1)/2 cells, per axis, of a test point p, so the cell of q -- and the neighbour the reference's fp32 rounding may pick instead --
+// has an index within B/2 of p's (the test point's block is taken from ITS exact cell index, >> LOG2B).  If every point lands in a clear
 // cell of the ray is occupied, so the exact march would test nothing but empty cells and need not run at all (see k_first_hit).
-static constexpr int RQ_COARSE_DILATE = 2;
-static constexpr float RQ_COARSE_STEP = 1.9f;     // in cells: every point of the ray is within 0.95 cell of a test point
+#ifndef RQ_COARSE_LOG2B
+#define RQ_COARSE_LOG2B 2
+#endif
+static constexpr int RQ_COARSE_B = 1 << RQ_COARSE_LOG2B;
+static constexpr int RQ_COARSE_DILATE = RQ_COARSE_B / 2;
+static constexpr float RQ_COARSE_STEP = (float)RQ_COARSE_B - 0.1f;     // in cells
 
 __global__ void __launch_bounds__(RQ_TPB) k_bitfield_coarsen(const uint8_t* __restrict__ lin_bits_all, uint32_t H, uint32_t log2H, uint32_t bytes_per_scene,
                                                               uint8_t* __restrict__ coarse_all) {
-    const uint32_t Hc = H >> 1, log2Hc = log2H - 1;
+    const uint32_t Hc = H >> RQ_COARSE_LOG2B, log2Hc = log2H - RQ_COARSE_LOG2B;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;               // coarse cell, x fastest
     const uint8_t* lin = lin_bits_all + (uint64_t)blockIdx.y * bytes_per_scene;
     bool occ = false;
     if (i < Hc * Hc * Hc) {
         const int cx = (int)(i & (Hc - 1)), cy = (int)((i >> log2Hc) & (Hc - 1)), cz = (int)(i >> (2 * log2Hc));
-        const int x0 = max(2 * cx - RQ_COARSE_DILATE, 0), x1 = min(2 * cx + 1 + RQ_COARSE_DILATE, (int)H - 1);
-        for (int z = max(2 * cz - RQ_COARSE_DILATE, 0); z <= min(2 * cz + 1 + RQ_COARSE_DILATE, (int)H - 1); ++z)
-            for (int y = max(2 * cy - RQ_COARSE_DILATE, 0); y <= min(2 * cy + 1 + RQ_COARSE_DILATE, (int)H - 1); ++y)
+        constexpr int B = RQ_COARSE_B, D = RQ_COARSE_DILATE;
+        const int x0 = max(B * cx - D, 0), x1 = min(B * cx + B - 1 + D, (int)H - 1);
+        for (int z = max(B * cz - D, 0); z <= min(B * cz + B - 1 + D, (int)H - 1); ++z)
+            for (int y = max(B * cy - D, 0); y <= min(B * cy + B - 1 + D, (int)H - 1); ++y)
                 for (int x = x0; x <= x1; ++x) {
                     const uint32_t idx = ((((uint32_t)z << log2H) + (uint32_t)y) << log2H) + (uint32_t)x;
                     occ |= (lin[idx >> 3] >> (idx & 7u)) & 1u;
@@ -145,7 +152,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t*
     if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
     // this scene's coarse bitfield -> LDS ((H/2)^3 bits; 4 KiB for H = 64)
     __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
-    const uint32_t Hc = c.m.H >> 1, log2Hc = c.m.log2H - 1, coarse_bytes = (Hc * Hc * Hc) >> 3;
+    const uint32_t Hc = c.m.H >> RQ_COARSE_LOG2B, log2Hc = c.m.log2H - RQ_COARSE_LOG2B, coarse_bytes = (Hc * Hc * Hc) >> 3;
     const bool use_coarse = coarse_bits != nullptr && coarse_bytes <= RQ_COARSE_MAX_BYTES && coarse_bytes % 16 == 0;
     if (use_coarse) {
         const uint4* src = reinterpret_cast<const uint4*>(coarse_bits + (uint64_t)scene * coarse_bytes);
@@ -162,13 +169,13 @@ __global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t*
         if (use_coarse && t < far_) {
             const float len = sqrtf(ssd_fma(r.dx, r.dx, ssd_fma(r.dy, r.dy, r.dz * r.dz)));
             const float step_t = (RQ_COARSE_STEP * c.m.two_rH * c.m.mip_bound) / fmaxf(len, 1e-20f);   // RQ_COARSE_STEP cells of world length, in t
-            const float quarter_H = 0.5f * c.m.half_H, Hcm1 = (float)(Hc - 1);
+
             bool any = false;
             for (float tc = t; ; tc += step_t) {                             // test points from near to (at least) far
                 const float u = fminf(tc, far_);
-                const int bx = (int)ssd_clamp(ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f) * quarter_H, 0.0f, Hcm1);
-                const int by = (int)ssd_clamp(ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f) * quarter_H, 0.0f, Hcm1);
-                const int bz = (int)ssd_clamp(ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f) * quarter_H, 0.0f, Hcm1);
+                const int bx = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;   // block of the point's exact cell
+                const int by = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
+                const int bz = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
                 const uint32_t ci = ((((uint32_t)bz << log2Hc) + (uint32_t)by) << log2Hc) + (uint32_t)bx;
                 any |= (coarse_lds[ci >> 3] >> (ci & 7u)) & 1u;
                 if (any || !(tc < far_)) break;
@@ -409,8 +416,8 @@ extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_s
     const RqWorkspace w = rq_carve(workspace, S, grid_size);
     if (hipMemsetAsync(w.counters, 0, (size_t)S * 8, s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "render_first_hit: memset failed");   // hit counts + slice tickets
     hipLaunchKernelGGL(k_bitfield_linearize, dim3(ssd_blocks(c.bitfield_stride, RQ_TPB), S), dim3(RQ_TPB), 0, s, bitfield, grid_size, c.m.log2H, c.bitfield_stride, w.lin_bits);
-    const uint32_t hc = grid_size / 2;
-    const bool coarse_ok = grid_size >= 16 && (hc * hc * hc / 8) <= RQ_COARSE_MAX_BYTES && bound <= 1.0f && getenv("SSDNERF_NO_COARSE") == nullptr;
+    const uint32_t hc = grid_size >> RQ_COARSE_LOG2B;    // (the workspace reserves room for the finest block size, 2 cells)
+    const bool coarse_ok = hc >= 8 && (hc * hc * hc / 8) <= RQ_COARSE_MAX_BYTES && (hc * hc * hc / 8) % 16 == 0 && bound <= 1.0f && getenv("SSDNERF_NO_COARSE") == nullptr;
     if (coarse_ok)
         hipLaunchKernelGGL(k_bitfield_coarsen, dim3(ssd_blocks(hc * hc * hc, RQ_TPB), S), dim3(RQ_TPB), 0, s, w.lin_bits, grid_size, c.m.log2H, c.bitfield_stride, w.coarse);
     hipLaunchKernelGGL(k_first_hit, dim3(ssd_blocks(N, RQ_TPB), S), dim3(RQ_TPB), 0, s, c, w.lin_bits, coarse_ok ? w.coarse : (const uint8_t*)nullptr, rays_o, rays_d, image,

@@ -97,6 +97,12 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
 
 def quantize_u8(image: torch.Tensor) -> torch.Tensor:
     """clamp [0,1] and round to k/255 as ``eval_and_viz`` does (base_nerf.py:551-553), kept as uint8 (what is all-gathered)."""
+    if image.is_cuda and image.dtype == torch.float32 and image.is_contiguous():
+        import ctypes
+        from . import _cabi as C
+        out = torch.empty(image.shape, dtype=torch.uint8, device=image.device)
+        C.check(C.lib().ssdnerf_quantize_u8(C.ptr(image), ctypes.c_uint64(image.numel()), C.ptr(out), C.stream()), "quantize_u8")
+        return out
     return torch.round(image.clamp(0, 1) * 255).to(torch.uint8)
 
 

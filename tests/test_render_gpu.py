@@ -280,3 +280,13 @@ def test_cam_rays_kernel_matches_tensor_op_form():
     ro, rd = nerf.get_cam_rays(torch.from_numpy(f["pose"]).cuda(), torch.from_numpy(f["intrinsics"]).cuda(), 64, 64)     # 1 scene, 1 view, 64x64
     assert np.abs(rd.cpu().numpy().reshape(f["rays_d"].shape) - f["rays_d"]).max() <= 3e-7
     assert np.array_equal(ro.cpu().numpy().reshape(f["rays_o"].shape), f["rays_o"])
+
+
+def test_quantize_u8_kernel_matches_torch():
+    from ssdnerf_amd import nerf
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1003, 3, generator=g) * 1.4 - 0.2
+    x[:8, 0] = torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, 0.0, 1.0, -1.0, 2.0, 127.5 / 255])       # ties round to even, clamps
+    got = nerf.quantize_u8(x.cuda()).cpu()
+    want = torch.round(x.clamp(0, 1) * 255).to(torch.uint8)
+    assert got.dtype == torch.uint8 and torch.equal(got, want)
