@@ -103,6 +103,9 @@ SSD_DEV void sm_swap_u(uint32_t& a, uint32_t& b) {
 #ifndef SM_DEFAULT_VARIANT
 #define SM_DEFAULT_VARIANT 4                       // measured r01 (bench scene / fog scene): variant 2 9.66 / 29.2 ms, 3 9.36 / 28.1 ms, 4 8.10 / 26.0 ms
 #endif
+#ifndef SM_HEAD_GROUP
+#define SM_HEAD_GROUP 3                            // variant 4: SiLU pairs per scheduling group minus one (3 = four pairs)
+#endif
 #ifndef SM_REFILL_MIN
 #define SM_REFILL_MIN 1                            // refill only when this many lanes are idle (the divergent refill code then runs every few iterations instead of every iteration)
 #endif
@@ -524,7 +527,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                     const int mt = q >> 3, p2 = q & 7;
                     const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
                     ps = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]}), ps);
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // four pairs at a time (see VAR 3)
+                    if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);    // four pairs at a time (see VAR 3)
                 }
                 // h += Wd [SH(d); 1]: SH operands pre-split per ray in LDS, [term][sample][k 0-7 | k 8-15]
                 sm_bf16x8 sb[3];
@@ -549,7 +552,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                     pr = sm_fma2(floatx2{w0.z, w0.w}, cc, pr);
                     pg = sm_fma2(floatx2{w1.x, w1.y}, cc, pg);
                     pb = sm_fma2(floatx2{w1.z, w1.w}, cc, pb);
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);
                 }
                 res[nt][0] = ps.x + ps.y; res[nt][1] = pr.x + pr.y; res[nt][2] = pg.x + pg.y; res[nt][3] = pb.x + pb.y;
             }

@@ -290,3 +290,28 @@ def test_quantize_u8_kernel_matches_torch():
     got = nerf.quantize_u8(x.cuda()).cpu()
     want = torch.round(x.clamp(0, 1) * 255).to(torch.uint8)
     assert got.dtype == torch.uint8 and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("grid", [16, 32, 128])
+def test_coarse_pretest_other_grid_sizes(decoder, scene, grid, monkeypatch):
+    """The pre-test adapts to the grid (block = 4 cells; it switches itself off where the coarse table would not fit): random sparse
+    bitfields at 16^3 / 32^3 / 128^3, every output bit-identical with the pre-test on and off."""
+    from ssdnerf_amd.decoders import pack_triplanes
+    g = torch.Generator().manual_seed(grid)
+    code = scene["code"].cuda()[None]
+    planes = pack_triplanes(code)
+    occ = (torch.rand(grid ** 3, generator=g) < 0.02)
+    occ.view(grid, grid, grid)[grid // 4: grid // 2, grid // 4: grid // 2, grid // 4: grid // 2] |= torch.rand(grid // 4, grid // 4, grid // 4, generator=g) < 0.5
+    bits = torch.from_numpy(np.packbits(occ.numpy().astype(np.uint8), bitorder="little")).cuda()[None]        # morton-ordered index space: any pattern is a valid field
+    ro, rd = _view(90)
+    o, d = torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None]
+
+    def run():
+        out = decoder.render_packed(planes, o, d, bits, [grid], [0.0], 1e-4, bg_color=1.0, want_counts=True, check_overflow=False)
+        return out["image"][0].clone(), out["depth"][0].clone(), decoder.last_render_stats["sample_counts"][0].clone()
+    a = run()
+    monkeypatch.setenv("SSDNERF_NO_COARSE", "1")
+    b = run()
+    monkeypatch.delenv("SSDNERF_NO_COARSE")
+    assert int((b[2] > 0).sum()) > 100 and int((b[2] == 0).sum()) > 100
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
