@@ -262,6 +262,18 @@ int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t Cin1, const
                              uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint, void* splitk_ws,
                              size_t splitk_ws_bytes, int splits_hint, void* stream);
 
+/* The same convolution for fp32 activations with fp32-class products on the bf16 matrix cores: x (and x2), residual, y are fp32
+ * channel-last; the weights are passed pre-split, w_hi = bf16(w), w_lo = bf16(w - w_hi), each [Cout][ksize][ksize][Cin]; activations are
+ * split in the kernel; hi*hi + hi*lo + lo*hi accumulate in fp32 (>= 16 significand bits per product; TF32, the reference's cuDNN default on
+ * Ampere, keeps 11).  tile_hint 0 = choose, 1 = 128x128, 3 = 64x64; layers with too few tiles are cut along K (splits_hint 0 = choose) and
+ * reduced straight into the output, which the call zeroes first unless y_is_zero != 0 (ssdnerf_conv2d_nhwc_f32x2_plan tells a caller in
+ * advance: tile | splits << 8).  Residual must not alias y.  Other arguments as ssdnerf_conv2d_nhwc_bf16. */
+int ssdnerf_conv2d_nhwc_f32x2_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int splits_hint);
+int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, const void* w_hi, const void* w_lo, const float* bias,
+                              const void* residual, void* y, uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout,
+                              uint32_t ksize, uint32_t stride, uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint,
+                              int splits_hint, int y_is_zero, void* stream);
+
 /* Self-attention of MultiHeadAttentionMod (modules.py:12-48; mmgen QKVAttention) over the qkv projection of a channel-last
  * activation: qkv bf16 [B][T][3*heads*ch] with the reference's channel order [head][q | k | v][ch], out bf16 [B][T][heads*ch]
  * (channel = head*ch + i):  out = softmax(q k^T / sqrt(ch)) v  per (sample, head), softmax statistics and accumulation in fp32,

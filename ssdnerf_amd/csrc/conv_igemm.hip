@@ -296,6 +296,282 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
     }
 }
 
+// ================================================================================================================================
+// fp32 activations, fp32-class products on the bf16 matrix cores ("bf16 x 2"): every fp32 operand is split into two bf16 terms
+// (x ~ hi + lo, 16 significand bits, relative error <= 2^-16; TF32 -- what the reference's cuDNN convolutions use on Ampere -- has 11)
+// and hi*hi + hi*lo + lo*hi are accumulated in fp32.  For configs that run the UNet in fp32 (every paper config but the fp16 one).
+//   * x fp32 [B][H][W][Cin]: the A tile goes global -> registers -> (split) -> LDS, one K-tile ahead of the MFMAs (the loads of tile kt+1
+//     are issued before the MFMAs of tile kt and written to LDS after them); weights are pre-split on the host into two bf16 tensors and
+//     go L2 -> LDS by global_load_lds like the bf16 kernel's;
+//   * K-tile 32 (64-byte rows, chunks XOR-swizzled by (row >> 2) & 3: conflict-free ds_read_b128), 24 MFMAs per K-tile and wave for the
+//     128 x 128 tile -- three times the bf16 kernel's MFMA work per byte of L2 traffic, which is what that DMA-issue-bound kernel had spare;
+//   * epilogue as in the bf16 kernel, fp32 out (+ bias, + fp32 residual, + GroupNorm sums).
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, const unsigned char* __restrict__ w_lo) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, ROWB = BK * 2;          // 64-byte bf16 rows
+    constexpr int A_PIECES = BM * (BK / 4) / 256;                              // 16-byte fp32 pieces (4 channels) per thread per K-tile
+    constexpr int B_INST = BN / 16 / 4;                                        // DMA instructions (16 rows x 64 B) per wave per K-tile and term
+    constexpr int STAGE = 2 * (BM + BN) * ROWB;                                // [A hi | A lo | B hi | B lo]
+    constexpr int EPI = BM * BN * 4;
+    constexpr int LDS_BYTES = ((2 * STAGE > EPI) ? 2 * STAGE : EPI) + 512;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+
+    const uint32_t n_blocks = a.m_tiles * a.n_tiles * a.splits;
+    uint32_t tile, split;
+    {
+        const uint32_t xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n_blocks >> 3, r = n_blocks & 7;
+        const uint32_t lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile = lin / a.splits; split = lin % a.splits;
+    }
+    const uint32_t m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
+    const uint32_t taps = a.ksize * a.ksize;
+    const uint32_t Hv = a.upsample ? a.H * 2 : a.H, Wv = a.upsample ? a.W * 2 : a.W;
+    const uint32_t Cin2 = a.Cin - a.Cin1;
+
+    // ---- A loader: piece p = tid + 256 i -> tile row p / 8, channels 4 (p % 8) .. + 3 of the K-tile ------------------------------------
+    int32_t a_y0[A_PIECES], a_x0[A_PIECES];
+    uint32_t a_img[A_PIECES], a_dst[A_PIECES];
+    bool a_ok[A_PIECES];
+    const uint32_t c4 = tid & 7;
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+        const uint32_t r = (tid >> 3) + 32 * i, m = m0 + r;
+        a_ok[i] = m < a.M;
+        const uint32_t mm = a_ok[i] ? m : 0;
+        const uint32_t b = mm / (a.Ho * a.Wo), rem = mm % (a.Ho * a.Wo);
+        a_y0[i] = (int32_t)((rem / a.Wo) * a.stride) - (int32_t)a.pad;
+        a_x0[i] = (int32_t)((rem % a.Wo) * a.stride) - (int32_t)a.pad;
+        a_img[i] = b * a.H * a.W;
+        a_dst[i] = r * ROWB + (((c4 >> 1) ^ ((r >> 2) & 3)) * 16) + (c4 & 1) * 8;         // swizzled 8-byte slot of this piece's 4 bf16
+    }
+    const float* a_src[A_PIECES];
+    const float* a_src2[A_PIECES];
+    auto set_tap = [&](uint32_t tap) {
+        const int32_t kh = (int32_t)(tap / a.ksize), kw = (int32_t)(tap % a.ksize);
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            const int32_t yv = a_y0[i] + kh, xv = a_x0[i] + kw;
+            const bool ok = a_ok[i] && yv >= 0 && xv >= 0 && yv < (int32_t)Hv && xv < (int32_t)Wv;
+            const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
+            const uint64_t pix = (uint64_t)(a_img[i] + yi * a.W + xi);
+            a_src[i] = ok ? reinterpret_cast<const float*>(a.x) + pix * a.Cin1 + c4 * 4 : nullptr;
+            a_src2[i] = (ok && a.x2) ? reinterpret_cast<const float*>(a.x2) + pix * Cin2 + c4 * 4 : nullptr;
+        }
+    };
+    float4 a_reg[A_PIECES];
+    auto a_load = [&](uint32_t ci0) {
+        const bool second = ci0 >= a.Cin1;
+        const uint32_t coff = second ? ci0 - a.Cin1 : ci0;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            const float* p = second ? a_src2[i] : a_src[i];
+            a_reg[i] = p ? *reinterpret_cast<const float4*>(p + coff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto a_store = [&](uint32_t buf) {                                          // split and park: hi = truncation to bf16, lo = truncation of the exact remainder
+        unsigned char* sa = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            const float v[4] = {a_reg[i].x, a_reg[i].y, a_reg[i].z, a_reg[i].w};
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hi[k] = __float_as_uint(v[k]) & 0xffff0000u;
+                lo[k] = __float_as_uint(v[k] - __uint_as_float(hi[k]));
+            }
+            *reinterpret_cast<uint2*>(sa + a_dst[i]) = make_uint2(__builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u), __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u));
+            *reinterpret_cast<uint2*>(sa + BM * ROWB + a_dst[i]) = make_uint2(__builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u), __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u));
+        }
+    };
+    // ---- B loader: DMA instruction i of this wave covers rows (wave*B_INST + i)*16 + (lane >> 2), 16-byte chunk lane & 3 ----------------
+    uint32_t b_off[B_INST];
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+        const uint32_t r = (wave * B_INST + i) * 16 + (lane >> 2);
+        b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 3) ^ ((r >> 2) & 3)) * 16;
+    }
+    auto b_issue = [&](uint32_t tap, uint32_t ci0, uint32_t buf) {
+        unsigned char* sb = lds + buf * STAGE + 2 * BM * ROWB;
+        const uint64_t koff = (uint64_t)(tap * a.Cin + ci0) * 2;
+#pragma unroll
+        for (int i = 0; i < B_INST; ++i) {
+            cv_glds16(a.w + b_off[i] + koff, sb + (wave * B_INST + i) * 1024);
+            cv_glds16(w_lo + b_off[i] + koff, sb + BN * ROWB + (wave * B_INST + i) * 1024);
+        }
+    };
+    // ---- reader geometry ---------------------------------------------------------------------------------------------------------------
+    const uint32_t rd_row = lane & 31;
+    const uint32_t rd_c0 = ((lane >> 5) ^ ((lane >> 2) & 3)) * 16;             // chunk of k-step 0 (rows of a 32-row tile: (row >> 2) & 3 == (lane >> 2) & 3); k-step 1 is ^ 32
+    const uint32_t a_rd = (wm * 32 * TM + rd_row) * ROWB + rd_c0;
+    const uint32_t b_rd = 2 * BM * ROWB + (wn * 32 * TN + rd_row) * ROWB + rd_c0;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const uint32_t kc = a.Cin / BK, KT_all = taps * kc;
+    const uint32_t kt_begin = (uint32_t)((uint64_t)split * KT_all / a.splits), KT = (uint32_t)((uint64_t)(split + 1) * KT_all / a.splits) - kt_begin;
+    uint32_t tap = kt_begin / kc, ci = kt_begin % kc;
+    set_tap(tap);
+    a_load(ci * BK);
+    b_issue(tap, ci * BK, 0);
+    a_store(0);
+    __syncthreads();
+    for (uint32_t kt = 0; kt < KT; ++kt) {
+        const uint32_t buf = kt & 1;
+        const bool more = kt + 1 < KT;
+        if (more) {
+            if (++ci == kc) { ci = 0; ++tap; set_tap(tap); }
+            a_load(ci * BK);                                                 // tile kt+1: fp32 -> registers (in flight under the MFMAs below)
+            b_issue(tap, ci * BK, buf ^ 1);
+        }
+        const unsigned char* st = lds + buf * STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(st + ((a_rd + i * 32 * ROWB) ^ (s2 * 32)));
+                al[i] = *reinterpret_cast<const bf16x8*>(st + BM * ROWB + ((a_rd + i * 32 * ROWB) ^ (s2 * 32)));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(st + ((b_rd + j * 32 * ROWB) ^ (s2 * 32)));
+                bl[j] = *reinterpret_cast<const bf16x8*>(st + BN * ROWB + ((b_rd + j * 32 * ROWB) ^ (s2 * 32)));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) a_store(buf ^ 1);                                          // the other buffer was last read in iteration kt-1 (barrier below it)
+        __syncthreads();
+    }
+
+    // ---- split-K: partial sums are added straight into the (pre-zeroed) fp32 output; k_conv_f32_finish adds bias / residual / statistics ------
+    if (a.splits > 1) {
+        float* yo = reinterpret_cast<float*>(a.y);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (m < a.M) unsafeAtomicAdd(yo + (size_t)m * a.Cout + n0 + wn * 32 * TN + j * 32 + (lane & 31), acc[i][j][e]);
+                }
+        return;
+    }
+
+    // ---- epilogue: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> fp32 rows ----------------------------------------------------
+    float* tile_f = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                tile_f[(wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * BN + wn * 32 * TN + j * 32 + (lane & 31)] = acc[i][j][e];
+    constexpr int CPR = BN / 8;
+    float* red = reinterpret_cast<float*>(lds + EPI);
+    if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
+    __syncthreads();
+    const uint32_t cc = tid % CPR, co = n0 + cc * 8;
+    float bias_v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
+    float* yo = reinterpret_cast<float*>(a.y);
+    const float* ro = reinterpret_cast<const float*>(a.res);
+#pragma unroll 2
+    for (uint32_t row = tid / CPR; row < (uint32_t)BM; row += 256 / CPR) {
+        const uint32_t m = m0 + row;
+        if (m >= a.M) break;
+        const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8), v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
+        float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += bias_v[k];
+        const size_t o = (size_t)m * a.Cout + co;
+        if (ro) {
+            const float4 r0 = *reinterpret_cast<const float4*>(ro + o), r1 = *reinterpret_cast<const float4*>(ro + o + 4);
+            f[0] += r0.x; f[1] += r0.y; f[2] += r0.z; f[3] += r0.w; f[4] += r1.x; f[5] += r1.y; f[6] += r1.z; f[7] += r1.w;
+        }
+        *reinterpret_cast<float4*>(yo + o) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(yo + o + 4) = make_float4(f[4], f[5], f[6], f[7]);
+        if (a.gn_sums) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gs[k >> 2] += f[k]; gq[k >> 2] = __builtin_fmaf(f[k], f[k], gq[k >> 2]); }
+        }
+    }
+    if (a.gn_sums) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
+        __syncthreads();
+        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;
+        if (tid < ng && m0 < a.M) {
+            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
+            float ss = 0.f, qq = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
+            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
+            atomicAdd(dst, (double)ss);
+            atomicAdd(dst + 1, (double)qq);
+        }
+    }
+}
+
+// fp32 split-K finish, in place: y += bias + residual, plus the GroupNorm sums of the result.  Same thread layout as k_conv_splitk_finish.
+__global__ __launch_bounds__(256) void k_conv_f32_finish(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ res, uint32_t HW, uint32_t cpr,
+                                                         uint32_t rows_per_block, double* __restrict__ gn_sums, uint32_t G) {
+    __shared__ float red[512];
+    const uint32_t tid = threadIdx.x, cc = tid % cpr, rstep = 256 / cpr, b = blockIdx.y;
+    const uint32_t Cout = cpr * 8, co = cc * 8;
+    if (gn_sums) { for (uint32_t i = tid; i < cpr * 4; i += 256) red[i] = 0.f; __syncthreads(); }
+    float bv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bv[k] = bias ? bias[co + k] : 0.f;
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
+    const uint32_t row_end = (tid / cpr < rstep) ? min((blockIdx.x + 1) * rows_per_block, HW) : 0u;
+    for (uint32_t row = blockIdx.x * rows_per_block + tid / cpr; row < row_end; row += rstep) {
+        const size_t o = (((size_t)b * HW + row) * cpr + cc) * 8;
+        float4 v0 = *reinterpret_cast<const float4*>(y + o), v1 = *reinterpret_cast<const float4*>(y + o + 4);
+        float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += bv[k];
+        if (res) {
+            const float4 r0 = *reinterpret_cast<const float4*>(res + o), r1 = *reinterpret_cast<const float4*>(res + o + 4);
+            f[0] += r0.x; f[1] += r0.y; f[2] += r0.z; f[3] += r0.w; f[4] += r1.x; f[5] += r1.y; f[6] += r1.z; f[7] += r1.w;
+        }
+        *reinterpret_cast<float4*>(y + o) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(y + o + 4) = make_float4(f[4], f[5], f[6], f[7]);
+        if (gn_sums) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gs[k >> 2] += f[k]; gq[k >> 2] = __builtin_fmaf(f[k], f[k], gq[k >> 2]); }
+        }
+    }
+    if (gn_sums) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
+        __syncthreads();
+        const uint32_t hpg = (Cout / G) / 4;
+        for (uint32_t g = tid; g < G; g += 256) {
+            float ss = 0.f, qq = 0.f;
+            for (uint32_t i = g * hpg; i < (g + 1) * hpg; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
+            double* dst = gn_sums + ((size_t)b * G + g) * 2;
+            atomicAdd(dst, (double)ss);
+            atomicAdd(dst + 1, (double)qq);
+        }
+    }
+}
+
 // y = bf16(ws + bias + residual), ws goes back to zero for the next split-K convolution, and (optionally) the GroupNorm sums of y are
 // accumulated for the norm that follows.  grid (row slabs, B); 256 threads = (256 / cpr) rows x cpr 8-channel chunks.
 __global__ __launch_bounds__(256) void k_conv_splitk_finish(float* __restrict__ ws, const float* __restrict__ bias, const unsigned char* __restrict__ res,
@@ -396,6 +672,66 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16_plan(uint32_t M, uint32_t Cin, uint32_t 
     int choice; uint32_t splits;
     cv_plan(M, Cin, Cout, ksize, tile_hint, may_split != 0, splits_hint, &choice, &splits);
     return choice | (int)(splits << 8);
+}
+
+// tile (1 = 128x128, 3 = 64x64) | splits << 8 of the fp32 kernel for M output pixels
+extern "C" int ssdnerf_conv2d_nhwc_f32x2_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int splits_hint) {
+    int choice = tile_hint;
+    if (choice != 1 && choice != 3) choice = (Cout % 128 == 0 && (uint64_t)((M + 127) / 128) * (Cout / 128) >= 384) ? 1 : 3;
+    const uint32_t bm = choice == 1 ? 128 : 64, tiles = ((M + bm - 1) / bm) * (Cout / bm), KT = ksize * ksize * (Cin / 32);
+    uint32_t splits = 1;
+    if (splits_hint > 0) splits = (uint32_t)splits_hint;
+    else if (tiles < 512 && (uint64_t)M * Cout <= (1u << 21) && Cout <= 1024) splits = (1024 + tiles - 1) / tiles;
+    if (splits > 16) splits = 16;
+    if (splits > KT / 2) splits = KT / 2 ? KT / 2 : 1;
+    return choice | (int)(splits << 8);
+}
+
+extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, const void* w_hi, const void* w_lo, const float* bias, const void* residual,
+                                         void* y, uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample,
+                                         void* gn_sums, uint32_t gn_groups, int tile_hint, int splits_hint, int y_is_zero, void* stream) {
+    if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x && w_hi && w_lo && y, "conv2d_nhwc_f32x2: null pointer");
+    SSD_REQUIRE((Cin % 64 == 0) && (Cout % 64 == 0) && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && !(upsample && stride != 1),
+                "conv2d_nhwc_f32x2: needs Cin %% 64 == 0, Cout %% 64 == 0, ksize 1|3, stride 1|2 (no stride with upsample)");
+    if (!x2) Cin1 = Cin;
+    SSD_REQUIRE(Cin1 <= Cin && Cin1 % 64 == 0 && (x2 || Cin1 == Cin), "conv2d_nhwc_f32x2: the first input's channel count must be a multiple of 64 and <= Cin");
+    SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0), "conv2d_nhwc_f32x2: fused GroupNorm statistics need groups of a multiple of 4 channels");
+    ConvArgs a;
+    a.x2 = (const unsigned char*)x2; a.Cin1 = Cin1;
+    a.x = (const unsigned char*)x; a.w = (const unsigned char*)w_hi; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
+    a.gn_sums = (double*)gn_sums; a.G = gn_groups ? gn_groups : 1;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.ksize = ksize; a.stride = stride; a.pad = ksize / 2; a.upsample = upsample;
+    const uint32_t Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    a.Ho = (Hv + 2 * a.pad - ksize) / stride + 1;
+    a.Wo = (Wv + 2 * a.pad - ksize) / stride + 1;
+    SSD_REQUIRE((uint64_t)B * a.Ho * a.Wo < (1ull << 31), "conv2d_nhwc_f32x2: tensor too large");
+    a.M = B * a.Ho * a.Wo;
+    a.splitk_ws = nullptr;
+    const int plan = ssdnerf_conv2d_nhwc_f32x2_plan(a.M, Cin, Cout, ksize, tile_hint, splits_hint);
+    const int choice = plan & 0xff;
+    const uint32_t splits = (uint32_t)plan >> 8, bm = choice == 1 ? 128 : 64;
+    if (choice == 1) SSD_REQUIRE(Cout % 128 == 0, "conv2d_nhwc_f32x2: 128-wide tiles need Cout %% 128 == 0");
+    a.splits = splits;
+    SSD_REQUIRE(!gn_sums || splits > 1 || (a.Ho * a.Wo) % bm == 0, "conv2d_nhwc_f32x2: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
+    hipStream_t st = (hipStream_t)stream;
+    double* stats = a.gn_sums;
+    if (splits > 1) {
+        a.gn_sums = nullptr;
+        if (!y_is_zero && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2: memset failed");
+    }
+    a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = Cout / bm;
+    if (choice == 1) hipLaunchKernelGGL((k_conv_igemm_f32x2<2, 2>), dim3(a.m_tiles * a.n_tiles * splits), dim3(256), 0, st, a, (const unsigned char*)w_lo);
+    else hipLaunchKernelGGL((k_conv_igemm_f32x2<1, 1>), dim3(a.m_tiles * a.n_tiles * splits), dim3(256), 0, st, a, (const unsigned char*)w_lo);
+    if (splits > 1) {
+        const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
+        uint32_t rows = HWo;
+        while (rows > rstep && rows % 2 == 0 && (uint64_t)B * (HWo / rows) < 1024) rows /= 2;
+        hipLaunchKernelGGL(k_conv_f32_finish, dim3((HWo + rows - 1) / rows, B), dim3(256), 0, st, (float*)y, bias, (const float*)residual, HWo, cpr, rows, stats, a.G);
+    }
+    SSD_CHECK_LAUNCH("conv2d_nhwc_f32x2");
+    return SSDNERF_OK;
 }
 
 extern "C" int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample) {

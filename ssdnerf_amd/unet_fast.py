@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -122,6 +123,47 @@ def conv2d_nhwc_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def split_bf16x2(w: torch.Tensor):
+    """fp32 -> (hi, lo) bf16 pair with hi + lo == w to 16 significand bits (round to nearest for both terms)."""
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def conv2d_nhwc_f32x2(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                      stride: int = 1, upsample: bool = False, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0, tile_hint: int = 0,
+                      x2: Optional[torch.Tensor] = None, splits_hint: int = 0) -> torch.Tensor:
+    """fp32 convolution with fp32-class (bf16 x 2) products on the matrix cores (csrc/conv_igemm.hip, k_conv_igemm_f32x2).  ``x`` (B, Cin, H, W)
+    fp32 channels_last, ``w_hi`` / ``w_lo`` = ``split_bf16x2(weight)`` in channels_last, ``residual`` / result fp32 channels_last."""
+    if x.dtype != torch.float32 or w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16:
+        raise RuntimeError("conv2d_nhwc_f32x2: fp32 input, bf16 weight pair")
+    if not (x.is_contiguous(memory_format=torch.channels_last) and w_hi.is_contiguous(memory_format=torch.channels_last) and w_lo.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("conv2d_nhwc_f32x2: input and weights must be channels_last")
+    B, Cin1, H, W = x.shape
+    Cin = Cin1
+    if x2 is not None:
+        if x2.dtype != torch.float32 or not x2.is_contiguous(memory_format=torch.channels_last) or x2.shape[0] != B or x2.shape[2:] != x.shape[2:]:
+            raise RuntimeError("conv2d_nhwc_f32x2: x2 must match x in batch, spatial size, dtype and layout")
+        Cin = Cin1 + x2.shape[1]
+    Cout, Cin_w, k, k2 = w_hi.shape
+    if Cin_w != Cin or k != k2 or w_lo.shape != w_hi.shape:
+        raise RuntimeError("conv2d_nhwc_f32x2: weight shape does not match the input")
+    Hv, Wv = (2 * H, 2 * W) if upsample else (H, W)
+    pad = k // 2
+    Ho, Wo = (Hv + 2 * pad - k) // stride + 1, (Wv + 2 * pad - k) // stride + 1
+    plan = C.lib().ssdnerf_conv2d_nhwc_f32x2_plan(C.u32(B * Ho * Wo), C.u32(Cin), C.u32(Cout), C.u32(k), int(tile_hint), int(splits_hint))
+    split = (plan >> 8) > 1                             # split-K accumulates into the output: hand it over zeroed (a fill kernel, graph-capturable like any other)
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if split:
+        y.zero_()
+    if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("conv2d_nhwc_f32x2: residual must match the output's shape, dtype and layout")
+    C.check(C.lib().ssdnerf_conv2d_nhwc_f32x2(C.ptr(x), C.ptr(x2), C.u32(Cin1), C.ptr(w_hi), C.ptr(w_lo), C.ptr(bias), C.ptr(residual), C.ptr(y), C.u32(B), C.u32(H),
+                                               C.u32(W), C.u32(Cin), C.u32(Cout), C.u32(k), C.u32(stride), C.u32(int(upsample)), C.ptr(gn_sums), C.u32(gn_groups),
+                                               int(tile_hint), int(splits_hint), int(split), C.stream()), "conv2d_nhwc_f32x2")
+    return y
+
+
 def attention_qkv_bf16(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     """Hand-written MFMA flash attention (csrc/attention.hip).  ``qkv`` (B, T, 3C) bf16 contiguous, per-head channel order [q | k | v];
     returns (B, T, C) bf16."""
@@ -137,7 +179,7 @@ def attention_qkv_bf16(qkv: torch.Tensor, heads: int) -> torch.Tensor:
 class _Conv:
     """A convolution split into its bias-less GEMM part (``mm``) and an fp32 bias that the *consumer* folds in: the following
     GroupNorm (``pre_bias``) or the residual epilogue -- the library convolution would spend a pass of its own on it."""
-    __slots__ = ("w", "bias", "stride", "padding", "fold", "own")
+    __slots__ = ("w", "w_lo", "bias", "stride", "padding", "fold", "own")
     SPLITK_BYTES = 16 << 20
 
     def __init__(self, conv: torch.nn.Conv2d, dtype):
@@ -147,14 +189,24 @@ class _Conv:
         self.stride, self.padding = conv.stride, conv.padding
         self.fold = conv.out_channels % 8 == 0                      # the 16-byte vector kernels need C % 8 == 0 (the 18-channel head does not)
         k = conv.kernel_size
-        # the hand-written MFMA implicit GEMM (csrc/conv_igemm.hip) takes every bf16 layer whose channel counts are multiples of 64
-        self.own = bool(dtype == torch.bfloat16 and self.w.is_cuda and k[0] == k[1] and conv.stride[0] == conv.stride[1]
+        # the hand-written MFMA implicit GEMM (csrc/conv_igemm.hip) takes every layer whose channel counts are multiples of 64: bf16 as is,
+        # fp32 with fp32-class products (weights pre-split into a bf16 pair; the library's fp32 convolution is kept for everything else)
+        self.own = bool(dtype in (torch.bfloat16, torch.float32) and self.w.is_cuda and k[0] == k[1] and conv.stride[0] == conv.stride[1]
                         and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and tuple(conv.dilation) == (1, 1)
                         and C.lib().ssdnerf_conv2d_nhwc_bf16_supported(conv.in_channels, conv.out_channels, k[0], conv.stride[0], 0))
+        self.w_lo = None
+        if self.own and dtype == torch.float32 and _Conv.F32X2:
+            hi, lo = split_bf16x2(conv.weight.detach().float())
+            self.w_lo = (hi.contiguous(memory_format=torch.channels_last), lo.contiguous(memory_format=torch.channels_last))
+        elif dtype == torch.float32:
+            self.own = False
 
     splitk_ws: Optional[torch.Tensor] = None        # shared all-zero fp32 scratch for the small layers' split-K (set by the executor)
+    F32X2 = os.environ.get("SSDNERF_UNET_F32X2", "1") != "0"      # fp32 executor: own bf16 x 2 convolution (default) or the library's fp32 one
 
     def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0, x2=None):
+        if self.w_lo is not None:
+            return conv2d_nhwc_f32x2(x, self.w_lo[0], self.w_lo[1], bias, residual, self.stride[0], upsample, gn_sums, gn_groups, x2=x2)
         return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups, splitk_ws=_Conv.splitk_ws, x2=x2)
 
     def mm(self, x):
@@ -279,6 +331,11 @@ class FastUnet:
         cout, cin, k = conv.w.size(0), conv.w.size(1), conv.w.size(2)
         if (cout // gn.groups) % 4 != 0:
             return False                                                    # csrc/conv_igemm.hip: statistics per 4-channel half chunk
+        if conv.w_lo is not None:                                           # fp32 kernel (mirrors ssdnerf_conv2d_nhwc_f32x2's choice of tile and split)
+            plan = C.lib().ssdnerf_conv2d_nhwc_f32x2_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, 0)
+            if plan >> 8 != 1:
+                return True                                                 # split along K: the finishing pass takes the statistics
+            return hw % (128 if (plan & 0xff) == 1 else 64) == 0
         plan = C.lib().ssdnerf_conv2d_nhwc_bf16_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, int(_Conv.splitk_ws is not None), 0)
         if plan >> 8 != 1:
             return True                                                     # a split-K layer: its finishing pass takes the statistics

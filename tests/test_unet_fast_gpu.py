@@ -272,3 +272,68 @@ def test_statistics_from_split_k_and_residual_add():
     assert torch.equal(got, want)
     wf = want.double().reshape(B, H * H, G, C // G)
     assert torch.allclose(sums[..., 0], wf.sum((1, 3)), rtol=1e-6, atol=1e-3) and torch.allclose(sums[..., 1], wf.square().sum((1, 3)), rtol=1e-6, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ fp32-class (bf16 x 2) convolution
+F32X2_CASES = [
+    # B, H, W, Cin, Cout, k, stride, upsample, tile_hint
+    (2, 16, 16, 64, 64, 3, 1, False, 3),
+    (2, 16, 16, 128, 128, 3, 1, False, 1),
+    (1, 5, 7, 64, 128, 3, 1, False, 0),
+    (3, 9, 6, 128, 256, 1, 1, False, 0),
+    (2, 16, 16, 128, 128, 3, 2, False, 0),
+    (2, 8, 8, 128, 128, 3, 1, True, 0),
+    (1, 32, 32, 384, 256, 3, 1, False, 1),
+    (4, 8, 8, 1024, 512, 3, 1, False, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,upsample,hint", F32X2_CASES)
+def test_conv_f32x2_is_fp32_class(B, H, W, Cin, Cout, k, stride, upsample, hint):
+    g = torch.Generator().manual_seed(B * 100 + Cin + k + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    hi, lo = unet_fast.split_bf16x2(w)
+    hi, lo = hi.contiguous(memory_format=torch.channels_last), lo.contiguous(memory_format=torch.channels_last)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if upsample else x
+    want = F.conv2d(xin.double(), w.double(), bias.double(), stride, k // 2)
+    res = torch.randn(want.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    got = unet_fast.conv2d_nhwc_f32x2(x, hi, lo, bias, res, stride, upsample, tile_hint=hint)
+    assert got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
+    rel = ((got.double() - (want + res.double())).norm() / want.norm()).item()
+    assert rel < 3e-5, rel                                                    # products carry >= 16 significand bits (bf16 alone: ~4e-3, TF32: ~5e-4)
+    lib = F.conv2d(xin, w, bias, stride, k // 2) + res                        # the library's fp32 convolution, for scale
+    assert rel < 20 * max(((lib.double() - (want + res.double())).norm() / want.norm()).item(), 1e-7) or rel < 1e-5
+
+
+def test_conv_f32x2_concat_and_statistics():
+    g = torch.Generator().manual_seed(9)
+    B, C1, C2, Cout, H, G = 2, 128, 64, 128, 16, 32
+    a = torch.randn(B, C1, H, H, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(B, C2, H, H, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, C1 + C2, 3, 3, generator=g) / 40).cuda()
+    hi, lo = [t.contiguous(memory_format=torch.channels_last) for t in unet_fast.split_bf16x2(w)]
+    cat = torch.cat([a, b], 1).contiguous(memory_format=torch.channels_last)
+    sums = torch.zeros(B, G, 2, dtype=torch.float64, device="cuda")
+    y2 = unet_fast.conv2d_nhwc_f32x2(a, hi, lo, x2=b, gn_sums=sums, gn_groups=G, tile_hint=1, splits_hint=1)   # unsplit: a fixed summation order
+    y1 = unet_fast.conv2d_nhwc_f32x2(cat, hi, lo, tile_hint=1, splits_hint=1)
+    assert torch.equal(y1, y2)
+    yf = y2.double().reshape(B, G, Cout // G, H * H)
+    assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-6, atol=1e-4) and torch.allclose(sums[..., 1], yf.square().sum((2, 3)), rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,splits", [(8, 8, 512, 512, 3, 0), (2, 16, 1024, 512, 3, 5), (4, 8, 256, 512, 1, 2)])
+def test_conv_f32x2_split_k(B, H, Cin, Cout, k, splits):
+    g = torch.Generator().manual_seed(Cin + Cout + k + 1)
+    x = torch.randn(B, Cin, H, H, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda()
+    hi, lo = [t.contiguous(memory_format=torch.channels_last) for t in unet_fast.split_bf16x2(w)]
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, Cout, H, H, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    sums = torch.zeros(B, 32, 2, dtype=torch.float64, device="cuda")
+    got = unet_fast.conv2d_nhwc_f32x2(x, hi, lo, bias, res, gn_sums=sums, gn_groups=32, splits_hint=splits)
+    want = F.conv2d(x.double(), w.double(), bias.double(), 1, k // 2) + res.double()
+    assert ((got.double() - want).norm() / want.norm()).item() < 3e-5
+    yf = got.double().reshape(B, 32, Cout // 32, H * H)
+    assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-6, atol=1e-4) and torch.allclose(sums[..., 1], yf.square().sum((2, 3)), rtol=1e-6, atol=1e-4)

@@ -11,12 +11,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--dtypes", default="fp32,bf16"); ap.add_argument("--modes", default="eager,fast")
 ap.add_argument("--tune", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes)")
+ap.add_argument("--lib-fp32-conv", action="store_true", help="fp32 executor with the library convolution instead of the bf16 x 2 kernel")
 ap.add_argument("--no-graph", action="store_true", help="launch the executor's kernels eagerly (needed for a complete profiler table)")
 ap.add_argument("--profile", default="", help="mode:dtype to print a torch-profiler kernel table for")
 a = ap.parse_args()
 torch.backends.cudnn.benchmark = a.tune
 from ssdnerf_amd import unet_fast
 unet_fast.FastUnet.capture_by_default = not a.no_graph
+if a.lib_fp32_conv: unet_fast._Conv.F32X2 = False
 net = MODULES.build(dict(type="DenoisingUnetMod", image_size=128, in_channels=18, base_channels=128, channels_cfg=[1, 2, 2, 4, 4], resblocks_per_downsample=2,
                          dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4, attention_res=[32, 16, 8])).cuda().eval()
 g = torch.Generator().manual_seed(0)
