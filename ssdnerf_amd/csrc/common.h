@@ -31,6 +31,18 @@ static inline int ssdnerf_fail(int code, const char* fmt, ...) {
 static inline unsigned ssd_blocks(uint64_t work, unsigned threads) { return (unsigned)((work + threads - 1) / threads); }
 
 // ------------------------------------------------------------------------------------------------
+// conservative coarse occupancy shared by k_first_hit (pre-test, render_queue.hip) and the shading kernels (tail bound):
+// one bit per block of B^3 cells, B = 2^SSD_COARSE_LOG2B, dilated by B/2 cells; rays are sampled every SSD_COARSE_STEP cells.
+#ifndef RQ_COARSE_LOG2B
+#define RQ_COARSE_LOG2B 2
+#endif
+#define SSD_COARSE_STEP ((float)(1 << RQ_COARSE_LOG2B) - 0.1f)
+// hit-queue entries carry, above the 24-bit ray index, the index of the LAST coarse test point of the ray that was not clear
+// (0..126; 127 = no bound): beyond near + (j + 1) steps the ray cannot meet an occupied cell, so marching may stop there.
+#define SSD_RAY_ID_MASK 0x00ffffffu
+#define SSD_TAIL_NONE 127u
+
+// ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
 #define SSD_DEV __device__ __forceinline__

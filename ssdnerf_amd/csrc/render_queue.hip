@@ -103,12 +103,9 @@ __global__ void k_bitfield_linearize(const uint8_t* __restrict__ morton_bits, ui
 // (B - 0.1)/2 cells, per axis, of a test point p, so the cell of q -- and the neighbour the reference's fp32 rounding may pick instead --
 // has an index within B/2 of p's (the test point's block is taken from ITS exact cell index, >> LOG2B).  If every point lands in a clear
 // cell of the ray is occupied, so the exact march would test nothing but empty cells and need not run at all (see k_first_hit).
-#ifndef RQ_COARSE_LOG2B
-#define RQ_COARSE_LOG2B 2
-#endif
-static constexpr int RQ_COARSE_B = 1 << RQ_COARSE_LOG2B;
+static constexpr int RQ_COARSE_B = 1 << RQ_COARSE_LOG2B;                 // (common.h)
 static constexpr int RQ_COARSE_DILATE = RQ_COARSE_B / 2;
-static constexpr float RQ_COARSE_STEP = (float)RQ_COARSE_B - 0.1f;     // in cells
+static constexpr float RQ_COARSE_STEP = SSD_COARSE_STEP;                 // in cells
 
 __global__ void __launch_bounds__(RQ_TPB) k_bitfield_coarsen(const uint8_t* __restrict__ lin_bits_all, uint32_t H, uint32_t log2H, uint32_t bytes_per_scene,
                                                               uint8_t* __restrict__ coarse_all) {
@@ -161,6 +158,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t*
     }
     bool hit = false;
     float t = 0.f;
+    uint32_t tail = SSD_TAIL_NONE;
     if (n < c.N) {
         const RayGeom r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
         float far_;
@@ -169,18 +167,24 @@ __global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t*
         if (use_coarse && t < far_) {
             const float len = sqrtf(ssd_fma(r.dx, r.dx, ssd_fma(r.dy, r.dy, r.dz * r.dz)));
             const float step_t = (RQ_COARSE_STEP * c.m.two_rH * c.m.mip_bound) / fmaxf(len, 1e-20f);   // RQ_COARSE_STEP cells of world length, in t
-
-            bool any = false;
-            for (float tc = t; ; tc += step_t) {                             // test points from near to (at least) far
+            int j_last = -1, j = 0;
+            float t_last = 0.f;
+            for (float tc = t; ; tc += step_t, ++j) {                        // test points from near to (at least) far
                 const float u = fminf(tc, far_);
                 const int bx = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;   // block of the point's exact cell
                 const int by = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
                 const int bz = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
                 const uint32_t ci = ((((uint32_t)bz << log2Hc) + (uint32_t)by) << log2Hc) + (uint32_t)bx;
-                any |= (coarse_lds[ci >> 3] >> (ci & 7u)) & 1u;
-                if (any || !(tc < far_)) break;
+                if ((coarse_lds[ci >> 3] >> (ci & 7u)) & 1u) { j_last = j; t_last = tc; }
+                if (!(tc < far_)) break;
             }
-            if (!any) t = far_;                                              // nothing within a cell of this ray: skip the march
+            if (j_last < 0) t = far_;                                        // nothing within a cell of this ray: skip the march
+            else {
+                // every test point after j_last is clear: past t_last + step no cell the march could test is occupied, so the march (here and
+                // in the shading kernel, which gets j_last with the queue entry) may stop there; it still starts at `near`
+                far_ = fminf(far_, t_last + step_t);
+                if (c.N <= SSD_RAY_ID_MASK + 1u && j_last < (int)SSD_TAIL_NONE) tail = (uint32_t)j_last;
+            }
         }
         while (t < far_) {
             const FastProbe p = rq_probe(c.m, lin_bits, r, t);
@@ -202,7 +206,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t*
         base = __shfl(base, __builtin_ctzll(hits), 64);
         if (hit) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-            queue[(uint64_t)scene * c.N + base + rank] = make_uint2(n, __float_as_uint(t));
+            queue[(uint64_t)scene * c.N + base + rank] = make_uint2(c.N <= SSD_RAY_ID_MASK + 1u ? (n | (tail << 24)) : n, __float_as_uint(t));
         }
     }
 }
@@ -279,9 +283,9 @@ __global__ void __launch_bounds__(RQ_TPB) k_shade_queue(QueueCfg c, uint32_t sli
             const uint32_t cand = next + rank;
             if (ray < 0 && cand < end) {
                 const uint2 e = queue[cand];
-                ray = (int)e.x;
+                ray = (int)(c.N <= SSD_RAY_ID_MASK + 1u ? (e.x & SSD_RAY_ID_MASK) : e.x);       // (the tail bound in the upper bits is ignored here)
                 t = __uint_as_float(e.y);
-                const uint64_t gi = ray0 + e.x;
+                const uint64_t gi = ray0 + (uint32_t)ray;
                 r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
                 float near_;
                 ssd_near_far(c.aabb, r, c.min_near, near_, far_);

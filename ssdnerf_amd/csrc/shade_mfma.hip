@@ -149,6 +149,16 @@ SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, fl
     return t;
 }
 
+// Tail bound of a queued ray (common.h): past near + (j_last + 1) coarse steps no occupied cell can be met; + 0.5 step of slack for the
+// difference between k_first_hit's accumulated test parameters and this product form.
+SSD_DEV float sm_tail_far(const FastMarchB& m, const RayGeom& q, float near_, float far_, uint32_t packed, bool packing) {
+    const uint32_t jl = packed >> 24;
+    if (!packing || jl >= SSD_TAIL_NONE) return far_;
+    const float len = sqrtf(ssd_fma(q.dx, q.dx, ssd_fma(q.dy, q.dy, q.dz * q.dz)));
+    const float step_t = (SSD_COARSE_STEP * m.two_rH * m.mip_bound) / fmaxf(len, 1e-20f);
+    return fminf(far_, ssd_fma((float)jl + 1.5f, step_t, near_));
+}
+
 // v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.
 SSD_DEV void sm_swap(float& a, float& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -288,8 +298,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
     uint32_t sp_head = 0, sp_count = 0, rp_head = 0, rp_count = 0;    // wave-uniform pool cursors
     uint32_t st_head = 0, st_count = 0;                                // staged (prepared) rays
 
+    const bool packing = c.N <= SSD_RAY_ID_MASK + 1u;           // queue / pool ray words carry the tail bound in their upper 8 bits
+    const uint32_t id_mask = packing ? SSD_RAY_ID_MASK : 0xffffffffu;
     auto write_out = [&](uint32_t rid, float ws_, float dep_, float cr_, float cg_, float cb_, uint32_t cnt_) {
-        const uint64_t gi = ray0 + rid;
+        const uint64_t gi = ray0 + (rid & id_mask);
         const float bgk = c.bg * (1.0f - ws_);
         image[3 * gi + 0] = cr_ + bgk;
         image[3 * gi + 1] = cg_ + bgk;
@@ -299,10 +311,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
         if (sample_counts) sample_counts[gi] = (int32_t)cnt_;
     };
     auto load_geometry = [&](uint32_t rid) {
-        const uint64_t gi = ray0 + rid;
+        const uint64_t gi = ray0 + (rid & id_mask);
         r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
         float near_;
         ssd_near_far(c.aabb, r, c.min_near, near_, far_);
+        far_ = sm_tail_far(c.m, r, near_, far_, rid, packing);
         sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f); sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f); sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
     };
     auto begin_ray = [&]() {   // geometry is loaded and t points at an occupied probe
@@ -367,10 +380,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                 const uint32_t n = min(end - next, SM_STAGE);
                 if ((uint32_t)lane < n) {                    // stage fill: one queue entry per lane, all lanes busy
                     const uint2 e = queue[next + lane];
-                    const uint64_t gi = ray0 + e.x;
+                    const uint64_t gi = ray0 + (e.x & id_mask);
                     const RayGeom q = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
                     float qn, qf;
                     ssd_near_far(c.aabb, q, c.min_near, qn, qf);
+                    qf = sm_tail_far(c.m, q, qn, qf, e.x, packing);
                     const float qt = __uint_as_float(e.y);
                     const ProbeB p = sm_probe(c.m, lin_bits, q, qt);      // the queued t is an occupied probe by construction
                     float4* dst = stage + lane * 4;
@@ -427,10 +441,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             if (mine) {
                 const uint32_t* e = pool_search + ((sp_head + lane) % SM_POOL) * 8;
                 e0 = *reinterpret_cast<const uint4*>(e); e1 = *reinterpret_cast<const uint4*>(e + 4);
-                const uint64_t gi = ray0 + e0.x;
+                const uint64_t gi = ray0 + (e0.x & id_mask);
                 const RayGeom q = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
                 float qn, qf;
                 ssd_near_far(c.aabb, q, c.min_near, qn, qf);
+                qf = sm_tail_far(c.m, q, qn, qf, e0.x, packing);
                 const float qx = ssd_fma(0.5f, ssd_sign1(q.dx), 0.5f), qy = ssd_fma(0.5f, ssd_sign1(q.dy), 0.5f), qz = ssd_fma(0.5f, ssd_sign1(q.dz), 0.5f);
                 float qt = __uint_as_float(e0.y);
                 while (qt < qf) {
