@@ -198,6 +198,7 @@ class _Conv:
         if self.own and dtype == torch.float32 and _Conv.F32X2:
             hi, lo = split_bf16x2(conv.weight.detach().float())
             self.w_lo = (hi.contiguous(memory_format=torch.channels_last), lo.contiguous(memory_format=torch.channels_last))
+            self.w = self.w_lo[0]                                   # (the fp32 copy is not needed; shape queries go through the hi term)
         elif dtype == torch.float32:
             self.own = False
 
@@ -209,8 +210,11 @@ class _Conv:
             return conv2d_nhwc_f32x2(x, self.w_lo[0], self.w_lo[1], bias, residual, self.stride[0], upsample, gn_sums, gn_groups, x2=x2)
         return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups, splitk_ws=_Conv.splitk_ws, x2=x2)
 
+    def _w_lib(self):                                               # weight for the library path of a block whose other convolutions do not fit the own kernel
+        return self.w if self.w_lo is None else (self.w_lo[0].float() + self.w_lo[1].float()).contiguous(memory_format=torch.channels_last)
+
     def mm(self, x):
-        return F.conv2d(x, self.w, None, self.stride, self.padding)
+        return F.conv2d(x, self._w_lib(), None, self.stride, self.padding)
 
     def __call__(self, x):
         if self.own:
