@@ -9,7 +9,9 @@
 //   stage A  k_first_hit   one lane per ray, ~40 VGPRs -> 8 waves/SIMD hide the dependent bitfield loads; every lane
 //                          is busy.  A ray that never meets an occupied voxel is finished here (background colour
 //                          written, 44 B of HBM traffic, nothing else).  A ray that does is appended - with ONE
-//                          atomic per wave (ballot + mbcnt rank) - to its scene's hit queue as (ray id, t_first).
+//                          atomic per wave (ballot + mbcnt rank) - to its scene's hit queue as (ray id | tail bound << 24, t_first).
+//                          Before marching, a conservative coarse-occupancy scan (k_bitfield_coarsen's table, in LDS) finishes
+//                          the rays that cannot meet an occupied cell at all and bounds the march of the others (see k_first_hit).
 //   stage B  k_shade_queue persistent waves; each wave owns a slice of one scene's hit queue and keeps 64 LIVE hitting
 //                          rays, refilling finished lanes from the slice (ballot + mbcnt compaction, no atomics):
 //                          gather -> tiny MLP -> composite -> advance to the next occupied sample, all in registers.
@@ -26,7 +28,7 @@
 
 static constexpr unsigned RQ_TPB = 256;
 static constexpr unsigned RQ_SLICE = 256;        // hit-queue entries per shading wave
-static constexpr unsigned RQ_COARSE_MAX_BYTES = 4096; // coarse occupancy ((H/2)^3 bits) staged in LDS by k_first_hit: H <= 64
+static constexpr unsigned RQ_COARSE_MAX_BYTES = 4096; // coarse occupancy ((H >> RQ_COARSE_LOG2B)^3 bits) staged in LDS by k_first_hit
 static constexpr unsigned RQ_HD_STRIDE = 68;     // floats per LDS row of the per-ray direction term (64 + 4 pad)
 
 struct FastMarch {

@@ -4,6 +4,9 @@
 // k_first_hit.  Two changes, both driven by the r01 profiles (k_shade_queue was ISSUE-bound: ~5600 VALU instructions
 // per 64-sample iteration at ~50 % lane utilisation):
 //
+// (The numbered points describe the f32-MFMA form, variants 2 and 3; the default, variant 4, keeps the structure and runs the same two layers on
+//  the bf16 matrix cores with exact three-term operand splitting -- see the variant list above SmGeo below.)
+//
 // 1. The two wide layers of the tiny MLP run on the matrix pipe in exact fp32:
 //        h      = W1 . [f ; 1]        64 x (18+1)   -> v_mfma_f32_32x32x2_f32, 10 k-steps x (2 M-tiles x 2 N-tiles)
 //        h_col  = h + Wd . [SH(d); 1] 64 x (16+1)   ->  9 k-steps, accumulated IN PLACE on top of h
