@@ -296,6 +296,66 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
     }
 }
 
+// fp32 epilogue shared by the fp32-class kernels: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> fp32 rows (+ GroupNorm sums)
+template <int TM, int TN>
+SSD_DEV void cv_epilogue_f32(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* lds, uint32_t m0, uint32_t n0) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, EPI = BM * BN * 4;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    float* tile_f = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                tile_f[(wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * BN + wn * 32 * TN + j * 32 + (lane & 31)] = acc[i][j][e];
+    constexpr int CPR = BN / 8;
+    float* red = reinterpret_cast<float*>(lds + EPI);
+    if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
+    __syncthreads();
+    const uint32_t cc = tid % CPR, co = n0 + cc * 8;
+    float bias_v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
+    float* yo = reinterpret_cast<float*>(a.y);
+    const float* ro = reinterpret_cast<const float*>(a.res);
+#pragma unroll 2
+    for (uint32_t row = tid / CPR; row < (uint32_t)BM; row += 256 / CPR) {
+        const uint32_t m = m0 + row;
+        if (m >= a.M) break;
+        const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8), v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
+        float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += bias_v[k];
+        const size_t o = (size_t)m * a.Cout + co;
+        if (ro) {
+            const float4 r0 = *reinterpret_cast<const float4*>(ro + o), r1 = *reinterpret_cast<const float4*>(ro + o + 4);
+            f[0] += r0.x; f[1] += r0.y; f[2] += r0.z; f[3] += r0.w; f[4] += r1.x; f[5] += r1.y; f[6] += r1.z; f[7] += r1.w;
+        }
+        *reinterpret_cast<float4*>(yo + o) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(yo + o + 4) = make_float4(f[4], f[5], f[6], f[7]);
+        if (a.gn_sums) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gs[k >> 2] += f[k]; gq[k >> 2] = __builtin_fmaf(f[k], f[k], gq[k >> 2]); }
+        }
+    }
+    if (a.gn_sums) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
+        __syncthreads();
+        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;
+        if (tid < ng && m0 < a.M) {
+            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
+            float ss = 0.f, qq = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
+            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
+            atomicAdd(dst, (double)ss);
+            atomicAdd(dst + 1, (double)qq);
+        }
+    }
+}
+
 // ================================================================================================================================
 // fp32 activations, fp32-class products on the bf16 matrix cores ("bf16 x 2"): every fp32 operand is split into two bf16 terms
 // (x ~ hi + lo, 16 significand bits, relative error <= 2^-16; TF32 -- what the reference's cuDNN convolutions use on Ampere -- has 11)
@@ -472,60 +532,182 @@ __global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, cons
         return;
     }
 
-    // ---- epilogue: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> fp32 rows ----------------------------------------------------
-    float* tile_f = reinterpret_cast<float*>(lds);
+    cv_epilogue_f32<TM, TN>(a, acc, lds, m0, n0);
+}
+
+// 3x3 / stride 1 variant of k_conv_igemm_f32x2 that loads the A tile ONCE per (kh, channel tile) and serves the three kw taps from it:
+// the 128 output pixels of a tile are whole image rows (W in {32, 64, 128}), so the tap kw just reads the tile shifted by kw - 1 pixels,
+// and the pixels it shifts in at a row's ends are padding -- a zero row kept in LDS in front of every image row and after the last
+// (pixel x of image row r of the tile sits in LDS row 1 + r (W + 1) + x).  A loads per K-tile drop to a third (the kernel is bound by the
+// number of memory instructions it has to issue, not by their bytes).  128 x 128 tile, no split-K.
+__global__ __launch_bounds__(256) void k_conv3x3_f32x2_rows(const ConvArgs a, const unsigned char* __restrict__ w_lo) {
+    constexpr int TM = 2, TN = 2, BM = 128, BN = 128, BK = 32, ROWB = BK * 2;
+    constexpr int A_PIECES = BM * (BK / 4) / 256, B_INST = BN / 16 / 4;
+    constexpr int A_ROWS = BM + 4 + 1;                                         // up to four image rows per tile (W = 32) + their zero rows
+    constexpr int A_BUF = 2 * A_ROWS * ROWB;                                   // [hi | lo]
+    constexpr int B_BUF = 2 * BN * ROWB;                                       // [hi | lo]
+    constexpr int EPI = BM * BN * 4;
+    constexpr int LDS_BYTES = ((2 * A_BUF + 2 * B_BUF > EPI) ? 2 * A_BUF + 2 * B_BUF : EPI) + 512;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    unsigned char* const abuf = lds;                                           // two A buffers, then two B buffers
+    unsigned char* const bbuf = lds + 2 * A_BUF;
+
+    const uint32_t n_blocks = a.m_tiles * a.n_tiles;
+    uint32_t tile;
+    {
+        const uint32_t xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n_blocks >> 3, r = n_blocks & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const uint32_t m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
+    const uint32_t W = a.W, Cin2 = a.Cin - a.Cin1;
+    const uint32_t n_seg = W >= (uint32_t)BM ? 1u : (uint32_t)BM / W, seg_w = W >= (uint32_t)BM ? (uint32_t)BM : W;
+
+    // zero rows (never overwritten): LDS rows s * (seg_w + 1), s = 0 .. n_seg, of both terms of both A buffers
+    for (uint32_t i = tid; i < 2 * 2 * (n_seg + 1) * (ROWB / 16); i += 256) {
+        const uint32_t chunk = i % (ROWB / 16), row = (i / (ROWB / 16)) % (n_seg + 1), which = i / ((ROWB / 16) * (n_seg + 1));   // which: buffer * 2 + term
+        *reinterpret_cast<uint4*>(abuf + (which >> 1) * A_BUF + (which & 1) * A_ROWS * ROWB + row * (seg_w + 1) * ROWB + chunk * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- A loader: piece p = tid + 256 i -> tile row p / 8 (an output pixel; its own x, the kw shift happens at read time) -----------------
+    int32_t a_y0[A_PIECES];
+    uint32_t a_pix0[A_PIECES], a_dst[A_PIECES];
+    bool a_ok[A_PIECES];
+    const uint32_t c4 = tid & 7;
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+        const uint32_t r = (tid >> 3) + 32 * i, m = m0 + r;
+        a_ok[i] = m < a.M;
+        const uint32_t mm = a_ok[i] ? m : 0;
+        const uint32_t b = mm / (a.H * W), rem = mm % (a.H * W);
+        a_y0[i] = (int32_t)(rem / W) - 1;
+        a_pix0[i] = b * a.H * W + (rem % W);                                    // + y * W
+        const uint32_t rho = r + r / seg_w + 1;                                 // LDS row of this pixel
+        a_dst[i] = rho * ROWB + (((c4 >> 1) ^ ((rho >> 2) & 3)) * 16) + (c4 & 1) * 8;
+    }
+    const float* a_src[A_PIECES];
+    const float* a_src2[A_PIECES];
+    auto set_kh = [&](uint32_t kh) {
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            const int32_t yv = a_y0[i] + (int32_t)kh;
+            const bool ok = a_ok[i] && yv >= 0 && yv < (int32_t)a.H;
+            const uint64_t pix = (uint64_t)a_pix0[i] + (uint64_t)(ok ? yv : 0) * W;
+            a_src[i] = ok ? reinterpret_cast<const float*>(a.x) + pix * a.Cin1 + c4 * 4 : nullptr;
+            a_src2[i] = (ok && a.x2) ? reinterpret_cast<const float*>(a.x2) + pix * Cin2 + c4 * 4 : nullptr;
+        }
+    };
+    float4 a_reg[A_PIECES];
+    auto a_load = [&](uint32_t ci0) {
+        const bool second = ci0 >= a.Cin1;
+        const uint32_t coff = second ? ci0 - a.Cin1 : ci0;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            const float* p = second ? a_src2[i] : a_src[i];
+            a_reg[i] = p ? *reinterpret_cast<const float4*>(p + coff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto a_store = [&](uint32_t buf) {
+        unsigned char* sa = abuf + buf * A_BUF;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            const float v[4] = {a_reg[i].x, a_reg[i].y, a_reg[i].z, a_reg[i].w};
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hi[k] = __float_as_uint(v[k]) & 0xffff0000u;
+                lo[k] = __float_as_uint(v[k] - __uint_as_float(hi[k]));
+            }
+            *reinterpret_cast<uint2*>(sa + a_dst[i]) = make_uint2(__builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u), __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u));
+            *reinterpret_cast<uint2*>(sa + A_ROWS * ROWB + a_dst[i]) = make_uint2(__builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u), __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u));
+        }
+    };
+    uint32_t b_off[B_INST];
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+        const uint32_t r = (wave * B_INST + i) * 16 + (lane >> 2);
+        b_off[i] = ((n0 + r) * 9 * a.Cin) * 2 + ((lane & 3) ^ ((r >> 2) & 3)) * 16;
+    }
+    auto b_issue = [&](uint32_t tap, uint32_t ci0, uint32_t buf) {
+        unsigned char* sb = bbuf + buf * B_BUF;
+        const uint64_t koff = (uint64_t)(tap * a.Cin + ci0) * 2;
+#pragma unroll
+        for (int i = 0; i < B_INST; ++i) {
+            cv_glds16(a.w + b_off[i] + koff, sb + (wave * B_INST + i) * 1024);
+            cv_glds16(w_lo + b_off[i] + koff, sb + BN * ROWB + (wave * B_INST + i) * 1024);
+        }
+    };
+    // ---- reader geometry: MFMA tile i of this wave covers tile rows t0 = wm*64 + i*32 .. +31, all in image row (segment) t0 / seg_w -------
+    uint32_t a_rd[TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const uint32_t t0 = wm * 32 * TM + i * 32;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const uint32_t rho = t0 + (lane & 31) + t0 / seg_w + kw;            // = 1 + seg (seg_w + 1) + x + (kw - 1)
+            a_rd[i][kw] = rho * ROWB + (((lane >> 5) ^ ((rho >> 2) & 3)) * 16);
+        }
+    }
+    const uint32_t b_rd = (wn * 32 * TN + (lane & 31)) * ROWB + (((lane >> 5) ^ ((lane >> 2) & 3)) * 16);
+
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                tile_f[(wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * BN + wn * 32 * TN + j * 32 + (lane & 31)] = acc[i][j][e];
-    constexpr int CPR = BN / 8;
-    float* red = reinterpret_cast<float*>(lds + EPI);
-    if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const uint32_t kc = a.Cin / BK, G = 3 * kc, KT = 3 * G;                     // groups (kh, ci tile); K-tiles (group, kw)
+    uint32_t kh = 0, ci = 0;
+    set_kh(0);
+    a_load(0);
+    b_issue(0, 0, 0);
+    a_store(0);
     __syncthreads();
-    const uint32_t cc = tid % CPR, co = n0 + cc * 8;
-    float bias_v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
-    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
-    float* yo = reinterpret_cast<float*>(a.y);
-    const float* ro = reinterpret_cast<const float*>(a.res);
-#pragma unroll 2
-    for (uint32_t row = tid / CPR; row < (uint32_t)BM; row += 256 / CPR) {
-        const uint32_t m = m0 + row;
-        if (m >= a.M) break;
-        const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8), v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
-        float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] += bias_v[k];
-        const size_t o = (size_t)m * a.Cout + co;
-        if (ro) {
-            const float4 r0 = *reinterpret_cast<const float4*>(ro + o), r1 = *reinterpret_cast<const float4*>(ro + o + 4);
-            f[0] += r0.x; f[1] += r0.y; f[2] += r0.z; f[3] += r0.w; f[4] += r1.x; f[5] += r1.y; f[6] += r1.z; f[7] += r1.w;
+    for (uint32_t kt = 0, g = 0, kw = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) {
+            const uint32_t kw1 = kw == 2 ? 0 : kw + 1;
+            uint32_t kh1 = kh, ci1 = ci;
+            if (kw == 2) { if (++ci1 == kc) { ci1 = 0; ++kh1; } }
+            b_issue(kh1 * 3 + kw1, ci1 * BK, (kt + 1) & 1);
         }
-        *reinterpret_cast<float4*>(yo + o) = make_float4(f[0], f[1], f[2], f[3]);
-        *reinterpret_cast<float4*>(yo + o + 4) = make_float4(f[4], f[5], f[6], f[7]);
-        if (a.gn_sums) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { gs[k >> 2] += f[k]; gq[k >> 2] = __builtin_fmaf(f[k], f[k], gq[k >> 2]); }
+        const bool next_group = kw == 0 && g + 1 < G;
+        if (next_group) {                                                    // the next group's A tile: fp32 -> registers now, split -> LDS after the MFMAs
+            uint32_t kh1 = kh, ci1 = ci;
+            if (++ci1 == kc) { ci1 = 0; ++kh1; set_kh(kh1); }
+            a_load(ci1 * BK);
         }
-    }
-    if (a.gn_sums) {
+        const unsigned char* sa = abuf + (g & 1) * A_BUF;
+        const unsigned char* sb = bbuf + (kt & 1) * B_BUF;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const uint32_t off = kw == 0 ? a_rd[i][0] : kw == 1 ? a_rd[i][1] : a_rd[i][2];
+                ah[i] = *reinterpret_cast<const bf16x8*>(sa + (off ^ (s2 * 32)));
+                al[i] = *reinterpret_cast<const bf16x8*>(sa + A_ROWS * ROWB + (off ^ (s2 * 32)));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(sb + ((b_rd + j * 32 * ROWB) ^ (s2 * 32)));
+                bl[j] = *reinterpret_cast<const bf16x8*>(sb + BN * ROWB + ((b_rd + j * 32 * ROWB) ^ (s2 * 32)));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (next_group) a_store((g + 1) & 1);                                // last read two barriers ago (group g-1, kw = 2)
         __syncthreads();
-        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;
-        if (tid < ng && m0 < a.M) {
-            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
-            float ss = 0.f, qq = 0.f;
-            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
-            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
-            atomicAdd(dst, (double)ss);
-            atomicAdd(dst + 1, (double)qq);
-        }
+        if (++kw == 3) { kw = 0; ++g; if (++ci == kc) { ci = 0; ++kh; } }
     }
+    cv_epilogue_f32<TM, TN>(a, acc, lds, m0, n0);
 }
 
 // fp32 split-K finish, in place: y += bias + residual, plus the GroupNorm sums of the result.  Same thread layout as k_conv_splitk_finish.
@@ -722,7 +904,11 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
         if (!y_is_zero && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2: memset failed");
     }
     a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = Cout / bm;
-    if (choice == 1) hipLaunchKernelGGL((k_conv_igemm_f32x2<2, 2>), dim3(a.m_tiles * a.n_tiles * splits), dim3(256), 0, st, a, (const unsigned char*)w_lo);
+    // 3x3 / stride 1 layers whose 128-pixel tiles are whole image rows take the row-reuse kernel (A loaded once per kh, shared by the three kw taps)
+    static const bool rows_ok = getenv("SSDNERF_CONV_NO_ROW_REUSE") == nullptr;
+    const bool rows = rows_ok && choice == 1 && splits == 1 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 128 == 0;
+    if (rows) hipLaunchKernelGGL(k_conv3x3_f32x2_rows, dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a, (const unsigned char*)w_lo);
+    else if (choice == 1) hipLaunchKernelGGL((k_conv_igemm_f32x2<2, 2>), dim3(a.m_tiles * a.n_tiles * splits), dim3(256), 0, st, a, (const unsigned char*)w_lo);
     else hipLaunchKernelGGL((k_conv_igemm_f32x2<1, 1>), dim3(a.m_tiles * a.n_tiles * splits), dim3(256), 0, st, a, (const unsigned char*)w_lo);
     if (splits > 1) {
         const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;

@@ -337,3 +337,26 @@ def test_conv_f32x2_split_k(B, H, Cin, Cout, k, splits):
     assert ((got.double() - want).norm() / want.norm()).item() < 3e-5
     yf = got.double().reshape(B, 32, Cout // 32, H * H)
     assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-6, atol=1e-4) and torch.allclose(sums[..., 1], yf.square().sum((2, 3)), rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 128, 64, 128), (2, 64, 64, 128, 128), (3, 32, 32, 192, 256), (1, 4, 32, 64, 128)])
+def test_conv_f32x2_row_reuse_kernel(B, H, W, Cin, Cout):
+    """3x3 / stride-1 layers whose 128-pixel tiles are whole image rows: the A tile is loaded once per kh and shifted in LDS for the kw taps."""
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+    hi, lo = [t.contiguous(memory_format=torch.channels_last) for t in unet_fast.split_bf16x2(w)]
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, Cout, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    sums = torch.zeros(B, 32, 2, dtype=torch.float64, device="cuda")
+    got = unet_fast.conv2d_nhwc_f32x2(x, hi, lo, bias, res, gn_sums=sums, gn_groups=32, tile_hint=1, splits_hint=1)
+    want = F.conv2d(x.double(), w.double(), bias.double(), 1, 1) + res.double()
+    assert ((got.double() - want).norm() / want.norm()).item() < 3e-5
+    assert (got.double() - want).abs().max().item() < 1e-3                      # every border pixel (zero rows) included
+    yf = got.double().reshape(B, 32, Cout // 32, H * W)
+    assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-6, atol=1e-4)
+    # the concatenated-input form
+    c1 = Cin // 2 if (Cin // 2) % 64 == 0 else 64
+    a_, b_ = x[:, :c1].contiguous(memory_format=torch.channels_last), x[:, c1:].contiguous(memory_format=torch.channels_last)
+    got2 = unet_fast.conv2d_nhwc_f32x2(a_, hi, lo, bias, res, tile_hint=1, splits_hint=1, x2=b_)
+    assert torch.equal(got, got2)
