@@ -72,6 +72,85 @@ template <int N> SSD_DEV void cv_wait_tiles_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// bf16 epilogue shared by the bf16 kernels: accumulators -> fp32 tile in LDS (EP_ROWS rows per pass) -> (+bias, +residual) -> bf16 rows (+ GroupNorm sums)
+template <int TM, int TN, int WM, int WN>
+SSD_DEV void cv_epilogue_bf16(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* lds, uint32_t m0, uint32_t n0) {
+    constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int EP_ROWS = BM < 128 ? BM : 128, EPI = EP_ROWS * BN * 4;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    float* tile_f = reinterpret_cast<float*>(lds);
+    constexpr int CPR = BN / 8;                                              // 8-channel chunks per row; NT % CPR == 0, so a thread keeps its chunk column
+    float* red = reinterpret_cast<float*>(lds + EPI);                        // [CPR][2 halves][sum, sumsq] block partials for the GroupNorm statistics
+    if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
+    const uint32_t cc = tid % CPR, co = n0 + cc * 8;
+    float bias_v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+        if (pass) __syncthreads();                                           // the previous pass has been read out
+        if ((wm * 32 * TM) / EP_ROWS == (uint32_t)pass) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t row = (wm * 32 * TM) % EP_ROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const uint32_t col = wn * 32 * TN + j * 32 + (lane & 31);
+                        tile_f[row * BN + col] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (uint32_t row = tid / CPR; row < (uint32_t)EP_ROWS; row += NT / CPR) {
+            const uint32_t m = m0 + pass * EP_ROWS + row;
+            if (m >= a.M) break;
+            const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
+            float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] += bias_v[k];
+            const size_t o = ((size_t)m * a.Cout + co) * 2;
+            if (a.res) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + o);
+                const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { f[2 * k] += __uint_as_float(rw[k] << 16); f[2 * k + 1] += __uint_as_float(rw[k] & 0xffff0000u); }
+            }
+            uint32_t pk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
+            *reinterpret_cast<uint4*>(a.y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (a.gn_sums) {                                                 // statistics of what the next norm will read (the rounded values)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(pk[k] << 16), hi = __uint_as_float(pk[k] & 0xffff0000u);
+                    gs[k >> 1] += lo + hi;
+                    gq[k >> 1] = __builtin_fmaf(lo, lo, gq[k >> 1]);
+                    gq[k >> 1] = __builtin_fmaf(hi, hi, gq[k >> 1]);
+                }
+            }
+        }
+    }
+    if (a.gn_sums) {                                                         // host guarantees: the tile lies in ONE sample, groups are multiples of 4 channels
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
+        __syncthreads();
+        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;   // groups this tile touches (BN and cpg are multiples of 4)
+        if (tid < ng && m0 < a.M) {
+            // half chunks of group g0 + tid inside this tile: global half-chunk index range [g*hpg, (g+1)*hpg) minus the tile's first, n0/4
+            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
+            float ss = 0.f, qq = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
+            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
+            atomicAdd(dst, (double)ss);
+            atomicAdd(dst + 1, (double)qq);
+        }
+    }
+}
+
 // TM x TN MFMA tiles (32 x 32) per wave, WM x WN waves per block, NS staging buffers.
 template <int TM, int TN, int WM, int WN, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs a) {
@@ -222,78 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
         return;
     }
 
-    // ---- epilogue: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> bf16 rows, EP_ROWS rows per pass ---------------------------
-    float* tile_f = reinterpret_cast<float*>(lds);
-    constexpr int CPR = BN / 8;                                              // 8-channel chunks per row; NT % CPR == 0, so a thread keeps its chunk column
-    float* red = reinterpret_cast<float*>(lds + EPI);                        // [CPR][2 halves][sum, sumsq] block partials for the GroupNorm statistics
-    if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
-    const uint32_t cc = tid % CPR, co = n0 + cc * 8;
-    float bias_v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
-    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
-#pragma unroll
-    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
-        if (pass) __syncthreads();                                           // the previous pass has been read out
-        if ((wm * 32 * TM) / EP_ROWS == (uint32_t)pass) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const uint32_t row = (wm * 32 * TM) % EP_ROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        const uint32_t col = wn * 32 * TN + j * 32 + (lane & 31);
-                        tile_f[row * BN + col] = acc[i][j][e];
-                    }
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (uint32_t row = tid / CPR; row < (uint32_t)EP_ROWS; row += NT / CPR) {
-            const uint32_t m = m0 + pass * EP_ROWS + row;
-            if (m >= a.M) break;
-            const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8);
-            const float4 v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
-            float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] += bias_v[k];
-            const size_t o = ((size_t)m * a.Cout + co) * 2;
-            if (a.res) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + o);
-                const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { f[2 * k] += __uint_as_float(rw[k] << 16); f[2 * k + 1] += __uint_as_float(rw[k] & 0xffff0000u); }
-            }
-            uint32_t pk[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
-            *reinterpret_cast<uint4*>(a.y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            if (a.gn_sums) {                                                 // statistics of what the next norm will read (the rounded values)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float lo = __uint_as_float(pk[k] << 16), hi = __uint_as_float(pk[k] & 0xffff0000u);
-                    gs[k >> 1] += lo + hi;
-                    gq[k >> 1] = __builtin_fmaf(lo, lo, gq[k >> 1]);
-                    gq[k >> 1] = __builtin_fmaf(hi, hi, gq[k >> 1]);
-                }
-            }
-        }
-    }
-    if (a.gn_sums) {                                                         // host guarantees: the tile lies in ONE sample, groups are multiples of 4 channels
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
-        __syncthreads();
-        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;   // groups this tile touches (BN and cpg are multiples of 4)
-        if (tid < ng && m0 < a.M) {
-            // half chunks of group g0 + tid inside this tile: global half-chunk index range [g*hpg, (g+1)*hpg) minus the tile's first, n0/4
-            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
-            float ss = 0.f, qq = 0.f;
-            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
-            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
-            atomicAdd(dst, (double)ss);
-            atomicAdd(dst + 1, (double)qq);
-        }
-    }
+    cv_epilogue_bf16<TM, TN, WM, WN>(a, acc, lds, m0, n0);
 }
 
 // fp32 epilogue shared by the fp32-class kernels: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> fp32 rows (+ GroupNorm sums)
@@ -354,6 +362,146 @@ SSD_DEV void cv_epilogue_f32(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned 
             atomicAdd(dst + 1, (double)qq);
         }
     }
+}
+
+// 3x3 / stride 1 variant of the bf16 kernel with the A tile loaded once per (kh, channel tile) and the three kw taps served from it by
+// shifted LDS reads (zero rows in front of every image row of the tile and after the last; see k_conv3x3_f32x2_rows).  The A rows still
+// arrive by global_load_lds: an instruction's 8 consecutive tile rows lie in one image row (W is a multiple of 8), so they are 8 consecutive
+// LDS rows too.  128 x 128 tile, K-tile 64, two buffers per operand, no split-K.
+__global__ __launch_bounds__(256) void k_conv3x3_bf16_rows(const ConvArgs a) {
+    constexpr int TM = 2, TN = 2, BM = 128, BN = 128;
+    constexpr int A_INST = BM / 32, B_INST = BN / 32;
+    constexpr int A_ROWS = BM + 4 + 1, A_BUF = A_ROWS * CV_ROWB, B_BUF = BN * CV_ROWB;
+    constexpr int EPI = BM * BN * 4;
+    constexpr int LDS_BYTES = ((2 * A_BUF + 2 * B_BUF > EPI) ? 2 * A_BUF + 2 * B_BUF : EPI) + 512;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    unsigned char* const abuf = lds;
+    unsigned char* const bbuf = lds + 2 * A_BUF;
+
+    const uint32_t n_blocks = a.m_tiles * a.n_tiles;
+    uint32_t tile;
+    {
+        const uint32_t xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n_blocks >> 3, r = n_blocks & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const uint32_t m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
+    const uint32_t W = a.W, Cin2 = a.Cin - a.Cin1;
+    const uint32_t n_seg = W >= (uint32_t)BM ? 1u : (uint32_t)BM / W, seg_w = W >= (uint32_t)BM ? (uint32_t)BM : W;
+    for (uint32_t i = tid; i < 2 * (n_seg + 1) * (CV_ROWB / 16); i += 256) {   // zero rows of both A buffers
+        const uint32_t chunk = i % (CV_ROWB / 16), row = (i / (CV_ROWB / 16)) % (n_seg + 1), buf = i / ((CV_ROWB / 16) * (n_seg + 1));
+        *reinterpret_cast<uint4*>(abuf + buf * A_BUF + row * (seg_w + 1) * CV_ROWB + chunk * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // ---- A loader: instruction i of this wave covers tile rows (wave*A_INST + i)*8 + (lane >> 3) = LDS rows rho0 + (lane >> 3) -------------
+    int32_t a_y0[A_INST];
+    uint32_t a_pix0[A_INST], a_chunk[A_INST], a_lds[A_INST];
+    bool a_ok[A_INST];
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const uint32_t r8 = (wave * A_INST + i) * 8, r = r8 + (lane >> 3), m = m0 + r;
+        a_ok[i] = m < a.M;
+        const uint32_t mm = a_ok[i] ? m : 0;
+        const uint32_t b = mm / (a.H * W), rem = mm % (a.H * W);
+        a_y0[i] = (int32_t)(rem / W) - 1;
+        a_pix0[i] = b * a.H * W + (rem % W);
+        const uint32_t rho = r + r / seg_w + 1;
+        a_chunk[i] = ((lane & 7) ^ ((rho >> 1) & 7)) * 16;                       // source-side swizzle keyed by the LDS row
+        a_lds[i] = (r8 + r8 / seg_w + 1) * CV_ROWB;                              // LDS byte offset of the instruction's first row (wave-uniform)
+    }
+    uint32_t b_off[B_INST];
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+        const uint32_t r = (wave * B_INST + i) * 8 + (lane >> 3);
+        b_off[i] = ((n0 + r) * 9 * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+    }
+    uint64_t a_src[A_INST], a_src2[A_INST];
+    bool a_zero[A_INST];
+    auto set_kh = [&](uint32_t kh) {
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) {
+            const int32_t yv = a_y0[i] + (int32_t)kh;
+            const bool ok = a_ok[i] && yv >= 0 && yv < (int32_t)a.H;
+            const uint64_t pix = (uint64_t)a_pix0[i] + (uint64_t)(ok ? yv : 0) * W;
+            a_zero[i] = !ok;
+            a_src[i] = ok ? (uint64_t)a.x + pix * a.Cin1 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
+            a_src2[i] = (ok && a.x2) ? (uint64_t)a.x2 + pix * Cin2 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
+        }
+    };
+    auto a_issue = [&](uint32_t ci0, uint32_t buf) {
+        const bool second = ci0 >= a.Cin1;
+        const uint64_t coff = (uint64_t)(second ? ci0 - a.Cin1 : ci0) * 2;
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i)
+            cv_glds16((const void*)((second ? a_src2[i] : a_src[i]) + (a_zero[i] ? 0 : coff)), abuf + buf * A_BUF + __builtin_amdgcn_readfirstlane(a_lds[i]));
+    };
+    auto b_issue = [&](uint32_t tap, uint32_t ci0, uint32_t buf) {
+#pragma unroll
+        for (int i = 0; i < B_INST; ++i)
+            cv_glds16(a.w + b_off[i] + (uint64_t)(tap * a.Cin + ci0) * 2, bbuf + buf * B_BUF + (wave * B_INST + i) * 1024);
+    };
+    // ---- reader geometry ---------------------------------------------------------------------------------------------------------------
+    uint32_t a_rd[TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const uint32_t t0 = wm * 32 * TM + i * 32;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const uint32_t rho = t0 + (lane & 31) + t0 / seg_w + kw;
+            a_rd[i][kw] = rho * CV_ROWB + (((lane >> 5) ^ ((rho >> 1) & 7)) * 16);
+        }
+    }
+    const uint32_t b_rd = (wn * 32 * TN + (lane & 31)) * CV_ROWB + (((lane >> 5) ^ ((lane >> 1) & 7)) * 16);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const uint32_t kc = a.Cin / CV_BK, G = 3 * kc, KT = 3 * G;
+    uint32_t kh = 0, ci = 0;
+    set_kh(0);
+    a_issue(0, 0);
+    b_issue(0, 0, 0);
+    __syncthreads();
+    for (uint32_t kt = 0, g = 0, kw = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) {
+            const uint32_t kw1 = kw == 2 ? 0 : kw + 1;
+            uint32_t kh1 = kh, ci1 = ci;
+            if (kw == 2) { if (++ci1 == kc) { ci1 = 0; ++kh1; } }
+            b_issue(kh1 * 3 + kw1, ci1 * CV_BK, (kt + 1) & 1);
+        }
+        if (kw == 0 && g + 1 < G) {                                          // the next group's A tile; its buffer was last read two barriers ago
+            uint32_t kh1 = kh, ci1 = ci;
+            if (++ci1 == kc) { ci1 = 0; ++kh1; set_kh(kh1); }
+            a_issue(ci1 * CV_BK, (g + 1) & 1);
+        }
+        const unsigned char* sa = abuf + (g & 1) * A_BUF;
+        const unsigned char* sb = bbuf + (kt & 1) * B_BUF;
+        bf16x8 fa[4][TM], fb[4][TN];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const uint32_t off = kw == 0 ? a_rd[i][0] : kw == 1 ? a_rd[i][1] : a_rd[i][2];
+                fa[s][i] = *reinterpret_cast<const bf16x8*>(sa + (off ^ (s * 32)));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(sb + ((b_rd + j * 32 * CV_ROWB) ^ (s * 32)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+        if (++kw == 3) { kw = 0; ++g; if (++ci == kc) { ci = 0; ++kh; } }
+    }
+    cv_epilogue_bf16<TM, TN, 2, 2>(a, acc, lds, m0, n0);
 }
 
 // ================================================================================================================================
@@ -954,7 +1102,12 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     double* stats = a.gn_sums;
     if (splits > 1) a.gn_sums = nullptr;                                     // a split layer's statistics are taken by the finishing pass
     hipStream_t st = (hipStream_t)stream;
-    if (choice == 4) cv_launch<2, 2, 4, 2, 3>(a, st); else if (choice == 1) cv_launch<2, 2, 2, 2, 2>(a, st); else if (choice == 2) cv_launch<1, 2, 2, 2, 3>(a, st); else cv_launch<1, 1, 2, 2, 4>(a, st);
+    static const bool rows_ok = getenv("SSDNERF_CONV_NO_ROW_REUSE") == nullptr;
+    const bool rows = rows_ok && choice == 1 && splits == 1 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 128 == 0;
+    if (rows) {
+        a.m_tiles = (a.M + 127) / 128; a.n_tiles = Cout / 128;
+        hipLaunchKernelGGL(k_conv3x3_bf16_rows, dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    } else if (choice == 4) cv_launch<2, 2, 4, 2, 3>(a, st); else if (choice == 1) cv_launch<2, 2, 2, 2, 2>(a, st); else if (choice == 2) cv_launch<1, 2, 2, 2, 3>(a, st); else cv_launch<1, 1, 2, 2, 4>(a, st);
     if (splits > 1) {
         const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
         uint32_t rows = HWo;                                                 // rows per block: >= one pass of the rows in flight, ~1024 blocks

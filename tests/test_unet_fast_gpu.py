@@ -360,3 +360,22 @@ def test_conv_f32x2_row_reuse_kernel(B, H, W, Cin, Cout):
     a_, b_ = x[:, :c1].contiguous(memory_format=torch.channels_last), x[:, c1:].contiguous(memory_format=torch.channels_last)
     got2 = unet_fast.conv2d_nhwc_f32x2(a_, hi, lo, bias, res, tile_hint=1, splits_hint=1, x2=b_)
     assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 128, 64, 128), (2, 64, 64, 128, 128), (3, 32, 32, 192, 256), (1, 4, 32, 64, 128)])
+def test_conv_bf16_row_reuse_kernel(B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(H * W + Cin + 1)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, Cout, H, W, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    sums = torch.zeros(B, 32, 2, dtype=torch.float64, device="cuda")
+    got = unet_fast.conv2d_nhwc_bf16(x, w, bias, res, gn_sums=sums, gn_groups=32, tile_hint=1)      # no scratch -> unsplit -> the row-reuse kernel
+    want = _conv_ref(x, w, bias, res, 1, False)
+    assert ((got.float() - want).norm() / want.norm()).item() < 4e-3
+    assert (got.float() - want).abs().max().item() <= 3e-2 * max(1.0, want.abs().max().item())
+    yf = got.double().reshape(B, 32, Cout // 32, H * W)
+    assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-5, atol=1e-3)
+    c1 = Cin // 2 if (Cin // 2) % 64 == 0 else 64
+    a_, b_ = x[:, :c1].contiguous(memory_format=torch.channels_last), x[:, c1:].contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, unet_fast.conv2d_nhwc_bf16(a_, w, bias, res, tile_hint=1, x2=b_))
