@@ -107,3 +107,29 @@ def test_reference_configs_load_and_build_unchanged():
     t = build_model(Config.fromfile(f"{REF}/configs/new_cfgs/ssdnerf_cars_recons1v_tiled.py"))       # tiled (6,128,384) layout, base 80
     x = torch.zeros(1, 3, 6, 128, 128)
     assert t.code_diff_pr(x).shape == (1, 6, 128, 384) and t.code_diff_pr_inv(t.code_diff_pr(x)).shape == x.shape
+
+
+def test_conv_plans_and_operand_split_host_side():
+    """Host-only pieces of the UNet convolution path: the decomposition the C ABI reports for a layer, and the bf16 x 2 weight split."""
+    import ctypes
+    import torch
+    from ssdnerf_amd import _cabi as C
+    from ssdnerf_amd.unet_fast import split_bf16x2
+    lib = C.lib()
+    u32 = ctypes.c_uint32
+    # big layers: 128x128 tiles, unsplit; tiny layers: 64x64 tiles cut along K
+    big = lib.ssdnerf_conv2d_nhwc_bf16_plan(u32(8 * 128 * 128), u32(128), u32(128), u32(3), 0, 1, 0)
+    assert big & 0xff == 1 and big >> 8 == 1
+    small = lib.ssdnerf_conv2d_nhwc_bf16_plan(u32(8 * 8 * 8), u32(512), u32(512), u32(3), 0, 1, 0)
+    assert small & 0xff == 3 and 2 <= small >> 8 <= 16
+    assert lib.ssdnerf_conv2d_nhwc_bf16_plan(u32(8 * 8 * 8), u32(512), u32(512), u32(3), 0, 0, 0) >> 8 == 1        # no scratch -> no split
+    f32 = lib.ssdnerf_conv2d_nhwc_f32x2_plan(u32(8 * 16 * 16), u32(512), u32(512), u32(3), 0, 0)
+    assert f32 & 0xff == 3 and f32 >> 8 >= 2
+    assert lib.ssdnerf_conv2d_nhwc_f32x2_plan(u32(8 * 64 * 64), u32(256), u32(256), u32(3), 0, 0) == (1 | (1 << 8))
+    assert lib.ssdnerf_conv2d_nhwc_bf16_supported(u32(128), u32(256), u32(3), u32(1), u32(0)) == 1
+    assert lib.ssdnerf_conv2d_nhwc_bf16_supported(u32(18), u32(128), u32(3), u32(1), u32(0)) == 0
+    w = torch.randn(4096, generator=torch.Generator().manual_seed(0)) * torch.logspace(-6, 3, 4096)
+    hi, lo = split_bf16x2(w)
+    assert hi.dtype == lo.dtype == torch.bfloat16
+    rel = ((hi.double() + lo.double() - w.double()).abs() / w.double().abs()).max().item()
+    assert rel <= 2.0 ** -16, rel                                              # 16 significand bits survive the split (bf16 alone: 2^-9)
