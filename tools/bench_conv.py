@@ -8,7 +8,8 @@ import torch.nn.functional as F
 from ssdnerf_amd import unet_fast
 
 ap = argparse.ArgumentParser(); ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--hints", default="0,1,2,3,4"); ap.add_argument("--no-lib", action="store_true")
+ap.add_argument("--hints", default="0"); ap.add_argument("--no-lib", action="store_true")
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="bf16: k_conv_igemm_bf16; fp32: the fp32-class bf16x2 kernels vs the library's fp32 convolution")
 a = ap.parse_args()
 B = a.scenes
 WS = torch.zeros(4 << 20, dtype=torch.float32, device="cuda")     # split-K scratch (all zero between calls)
@@ -38,10 +39,13 @@ def timeit(fn):
 tot = dict(lib=0.0, own=0.0, flop=0.0)
 rows = []
 for (H, Cin, Cout, k, stride, up, count) in LAYERS:
-    x = torch.randn(B, Cin, H, H, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(Cout, Cin, k, k, device="cuda") * 0.02).bfloat16().contiguous(memory_format=torch.channels_last)
+    DT = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    x = torch.randn(B, Cin, H, H, device="cuda").to(DT).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, device="cuda") * 0.02).to(DT).contiguous(memory_format=torch.channels_last)
     bias = torch.randn(Cout, device="cuda")
-    bias16 = bias.bfloat16()
+    bias16 = bias.to(DT)
+    if a.dtype == "fp32":
+        w_hi, w_lo = [t.contiguous(memory_format=torch.channels_last) for t in unet_fast.split_bf16x2(w)]
     Hv = 2 * H if up else H
     Ho = (Hv + 2 * (k // 2) - k) // stride + 1
     flop = 2.0 * B * Ho * Ho * Cout * Cin * k * k
@@ -55,7 +59,11 @@ for (H, Cin, Cout, k, stride, up, count) in LAYERS:
     per_hint = {}
     for h in [int(v) for v in a.hints.split(",")]:
         if h in (1, 2, 4) and Cout % 128: continue
-        t = timeit(lambda: unet_fast.conv2d_nhwc_bf16(x, w, bias, None, stride, bool(up), tile_hint=h, splitk_ws=WS))
+        if a.dtype == "fp32":
+            if h in (2, 4): continue
+            t = timeit(lambda: unet_fast.conv2d_nhwc_f32x2(x, w_hi, w_lo, bias, None, stride, bool(up), tile_hint=h))
+        else:
+            t = timeit(lambda: unet_fast.conv2d_nhwc_bf16(x, w, bias, None, stride, bool(up), tile_hint=h, splitk_ws=WS))
         per_hint[h] = round(t, 1)
         if h != 0 and (best is None or t < best[1]): best = (h, t)
     t_own = per_hint.get(0, best[1] if best else float("nan"))
