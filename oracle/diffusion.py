@@ -72,6 +72,34 @@ def ddim_sample(denoise: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], n
     return (x_t, trace) if return_all else x_t
 
 
+# ------------------------------------------------------------------------------------------------ diffusion prior loss
+def snr_timestep_weights(tables: Dict[str, np.ndarray], power: float = 0.5, mode: str = "V", bias: float = 0.0, prob_power: float = 0.0):
+    """``SNRWeightedTimeStepSampler`` (lib/models/diffusions/sampler.py:14-44): per-timestep loss weight (float32) and sampling
+    probabilities.  With the configs' power = 0.5, mode 'V', prob_power = 0 this is weight = sqrt(abar (1 - abar)), uniform sampling."""
+    mean, std = tables["sqrt_alphas_bar"], tables["sqrt_one_minus_alphas_bar"]
+    wx = (mean / std) ** (2 * power) + bias
+    raw = {"EPS": wx * (std / mean) ** 2, "START_X": wx, "V": wx * std ** 2}[mode]
+    prob = raw ** prob_power
+    prob = prob / prob.sum()
+    return (raw / (prob * len(mean))).astype(np.float32), prob
+
+
+def prior_loss_v(denoise: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x_0: torch.Tensor, t: torch.Tensor, noise: torch.Tensor,
+                 tables: Dict[str, np.ndarray], weight: Optional[np.ndarray], weight_scale: float = 1.0, norm_factor: float = 1.0) -> torch.Tensor:
+    """The V-prediction training loss ``val_optim`` back-propagates into the code (gaussian_diffusion.py:165-178, 389-433 with
+    lib/models/losses/ddpm_loss.py:12-142): x_t = a x_0 + b noise, target v = a noise - b x_0,
+    loss = mean_batch(0.5 mean_chw((v_pred - v)^2) w[t] c) / norm_factor.  ``t`` (B,) long."""
+    a = torch.from_numpy(tables["sqrt_alphas_bar"])[t].float().reshape(-1, 1, 1, 1)
+    b = torch.from_numpy(tables["sqrt_one_minus_alphas_bar"])[t].float().reshape(-1, 1, 1, 1)
+    x_t = x_0 * a + noise * b
+    v_pred = denoise(x_t, t)
+    v = a * noise - b * x_0
+    per = ((v_pred - v) ** 2).flatten(1).mean(dim=1) * 0.5
+    if weight is not None:
+        per = per * torch.from_numpy(weight)[t] * weight_scale
+    return per.mean() / norm_factor
+
+
 # ------------------------------------------------------------------------------------------------ UNet, functional
 def _gn(x, sd, p, groups=32):
     return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps=1e-5)

@@ -3,8 +3,10 @@ rendering-loss guidance hook (reference: lib/models/diffusions/gaussian_diffusio
 
 On the hot path: ``prepare_diffusion_vars`` (numpy float64 tables, :131-154),
 ``pred_x_0`` (:180-240), ``p_sample_ddim`` (:264-293), ``p_sample_langevin`` (:242-262), ``ddim_sample`` (:295-331).
-The training loss, the DDPM ancestral sampler and the timestep samplers are out of scope; their config entries are
-accepted and ignored so that the reference's configs build unchanged.
+Section 8(f) rank 1 (the fine-tuning half of ``cond_mode='guide_optim'``) adds the diffusion prior loss that
+``val_optim`` back-propagates into the code: ``q_sample`` (:165-178), ``loss`` (:389-405), ``forward_train`` (:407-433)
+with the timestep samplers (lib/models/diffusions/sampler.py) and ``DDPMMSELossMod`` (lib/models/losses/ddpm_loss.py).
+The DDPM ancestral sampler is out of scope.
 
 The per-step latent update (V-prediction -> x0, clamp, eps, x_prev) is one fused HIP kernel when no guidance closure is
 active (``ssdnerf_ddim_step_v``); the guided path keeps the reference's exact PyTorch expression order because autograd
@@ -29,10 +31,137 @@ def _noise_like(x):
     return torch.randn(x.shape, dtype=torch.float32).to(x.device)
 
 
+# ---------------------------------------------------------------------------------------------- timestep samplers
+@MODULES.register_module()
+class UniformTimeStepSampler:
+    """mmgen ``UniformTimeStepSampler``: t ~ ``np.random.choice(T, p=prob)`` drawn on the HOST, so a seeded
+    ``np.random`` gives the same timesteps on every device."""
+
+    def __init__(self, num_timesteps, **kwargs):
+        self.num_timesteps = num_timesteps
+        self.prob = [1 / self.num_timesteps for _ in range(self.num_timesteps)]
+
+    def sample(self, batch_size):
+        return torch.from_numpy(np.random.choice(self.num_timesteps, size=(batch_size,), p=self.prob)).long()
+
+    def __call__(self, batch_size):
+        return self.sample(batch_size)
+
+
+MODULES.register_module(name="UniformTimeStepSamplerMod", module=type("UniformTimeStepSamplerMod", (UniformTimeStepSampler,), {}))
+
+
+@MODULES.register_module()
+class SNRWeightedTimeStepSampler(UniformTimeStepSampler):
+    """Per-timestep loss weight ``SNR^power`` expressed for the network's output parameterisation, and the sampling density
+    ``weight^prob_power`` (lib/models/diffusions/sampler.py:14-44).  ``mean`` / ``std`` are the float64 sqrt(alpha_bar) tables."""
+
+    def __init__(self, num_timesteps, mean, std, mode, power=1, min=-1, max=-1, bias=0, prob_power=0.0):
+        self.num_timesteps = num_timesteps
+        mean, std = np.asarray(mean, np.float64), np.asarray(std, np.float64)
+        weight_x = (mean / std) ** (2 * power) + bias
+        if min > 0:
+            weight_x = weight_x.clip(min=min)
+        if max > 0:
+            weight_x = weight_x.clip(max=max)
+        if mode == "EPS":
+            weight_raw = weight_x * (std / mean) ** 2
+        elif mode == "START_X":
+            weight_raw = weight_x
+        elif mode == "V":
+            weight_raw = weight_x * (std ** 2)
+        else:
+            raise AttributeError(f"unknown denoising mean mode {mode!r}")
+        prob = weight_raw ** prob_power
+        prob /= prob.sum()
+        self.weight = torch.from_numpy(weight_raw / (prob * self.num_timesteps)).to(torch.float)
+        self.prob = prob.tolist()
+
+
+# ---------------------------------------------------------------------------------------------- diffusion prior loss
+@MODULES.register_module()
+class DDPMMSELossMod(nn.Module):
+    """``0.5 * mean_{chw}((pred - target)^2)`` per sample, times ``weight[t] * weight_scale`` (``rescale_mode='timestep_weight'``, the
+    weight table coming from the timestep sampler), optionally divided by the running ``norm_factor`` = EMA of mean(x_0^2), then reduced
+    over the batch (lib/models/losses/ddpm_loss.py:12-142 on top of mmgen's ``DDPMLoss``).
+
+    ``log_vars`` holds the quartile means as 0-dim device tensors (the reference calls ``.item()`` on each, a sync per quartile)."""
+
+    _default_data_info = dict(pred="eps_t_pred", target="noise")
+
+    def __init__(self, rescale_mode=None, rescale_cfg=None, sampler=None, weight=None, weight_scale=1.0, log_cfgs=None, reduction="mean",
+                 data_info=None, loss_name="loss_ddpm_mse", scale_norm=False, momentum=0.001):
+        super().__init__()
+        self.weight_scale = weight_scale
+        self.reduction = reduction
+        self.loss_name_ = loss_name
+        self.data_info = dict(self._default_data_info if data_info is None else data_info)
+        self.rescale_mode = rescale_mode
+        self.timestep_weight = None
+        if rescale_mode is not None:
+            if rescale_mode != "timestep_weight":
+                raise NotImplementedError(f"rescale_mode={rescale_mode!r}: the reference's configs only use 'timestep_weight'")
+            if sampler is not None and hasattr(sampler, "weight"):
+                weight = sampler.weight
+            if weight is None:
+                raise ValueError("rescale_mode='timestep_weight' needs a sampler with a weight table, or an explicit weight")
+            self.timestep_weight = torch.as_tensor(weight, dtype=torch.float)
+        self.log_cfgs = [log_cfgs] if isinstance(log_cfgs, dict) else list(log_cfgs or [])
+        self.log_vars = dict()
+        self.scale_norm = scale_norm
+        self.freeze_norm = False
+        if scale_norm:
+            self.register_buffer("norm_factor", torch.ones(1, dtype=torch.float))
+        self.momentum = momentum
+
+    def _reduce(self, loss):
+        if self.reduction == "mean":
+            return loss.mean()
+        if self.reduction == "sum":
+            return loss.sum()
+        if self.reduction == "none":
+            return loss
+        if self.reduction == "flatmean":
+            return loss.flatten(1).mean(dim=1) if loss.dim() > 1 else loss
+        raise ValueError(self.reduction)
+
+    def _collect_log(self, loss, timesteps):
+        self.log_vars = dict()
+        for cfg in self.log_cfgs:
+            if cfg.get("type") != "quartile":
+                continue
+            total, prefix = cfg.get("total_timesteps", 1000), cfg.get("prefix_name", "loss")
+            quartile = (timesteps.float() / total * 4).long()
+            ld = loss.detach()
+            for q in range(4):
+                m = (quartile == q).to(ld.dtype)
+                self.log_vars[f"{prefix}_quartile_{q}"] = (ld * m).sum() / m.sum().clamp(min=1)
+
+    def forward(self, output_dict):
+        assert isinstance(output_dict, dict) and "timesteps" in output_dict, "DDPM losses take the dict of network outputs with 'timesteps'"
+        timesteps = output_dict["timesteps"]
+        pred, target = output_dict[self.data_info["pred"]], output_dict[self.data_info["target"]]
+        loss = (pred - target).square().flatten(1).mean(dim=1) * 0.5
+        if self.timestep_weight is not None:
+            loss = loss * self.timestep_weight.to(timesteps.device)[timesteps] * self.weight_scale
+        self._collect_log(loss, timesteps)
+        loss = self._reduce(loss)
+        if self.scale_norm:
+            if self.training and not self.freeze_norm:
+                from .parallel import reduce_mean
+                norm_factor = reduce_mean(output_dict["x_0"].detach().square().mean())
+                self.norm_factor[:] = (1 - self.momentum) * self.norm_factor + self.momentum * norm_factor
+            loss = loss / self.norm_factor
+        return loss
+
+
+MODULES.register_module(name="DDPMMSELoss", module=type("DDPMMSELoss", (DDPMMSELossMod,), {}))
+
+
 @MODULES.register_module()
 class GaussianDiffusion(nn.Module):
-    def __init__(self, denoising, ddpm_loss=None, betas_cfg=dict(type="cosine"), num_timesteps=1000, num_classes=0, sample_method="ddim",
-                 timestep_sampler=None, denoising_var_mode="FIXED_LARGE", denoising_mean_mode="V", train_cfg=None, test_cfg=None):
+    def __init__(self, denoising, ddpm_loss=dict(type="DDPMMSELoss", log_cfgs=dict(type="quartile", prefix_name="loss_mse", total_timesteps=1000)), betas_cfg=dict(type="cosine"), num_timesteps=1000, num_classes=0, sample_method="ddim",
+                 timestep_sampler=dict(type="UniformTimeStepSampler"), denoising_var_mode="FIXED_LARGE", denoising_mean_mode="V", train_cfg=None, test_cfg=None):
         super().__init__()
         self.num_classes = num_classes
         self.num_timesteps = num_timesteps
@@ -45,9 +174,11 @@ class GaussianDiffusion(nn.Module):
         self.train_cfg = deepcopy(train_cfg) if train_cfg is not None else dict()
         self.test_cfg = deepcopy(test_cfg) if test_cfg is not None else dict()
         self.prepare_diffusion_vars()
-        # training-time objects: kept as plain config (out of scope), so that reference configs construct
-        self.sampler_cfg = deepcopy(timestep_sampler)
-        self.ddpm_loss_cfg = deepcopy(ddpm_loss)
+        # timestep sampler + prior loss (:55-62): what ``forward_train`` / ``val_optim`` use
+        self.sampler = build_module(timestep_sampler or dict(type="UniformTimeStepSampler"),
+                                    default_args=dict(num_timesteps=num_timesteps, mean=self.sqrt_alphas_bar, std=self.sqrt_one_minus_alphas_bar,
+                                                      mode=self.denoising_mean_mode))
+        self.ddpm_loss = build_module(ddpm_loss or dict(type="DDPMMSELoss"), default_args=dict(sampler=self.sampler))
         self.use_fused_step = True
 
     # ------------------------------------------------------------------------------------------ schedules
@@ -91,6 +222,16 @@ class GaussianDiffusion(nn.Module):
         self.log_tilde_betas_t_clipped = np.log(np.append(self.tilde_betas_t[1], self.tilde_betas_t[1:]))
         self.tilde_mu_t_coef1 = np.sqrt(self.alphas_bar_prev) / (1 - self.alphas_bar) * self.betas
         self.tilde_mu_t_coef2 = np.sqrt(self.alphas) * (1 - self.alphas_bar_prev) / (1 - self.alphas_bar)
+
+    # ------------------------------------------------------------------------------------------ forward process
+    def q_sample(self, x_0, t, noise=None):
+        """x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) noise; also returns the two broadcastable coefficients (:165-178)."""
+        if noise is None:
+            noise = _noise_like(x_0)
+        t_host = torch.as_tensor(t).cpu()
+        mean = x_0.new_tensor(self.sqrt_alphas_bar[t_host.numpy()], dtype=torch.float32).reshape(-1, 1, 1, 1)
+        std = x_0.new_tensor(self.sqrt_one_minus_alphas_bar[t_host.numpy()], dtype=torch.float32).reshape(-1, 1, 1, 1)
+        return x_0 * mean + noise * std, mean, std
 
     # ------------------------------------------------------------------------------------------ x0 prediction
     def pred_x_0(self, x_t, t, grad_guide_fn=None, concat_cond=None, cfg=dict(), update_denoising_output=False):
@@ -237,11 +378,45 @@ class GaussianDiffusion(nn.Module):
             raise AttributeError(f"Cannot find sample method [{name}] correspond to [{self.sample_method}].")
         return getattr(self, name)(noise=noise, **kwargs)
 
+    # ------------------------------------------------------------------------------------------ prior loss
+    def loss(self, denoising_output, x_0, noise, t, mean, std):
+        mode = self.denoising_mean_mode.upper()
+        if mode == "EPS":
+            loss_kwargs = dict(eps_t_pred=denoising_output)
+        elif mode == "START_X":
+            loss_kwargs = dict(x_0_pred=denoising_output)
+        elif mode == "V":
+            loss_kwargs = dict(v_t_pred=denoising_output)
+        else:
+            raise AttributeError(f"Unknown denoising mean output type [{self.denoising_mean_mode}].")
+        loss_kwargs.update(x_0=x_0, noise=noise, timesteps=t)
+        if "v_t_pred" in loss_kwargs:
+            loss_kwargs.update(v_t=mean * noise - std * x_0)
+        return self.ddpm_loss(loss_kwargs)
+
+    def forward_train(self, x_0, concat_cond=None, grad_guide_fn=None, cfg=dict(), x_t_detach=False, timesteps=None, noise=None, **kwargs):
+        """Diffusion prior loss of ``x_0`` (:407-433).  ``timesteps`` / ``noise`` (extra): injected draws; by default both are drawn on
+        the host exactly like the reference (``np.random.choice`` / CPU ``torch.randn``), so seeding reproduces them on any device.
+        ``log_vars['loss_ddpm_mse']`` is a detached 0-dim tensor instead of a Python float (no device sync here)."""
+        assert x_0.dim() == 4
+        device = x_0.device
+        t = (self.sampler(x_0.size(0)) if timesteps is None else torch.as_tensor(timesteps).long()).to(device)
+        if noise is None:
+            noise = _noise_like(x_0)
+        x_t, mean, std = self.q_sample(x_0, t, noise.to(device))
+        if x_t_detach:
+            x_t = x_t.detach()
+        _, denoising_output = self.pred_x_0(x_t, t, grad_guide_fn=grad_guide_fn, concat_cond=concat_cond, cfg=cfg, update_denoising_output=True)
+        loss = self.loss(denoising_output, x_0, noise.to(device), t, mean, std)
+        log_vars = self.ddpm_loss.log_vars
+        log_vars.update(loss_ddpm_mse=loss.detach())
+        return loss, log_vars
+
     def forward_test(self, data, **kwargs):
         assert data.dim() == 4
         return self.sample_from_noise(data, **kwargs)
 
     def forward(self, data, return_loss=False, **kwargs):
         if return_loss:
-            raise NotImplementedError("diffusion training loss is outside the hot path (SURVEY.md section 2, rows 14-15)")
+            return self.forward_train(data, **kwargs)
         return self.forward_test(data, **kwargs)

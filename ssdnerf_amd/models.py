@@ -5,8 +5,13 @@ exercise:
   render, get_density, update_extra_state, loss, ray_sample, load_scene / save_scene   (lib/models/autodecoders/base_nerf.py)
   val_uncond, val_guide + grad_guide_fn, code_diff_pr[_inv], val_step                 (lib/models/autodecoders/diffusion_nerf.py)
 
-Training (``train_step``), ``val_optim`` / ``inverse_code``, the scene cache and the evaluation/visualisation code are
-out of scope (SURVEY.md sections 2 and 8(f)); calling them raises ``NotImplementedError``.
+and, as the first row of SURVEY.md section 8(f), the fine-tuning half of ``cond_mode='guide_optim'``:
+
+  get_init_code_, build_optimizer, build_scheduler, loss_decoder, inverse_code          (base_nerf.py:184-229, 298-316, 403-492)
+  val_optim, the ``override_cfg`` switch in ``train()``                                  (diffusion_nerf.py:313-404, base_nerf.py:127-140)
+
+Training (``train_step``), the scene cache and the evaluation/visualisation code are out of scope (SURVEY.md sections 2
+and 8(f)); calling them raises ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -99,6 +104,34 @@ class RegLoss(nn.Module):
         return v * self.loss_weight
 
 
+def rgetattr(obj, attr, *default):
+    """dotted-path getattr (lib/core/utils/misc.py:129-134)."""
+    for name in attr.split("."):
+        obj = getattr(obj, name, *default)
+    return obj
+
+
+def rsetattr(obj, attr, val):
+    pre, _, post = attr.rpartition(".")
+    return setattr(rgetattr(obj, pre) if pre else obj, post, val)
+
+
+class _requires_grad:
+    """``module_requires_grad`` (lib/core/utils/misc.py): set the flag on every parameter inside the block, restore after."""
+
+    def __init__(self, module, flag):
+        self.params, self.flag = list(module.parameters()), flag
+
+    def __enter__(self):
+        self.prev = [p.requires_grad for p in self.params]
+        for p in self.params:
+            p.requires_grad_(self.flag)
+
+    def __exit__(self, *exc):
+        for p, r in zip(self.params, self.prev):
+            p.requires_grad_(r)
+
+
 class _ConfigOnly(nn.Module):
     """Training-only config entries (losses / samplers / hooks): constructed so configs build, never executed."""
 
@@ -110,7 +143,7 @@ class _ConfigOnly(nn.Module):
         raise NotImplementedError(f"{type(self).__name__} belongs to the training loop, which is outside the hot path")
 
 
-for _name in ("TVLoss", "L1LossMod", "DDPMMSELossMod", "SNRWeightedTimeStepSampler", "UniformTimeStepSampler"):
+for _name in ("TVLoss", "L1LossMod"):
     MODULES.register_module(name=_name, module=type(_name, (_ConfigOnly,), {}))
 
 
@@ -142,6 +175,25 @@ class BaseNeRF(nn.Module):
         if pretrained is not None and os.path.isfile(pretrained):
             sd = torch.load(pretrained, map_location="cpu")
             self.load_state_dict(sd.get("state_dict", sd), strict=False)
+        self.train_cfg_backup = dict()
+        self._backup_override_cfg()
+
+    # ---- test-time attribute overrides (base_nerf.py:127-140): ``test_cfg['override_cfg']`` maps dotted attribute paths to the values
+    # they take in eval mode, e.g. {'diffusion_ema.ddpm_loss.weight_scale': 1.0} in the recons configs -------------------------------
+    def _backup_override_cfg(self):
+        for key in self.test_cfg.get("override_cfg", dict()):
+            self.train_cfg_backup[key] = rgetattr(self, key, None)
+
+    def train(self, mode=True):
+        if mode:
+            for key, value in self.train_cfg_backup.items():
+                rsetattr(self, key, value)
+        else:
+            for key, value in self.test_cfg.get("override_cfg", dict()).items():
+                if self.training:
+                    self.train_cfg_backup[key] = rgetattr(self, key)
+                rsetattr(self, key, value)
+        return super().train(mode)
 
     # ---- scene wire format (base_nerf.py:143-170) -----------------------------------------------------------------
     def load_scene(self, data, load_density=False):
@@ -164,6 +216,35 @@ class BaseNeRF(nn.Module):
             torch.save(dict(scene_name=name, param=dict(code=code.data[i].cpu(), density_grid=density_grid.data[i].cpu(),
                                                         density_bitfield=density_bitfield.data[i].cpu())),
                        os.path.join(save_dir, name) + ".pth")
+
+    def get_init_code_(self, num_scenes, device=None):
+        """Pre-activation code leaf (base_nerf.py:184-192): U(-init_scale, init_scale), or the inverse-activated mean code."""
+        code_ = torch.empty(self.code_size if num_scenes is None else (num_scenes, *self.code_size), device=device, requires_grad=True,
+                            dtype=torch.float32)
+        if self.init_code is None:
+            code_.data.uniform_(-self.init_scale, self.init_scale)
+        else:
+            code_.data[:] = self.code_activation.inverse(self.init_code * self.mean_scale)
+        return code_
+
+    @staticmethod
+    def build_optimizer(code_, cfg):
+        """``cfg['optimizer'] = dict(type=<torch.optim class>, **kwargs)`` over the code leaf/leaves (base_nerf.py:204-214)."""
+        optimizer_cfg = dict(cfg["optimizer"])
+        optimizer_class = getattr(torch.optim, optimizer_cfg.pop("type"))
+        if isinstance(code_, list):
+            return [optimizer_class([c], **optimizer_cfg) for c in code_]
+        return optimizer_class([code_], **optimizer_cfg)
+
+    @staticmethod
+    def build_scheduler(code_optimizer, cfg):
+        if "lr_scheduler" not in cfg:
+            return None
+        scheduler_cfg = dict(cfg["lr_scheduler"])
+        scheduler_class = getattr(torch.optim.lr_scheduler, scheduler_cfg.pop("type"))
+        if isinstance(code_optimizer, list):
+            return [scheduler_class(o, **scheduler_cfg) for o in code_optimizer]
+        return scheduler_class(code_optimizer, **scheduler_cfg)
 
     def get_init_density_grid(self, num_scenes, device=None):
         return torch.zeros((num_scenes, self.grid_size ** 3), device=device, dtype=torch.float16)
@@ -233,8 +314,85 @@ class BaseNeRF(nn.Module):
     def train_step(self, *a, **k):
         raise NotImplementedError("training is outside the hot path (SURVEY.md section 2)")
 
-    def inverse_code(self, *a, **k):
-        raise NotImplementedError("inverse_code / val_optim are SURVEY.md section 8(f) 'next'")
+    def loss_decoder(self, decoder, code, density_bitfield, cond_rays_o, cond_rays_d, cond_imgs, dt_gamma=0.0, cfg=dict(), **kwargs):
+        """Rendering loss on ``n_decoder_rays`` freshly sampled rays (base_nerf.py:298-316); log values stay 0-dim tensors."""
+        decoder_training_prev = decoder.training
+        decoder.train(True)
+        rays_o, rays_d, target_rgbs = self.ray_sample(cond_rays_o, cond_rays_d, cond_imgs, n_samples=cfg.get("n_decoder_rays", 4096))
+        out_rgbs, loss, loss_dict = self.loss(decoder, code, density_bitfield, target_rgbs, rays_o, rays_d, dt_gamma, return_decoder_loss=True,
+                                              scale_num_ray=cond_rays_o.shape[1:4].numel(), cfg=cfg, **kwargs)
+        decoder.train(decoder_training_prev)
+        return loss, {k: v.detach() for k, v in loss_dict.items()}, out_rgbs, target_rgbs
+
+    def inverse_code(self, decoder, cond_imgs, cond_rays_o, cond_rays_d, dt_gamma=0, cfg=dict(), code_=None, density_grid=None,
+                     density_bitfield=None, iter_density=None, code_optimizer=None, code_scheduler=None, prior_grad=None, show_pbar=False,
+                     march_noises=None, density_jitters=None):
+        """Optimisation-based inverse rendering of the scene codes (base_nerf.py:403-492): ``n_inverse_steps`` iterations of
+        {activate code_, refresh the density grid every ``update_extra_interval`` steps, render a ray batch through the TRAIN branch,
+        seed the gradient with ``prior_grad`` (the diffusion-prior gradient of ``val_optim``) or zero it, back-propagate, optimizer
+        step, scheduler step}.  Works on the leaf ``code_`` in place.
+
+        ``march_noises`` / ``density_jitters`` (extra): iterators (or lists) of injected per-step march jitter (S,R) and per-refresh grid
+        jitter (H^3,3), replacing the reference's on-device ``torch.rand`` draws in parity runs."""
+        device = get_module_device(self)
+        decoder_training_prev = decoder.training
+        decoder.train(True)
+        march_noises = iter(march_noises) if march_noises is not None else None
+        density_jitters = iter(density_jitters) if density_jitters is not None else None
+        with _requires_grad(decoder, False):
+            n_inverse_steps = cfg.get("n_inverse_steps", 1000)
+            n_inverse_rays = cfg.get("n_inverse_rays", 4096)
+            num_scenes, num_imgs, h, w, _ = cond_imgs.size()
+            num_scene_pixels = num_imgs * h * w
+            raybatch_inds, num_raybatch = self.get_raybatch_inds(cond_imgs, n_inverse_rays)
+            if code_ is None:
+                code_ = self.get_init_code_(num_scenes, device=device)
+            if density_grid is None:
+                density_grid = self.get_init_density_grid(num_scenes, device)
+            if density_bitfield is None:
+                density_bitfield = self.get_init_density_bitfield(num_scenes, device)
+            if iter_density is None:
+                iter_density = 0
+            if code_optimizer is None:
+                assert code_scheduler is None
+                code_optimizer = self.build_optimizer(code_, cfg)
+            if code_scheduler is None:
+                code_scheduler = self.build_scheduler(code_optimizer, cfg)
+            assert n_inverse_steps > 0
+            optimizers = code_optimizer if isinstance(code_optimizer, list) else [code_optimizer]
+            schedulers = [] if code_scheduler is None else (code_scheduler if isinstance(code_scheduler, list) else [code_scheduler])
+
+            for inverse_step_id in range(n_inverse_steps):
+                code = self.code_activation(torch.stack(code_, dim=0) if isinstance(code_, list) else code_)
+                if inverse_step_id % self.update_extra_interval == 0:
+                    self.update_extra_state(decoder, code.detach(), density_grid, density_bitfield, iter_density,
+                                            density_thresh=cfg.get("density_thresh", 0.01),
+                                            jitter=None if density_jitters is None else next(density_jitters))
+                inds = raybatch_inds[inverse_step_id % num_raybatch] if raybatch_inds is not None else None
+                rays_o, rays_d, target_rgbs = self.ray_sample(cond_rays_o, cond_rays_d, cond_imgs, n_inverse_rays, sample_inds=inds)
+                if march_noises is not None:
+                    decoder.injected_noises = next(march_noises)
+                try:
+                    out_rgbs, loss, loss_dict = self.loss(decoder, code, density_bitfield, target_rgbs, rays_o, rays_d, dt_gamma,
+                                                          scale_num_ray=num_scene_pixels, cfg=cfg)
+                finally:
+                    decoder.injected_noises = None
+                if prior_grad is not None:
+                    if isinstance(code_, list):
+                        for c, g in zip(code_, prior_grad):
+                            c.grad.copy_(g)
+                    else:
+                        code_.grad.copy_(prior_grad)
+                else:
+                    for o in optimizers:
+                        o.zero_grad()
+                loss.backward()
+                for o in optimizers:
+                    o.step()
+                for sch in schedulers:
+                    sch.step()
+        decoder.train(decoder_training_prev)
+        return code.detach(), density_grid, density_bitfield, loss, loss_dict, out_rgbs, target_rgbs
 
 
 @MODELS.register_module()
@@ -267,6 +425,7 @@ class DiffusionNeRF(MultiSceneNeRF):
         self.code_reshape_inv = [self.code_size[a] for a in self.code_permute] if code_permute is not None else self.code_size
         self.code_permute_inv = [self.code_permute.index(a) for a in range(len(self.code_permute))] if code_permute is not None else None
         self.autocast_dtype = autocast_dtype
+        self._backup_override_cfg()     # the diffusion attributes exist only now (diffusion_nerf.py:47-48)
 
     # (3,6,128,128) <-> (18,128,128) [or the tiled (6,128,384) layout via code_permute]   (diffusion_nerf.py:50-64)
     def code_diff_pr(self, code):
@@ -359,8 +518,75 @@ class DiffusionNeRF(MultiSceneNeRF):
             decoder.train(decoder_training_prev)
         return self.code_diff_pr_inv(code.float()), density_grid, density_bitfield
 
-    def val_optim(self, *a, **k):
-        raise NotImplementedError("val_optim (fine-tuning after guidance) is SURVEY.md section 8(f) 'next'")
+    # ---- fine-tuning with the diffusion prior (diffusion_nerf.py:313-404) ------------------------------------------------
+    def val_optim(self, data, code_=None, density_grid=None, density_bitfield=None, show_pbar=False, prior_timesteps=None, prior_noises=None,
+                  march_noises=None, density_jitters=None, **kwargs):
+        """``n_inverse_steps`` outer iterations of: diffusion-prior loss of the activated code (one UNet forward + backward at a sampled
+        timestep) -> its gradient on ``code_`` seeds ``extra_scene_step + 1`` rendering-loss iterations of ``inverse_code`` that share
+        one optimizer/scheduler; with ``extra_scene_step == 0`` a single ``loss_decoder`` backward + step instead.
+
+        Extras for parity runs: ``prior_timesteps`` / ``prior_noises`` (one entry per outer step) and ``march_noises`` /
+        ``density_jitters`` (one per inner step / per grid refresh, consumed in order) replace the reference's random draws."""
+        device = get_module_device(self)
+        decoder = self.decoder_ema if self.decoder_use_ema else self.decoder
+        diffusion = self.diffusion_ema if self.diffusion_use_ema else self.diffusion
+        cond_imgs, cond_intrinsics, cond_poses = data["cond_imgs"], data["cond_intrinsics"], data["cond_poses"]
+        num_scenes, num_imgs, h, w, _ = cond_imgs.size()
+        cond_rays_o, cond_rays_d = nerf.get_cam_rays(cond_poses, cond_intrinsics, h, w)
+        dt_gamma_scale = self.test_cfg.get("dt_gamma_scale", 0.0)
+        dt_gamma = dt_gamma_scale / cond_intrinsics[..., :2].mean(dim=(-2, -1))
+        if self.image_cond:
+            raise NotImplementedError("image-conditioned UNets (concat_cond) are not part of the north-star configs")
+        decoder_training_prev = decoder.training
+        decoder.train(True)
+        extra_scene_step = self.test_cfg.get("extra_scene_step", 0)
+        n_inverse_steps = self.test_cfg.get("n_inverse_steps", 100)
+        assert n_inverse_steps > 0
+        march_noises = iter(march_noises) if march_noises is not None else None
+        density_jitters = iter(density_jitters) if density_jitters is not None else None
+        try:
+            with _requires_grad(diffusion, False), _requires_grad(decoder, False), torch.enable_grad():
+                if code_ is None:
+                    code_ = self.get_init_code_(num_scenes, cond_imgs.device)
+                if density_grid is None:
+                    density_grid = self.get_init_density_grid(num_scenes, cond_imgs.device)
+                if density_bitfield is None:
+                    density_bitfield = self.get_init_density_bitfield(num_scenes, cond_imgs.device)
+                code_optimizer = self.build_optimizer(code_, self.test_cfg)
+                code_scheduler = self.build_scheduler(code_optimizer, self.test_cfg)
+                inner_cfg = dict(self.test_cfg)
+                inner_cfg["n_inverse_steps"] = extra_scene_step + 1
+                for inverse_step_id in range(n_inverse_steps):
+                    code_optimizer.zero_grad()
+                    code = self.code_activation(code_)
+                    with self._autocast():
+                        loss, log_vars = diffusion(self.code_diff_pr(code), return_loss=True, concat_cond=None,
+                                                   x_t_detach=self.test_cfg.get("x_t_detach", False), cfg=self.test_cfg,
+                                                   timesteps=None if prior_timesteps is None else prior_timesteps[inverse_step_id],
+                                                   noise=None if prior_noises is None else prior_noises[inverse_step_id], **kwargs)
+                    loss.backward()
+                    if extra_scene_step > 0:
+                        prior_grad = code_.grad.data.clone()
+                        self.inverse_code(decoder, cond_imgs, cond_rays_o, cond_rays_d, dt_gamma=dt_gamma, cfg=inner_cfg, code_=code_,
+                                          density_grid=density_grid, density_bitfield=density_bitfield, code_optimizer=code_optimizer,
+                                          code_scheduler=code_scheduler, prior_grad=prior_grad, march_noises=march_noises,
+                                          density_jitters=density_jitters)
+                    else:        # the prior gradient is still in code_.grad; the rendering gradient accumulates onto it
+                        code = self.code_activation(code_)
+                        if march_noises is not None:
+                            decoder.injected_noises = next(march_noises)
+                        try:
+                            loss_decoder, _, _, _ = self.loss_decoder(decoder, code, density_bitfield, cond_rays_o, cond_rays_d, cond_imgs,
+                                                                      dt_gamma, cfg=self.test_cfg)
+                        finally:
+                            decoder.injected_noises = None
+                        loss_decoder.backward()
+                        code_optimizer.step()
+                        if code_scheduler is not None:
+                            code_scheduler.step()
+        finally:
+            decoder.train(decoder_training_prev)
+        return self.code_activation(code_).detach(), density_grid, density_bitfield
 
     # ---- dispatch (diffusion_nerf.py:406-469), rendering only ----------------------------------------------------------
     def val_step(self, data, **kwargs):
@@ -370,10 +596,21 @@ class DiffusionNeRF(MultiSceneNeRF):
                 code, density_grid, density_bitfield = self.load_scene(data, load_density=True)
             elif "cond_imgs" in data:
                 mode = self.test_cfg.get("cond_mode", "guide")
-                if mode not in ("guide", "guide_optim"):
-                    raise NotImplementedError(f"cond_mode={mode!r}: only the guidance half is on the hot path")
-                with torch.enable_grad():
-                    code, density_grid, density_bitfield = self.val_guide(data, **kwargs)
+                if mode == "guide":
+                    with torch.enable_grad():
+                        code, density_grid, density_bitfield = self.val_guide(data, **kwargs)
+                elif mode == "optim":
+                    code, density_grid, density_bitfield = self.val_optim(data, **kwargs)
+                elif mode == "guide_optim":
+                    optim_kw = {k: kwargs.pop(k) for k in ("prior_timesteps", "prior_noises", "march_noises") if k in kwargs}
+                    with torch.enable_grad():
+                        code, density_grid, density_bitfield = self.val_guide(data, **kwargs)
+                    kwargs.pop("guide_noises", None), kwargs.pop("density_jitters", None)
+                    code, density_grid, density_bitfield = self.val_optim(
+                        data, code_=self.code_activation.inverse(code).requires_grad_(True), density_grid=density_grid,
+                        density_bitfield=density_bitfield, **optim_kw, **kwargs)
+                else:
+                    raise AttributeError(f"cond_mode={mode!r}")
             else:
                 code, density_grid, density_bitfield = self.val_uncond(data, **kwargs)
             pred_imgs = None

@@ -115,3 +115,185 @@ def test_code_layout_roundtrip_and_losses():
     assert float(c.abs().max()) <= 2 and torch.allclose(tc(tc.inverse(c)), c, atol=1e-4)
     nt = NormalizedTanhCode(std=0.5, clip_range=2)
     assert torch.allclose(nt(nt.inverse(nt(x))), nt(x), atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------- fine-tuning
+def _recons_diffusion(weight_scale=4.0):
+    """the recons configs' sampler / prior-loss entries (configs/paper_cfgs/ssdnerf_cars_recons1v.py:28-39) on the tiny UNet"""
+    import ssdnerf_amd.unet  # noqa: F401
+    from ssdnerf_amd.diffusion import GaussianDiffusion
+    d = GaussianDiffusion(denoising=_tiny_unet_cfg(), betas_cfg=dict(type="linear"), num_timesteps=1000, denoising_mean_mode="V",
+                          timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+                          ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight",
+                                         log_cfgs=dict(type="quartile", prefix_name="loss_mse", total_timesteps=1000),
+                                         data_info=dict(pred="v_t_pred", target="v_t"), weight_scale=weight_scale, scale_norm=True),
+                          test_cfg=dict(num_timesteps=10, clip_range=[-2, 2]))
+    _randomize(d.denoising, 5)
+    return d.eval()
+
+
+def test_snr_sampler_weights_and_draws():
+    d = _recons_diffusion()
+    t = OD.schedule_tables(1000, "linear")
+    w, prob = OD.snr_timestep_weights(t, power=0.5, mode="V")
+    np.testing.assert_array_equal(d.sampler.weight.numpy(), w)
+    np.testing.assert_allclose(w, np.sqrt(t["alphas_bar"] * (1 - t["alphas_bar"])).astype(np.float32), rtol=2e-7)   # sqrt(SNR) * (1 - abar)
+    np.testing.assert_allclose(d.sampler.prob, prob, rtol=1e-15)
+    np.random.seed(3)
+    a = d.sampler(8)
+    np.random.seed(3)
+    b = torch.from_numpy(np.random.choice(1000, size=(8,), p=prob)).long()       # host-side draw, as mmgen's sampler
+    assert a.dtype == torch.long and torch.equal(a, b)
+    from ssdnerf_amd.diffusion import SNRWeightedTimeStepSampler
+    s2 = SNRWeightedTimeStepSampler(1000, t["sqrt_alphas_bar"], t["sqrt_one_minus_alphas_bar"], "EPS", power=1, min=0.5, max=4, prob_power=0.5)
+    assert abs(sum(s2.prob) - 1) < 1e-12 and s2.weight.shape == (1000,)
+
+
+def test_prior_loss_and_its_gradient_match_oracle():
+    d = _recons_diffusion(weight_scale=4.0)
+    d.ddpm_loss.norm_factor.fill_(1.7)                                           # as if loaded from a trained checkpoint
+    g = torch.Generator().manual_seed(11)
+    x0 = (torch.randn(3, 18, 16, 16, generator=g) * 0.7).requires_grad_(True)
+    noise = torch.randn(3, 18, 16, 16, generator=g)
+    ts = torch.tensor([17, 480, 995])
+    loss, log_vars = d(x0, return_loss=True, timesteps=ts, noise=noise, cfg=d.test_cfg)
+    (g1,) = torch.autograd.grad(loss, x0)
+    x0b = x0.detach().clone().requires_grad_(True)
+    sd = d.denoising.state_dict()
+    den = lambda x, t: OD.unet_forward(sd, x, t, image_size=16, base_channels=32, channels_cfg=(1, 2), resblocks_per_downsample=1,
+                                       num_heads=4, attention_res=(8,), norm_groups=8)
+    w, _ = OD.snr_timestep_weights(OD.schedule_tables(1000, "linear"), 0.5, "V")
+    want = OD.prior_loss_v(den, x0b, ts, noise, OD.schedule_tables(1000, "linear"), w, weight_scale=4.0, norm_factor=1.7)
+    (g0,) = torch.autograd.grad(want, x0b)
+    assert abs(float(loss.detach()) - float(want.detach())) <= 1e-5 * abs(float(want.detach()))
+    assert float((g1 - g0).abs().max()) <= 2e-4 * float(g0.abs().max())
+    assert float(d.ddpm_loss.norm_factor) == pytest.approx(1.7)                  # eval mode: the running norm is frozen
+    assert set(log_vars) == {"loss_mse_quartile_0", "loss_mse_quartile_1", "loss_mse_quartile_2", "loss_mse_quartile_3", "loss_ddpm_mse"}
+    assert float(log_vars["loss_mse_quartile_2"]) == 0.0 and float(log_vars["loss_mse_quartile_0"]) > 0   # no sample fell in [500, 750)
+    # seeded default draws: timesteps from np.random on the host, noise from the CPU generator
+    np.random.seed(5); torch.manual_seed(5)
+    l1, _ = d(x0.detach(), return_loss=True, cfg=d.test_cfg)
+    np.random.seed(5); torch.manual_seed(5)
+    l2, _ = d(x0.detach(), return_loss=True, cfg=d.test_cfg)
+    assert float(l1.detach()) == float(l2.detach())
+    # training mode moves the running norm: EMA of mean(x_0^2)
+    d.train()
+    d(x0.detach(), return_loss=True, timesteps=ts, noise=noise, cfg=d.test_cfg)
+    assert float(d.ddpm_loss.norm_factor) == pytest.approx(0.999 * 1.7 + 0.001 * float(x0.detach().square().mean()), rel=1e-6)
+    d.eval()
+
+
+def _finetune_model(test_cfg):
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.registry import MODELS
+    cfg = dict(type="DiffusionNeRF", code_size=(3, 6, 16, 16), code_reshape=(18, 16, 16), code_activation=dict(type="TanhCode", scale=2),
+               grid_size=64,
+               diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"), denoising=_tiny_unet_cfg(),
+                              timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+                              ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight", data_info=dict(pred="v_t_pred", target="v_t"),
+                                             weight_scale=4.0, scale_norm=True)),
+               decoder=dict(type="TriPlaneDecoder", interp_mode="bilinear", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3],
+                            use_dir_enc=True, dir_layers=[16, 64], activation="silu", sigma_activation="trunc_exp", sigmoid_saturation=0.001,
+                            max_steps=256),
+               decoder_use_ema=True, freeze_decoder=False, bg_color=1, pixel_loss=dict(type="MSELoss", loss_weight=20.0),
+               reg_loss=dict(type="RegLoss", power=2, loss_weight=3e-3), cache_size=0, test_cfg=test_cfg)
+    m = MODELS.build(cfg)
+    _randomize(m.diffusion_ema.denoising, 9)
+    return m
+
+
+def test_override_cfg_switches_with_train_and_eval():
+    m = _finetune_model(dict(override_cfg={"diffusion_ema.ddpm_loss.weight_scale": 1.0}))
+    assert m.diffusion_ema.ddpm_loss.weight_scale == 4.0 and m.train_cfg_backup == {"diffusion_ema.ddpm_loss.weight_scale": 4.0}
+    m.eval()
+    assert m.diffusion_ema.ddpm_loss.weight_scale == 1.0
+    m.train()
+    assert m.diffusion_ema.ddpm_loss.weight_scale == 4.0
+    m.eval(); m.eval()                                                          # a second eval() must not overwrite the backup
+    m.train()
+    assert m.diffusion_ema.ddpm_loss.weight_scale == 4.0
+
+
+def test_val_optim_gradient_seeding_optimizer_and_schedule(monkeypatch):
+    """Host logic of val_optim / inverse_code with the renderer replaced by a differentiable stand-in (the train-branch render needs the
+    GPU library): the prior gradient seeds every inner step, the rendering gradient accumulates onto it, one optimizer and one LR
+    schedule run across all outer x inner steps, and the grid is refreshed once per inverse_code call."""
+    m = _finetune_model(dict(n_inverse_steps=3, extra_scene_step=2, n_inverse_rays=2 ** 14, density_thresh=0.1, dt_gamma_scale=0.5,
+                             optimizer=dict(type="SGD", lr=0.05), lr_scheduler=dict(type="ExponentialLR", gamma=0.9),
+                             override_cfg={"diffusion_ema.ddpm_loss.weight_scale": 1.0})).eval()
+    g = torch.Generator().manual_seed(21)
+    cond = torch.rand(1, 1, 8, 8, 3, generator=g)
+    poses, intr = torch.eye(4)[None, None], torch.tensor([[[8.0, 8.0, 4.0, 4.0]]])
+    target_vec = torch.randn(3 * 6 * 16 * 16, generator=g)
+    refreshes, seen = [], []
+
+    def fake_update(decoder, code, grid, bits, iter_density, density_thresh=0.01, decay=0.9, S=128, jitter=None):
+        refreshes.append((iter_density, density_thresh, decay, jitter))
+
+    def fake_loss(decoder, code, bits, target_rgbs, rays_o, rays_d, dt_gamma=0.0, return_decoder_loss=False, scale_num_ray=1.0, cfg=dict(),
+                  perturb=True, **kw):
+        assert decoder.training and target_rgbs.shape == (1, 64, 3) and scale_num_ray == 64
+        seen.append(decoder.injected_noises)
+        loss = (code.reshape(-1) * target_vec).sum() * 0.01 + code.square().mean()
+        return target_rgbs, loss, dict(pixel_loss=loss)
+
+    monkeypatch.setattr(m, "update_extra_state", fake_update)
+    monkeypatch.setattr(m, "loss", fake_loss)
+    code0_ = (torch.randn(1, 3, 6, 16, 16, generator=g) * 0.3)
+    ts = [torch.tensor([900]), torch.tensor([500]), torch.tensor([40])]
+    ns = [torch.randn(1, 18, 16, 16, generator=g) for _ in range(3)]
+    marks = [torch.full((1, 64), float(i)) for i in range(9)]
+    code, grid, bits = m.val_optim(dict(cond_imgs=cond, cond_intrinsics=intr, cond_poses=poses), code_=code0_.clone().requires_grad_(True),
+                                   prior_timesteps=ts, prior_noises=ns, march_noises=marks, density_jitters=["j0", "j1", "j2"])
+    assert [r[3] for r in refreshes] == ["j0", "j1", "j2"] and all(r[:3] == (0, 0.1, 0.9) for r in refreshes)
+    assert [float(s[0, 0]) for s in seen] == [float(i) for i in range(9)]
+    assert grid.dtype == torch.float16 and bits.dtype == torch.uint8 and not code.requires_grad
+    assert not m.decoder_ema.training and all(p.requires_grad for p in m.diffusion_ema.parameters())
+
+    # the same loop written out by hand
+    sd = m.diffusion_ema.denoising.state_dict()
+    den = lambda x, t: OD.unet_forward(sd, x, t, image_size=16, base_channels=32, channels_cfg=(1, 2), resblocks_per_downsample=1,
+                                       num_heads=4, attention_res=(8,), norm_groups=8)
+    tables = OD.schedule_tables(1000, "linear")
+    w, _ = OD.snr_timestep_weights(tables, 0.5, "V")
+    c_ = code0_.clone().requires_grad_(True)
+    lr = 0.05
+    for k in range(3):
+        prior = OD.prior_loss_v(den, (c_.tanh() * 2).reshape(1, 18, 16, 16), ts[k], ns[k], tables, w, weight_scale=1.0, norm_factor=1.0)
+        (pg,) = torch.autograd.grad(prior, c_)
+        for i in range(3):
+            cc = c_.tanh() * 2
+            (rg,) = torch.autograd.grad((cc.reshape(-1) * target_vec).sum() * 0.01 + cc.square().mean(), c_)
+            with torch.no_grad():
+                c_ -= lr * (pg + rg)
+            lr *= 0.9
+    np.testing.assert_allclose(code.numpy(), (c_.tanh() * 2).detach().numpy(), rtol=0, atol=2e-6)
+
+    # extra_scene_step = 0: one loss_decoder backward + step per outer iteration, prior gradient still included
+    m.test_cfg.update(extra_scene_step=0, n_inverse_steps=2)
+    del seen[:]
+    code1, _, _ = m.val_optim(dict(cond_imgs=cond, cond_intrinsics=intr, cond_poses=poses), code_=code0_.clone().requires_grad_(True),
+                              prior_timesteps=ts, prior_noises=ns, march_noises=marks)
+    assert len(seen) == 2
+    c_ = code0_.clone().requires_grad_(True)
+    lr = 0.05
+    for k in range(2):
+        prior = OD.prior_loss_v(den, (c_.tanh() * 2).reshape(1, 18, 16, 16), ts[k], ns[k], tables, w, weight_scale=1.0, norm_factor=1.0)
+        cc = c_.tanh() * 2
+        (gsum,) = torch.autograd.grad(prior + (cc.reshape(-1) * target_vec).sum() * 0.01 + cc.square().mean(), c_)
+        with torch.no_grad():
+            c_ -= lr * gsum
+        lr *= 0.9
+    np.testing.assert_allclose(code1.numpy(), (c_.tanh() * 2).detach().numpy(), rtol=0, atol=2e-6)
+
+
+def test_init_code_optimizer_and_scheduler_builders():
+    m = _finetune_model(dict(optimizer=dict(type="Adam", lr=0.005, weight_decay=0.0), lr_scheduler=dict(type="ExponentialLR", gamma=0.998)))
+    c = m.get_init_code_(2, device="cpu")
+    assert c.shape == (2, 3, 6, 16, 16) and c.requires_grad and c.is_leaf and float(c.abs().max()) <= m.init_scale
+    opt = m.build_optimizer(c, m.test_cfg)
+    sch = m.build_scheduler(opt, m.test_cfg)
+    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == 0.005 and isinstance(sch, torch.optim.lr_scheduler.ExponentialLR)
+    assert m.build_scheduler(opt, dict()) is None
+    opts = m.build_optimizer([m.get_init_code_(None), m.get_init_code_(None)], m.test_cfg)
+    assert isinstance(opts, list) and len(opts) == 2 and len(m.build_scheduler(opts, m.test_cfg)) == 2

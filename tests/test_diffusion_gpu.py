@@ -171,3 +171,118 @@ def test_val_guide_runs_the_guidance_closure_every_step(model):
     assert all(p.requires_grad for p in model.diffusion_ema.parameters())      # requires_grad flags restored
     # (the quantitative check of the guidance term is test_guidance_loss_and_gradient_match_oracle; with random UNet weights the
     #  predicted x0 holds no occupied voxels, so the rendering loss has nothing to push against here)
+
+
+# ---------------------------------------------------------------------------------------------- fine-tuning
+@pytest.fixture(scope="module")
+def recons_model():
+    """the recons1v configuration (configs/paper_cfgs/ssdnerf_cars_recons1v.py:5-110) with a small UNet and a short schedule"""
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.registry import MODELS
+    from ssdnerf_amd import synthetic as S
+    cfg = dict(type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2),
+               grid_size=64,
+               diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"),
+                              denoising=dict(type="DenoisingUnetMod", image_size=128, in_channels=18, base_channels=32, channels_cfg=[1, 1, 2],
+                                             resblocks_per_downsample=1, dropout=0.0, use_scale_shift_norm=True, num_heads=4, attention_res=[32],
+                                             norm_cfg=dict(type="GN", num_groups=8)),
+                              timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+                              ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight",
+                                             log_cfgs=dict(type="quartile", prefix_name="loss_mse", total_timesteps=1000),
+                                             data_info=dict(pred="v_t_pred", target="v_t"), weight_scale=4.0, scale_norm=True)),
+               decoder=dict(type="TriPlaneDecoder", interp_mode="bilinear", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3],
+                            use_dir_enc=True, dir_layers=[16, 64], activation="silu", sigma_activation="trunc_exp", sigmoid_saturation=0.001,
+                            max_steps=256),
+               decoder_use_ema=True, freeze_decoder=False, bg_color=1, pixel_loss=dict(type="MSELoss", loss_weight=20.0),
+               reg_loss=dict(type="RegLoss", power=2, loss_weight=3e-3), cache_size=0,
+               test_cfg=dict(img_size=(128, 128), num_timesteps=2, clip_range=[-2, 2], density_thresh=0.1, dt_gamma_scale=0.5,
+                             n_inverse_rays=2 ** 14, override_cfg={"diffusion_ema.ddpm_loss.weight_scale": 1.0}, loss_coef=0.1 / (128 * 128),
+                             guidance_gain=3.2 * (2 ** 14), cond_mode="guide_optim", n_inverse_steps=2, extra_scene_step=1,
+                             optimizer=dict(type="Adam", lr=0.005, weight_decay=0.0), lr_scheduler=dict(type="ExponentialLR", gamma=0.998)))
+    m = MODELS.build(cfg)
+    _randomize(m.diffusion_ema.denoising, 9)
+    m.diffusion_ema.ddpm_loss.norm_factor.fill_(0.8)
+    m.decoder_ema.load_state_dict(S.make_decoder_params(), strict=False)
+    return m.cuda().eval()
+
+
+def test_val_optim_matches_oracle(recons_model):
+    """2 outer x 2 inner fine-tuning iterations of one scene (prior loss through the UNet, train-branch render, grid refresh with decay,
+    SGD + exponential LR so that the update is linear in the gradients) against the CPU restatement with every random draw injected."""
+    from oracle import diffusion as OD, guidance as OG, render as R
+    from ssdnerf_amd import synthetic as S
+    m = recons_model
+    params = S.make_decoder_params()
+    g = torch.Generator().manual_seed(33)
+    code0 = S.make_triplane(31)
+    code0_ = m.code_activation.inverse(code0).contiguous()
+    jit0 = [torch.rand(64 ** 3, 3, generator=g).numpy() for _ in range(2)]
+    grid0, bits0, _ = R.get_density(params, code0, jit0, density_thresh=0.1, dtype=np.float32)
+    ro, rd = R.get_cam_rays(S.spiral_poses()[64][None], S.cars_intrinsics()[None], 128, 128)
+    ro, rd = ro.reshape(-1, 3).numpy(), rd.reshape(-1, 3).numpy()
+    target = torch.rand(128 * 128, 3, generator=g)
+    ts = [torch.tensor([700]), torch.tensor([150])]
+    ns = [torch.randn(1, 18, 128, 128, generator=g) for _ in range(2)]
+    marches = [torch.rand(128 * 128, generator=g) for _ in range(4)]
+    jits = [torch.rand(64 ** 3, 3, generator=g) for _ in range(2)]
+    opt = dict(type="SGD", lr=100.0)
+
+    sd = {k: v.cpu() for k, v in m.diffusion_ema.denoising.state_dict().items()}
+    den = lambda x, t: OD.unet_forward(sd, x, t, image_size=128, base_channels=32, channels_cfg=(1, 1, 2), resblocks_per_downsample=1,
+                                       num_heads=4, attention_res=(32,), norm_groups=8)
+    tables = OD.schedule_tables(1000, "linear")
+    w, _ = OD.snr_timestep_weights(tables, 0.5, "V")
+    act = lambda c: c.tanh() * 2
+    grid_cpu = grid0.copy()
+    want, bits_want, losses_want = OG.finetune_code(
+        params, den, code0_.clone(), act, tables, w, grid_cpu, ro, rd, target, 0.5 / 131.25, ts, ns, [n.numpy() for n in marches],
+        [j.numpy() for j in jits], n_outer=2, n_inner=2, optimizer=opt, lr_gamma=0.998, weight_scale=1.0, norm_factor=0.8, density_thresh=0.1)
+
+    saved = dict(m.test_cfg)
+    m.test_cfg.update(optimizer=opt)
+    losses = []
+    orig = m.loss
+    m.loss = lambda *a, **k: (lambda r: (losses.append(r[1].detach()), r)[1])(orig(*a, **k))
+    try:
+        data = dict(cond_imgs=target.reshape(1, 1, 128, 128, 3).cuda(), cond_intrinsics=S.cars_intrinsics().cuda()[None, None],
+                    cond_poses=S.spiral_poses()[[64]].cuda()[None])
+        code, grid, bits = m.val_optim(data, code_=code0_.clone().cuda()[None].requires_grad_(True), density_grid=torch.from_numpy(grid0).cuda()[None],
+                                       density_bitfield=torch.from_numpy(bits0).cuda()[None], prior_timesteps=ts,
+                                       prior_noises=[n.cuda() for n in ns], march_noises=[n.cuda()[None] for n in marches],
+                                       density_jitters=[j.cuda() for j in jits])
+    finally:
+        m.loss = orig
+        m.test_cfg.clear(); m.test_cfg.update(saved)
+    moved = float((want - code0).abs().max())
+    err = float((code[0].cpu() - want).abs().max())
+    lo = [float(v) for v in losses]
+    print(f"val_optim parity: max|code - oracle| = {err:.3e}, max|update| = {moved:.3e}, losses {lo} vs {losses_want}")
+    assert moved > 1e-3, "the fine-tuning steps must move the code measurably for this comparison to mean anything"
+    assert err <= 1e-3 * moved
+    assert len(lo) == 4 and all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(lo, losses_want))
+    assert int((np.unpackbits(bits[0].cpu().numpy()) != np.unpackbits(bits_want)).sum()) <= 8      # threshold-edge cells only
+    np.testing.assert_allclose(grid[0].cpu().numpy(), grid_cpu, rtol=2e-4, atol=1e-5)
+
+
+def test_guide_optim_end_to_end(recons_model):
+    """cond_mode='guide_optim' through val_step: guided DDIM, then fine-tuning with Adam + ExponentialLR as configured, then a render."""
+    from ssdnerf_amd import synthetic as S
+    m = recons_model
+    g = torch.Generator().manual_seed(12)
+    noise = torch.randn(2, 3, 6, 128, 128, generator=g).cuda()
+    poses = S.spiral_poses()[[64]].cuda()[None].expand(2, -1, -1, -1)
+    intr = S.cars_intrinsics().cuda()[None, None].expand(2, 1, -1)
+    cond = torch.rand(2, 1, 128, 128, 3, generator=g).cuda()
+    steps = []
+    orig = m.inverse_code
+    m.inverse_code = lambda *a, **k: (steps.append(k["cfg"]["n_inverse_steps"]), orig(*a, **k))[1]
+    try:
+        np.random.seed(0)
+        out = m.val_step(dict(cond_imgs=cond, cond_intrinsics=intr, cond_poses=poses, noise=noise, test_poses=poses, test_intrinsics=intr))
+    finally:
+        m.inverse_code = orig
+    assert steps == [2, 2]                                                       # n_inverse_steps outer calls of extra_scene_step + 1 iterations
+    assert out["code"].shape == (2, 3, 6, 128, 128) and bool(torch.isfinite(out["code"]).all()) and not out["code"].requires_grad
+    assert float(out["code"].abs().max()) <= 2.0 and out["pred_imgs"].shape == (2, 1, 3, 128, 128)
+    assert m.diffusion_ema.ddpm_loss.weight_scale == 1.0 and not m.decoder_ema.training
+    assert all(p.requires_grad for p in m.diffusion_ema.denoising.parameters())

@@ -20,7 +20,8 @@ cfg = dict(type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 1
                                          resblocks_per_downsample=2, dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True,
                                          num_heads=4, attention_res=[32, 16, 8]),
                           timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5), denoising_mean_mode="V",
-                          ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="constant", log_cfgs=None, weight_scale=4.0)),
+                          ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight", log_cfgs=None, data_info=dict(pred="v_t_pred", target="v_t"),
+                                         weight_scale=4.0, scale_norm=True)),
            decoder=dict(type="TriPlaneDecoder", interp_mode="bilinear", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3],
                         use_dir_enc=True, dir_layers=[16, 64], activation="silu", sigma_activation="trunc_exp", sigmoid_saturation=0.001, max_steps=256),
            decoder_use_ema=True, freeze_decoder=False, bg_color=1, pixel_loss=dict(type="MSELoss", loss_weight=20.0),
