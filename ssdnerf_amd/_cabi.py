@@ -22,7 +22,7 @@ EXPORTS = [
     "ssdnerf_last_error", "ssdnerf_abi_version", "ssdnerf_near_far_from_aabb", "ssdnerf_sph_from_ray", "ssdnerf_morton3D",
     "ssdnerf_morton3D_invert", "ssdnerf_packbits", "ssdnerf_march_rays_train_workspace", "ssdnerf_march_rays_train",
     "ssdnerf_composite_rays_train_forward", "ssdnerf_composite_rays_train_backward", "ssdnerf_march_rays", "ssdnerf_composite_rays",
-    "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode",
+    "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode", "ssdnerf_point_decode_backward",
     "ssdnerf_render_rays_fused", "ssdnerf_render_rays_fused_batch", "ssdnerf_render_queue_workspace", "ssdnerf_render_first_hit",
     "ssdnerf_render_shade_queue", "ssdnerf_render_shade_queue_mfma", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh", "ssdnerf_ddim_step_v",
     "ssdnerf_group_norm_workspace", "ssdnerf_group_norm_nhwc", "ssdnerf_bias_residual_nhwc",

@@ -1,6 +1,9 @@
 // ssdnerf_amd/csrc/decode.hip -- Part 2 of the C ABI: triplane repack, fused point decode and the fused
 // density-grid refresh (BaseNeRF.update_extra_state), for gfx950.
 #include "decode_core.h"
+#include "decode_bwd_math.h"
+
+static_assert(SSDB_OFF_WD == MLP_OFF_WD && SSDB_OFF_BD == MLP_OFF_BD && SSDB_OFF_TAIL == MLP_OFF_TAIL, "parameter block layout: decode_core.h and decode_bwd_math.h must agree");
 
 static constexpr unsigned DEC_TPB = 256;
 
@@ -86,6 +89,54 @@ extern "C" int ssdnerf_point_decode(const void* planes, int planes_dtype, uint32
         else hipLaunchKernelGGL((k_point_decode<__half, false>), gr, b, 0, s, (const __half*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, sigmas, rgbs);
     }
     SSD_CHECK_LAUNCH("point_decode");
+    return SSDNERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient of the point decode w.r.t. the planes (decoder frozen): one sample per lane, the arithmetic of decode_bwd_math.h --
+// re-gather the 18 features, run the 64 hidden units twice (outputs, then gradient), scatter d/df to the 3 x 4 bilinear corners
+// with fp32 hardware atomics into a (3, Hp, Wp, 8) gradient image (1.5 MiB per scene at 128^2: L2-resident, like the planes).
+// Points whose upstream gradient is exactly zero (the 128-alignment padding, samples behind the T_thresh cut) return at once.
+template <typename PT, bool COLOR>
+__global__ void __launch_bounds__(DEC_TPB) k_point_decode_bwd(const PT* __restrict__ planes, PlaneGeom g, const float* __restrict__ P,
+                                                               const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t n, float sat,
+                                                               const float* __restrict__ g_sigmas, const float* __restrict__ g_rgbs,
+                                                               float* __restrict__ gplanes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gs = g_sigmas ? g_sigmas[i] : 0.0f;
+    float gc[3] = {0.0f, 0.0f, 0.0f};
+    if (COLOR) { gc[0] = g_rgbs[3ull * i]; gc[1] = g_rgbs[3ull * i + 1]; gc[2] = g_rgbs[3ull * i + 2]; }
+    if (gs == 0.0f && gc[0] == 0.0f && gc[1] == 0.0f && gc[2] == 0.0f) return;
+    const float x = xyzs[3ull * i], y = xyzs[3ull * i + 1], z = xyzs[3ull * i + 2];
+    float f[18], gf[18], sh[16];
+    ssd_gather18<PT>(planes, g, x, y, z, f);
+    if (COLOR) shb::eval<4, false>(dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2], sh, nullptr, nullptr, nullptr);
+    ssdb_mlp_backward(P, f, COLOR ? sh : f, sat, gs, gc, COLOR ? 1 : 0, gf);
+    ssdb_scatter18(gplanes, g.Hp, g.Wp, x, y, z, gf);
+}
+
+extern "C" int ssdnerf_point_decode_backward(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params, const float* xyzs,
+                                             const float* dirs, uint32_t n, float sigmoid_saturation, const float* grad_sigmas, const float* grad_rgbs,
+                                             float* grad_planes, void* stream) {
+    if (n == 0) return SSDNERF_OK;
+    SSD_REQUIRE(planes && mlp_params && xyzs && grad_planes, "point_decode_backward: null pointer");
+    SSD_REQUIRE((grad_rgbs == nullptr) == (dirs == nullptr), "point_decode_backward: grad_rgbs and dirs must both be given or both be NULL");
+    SSD_REQUIRE(grad_sigmas || grad_rgbs, "point_decode_backward: no upstream gradient given");
+    SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "point_decode_backward: unsupported plane dtype");
+    SSD_REQUIRE(Hp >= 1 && Wp >= 1, "point_decode_backward: empty plane");
+    const PlaneGeom g = ssd_plane_geom(Hp, Wp);
+    dim3 gr(ssd_blocks(n, DEC_TPB)), b(DEC_TPB);
+    hipStream_t s = (hipStream_t)stream;
+    const bool color = grad_rgbs != nullptr;
+    if (planes_dtype == 0) {
+        if (color) hipLaunchKernelGGL((k_point_decode_bwd<float, true>), gr, b, 0, s, (const float*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, grad_sigmas, grad_rgbs, grad_planes);
+        else hipLaunchKernelGGL((k_point_decode_bwd<float, false>), gr, b, 0, s, (const float*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, grad_sigmas, grad_rgbs, grad_planes);
+    } else {
+        if (color) hipLaunchKernelGGL((k_point_decode_bwd<__half, true>), gr, b, 0, s, (const __half*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, grad_sigmas, grad_rgbs, grad_planes);
+        else hipLaunchKernelGGL((k_point_decode_bwd<__half, false>), gr, b, 0, s, (const __half*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, grad_sigmas, grad_rgbs, grad_planes);
+    }
+    SSD_CHECK_LAUNCH("point_decode_backward");
     return SSDNERF_OK;
 }
 

@@ -6,8 +6,10 @@ fast path behind them:
 * eval branch (``self.training == False``)  -> ONE fused HIP launch per scene
   (``ssdnerf_render_rays_fused``: AABB + march + gather + MLP + composite on chip, on-device compaction)
   instead of the reference's <=256-iteration host loop with a device->host sync per iteration.
-* ``point_decode`` / ``point_density_decode`` on packed sample lists -> one fused HIP decode per scene
-  (no grad) or an eager PyTorch-ROCm path (autograd; also the "reference-shaped eager" baseline B1).
+* ``point_decode`` / ``point_density_decode`` on packed sample lists -> one fused HIP decode per scene; when only the
+  scene code needs a gradient (guidance, fine-tuning) the backward is fused too (``_PointDecodeFn``: re-gather +
+  recomputed MLP + atomic scatter); an eager PyTorch-ROCm path remains for decoder-parameter gradients (autograd;
+  also the "reference-shaped eager" baseline B1).
 * train branch -> per-scene ``march_rays_train`` (deterministic prefix-sum packing) + decode +
   ``batch_composite_rays_train`` (HIP forward/backward kernels).
 
@@ -16,6 +18,7 @@ parity tests and as the exact fallback when the fused kernel reports a ray at th
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -65,6 +68,45 @@ def pack_mlp_params(sd: Dict[str, torch.Tensor], device) -> torch.Tensor:
     out = torch.cat([rec.reshape(-1), wd.reshape(-1), bd.reshape(-1), bs.reshape(-1), bc.reshape(-1)])
     assert out.numel() == MLP_PARAM_FLOATS
     return out.to(device).contiguous()
+
+
+class _PointDecodeFn(torch.autograd.Function):
+    """Fused point decode, differentiable w.r.t. the scene code with the decoder frozen: forward = ``ssdnerf_point_decode`` per scene,
+    backward = ``ssdnerf_point_decode_backward`` (re-gather, recompute the hidden units, scatter to the bilinear corners with atomics)
+    instead of autograd through grid_sample + 4 nn.Linear (~20 eager kernels each way and ``grid_sampler_2d_backward``, which alone was
+    30 % of a guided DDIM step).  Sample positions and view directions are data: no gradient flows to them."""
+
+    @staticmethod
+    def forward(ctx, code, decoder, xyzs, dirs):
+        planes = pack_triplanes(code.detach(), decoder.plane_dtype)
+        xyzs = [x.detach().reshape(-1, 3).float().contiguous() for x in xyzs]
+        dirs = [d.detach().reshape(-1, 3).float().contiguous() for d in dirs]
+        sigmas, rgbs, num_points = decoder._point_decode_hip(xyzs, dirs, code, False, planes=planes)
+        ctx.decoder, ctx.planes, ctx.xyzs, ctx.dirs, ctx.num_points = decoder, planes, xyzs, dirs, num_points
+        ctx.code_meta = (code.shape, code.dtype)
+        return sigmas, rgbs
+
+    @staticmethod
+    def backward(ctx, g_sigmas, g_rgbs):
+        decoder, planes = ctx.decoder, ctx.planes
+        shape, dtype = ctx.code_meta
+        s_, _, c, hp, wp = shape
+        total = sum(ctx.num_points)
+        dev = planes.device
+        g_sigmas = torch.zeros(total, dtype=torch.float32, device=dev) if g_sigmas is None else g_sigmas.float().contiguous()
+        g_rgbs = torch.zeros(total, 3, dtype=torch.float32, device=dev) if g_rgbs is None else g_rgbs.float().contiguous()
+        grad_planes = torch.zeros(s_, 3, hp, wp, 8, dtype=torch.float32, device=dev)
+        params = decoder.packed_params()
+        off = 0
+        for s, n in enumerate(ctx.num_points):
+            if n == 0:
+                continue
+            C.check(C.lib().ssdnerf_point_decode_backward(
+                C.ptr(planes[s]), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(ctx.xyzs[s]), C.ptr(ctx.dirs[s]), C.u32(n),
+                C.f32(decoder.sigmoid_saturation), C.ptr(g_sigmas[off:off + n]), C.ptr(g_rgbs[off:off + n]), C.ptr(grad_planes[s]), C.stream()),
+                "point_decode_backward")
+            off += n
+        return grad_planes[..., :c].permute(0, 1, 4, 2, 3).to(dtype).contiguous(), None, None, None
 
 
 class VolumeRenderer(nn.Module):
@@ -275,13 +317,25 @@ class TriPlaneDecoder(VolumeRenderer):
     def point_decode(self, xyzs, dirs, code, density_only=False):
         """xyzs/dirs: per-scene lists of (P_s,3) (or a (S,P,3) tensor); code (S,3,C,h,w).  Returns sigmas (sum P), rgbs (sum P,3),
         num_points (reference: triplane_decoder.py:119-179).  Uses the fused HIP decode when no gradient is required."""
-        need_grad = torch.is_grad_enabled() and (code.requires_grad or any(p.requires_grad for p in self.parameters()))
+        params_need_grad = any(p.requires_grad for p in self.parameters())
+        need_grad = torch.is_grad_enabled() and (code.requires_grad or params_need_grad)
         if not need_grad and self.fused_supported(code):
             return self._point_decode_hip(xyzs, dirs, code, density_only)
+        if (self.fused_code_grad and not params_need_grad and not density_only and dirs is not None and code.is_cuda
+                and self.fused_supported(code)):
+            # gradient w.r.t. the code only (guidance, val_optim / inverse_code with the decoder frozen): fused forward AND backward
+            if isinstance(xyzs, torch.Tensor):
+                xyzs, dirs = list(xyzs), list(dirs)
+            sigmas, rgbs = _PointDecodeFn.apply(code, self, xyzs, dirs)
+            return sigmas, rgbs, [int(x.size(-2)) for x in xyzs]
         return self.point_decode_eager(xyzs, dirs, code, density_only)
 
-    def _point_decode_hip(self, xyzs, dirs, code, density_only):
-        planes = pack_triplanes(code.detach(), self.plane_dtype)
+    #: SSDNERF_DECODE_GRAD=0 sends the code-gradient decode through PyTorch autograd (grid_sample + nn.Linear) instead of the fused kernels
+    fused_code_grad = os.environ.get("SSDNERF_DECODE_GRAD", "1") != "0"
+
+    def _point_decode_hip(self, xyzs, dirs, code, density_only, planes=None):
+        if planes is None:
+            planes = pack_triplanes(code.detach(), self.plane_dtype)
         params = self.packed_params()
         if isinstance(xyzs, torch.Tensor):
             xyzs = list(xyzs)

@@ -8,8 +8,10 @@ downsampling, sinusoidal time embedding) and keep mmgen's module/attribute names
 state-dict keys (``denoising.in_blocks.1.0.conv_1.2.weight`` ...) load unchanged.  **Unpinned**: there is no mmgen source
 on disk to check against.
 
-Compute: PyTorch-ROCm (MIOpen convolutions / rocBLAS GEMMs) in fp32 or under autocast.  Round 1 uses the library
-kernels; hand-written MFMA conv/attention kernels are the next step for this row.
+Compute: no-grad GPU calls run through ``unet_fast.FastUnet`` (hand-written MFMA convolutions / attention, fused GroupNorm,
+hipGraph replay).  Calls that need a gradient w.r.t. the INPUT with frozen weights (rendering guidance, the diffusion prior of
+``val_optim``) keep the eager module graph, but their 64-channel-aligned stride-1 convolutions go through ``_ConvF32x2Fn``: forward
+and backward-data on the same fp32-class matrix-core kernel (csrc/conv_igemm.hip) instead of MIOpen.  Everything else is PyTorch-ROCm.
 """
 from __future__ import annotations
 
@@ -23,6 +25,63 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .registry import MODULES, build_module
+
+
+def _device_ok(x: torch.Tensor) -> bool:
+    return x.is_cuda
+
+
+class _ConvF32x2Fn(torch.autograd.Function):
+    """y = conv2d(x, W) + b for a stride-1, 'same'-padded 1x1 / 3x3 convolution with FROZEN weights, differentiable w.r.t. x only.
+    Forward and backward are the same implicit-GEMM kernel: d/dx is the convolution of dy with the spatially flipped, in/out-swapped
+    weights (W'[ci, co, i, j] = W[co, ci, k-1-i, k-1-j])."""
+
+    @staticmethod
+    def forward(ctx, x, conv):
+        from . import unet_fast as UF
+        hi, lo = conv._split_pair(False)
+        ctx.conv = conv
+        return UF.conv2d_nhwc_f32x2(x.contiguous(memory_format=torch.channels_last), hi, lo, bias=conv.bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import unet_fast as UF
+        hi, lo = ctx.conv._split_pair(True)
+        return UF.conv2d_nhwc_f32x2(gy.contiguous(memory_format=torch.channels_last), hi, lo), None
+
+
+class _Conv2d(nn.Conv2d):
+    """``nn.Conv2d`` (same parameters and state-dict keys) that routes input-gradient-only fp32 GPU calls through ``_ConvF32x2Fn``."""
+
+    #: SSDNERF_UNET_GRAD_CONV=0 keeps MIOpen for the differentiable path
+    grad_conv = os.environ.get("SSDNERF_UNET_GRAD_CONV", "1") != "0"
+
+    def _eligible(self, x):
+        k = self.kernel_size[0]
+        return (self.grad_conv and torch.is_grad_enabled() and x.requires_grad and not self.weight.requires_grad and _device_ok(x)
+                and x.dtype == torch.float32 and not torch.is_autocast_enabled(x.device.type) and x.dim() == 4 and self.groups == 1
+                and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.dilation == (1, 1) and self.padding == (k // 2, k // 2)
+                and self.padding_mode == "zeros" and self.in_channels % 64 == 0 and self.out_channels % 64 == 0
+                and (self.bias is None or not self.bias.requires_grad))
+
+    def _split_pair(self, transposed):
+        """bf16 (hi, lo) operand pair of the weights, channels_last; ``transposed`` = the backward-data form.  Rebuilt when the weights change."""
+        from .unet_fast import split_bf16x2
+        w = self.weight
+        cache = self.__dict__.setdefault("_f32x2_cache", {})
+        key = (w._version, w.data_ptr(), str(w.device))
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+        if transposed not in cache:
+            wt = w.detach().flip(2, 3).transpose(0, 1) if transposed else w.detach()
+            cache[transposed] = tuple(t.contiguous(memory_format=torch.channels_last) for t in split_bf16x2(wt.contiguous()))
+        return cache[transposed]
+
+    def forward(self, x):
+        if self._eligible(x):
+            return _ConvF32x2Fn.apply(x, self)
+        return super().forward(x)
 
 
 def _build_norm(norm_cfg, channels):
@@ -99,18 +158,18 @@ class DenoisingResBlockMod(nn.Module):
         super().__init__()
         out_channels = in_channels if out_channels is None else out_channels
         self.conv_1 = nn.Sequential(_build_norm(norm_cfg, in_channels), _build_act(act_cfg),
-                                    nn.Conv2d(in_channels, out_channels, 3, padding=1, groups=groups))
+                                    _Conv2d(in_channels, out_channels, 3, padding=1, groups=groups))
         self.norm_with_embedding = build_module(dict(type="NormWithEmbedding"), default_args=dict(
             in_channels=out_channels, embedding_channels=embedding_channels, use_scale_shift=use_scale_shift_norm, norm_cfg=deepcopy(norm_cfg)))
         conv_2 = [_build_act(act_cfg)]
         if dropout > 0:
             conv_2.append(nn.Dropout(dropout))
-        conv_2.append(nn.Conv2d(out_channels, out_channels, 3, padding=1, groups=groups))
+        conv_2.append(_Conv2d(out_channels, out_channels, 3, padding=1, groups=groups))
         self.conv_2 = nn.Sequential(*conv_2)
         assert shortcut_kernel_size in (1, 3)
         self.learnable_shortcut = out_channels != in_channels
         if self.learnable_shortcut:
-            self.shortcut = nn.Conv2d(in_channels, out_channels, shortcut_kernel_size, padding=1 if shortcut_kernel_size == 3 else 0, groups=groups)
+            self.shortcut = _Conv2d(in_channels, out_channels, shortcut_kernel_size, padding=1 if shortcut_kernel_size == 3 else 0, groups=groups)
         self.init_weights()
 
     def init_weights(self):
@@ -178,7 +237,7 @@ class DenoisingUpsampleMod(nn.Module):
         super().__init__()
         self.with_conv = with_conv
         if with_conv:
-            self.conv = nn.Conv2d(in_channels, in_channels, 3, 1, 1, groups=groups)
+            self.conv = _Conv2d(in_channels, in_channels, 3, 1, 1, groups=groups)
 
     def forward(self, x):
         x = F.interpolate(x, scale_factor=2, mode="nearest")

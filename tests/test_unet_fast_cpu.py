@@ -85,3 +85,57 @@ def test_executor_refuses_conditioning():
                              use_scale_shift_norm=True, num_classes=3, attention_res=[]))
     with pytest.raises(RuntimeError):
         unet_fast.FastUnet(net)
+
+
+def _conv_f32x2_standin(x, w_hi, w_lo, bias=None, residual=None, stride=1, upsample=False, gn_sums=None, gn_groups=0, tile_hint=0, x2=None, splits_hint=0):
+    assert x.is_contiguous(memory_format=torch.channels_last) and w_hi.dtype == torch.bfloat16 and w_hi.is_contiguous(memory_format=torch.channels_last)
+    assert stride == 1 and not upsample and residual is None and x2 is None
+    return F.conv2d(x, w_hi.float() + w_lo.float(), bias, padding=w_hi.shape[-1] // 2).contiguous(memory_format=torch.channels_last)
+
+
+def test_input_gradient_convs_use_the_same_kernel_forward_and_backward(monkeypatch):
+    """The differentiable path (guidance / val_optim: gradient w.r.t. the input, frozen weights): eligible convolutions run forward and
+    backward-data through conv2d_nhwc_f32x2 (stand-in here), the backward with flipped / in-out-swapped weights; the input gradient
+    must equal plain autograd through the module."""
+    from ssdnerf_amd import unet
+    net = MODULES.build(dict(type="DenoisingUnetMod", image_size=16, in_channels=6, base_channels=64, channels_cfg=[1, 2], resblocks_per_downsample=1,
+                             dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4, attention_res=[8])).eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    x0 = torch.randn(2, 6, 16, 16, generator=g)
+    t = torch.tensor([700, 30])
+    probe = torch.randn(2, 6, 16, 16, generator=g)
+
+    def grad_of(x):
+        x = x.clone().requires_grad_(True)
+        y = net(x, t)
+        return y.detach(), torch.autograd.grad((y * probe).sum(), x)[0]
+
+    net.requires_grad_(False)
+    y_ref, g_ref = grad_of(x0)                                            # CPU tensors: every conv is nn.Conv2d's own forward
+    calls = []
+    monkeypatch.setattr(unet, "_device_ok", lambda x: True)
+    monkeypatch.setattr(unet_fast, "conv2d_nhwc_f32x2", lambda *a, **k: (calls.append(a[1].shape), _conv_f32x2_standin(*a, **k))[1])
+    y, gx = grad_of(x0)
+    n_fwd = sum(1 for m in net.modules() if isinstance(m, unet._Conv2d) and m.in_channels % 64 == 0 and m.out_channels % 64 == 0)
+    assert n_fwd >= 8 and len(calls) == 2 * n_fwd                         # each eligible conv: one forward launch + one backward-data launch
+    assert torch.allclose(y, y_ref, atol=1e-4, rtol=1e-4), (y - y_ref).abs().max()
+    assert float((gx - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
+    # weights that need their own gradient, autocast, and no-grad inputs all stay on the library path
+    del calls[:]
+    net.requires_grad_(True)
+    grad_of(x0)
+    net.requires_grad_(False)
+    with torch.no_grad():
+        net(x0, t)
+    assert calls == []
+    # the operand cache follows parameter updates
+    conv = next(m for m in net.modules() if isinstance(m, unet._Conv2d) and m.in_channels % 64 == 0 and m.kernel_size == (3, 3))
+    a = conv._split_pair(True)
+    assert conv._split_pair(True)[0] is a[0]
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    b = conv._split_pair(True)
+    assert b[0] is not a[0] and torch.equal(b[0].float(), (conv.weight.detach().flip(2, 3).transpose(0, 1)).to(torch.bfloat16).float())

@@ -14,6 +14,7 @@ from ssdnerf_amd import synthetic as S
 ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--guide-steps", type=int, default=3); ap.add_argument("--outer", type=int, default=3)
 ap.add_argument("--extra-scene-step", type=int, default=3); ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+ap.add_argument("--profile", action="store_true", help="instead of timing: torch.profiler tables (top kernels by device time) of one guided step and one outer iteration")
 a = ap.parse_args()
 cfg = dict(type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64,
            diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"),
@@ -55,6 +56,21 @@ def timed(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
     return r, time.perf_counter() - t0
 
+
+if a.profile:
+    from torch.profiler import profile, ProfilerActivity
+    code_ = model.code_activation.inverse(codes)
+    model.test_cfg["num_timesteps"] = 1; model.diffusion_ema.test_cfg["num_timesteps"] = 1; model.test_cfg["n_inverse_steps"] = 1
+    runs = dict(guided_ddim_step=lambda: model.val_guide(dict(data, noise=torch.randn(ns, 3, 6, 128, 128, generator=g).cuda())),
+                finetune_outer_iteration=lambda: model.val_optim(data, code_=code_.clone().requires_grad_(True), density_grid=grid.clone(),
+                                                                 density_bitfield=bits.clone()))
+    for name, fn in runs.items():
+        timed(fn)                                                             # warm-up
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            _, dt = timed(fn)
+        print(f"==== {name}: {dt * 1e3:.1f} ms wall (includes one-off setup: rays, optimizer, grids)")
+        print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=70))
+    sys.exit(0)
 
 out = dict(scenes=ns, unet_dtype=a.dtype)
 # guidance: time k and 1 step runs, the difference is the per-step cost without the fixed setup
