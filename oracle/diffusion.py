@@ -40,20 +40,25 @@ def ddim_timesteps(num_timesteps: int, n: int) -> List[int]:
 
 def ddim_sample(denoise: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], noise: torch.Tensor, tables: Dict[str, np.ndarray],
                 n_steps: int, clip_range=(-2.0, 2.0), grad_guide_fn: Optional[Callable] = None, guidance_gain: float = 1.0,
-                snr_weight_power: float = 0.5, return_all: bool = False):
+                snr_weight_power: float = 0.5, return_all: bool = False, langevin_steps: int = 0, langevin_delta: float = 0.1,
+                langevin_t_range=(0, 1000), langevin_noises=None):
     """V-prediction DDIM, eta = 0.  ``denoise(x_t, t_batch) -> v``.  With ``grad_guide_fn`` the x0 prediction is corrected by
-    grad_{x_t} L * sigma_t^(2-2w) * alpha_t^(2w-1) * gain exactly as gaussian_diffusion.py:193-227."""
+    grad_{x_t} L * sigma_t^(2-2w) * alpha_t^(2w-1) * gain exactly as gaussian_diffusion.py:193-227.  ``langevin_steps`` correction
+    steps at the noise level just reached follow every DDIM step whose t_prev lies strictly inside ``langevin_t_range``
+    (gaussian_diffusion.py:242-262, 318-323): x <- x - delta/2 * sigma * eps_pred(x, t_prev) + sqrt(delta) * sigma * z, with the same
+    guided x0 prediction; ``langevin_noises`` is an iterable of the z draws."""
     T = len(tables["betas"])
     ts = ddim_timesteps(T, n_steps)
     x_t = noise.clone()
     trace = []
-    for i, t in enumerate(ts):
-        t_prev = ts[i + 1] if i + 1 < len(ts) else -1
+    zs = iter(langevin_noises) if langevin_noises is not None else None
+
+    def predict_x0(x, t):
         a = torch.tensor(tables["sqrt_alphas_bar"], dtype=torch.float32)[t]
         b = torch.tensor(tables["sqrt_one_minus_alphas_bar"], dtype=torch.float32)[t]
-        tb = torch.full((x_t.size(0),), t, dtype=torch.long)
+        tb = torch.full((x.size(0),), t, dtype=torch.long)
         if grad_guide_fn is not None:
-            x_in = x_t.detach().requires_grad_(True)
+            x_in = x.detach().requires_grad_(True)
             with torch.enable_grad():
                 v = denoise(x_in, tb)
                 x0 = (a * x_in - b * v).clamp(*clip_range)
@@ -62,12 +67,22 @@ def ddim_sample(denoise: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], n
             x0 = x0.detach() - grad * ((b ** (2 - snr_weight_power * 2)) * (a ** (snr_weight_power * 2 - 1)) * guidance_gain)
         else:
             with torch.no_grad():
-                v = denoise(x_t, tb)
-            x0 = a * x_t - b * v
-        x0 = x0.clamp(*clip_range)
+                v = denoise(x, tb)
+            x0 = a * x - b * v
+        return x0.clamp(*clip_range)
+
+    for i, t in enumerate(ts):
+        t_prev = ts[i + 1] if i + 1 < len(ts) else -1
+        x0 = predict_x0(x_t, t)
         ab_prev = tables["alphas_bar"][t_prev] if t_prev >= 0 else tables["alphas_bar_prev"][0]
         eps = (x_t - tables["sqrt_alphas_bar"][t] * x0) / tables["sqrt_one_minus_alphas_bar"][t]
         x_t = (np.sqrt(ab_prev) * x0 + np.sqrt(1 - ab_prev) * eps).float()
+        if langevin_steps > 0 and langevin_t_range[0] < t_prev < langevin_t_range[1]:
+            sigma = tables["sqrt_one_minus_alphas_bar"][t_prev]
+            for _ in range(langevin_steps):
+                x0l = predict_x0(x_t, t_prev)
+                eps_l = (x_t - tables["sqrt_alphas_bar"][t_prev] * x0l) / sigma
+                x_t = (x_t - 0.5 * langevin_delta * sigma * eps_l + math.sqrt(langevin_delta) * sigma * next(zs)).float()
         trace.append((x0, x_t))
     return (x_t, trace) if return_all else x_t
 

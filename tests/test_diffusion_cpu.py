@@ -297,3 +297,45 @@ def test_init_code_optimizer_and_scheduler_builders():
     assert m.build_scheduler(opt, dict()) is None
     opts = m.build_optimizer([m.get_init_code_(None), m.get_init_code_(None)], m.test_cfg)
     assert isinstance(opts, list) and len(opts) == 2 and len(m.build_scheduler(opts, m.test_cfg)) == 2
+
+
+# ---------------------------------------------------------------------------------------------- Langevin correction
+def test_langevin_correction_steps_match_oracle(diffusion):
+    """``langevin_steps`` / ``langevin_delta`` of ssdnerf_chairs_recons1v (configs/paper_cfgs/ssdnerf_chairs_recons1v.py:95-96): the
+    correction steps run at t_prev after every DDIM step with 0 < t_prev < 1000, i.e. not after the last one; noise is drawn on the host."""
+    g = torch.Generator().manual_seed(6)
+    noise = torch.randn(2, 18, 16, 16, generator=g)
+    saved = dict(diffusion.test_cfg)
+    diffusion.test_cfg.update(num_timesteps=4, langevin_steps=2, langevin_delta=0.4)
+    sd = diffusion.denoising.state_dict()
+    den = lambda x, t: OD.unet_forward(sd, x, t, image_size=16, base_channels=32, channels_cfg=(1, 2), resblocks_per_downsample=1,
+                                       num_heads=4, attention_res=(8,), norm_groups=8)
+    try:
+        torch.manual_seed(77)
+        with torch.no_grad():
+            got = diffusion(noise, return_loss=False)
+        torch.manual_seed(77)
+        zs = [torch.randn(2, 18, 16, 16) for _ in range(6)]                    # 3 DDIM steps with t_prev >= 0, 2 corrections each
+        want = OD.ddim_sample(den, noise, OD.schedule_tables(1000, "linear"), 4, clip_range=(-2, 2), langevin_steps=2, langevin_delta=0.4,
+                              langevin_noises=zs)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=3e-4)
+        plain = OD.ddim_sample(den, noise, OD.schedule_tables(1000, "linear"), 4, clip_range=(-2, 2))
+        assert float((want - plain).abs().max()) > 1e-2                        # the corrections do change the sample
+        # guided variant: the guidance closure is evaluated in the correction steps too (1 + 2 calls per step, 1 for the last)
+        calls = []
+
+        def guide(x0):
+            calls.append(1)
+            return (x0 ** 2).mean() * 5.0
+
+        diffusion.test_cfg.update(guidance_gain=2.0)
+        torch.manual_seed(78)
+        got_g = diffusion(noise, return_loss=False, grad_guide_fn=guide)
+        assert len(calls) == 3 * 3 + 1
+        torch.manual_seed(78)
+        zs = [torch.randn(2, 18, 16, 16) for _ in range(6)]
+        want_g = OD.ddim_sample(den, noise, OD.schedule_tables(1000, "linear"), 4, clip_range=(-2, 2), grad_guide_fn=guide, guidance_gain=2.0,
+                                langevin_steps=2, langevin_delta=0.4, langevin_noises=zs)
+        np.testing.assert_allclose(got_g.detach().numpy(), want_g.numpy(), rtol=0, atol=3e-4)
+    finally:
+        diffusion.test_cfg.clear(); diffusion.test_cfg.update(saved)

@@ -133,3 +133,26 @@ def test_conv_plans_and_operand_split_host_side():
     assert hi.dtype == lo.dtype == torch.bfloat16
     rel = ((hi.double() + lo.double() - w.double()).abs() / w.double().abs()).max().item()
     assert rel <= 2.0 ** -16, rel                                              # 16 significand bits survive the split (bf16 alone: 2^-9)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference configs not present")
+def test_tiled_and_16bit_configs_build_and_lay_codes_out_as_the_reference_does():
+    """configs/new_cfgs: the tiled triplane (code_permute (1,2,0,3) -> 6 x 128 x 384 latent, base-80 UNet with 16 GroupNorm groups,
+    NormalizedTanhCode) and the 16-bit variants build from the unchanged files; the latent <-> code maps are mutual inverses and put
+    plane p in columns [p*128, (p+1)*128) of the latent."""
+    import torch
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.config import Config, build_model
+    m = build_model(Config.fromfile(os.path.join(REF, "configs/new_cfgs/ssdnerf_cars_recons1v_tiled.py")))
+    un = m.diffusion_ema.denoising
+    assert un.image_size == [128, 128] and un.in_blocks[0][0].in_channels == 6 and un.in_blocks[0][0].out_channels == 80
+    assert un.out.gn.num_groups == 16 and type(m.code_activation).__name__ == "NormalizedTanhCode"
+    code = torch.randn(2, 3, 6, 128, 128)
+    lat = m.code_diff_pr(code)
+    assert lat.shape == (2, 6, 128, 384)
+    for p in range(3):
+        assert torch.equal(lat[:, :, :, p * 128:(p + 1) * 128], code[:, p])
+    assert torch.equal(m.code_diff_pr_inv(lat), code)
+    for name in ("ssdnerf_cars_recons1v_16bit.py", "ssdnerf_cars_uncond_16bit.py"):
+        m16 = build_model(Config.fromfile(os.path.join(REF, "configs/new_cfgs", name)))
+        assert m16.code_size == (3, 6, 128, 128)

@@ -139,3 +139,27 @@ def test_input_gradient_convs_use_the_same_kernel_forward_and_backward(monkeypat
         conv.weight.mul_(2.0)
     b = conv._split_pair(True)
     assert b[0] is not a[0] and torch.equal(b[0].float(), (conv.weight.detach().flip(2, 3).transpose(0, 1)).to(torch.bfloat16).float())
+
+
+def test_tiled_triplane_unet_shapes_module_oracle_and_executor():
+    """The tiled layout of configs/new_cfgs/ssdnerf_cars_recons1v_tiled.py: (3,6,h,w) codes laid side by side as a 6-channel h x 3w image,
+    ``image_size`` an int although the input is not square, GroupNorm groups that do not divide into 4-channel vectors, head widths the
+    MFMA attention kernel does not cover.  Module forward vs the functional oracle, and the inference executor (SDPA / library fallbacks)."""
+    from oracle import diffusion as OD
+    net = MODULES.build(dict(type="DenoisingUnetMod", image_size=16, in_channels=6, base_channels=20, channels_cfg=[1, 2, 2], resblocks_per_downsample=1,
+                             dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4, attention_res=[8, 4],
+                             norm_cfg=dict(type="GN", num_groups=4))).eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    x = torch.randn(2, 6, 16, 48, generator=g)
+    t = torch.tensor([800, 10])
+    with torch.no_grad():
+        want = net(x, t)
+        ref = OD.unet_forward(net.state_dict(), x, t, image_size=16, base_channels=20, channels_cfg=(1, 2, 2), resblocks_per_downsample=1,
+                              num_heads=4, attention_res=(8, 4), norm_groups=4)
+        got = unet_fast.FastUnet(net, dtype=torch.float32, use_graph=False)(x, t)
+    assert want.shape == (2, 6, 16, 48)
+    assert torch.allclose(want, ref, atol=2e-5, rtol=1e-4), (want - ref).abs().max()
+    assert torch.allclose(got, want, atol=2e-4, rtol=2e-4), (got - want).abs().max()
