@@ -65,7 +65,12 @@ class NormalizedTanhCode(nn.Module):
         self.register_buffer("running_var", torch.tensor([std ** 2]))
 
     def forward(self, code_, update_stats=False):
-        # statistics are only updated during training (out of scope); test-time behaviour is the affine + tanh below
+        if update_stats and self.training:          # running statistics of the pre-activation codes (base_nerf.py:64-68)
+            from .parallel import reduce_mean
+            with torch.no_grad():
+                var, mean = torch.var_mean(code_)
+                self.running_mean.mul_(1 - self.momentum).add_(self.momentum * reduce_mean(mean))
+                self.running_var.mul_(1 - self.momentum).add_(self.momentum * reduce_mean(var))
         scale = (self.std / (self.running_var.sqrt() + self.eps)).to(code_.device)
         return (code_ * scale + (self.mean - self.running_mean.to(code_.device) * scale)).div(self.clip_range).tanh().mul(self.clip_range)
 
@@ -247,10 +252,12 @@ class BaseNeRF(nn.Module):
         return scheduler_class(code_optimizer, **scheduler_cfg)
 
     def get_init_density_grid(self, num_scenes, device=None):
-        return torch.zeros((num_scenes, self.grid_size ** 3), device=device, dtype=torch.float16)
+        """zero Morton grid, (H^3,) for one scene (``num_scenes=None``) or (S, H^3)   (base_nerf.py:194-197)"""
+        return torch.zeros(self.grid_size ** 3 if num_scenes is None else (num_scenes, self.grid_size ** 3), device=device, dtype=torch.float16)
 
     def get_init_density_bitfield(self, num_scenes, device=None):
-        return torch.zeros((num_scenes, self.grid_size ** 3 // 8), device=device, dtype=torch.uint8)
+        return torch.zeros(self.grid_size ** 3 // 8 if num_scenes is None else (num_scenes, self.grid_size ** 3 // 8), device=device,
+                           dtype=torch.uint8)
 
     # ---- density grid (base_nerf.py:318-401) ------------------------------------------------------------------------
     def update_extra_state(self, decoder, code, density_grid, density_bitfield, iter_density, density_thresh=0.01, decay=0.9, S=128,
@@ -397,10 +404,109 @@ class BaseNeRF(nn.Module):
 
 @MODELS.register_module()
 class MultiSceneNeRF(BaseNeRF):
+    """Adds the per-scene cache of pre-activation codes + optimizer states (multiscene_nerf.py:31-183; wire format and 16-bit casting
+    rules in ``ssdnerf_amd/scene_cache.py``).  The RAM cache is sharded over ranks with the same ``round(linspace)`` split as the
+    scene sampler, so a rank only ever holds the scenes it is handed."""
+
     def __init__(self, *args, cache_size=0, cache_16bit=False, num_file_writers=0, **kwargs):
         super().__init__(*args, **kwargs)
         self.cache_size, self.cache_16bit, self.num_file_writers = cache_size, cache_16bit, num_file_writers
-        self.cache = None   # the RAM/file scene cache belongs to training
+        if cache_size > 0:
+            import torch.distributed as dist
+            from .parallel import shard_scenes
+            rank, ws = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+            self.cache = {ind: None for ind in shard_scenes(cache_size, rank, ws)}
+        else:
+            self.cache = None
+        self.cache_loaded = False
+        self.file_writers = None
+
+    def load_cache(self, data):
+        """-> (list of pre-activation code leaves, their optimizers, density_grid (S,H^3), density_bitfield (S,H^3/8)) for the scenes
+        of ``data['scene_id']``: from the RAM cache (filled once from ``train_cfg['cache_load_from']`` when given), else from
+        ``data['code']``, else freshly initialised (multiscene_nerf.py:74-129)."""
+        from .scene_cache import optimizer_set_state
+        device = get_module_device(self)
+        num_scenes = len(data["scene_id"])
+        if self.cache is not None:
+            if not self.cache_loaded:
+                cache_load_from = self.train_cfg.get("cache_load_from", None)
+                if cache_load_from is not None:
+                    cache_files = sorted(os.listdir(cache_load_from))
+                    if len(cache_files) > 0:
+                        assert len(cache_files) == self.cache_size
+                        for ind in self.cache.keys():
+                            self.cache[ind] = torch.load(os.path.join(cache_load_from, cache_files[ind]), map_location="cpu")
+                self.cache_loaded = True
+            cache_list = [self.cache[int(i)] for i in data["scene_id"]]
+        elif "code" in data:
+            cache_list = data["code"]
+        else:
+            cache_list = [None for _ in range(num_scenes)]
+        code_list_, density_grid, density_bitfield = [], [], []
+        for st in cache_list:
+            if st is None:
+                code_list_.append(self.get_init_code_(None, device))
+                density_grid.append(self.get_init_density_grid(None, device))
+                density_bitfield.append(self.get_init_density_bitfield(None, device))
+            else:
+                if "code_" in st["param"]:
+                    code_ = st["param"]["code_"].to(dtype=torch.float32, device=device)
+                else:       # a test-time scene file (activated code only): invert the activation, as the reference does with a warning
+                    assert "code" in st["param"]
+                    import warnings
+                    warnings.warn("Pre-activation codes not found. Using on-the-fly inversion instead (which could be inconsistent).")
+                    code_ = self.code_activation.inverse(st["param"]["code"].to(dtype=torch.float32, device=device))
+                code_list_.append(code_.requires_grad_(True))
+                density_grid.append(st["param"]["density_grid"].to(device))
+                density_bitfield.append(st["param"]["density_bitfield"].to(device))
+        density_grid = torch.stack(density_grid, dim=0)
+        density_bitfield = torch.stack(density_bitfield, dim=0)
+        code_optimizers = self.build_optimizer(code_list_, self.train_cfg)
+        for ind, st in enumerate(cache_list):
+            if st is not None and "optimizer" in st:
+                optimizer_set_state(code_optimizers[ind], st["optimizer"])
+        return code_list_, code_optimizers, density_grid, density_bitfield
+
+    def save_cache(self, code_list_, code_optimizers, density_grid, density_bitfield, scene_id, scene_name):
+        """Write the scenes back to the RAM cache (in place when the entry exists) and, with ``train_cfg['save_dir']``, to
+        ``<save_dir>/<scene_name>.pth`` - fp16 code + bf16 optimizer moments when ``cache_16bit`` (multiscene_nerf.py:131-183)."""
+        from .scene_cache import _FileWriters, load_tensor_to_dict, optimizer_state_copy, optimizer_state_to, out_dict_to
+        if self.cache_16bit:
+            code_dtype = torch.float16 if code_list_[0].dtype == torch.float32 else code_list_[0].dtype
+            optimizer_dtype = torch.bfloat16
+        else:
+            code_dtype, optimizer_dtype = code_list_[0].dtype, torch.float32
+        save_dir = self.train_cfg.get("save_dir", None)
+        if save_dir is not None:
+            os.makedirs(save_dir, exist_ok=True)
+            if self.num_file_writers > 0 and self.file_writers is None:
+                self.file_writers = _FileWriters(save_dir, self.num_file_writers)
+        for ind, code_single_ in enumerate(code_list_):
+            sid = int(scene_id[ind])
+            out = dict(scene_id=scene_id[ind], scene_name=scene_name[ind],
+                       param=dict(code_=code_single_.data, density_grid=density_grid[ind], density_bitfield=density_bitfield[ind]),
+                       optimizer=code_optimizers[ind].state_dict())
+            if self.cache is not None:
+                if self.cache[sid] is None:
+                    self.cache[sid] = out_dict_to(out, device="cpu", code_dtype=code_dtype, optimizer_dtype=optimizer_dtype)
+                else:
+                    entry = self.cache[sid]
+                    entry.setdefault("scene_id", out["scene_id"])
+                    entry.setdefault("scene_name", out["scene_name"])
+                    entry["param"].pop("code", None)
+                    for key, val in out["param"].items():
+                        load_tensor_to_dict(entry["param"], key, val, device="cpu", dtype=code_dtype)
+                    if "optimizer" in entry:
+                        optimizer_state_copy(out["optimizer"], entry["optimizer"], device="cpu", dtype=optimizer_dtype)
+                    else:
+                        entry["optimizer"] = optimizer_state_to(out["optimizer"], device="cpu", dtype=optimizer_dtype)
+            if save_dir is not None:
+                obj = out_dict_to(out, device="cpu", code_dtype=code_dtype, optimizer_dtype=optimizer_dtype)
+                if self.file_writers is not None:
+                    self.file_writers.put(ind, obj)
+                else:        # (the reference joins the LIST scene_name here, multiscene_nerf.py:182, which raises; the per-scene name is meant)
+                    torch.save(obj, os.path.join(save_dir, scene_name[ind] + ".pth"))
 
 
 @MODELS.register_module()

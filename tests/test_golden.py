@@ -206,3 +206,129 @@ def test_hip_ddim_fused_step_matches_reference_fixture():
         traj = d.ddim_sample(torch.from_numpy(f["noise"]).cuda(), save_intermediates=True)
     np.testing.assert_allclose(np.stack([t.cpu().numpy() for t in traj[1::2]]), f["xt_steps"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(np.stack([t.cpu().numpy() for t in traj[0::2]]), f["x0_steps"], rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ fixtures of make_golden_recons.py
+def _toy_recons_diffusion(f):
+    import torch.nn as nn
+    from ssdnerf_amd.registry import MODULES
+    from ssdnerf_amd.diffusion import GaussianDiffusion
+
+    if "ToyDenoiser2" not in MODULES:
+        @MODULES.register_module()
+        class ToyDenoiser2(nn.Module):
+            def __init__(self, num_classes=0, num_timesteps=1000):
+                super().__init__()
+                self.conv = nn.Conv2d(18, 18, 3, padding=1)
+
+            def forward(self, x_t, t, concat_cond=None):
+                return torch.tanh(self.conv(x_t)) * (1 + t.float().view(-1, 1, 1, 1) / 1000)
+
+    d = GaussianDiffusion(denoising=dict(type="ToyDenoiser2"), betas_cfg=dict(type="linear"), num_timesteps=1000, denoising_mean_mode="V",
+                          timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+                          ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight", data_info=dict(pred="v_t_pred", target="v_t"),
+                                         weight_scale=4.0, scale_norm=True),
+                          test_cfg=dict(num_timesteps=4, clip_range=[-2, 2], langevin_steps=2, langevin_delta=0.4))
+    with torch.no_grad():
+        d.denoising.conv.weight.copy_(torch.from_numpy(f["conv_weight"]))
+        d.denoising.conv.bias.copy_(torch.from_numpy(f["conv_bias"]))
+        d.ddpm_loss.norm_factor.fill_(1.7)
+    return d.eval()
+
+
+def test_prior_loss_sampler_and_langevin_match_reference_gaussian_diffusion():
+    f = load("recons.npz")
+    d = _toy_recons_diffusion(f)
+    np.testing.assert_array_equal(d.sampler.weight.numpy(), f["snr_weight"])
+    np.testing.assert_allclose(np.asarray(d.sampler.prob), f["snr_prob"], rtol=1e-15)
+    # forward_train with the reference's host-side draws: same timesteps, same noise, same x_t, same loss and gradient
+    x0 = torch.from_numpy(f["prior_x0"]).requires_grad_(True)
+    np.random.seed(5); torch.manual_seed(5)
+    t = d.sampler(3)
+    noise = torch.randn(3, 18, 16, 16)
+    assert np.array_equal(t.numpy(), f["prior_t"]) and np.array_equal(noise.numpy(), f["prior_noise"])
+    x_t, _, _ = d.q_sample(x0.detach(), t, noise)
+    np.testing.assert_allclose(x_t.numpy(), f["prior_x_t"], rtol=0, atol=1e-6)
+    np.random.seed(5); torch.manual_seed(5)
+    loss, _ = d(x0, return_loss=True, cfg=d.test_cfg)
+    (gx,) = torch.autograd.grad(loss, x0)
+    assert abs(float(loss.detach()) - float(f["prior_loss"])) <= 2e-6 * abs(float(f["prior_loss"]))
+    np.testing.assert_allclose(gx.numpy(), f["prior_grad"], rtol=0, atol=1e-5 * float(np.abs(f["prior_grad"]).max()))
+    # DDIM with 2 Langevin corrections per step, unguided and guided
+    noise0, target = torch.from_numpy(f["noise"]), torch.from_numpy(f["target"])
+    for p in d.parameters():
+        p.requires_grad_(False)
+    torch.manual_seed(77)
+    with torch.no_grad():
+        lv = d.ddim_sample(noise0.clone())
+    np.testing.assert_allclose(lv.numpy(), f["langevin_final"], rtol=0, atol=5e-6)
+    d.test_cfg["guidance_gain"] = 2.0
+    torch.manual_seed(78)
+    with torch.no_grad():
+        lv_g = d.ddim_sample(noise0.clone(), grad_guide_fn=lambda x0_: ((x0_ - target) ** 2).mean() * 5.0)
+    np.testing.assert_allclose(lv_g.numpy(), f["langevin_guided_final"], rtol=0, atol=1e-5)
+
+
+def test_code_activations_match_reference_classes():
+    from ssdnerf_amd.models import NormalizedTanhCode, TanhCode
+    f = load("recons.npz")
+    c_ = torch.from_numpy(f["act_in"])
+    nt = NormalizedTanhCode(mean=0.0, std=0.5, clip_range=2).eval()
+    y = nt(c_)
+    np.testing.assert_allclose(y.numpy(), f["ntanh_eval"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(nt.inverse(y).numpy(), f["ntanh_inverse"], rtol=1e-5, atol=1e-5)
+    nt.train()
+    y2 = nt(c_, update_stats=True)                                           # running statistics move only in training mode
+    np.testing.assert_allclose(nt.running_mean.numpy(), f["ntanh_running_mean"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(nt.running_var.numpy(), f["ntanh_running_var"], rtol=1e-6)
+    np.testing.assert_allclose(y2.numpy(), f["ntanh_train"], rtol=0, atol=1e-6)
+    t2 = TanhCode(scale=2)
+    np.testing.assert_allclose(t2(c_).numpy(), f["tanh2"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(t2.inverse(t2(c_)).numpy(), f["tanh2_inverse"], rtol=1e-5, atol=1e-5)
+
+
+def _same_tree(a, b, path=""):
+    if isinstance(a, torch.Tensor):
+        assert isinstance(b, torch.Tensor) and a.dtype == b.dtype and a.shape == b.shape, path
+        assert torch.equal(a, b), path
+    elif isinstance(a, dict):
+        assert isinstance(b, dict) and set(a) == set(b), (path, set(a), set(b))
+        for k in a:
+            _same_tree(a[k], b[k], f"{path}/{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same_tree(x, y, f"{path}[{i}]")
+    else:
+        assert a == b, path
+
+
+def test_scene_cache_casting_rules_match_reference_helpers():
+    """fp16 code (clamped to +-65504, never inf) + bf16 optimizer moments, grids / bitfields / step untouched; in-place refresh of an existing
+    entry; restoring a bf16 state into an fp32 optimizer keeps the LIVE learning rate -- bit for bit what the reference's helpers produce."""
+    import copy
+    from ssdnerf_amd import scene_cache as SC
+    fx = torch.load(os.path.join(G, "scene_cache.pt"), map_location="cpu", weights_only=False)
+    live, live2 = fx["live"], fx["live2"]
+    c16 = SC.out_dict_to(live, device="cpu", code_dtype=torch.float16, optimizer_dtype=torch.bfloat16)
+    _same_tree(c16, fx["cached16"])
+    assert c16["param"]["code_"].dtype == torch.float16 and float(c16["param"]["code_"].max()) == 65504.0
+    assert c16["param"]["density_grid"].dtype == torch.float16 and c16["param"]["density_bitfield"].dtype == torch.uint8
+    st = next(iter(c16["optimizer"]["state"].values()))
+    assert st["exp_avg"].dtype == torch.bfloat16 and st["exp_avg_sq"].dtype == torch.bfloat16 and st["step"].dtype == torch.float32
+    _same_tree(SC.out_dict_to(live, device="cpu", code_dtype=torch.float32, optimizer_dtype=torch.float32), fx["cached32"])
+    refreshed = copy.deepcopy(c16)
+    keep = refreshed["param"]["code_"]
+    for key, val in live2["param"].items():
+        SC.load_tensor_to_dict(refreshed["param"], key, val, device="cpu", dtype=torch.float16)
+    SC.optimizer_state_copy(live2["optimizer"], refreshed["optimizer"], device="cpu", dtype=torch.bfloat16)
+    assert refreshed["param"]["code_"] is keep                                # refreshed in place
+    _same_tree(refreshed, fx["refreshed16"])
+    code_b = live2["param"]["code_"].clone().requires_grad_(True)
+    opt = torch.optim.Adam([code_b], lr=0.5)
+    SC.optimizer_set_state(opt, refreshed["optimizer"])
+    s = opt.state[code_b]
+    assert s["exp_avg"].dtype == torch.float32 and torch.equal(s["exp_avg"], fx["restored"]["exp_avg"]) and torch.equal(s["exp_avg_sq"], fx["restored"]["exp_avg_sq"])
+    assert float(s["step"]) == float(fx["restored"]["step"]) == 5.0 and opt.param_groups[0]["lr"] == fx["restored"]["lr"] == 0.5
+    opt.zero_grad(); (code_b ** 2).sum().backward(); opt.step()                 # and the optimizer keeps stepping from there
+    assert float(opt.state[code_b]["step"]) == 6.0

@@ -156,3 +156,75 @@ def test_tiled_and_16bit_configs_build_and_lay_codes_out_as_the_reference_does()
     for name in ("ssdnerf_cars_recons1v_16bit.py", "ssdnerf_cars_uncond_16bit.py"):
         m16 = build_model(Config.fromfile(os.path.join(REF, "configs/new_cfgs", name)))
         assert m16.code_size == (3, 6, 128, 128)
+
+
+def test_multiscene_cache_roundtrip_ram_and_files(tmp_path):
+    """MultiSceneNeRF.load_cache / save_cache (multiscene_nerf.py:74-183): fresh scenes are initialised, saved scenes come back with their
+    pre-activation code, grids and optimizer moments; the 16-bit cache stores fp16 codes + bf16 moments; files are <scene_name>.pth and a
+    cache directory can seed a new model; test-time files with only the activated code are inverted with a warning."""
+    import torch
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.registry import MODELS
+    save_dir = str(tmp_path / "cache")
+
+    def build(cache_16bit, **train_cfg):
+        return MODELS.build(dict(type="MultiSceneNeRF", code_size=(3, 6, 8, 8), code_activation=dict(type="TanhCode", scale=2), grid_size=16,
+                                 decoder=dict(type="TriPlaneDecoder", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3],
+                                              dir_layers=[16, 64]), cache_size=4, cache_16bit=cache_16bit, num_file_writers=2,
+                                 train_cfg=dict(optimizer=dict(type="Adam", lr=0.01), **train_cfg)))
+
+    m = build(True, save_dir=save_dir)
+    assert sorted(m.cache) == [0, 1, 2, 3] and all(v is None for v in m.cache.values())
+    data = dict(scene_id=[2, 0], scene_name=["s2", "s0"])
+    codes, opts, grid, bits = m.load_cache(data)
+    assert len(codes) == 2 and codes[0].shape == (3, 6, 8, 8) and codes[0].requires_grad and float(codes[0].detach().abs().max()) <= m.init_scale
+    assert grid.shape == (2, 16 ** 3) and grid.dtype == torch.float16 and bits.shape == (2, 16 ** 3 // 8)
+    for c, o in zip(codes, opts):
+        o.zero_grad(); (c ** 2).sum().backward(); o.step()
+    grid[0, :5] = 1.0
+    m.save_cache(codes, opts, grid, bits, data["scene_id"], data["scene_name"])
+    m.file_writers.flush()
+    e = m.cache[2]
+    assert e["param"]["code_"].dtype == torch.float16 and e["param"]["density_grid"].dtype == torch.float16 and m.cache[1] is None
+    assert next(iter(e["optimizer"]["state"].values()))["exp_avg"].dtype == torch.bfloat16
+    assert sorted(os.listdir(save_dir)) == ["s0.pth", "s2.pth"]
+    # second round: the cached scenes come back, the optimizer continues from step 1
+    codes2, opts2, grid2, _ = m.load_cache(data)
+    assert torch.equal(codes2[0].detach(), codes[0].detach().half().float()) and float(grid2[0, :5].sum()) == 5.0
+    st = opts2[0].state[codes2[0]]
+    assert float(st["step"]) == 1.0 and st["exp_avg"].dtype == torch.float32
+    keep = m.cache[2]["param"]["code_"]
+    for c, o in zip(codes2, opts2):
+        o.zero_grad(); (c ** 2).sum().backward(); o.step()
+    m.save_cache(codes2, opts2, grid2, bits, data["scene_id"], data["scene_name"])
+    m.file_writers.flush()
+    assert m.cache[2]["param"]["code_"] is keep and float(next(iter(m.cache[2]["optimizer"]["state"].values()))["step"]) == 2.0
+    # a file written by the cache seeds data['code'] of a cache-less model, and a test-time file (activated code) is inverted
+    from ssdnerf_amd.scene_cache import read_scene_files
+    m0 = MODELS.build(dict(type="MultiSceneNeRF", code_size=(3, 6, 8, 8), code_activation=dict(type="TanhCode", scale=2), grid_size=16,
+                           decoder=dict(type="TriPlaneDecoder", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], dir_layers=[16, 64]),
+                           train_cfg=dict(optimizer=dict(type="Adam", lr=0.01))))
+    assert m0.cache is None
+    scenes = read_scene_files([os.path.join(save_dir, "s2.pth")])
+    c3, o3, g3, b3 = m0.load_cache(dict(scene_id=[0], scene_name=["s2"], code=scenes))
+    assert torch.equal(c3[0].detach(), m.cache[2]["param"]["code_"].float()) and float(o3[0].state[c3[0]]["step"]) == 2.0
+    code, g, b = m0.load_scene(dict(code=scenes), load_density=True)
+    assert code.dtype == torch.float16        # a 16-bit cache file stays fp16 through load_scene, as in the reference (base_nerf.py:149-151)
+    assert torch.allclose(code[0].float(), torch.tanh(scenes[0]["param"]["code_"].float()) * 2, atol=2e-3)
+    m0.save_scene(str(tmp_path / "eval"), code, g, b, ["s2"])
+    ev = read_scene_files([str(tmp_path / "eval" / "s2.pth")])
+    assert set(ev[0]["param"]) == {"code", "density_grid", "density_bitfield"}
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        c4, _, _, _ = m0.load_cache(dict(scene_id=[0], scene_name=["s2"], code=ev))
+    assert any("on-the-fly inversion" in str(x.message) for x in w)
+    assert torch.allclose(torch.tanh(c4[0].detach()) * 2, code[0].float(), atol=2e-3)
+    # a cache directory seeds a new model's RAM cache
+    for i in (1, 3):
+        torch.save(dict(scene_id=i, scene_name=f"s{i}", param=dict(code_=torch.zeros(3, 6, 8, 8), density_grid=torch.zeros(16 ** 3).half(),
+                                                                    density_bitfield=torch.zeros(16 ** 3 // 8, dtype=torch.uint8))),
+                   os.path.join(save_dir, f"s{i}.pth"))
+    m2 = build(False, cache_load_from=save_dir)
+    c5, _, _, _ = m2.load_cache(dict(scene_id=[2], scene_name=["s2"]))
+    assert m2.cache_loaded and m2.cache[3] is not None and torch.equal(c5[0].detach(), m.cache[2]["param"]["code_"].float())
