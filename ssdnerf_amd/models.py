@@ -10,8 +10,10 @@ and, as the first row of SURVEY.md section 8(f), the fine-tuning half of ``cond_
   get_init_code_, build_optimizer, build_scheduler, loss_decoder, inverse_code          (base_nerf.py:184-229, 298-316, 403-492)
   val_optim, the ``override_cfg`` switch in ``train()``                                  (diffusion_nerf.py:313-404, base_nerf.py:127-140)
 
-Training (``train_step``), the scene cache and the evaluation/visualisation code are out of scope (SURVEY.md sections 2
-and 8(f)); calling them raises ``NotImplementedError``.
+and the remaining section 8(f) rows at the host level: the scene cache (``load_cache`` / ``save_cache``, ``scene_cache.py``) and the
+training steps ``MultiSceneNeRF.train_step`` / ``DiffusionNeRF.train_step`` (multiscene_nerf.py:185-245, diffusion_nerf.py:66-189),
+which compose the pieces above (the runner, hooks, EMA updates, datasets, evaluation and visualisation stay out of scope,
+SURVEY.md section 2).
 """
 from __future__ import annotations
 
@@ -312,14 +314,29 @@ class BaseNeRF(nn.Module):
             reg = self.reg_loss(code, **kwargs)
             loss = loss + reg
             loss_dict.update(reg_loss=reg)
+        if return_decoder_loss and outputs.get("decoder_reg_loss") is not None:
+            loss = loss + outputs["decoder_reg_loss"]
+            loss_dict.update(decoder_reg_loss=outputs["decoder_reg_loss"])
         return out_rgbs, loss, loss_dict
 
     # ---- render (base_nerf.py:494-533) ---------------------------------------------------------------------------------
     def render(self, decoder, code, density_bitfield, h, w, intrinsics, poses, cfg=dict()):
         return nerf.render(decoder, code, density_bitfield, h, w, intrinsics, poses, grid_size=self.grid_size, bg_color=self.bg_color, cfg=cfg)
 
-    def train_step(self, *a, **k):
-        raise NotImplementedError("training is outside the hot path (SURVEY.md section 2)")
+    def mean_ema_update(self, code):
+        """EMA of the batch-mean code into ``init_code`` (``init_from_mean=True`` models; base_nerf.py:612-617)."""
+        if self.init_code is None:
+            return
+        from .parallel import reduce_mean
+        self.init_code.mul_(1 - self.mean_ema_momentum).add_(reduce_mean(code.detach().mean(dim=0)).data, alpha=self.mean_ema_momentum)
+
+    def train_step(self, data, optimizer, running_status=None):
+        raise NotImplementedError("BaseNeRF has no training step of its own (base_nerf.py:619-620); MultiSceneNeRF / DiffusionNeRF do")
+
+    @staticmethod
+    def _train_log(log_vars, out_rgbs, target_rgbs, code):
+        """train_psnr / code_rms as 0-dim tensors (the reference converts every entry with float(), one sync each)."""
+        log_vars.update(train_psnr=nerf.eval_psnr(out_rgbs.detach(), target_rgbs).mean(), code_rms=code.detach().square().flatten(1).mean().sqrt().mean())
 
     def loss_decoder(self, decoder, code, density_bitfield, cond_rays_o, cond_rays_d, cond_imgs, dt_gamma=0.0, cfg=dict(), **kwargs):
         """Rendering loss on ``n_decoder_rays`` freshly sampled rays (base_nerf.py:298-316); log values stay 0-dim tensors."""
@@ -509,6 +526,44 @@ class MultiSceneNeRF(BaseNeRF):
                     torch.save(obj, os.path.join(save_dir, scene_name[ind] + ".pth"))
 
 
+    def _cond_rays(self, data):
+        cond_imgs, cond_intrinsics, cond_poses = data["cond_imgs"], data["cond_intrinsics"], data["cond_poses"]
+        _, _, h, w, _ = cond_imgs.size()
+        cond_rays_o, cond_rays_d = nerf.get_cam_rays(cond_poses, cond_intrinsics, h, w)
+        dt_gamma = self.train_cfg.get("dt_gamma_scale", 0.0) / cond_intrinsics[..., :2].mean(dim=(-2, -1))
+        return cond_imgs, cond_rays_o, cond_rays_d, dt_gamma
+
+    def train_step(self, data, optimizer, running_status=None):
+        """Stage-1 auto-decoder step (multiscene_nerf.py:185-245): ``extra_scene_step`` code-only iterations, then one joint iteration of
+        codes + decoder on ``n_decoder_rays`` rays, cache write-back.  ``optimizer`` = {'decoder': torch optimizer}; the per-scene code
+        optimizers come from the cache.  Log values are 0-dim tensors."""
+        code_list_, code_optimizers, density_grid, density_bitfield = self.load_cache(data)
+        cond_imgs, cond_rays_o, cond_rays_d, dt_gamma = self._cond_rays(data)
+        extra_scene_step = self.train_cfg.get("extra_scene_step", 0)
+        if extra_scene_step > 0:
+            cfg = dict(self.train_cfg)
+            cfg["n_inverse_steps"] = extra_scene_step
+            self.inverse_code(self.decoder, cond_imgs, cond_rays_o, cond_rays_d, dt_gamma=dt_gamma, cfg=cfg, code_=code_list_,
+                              density_grid=density_grid, density_bitfield=density_bitfield, code_optimizer=code_optimizers)
+        for o in code_optimizers:
+            o.zero_grad()
+        optimizer["decoder"].zero_grad()
+        code = self.code_activation(torch.stack(code_list_, dim=0), update_stats=True)
+        self.update_extra_state(self.decoder, code.detach(), density_grid, density_bitfield, 0, density_thresh=self.train_cfg.get("density_thresh", 0.01))
+        loss, log_vars, out_rgbs, target_rgbs = self.loss_decoder(self.decoder, code, density_bitfield, cond_rays_o, cond_rays_d, cond_imgs, dt_gamma,
+                                                                  cfg=self.train_cfg)
+        loss.backward()
+        log_vars.update(loss=loss.detach())
+        optimizer["decoder"].step()
+        for o in code_optimizers:
+            o.step()
+        self.save_cache(code_list_, code_optimizers, density_grid, density_bitfield, data["scene_id"], data["scene_name"])
+        with torch.no_grad():
+            self.mean_ema_update(code)
+            self._train_log(log_vars, out_rgbs, target_rgbs, code)
+        return dict(log_vars=log_vars, num_samples=len(data["scene_id"]))
+
+
 @MODELS.register_module()
 class DiffusionNeRF(MultiSceneNeRF):
     def __init__(self, *args, diffusion=dict(type="GaussianDiffusion"), diffusion_use_ema=True, freeze_decoder=True, image_cond=False,
@@ -553,6 +608,76 @@ class DiffusionNeRF(MultiSceneNeRF):
     def _autocast(self):
         return torch.autocast(device_type="cuda", enabled=self.autocast_dtype is not None,
                               dtype=getattr(torch, self.autocast_dtype) if self.autocast_dtype is not None else None)
+
+    # ---- single-stage training step (diffusion_nerf.py:66-189) ------------------------------------------------------------
+    def train_step(self, data, optimizer, running_status=None):
+        """One SSDNeRF iteration: diffusion loss on the activated codes -> step the denoiser; its gradient on the codes seeds
+        ``extra_scene_step`` rendering iterations (``inverse_code``) and the final joint iteration that also steps the decoder;
+        cache write-back.  ``optimizer`` = {'diffusion': ..., ['decoder': ...]} (any key starting with 'diffusion' is stepped after the
+        prior loss).  Without ``train_cfg['optimizer']`` the codes are fixed inputs (``data['code']``, stage-2 training)."""
+        diffusion = self.diffusion
+        decoder = self.decoder_ema if self.freeze_decoder and self.decoder_use_ema else self.decoder
+        num_scenes = len(data["scene_id"])
+        extra_scene_step = self.train_cfg.get("extra_scene_step", 0)
+        if "optimizer" in self.train_cfg:
+            code_list_, code_optimizers, density_grid, density_bitfield = self.load_cache(data)
+            code = self.code_activation(torch.stack(code_list_, dim=0), update_stats=True)
+        else:
+            assert "code" in data
+            code, density_grid, density_bitfield = self.load_scene(data, load_density="decoder" in optimizer)
+            code_list_, code_optimizers = [], []
+        for key in optimizer.keys():
+            if key.startswith("diffusion"):
+                optimizer[key].zero_grad()
+        for o in code_optimizers:
+            o.zero_grad()
+        if "decoder" in optimizer:
+            optimizer["decoder"].zero_grad()
+        if self.image_cond:
+            raise NotImplementedError("image-conditioned UNets (concat_cond) are not part of the north-star configs")
+        if "cond_imgs" in data:
+            cond_imgs, cond_rays_o, cond_rays_d, dt_gamma = self._cond_rays(data)
+        with self._autocast():
+            loss_diffusion, log_vars = diffusion(self.code_diff_pr(code), concat_cond=None, return_loss=True,
+                                                 x_t_detach=self.train_cfg.get("x_t_detach", False), cfg=self.train_cfg)
+        loss_diffusion.backward()
+        for key in optimizer.keys():
+            if key.startswith("diffusion"):
+                optimizer[key].step()
+        log_vars = dict(log_vars)
+        prior_grad = None
+        if extra_scene_step > 0:
+            assert len(code_optimizers) > 0
+            prior_grad = [c.grad.data.clone() for c in code_list_]
+            cfg = dict(self.train_cfg)
+            cfg["n_inverse_steps"] = extra_scene_step
+            code, _, _, loss_decoder, loss_dict_decoder, out_rgbs, target_rgbs = self.inverse_code(
+                decoder, cond_imgs, cond_rays_o, cond_rays_d, dt_gamma=dt_gamma, cfg=cfg, code_=code_list_, density_grid=density_grid,
+                density_bitfield=density_bitfield, code_optimizer=code_optimizers, prior_grad=prior_grad)
+            log_vars.update({k: v.detach() for k, v in loss_dict_decoder.items()})
+        if "decoder" in optimizer or len(code_optimizers) > 0:
+            if len(code_optimizers) > 0:
+                code = self.code_activation(torch.stack(code_list_, dim=0))
+            self.update_extra_state(decoder, code.detach(), density_grid, density_bitfield, 0,
+                                    density_thresh=self.train_cfg.get("density_thresh", 0.01))
+            loss_decoder, log_vars_decoder, out_rgbs, target_rgbs = self.loss_decoder(decoder, code, density_bitfield, cond_rays_o, cond_rays_d,
+                                                                                      cond_imgs, dt_gamma, cfg=self.train_cfg)
+            log_vars.update(log_vars_decoder)
+            if prior_grad is not None:
+                for c, g in zip(code_list_, prior_grad):
+                    c.grad.copy_(g)
+            loss_decoder.backward()
+            if "decoder" in optimizer:
+                optimizer["decoder"].step()
+            for o in code_optimizers:
+                o.step()
+            self.save_cache(code_list_, code_optimizers, density_grid, density_bitfield, data["scene_id"], data["scene_name"])
+            with torch.no_grad():
+                if len(code_optimizers) > 0:
+                    self.mean_ema_update(code)
+                self._train_log(log_vars, out_rgbs, target_rgbs, code)
+            log_vars.update(loss_decoder=loss_decoder.detach())
+        return dict(log_vars=log_vars, num_samples=num_scenes)
 
     # ---- unconditional sampling (diffusion_nerf.py:191-239) -----------------------------------------------------------
     @torch.no_grad()

@@ -1,4 +1,6 @@
 """CPU tests of the DDIM sampler and UNet module against the oracle restatements (oracle/diffusion.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -339,3 +341,100 @@ def test_langevin_correction_steps_match_oracle(diffusion):
         np.testing.assert_allclose(got_g.detach().numpy(), want_g.numpy(), rtol=0, atol=3e-4)
     finally:
         diffusion.test_cfg.clear(); diffusion.test_cfg.update(saved)
+
+
+# ---------------------------------------------------------------------------------------------- training steps
+def test_train_steps_compose_prior_gradient_inner_iterations_and_cache(monkeypatch, tmp_path):
+    """DiffusionNeRF.train_step / MultiSceneNeRF.train_step (diffusion_nerf.py:66-189, multiscene_nerf.py:185-245) with the renderer replaced by
+    a differentiable stand-in: denoiser stepped on the prior loss, its code gradient seeding extra_scene_step + 1 rendering iterations,
+    decoder stepped once, cache written back -- against the same arithmetic written out by hand."""
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.registry import MODELS
+    E, lr_c = 2, 0.05
+    cfg = dict(type="DiffusionNeRF", code_size=(3, 6, 16, 16), code_reshape=(18, 16, 16), code_activation=dict(type="TanhCode", scale=2), grid_size=16,
+               diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"), denoising=_tiny_unet_cfg(),
+                              timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+                              ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight", data_info=dict(pred="v_t_pred", target="v_t"),
+                                             weight_scale=4.0, scale_norm=True)),
+               decoder=dict(type="TriPlaneDecoder", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], dir_layers=[16, 64]),
+               decoder_use_ema=True, freeze_decoder=False, bg_color=1, pixel_loss=dict(type="MSELoss", loss_weight=20.0), cache_size=4,
+               train_cfg=dict(dt_gamma_scale=0.5, density_thresh=0.1, extra_scene_step=E, n_inverse_rays=2 ** 12, n_decoder_rays=2 ** 12,
+                              loss_coef=0.1 / (128 * 128), optimizer=dict(type="SGD", lr=lr_c), save_dir=str(tmp_path / "cache")))
+    m = MODELS.build(cfg)
+    _randomize(m.diffusion.denoising, 9)
+    m.train()
+    g = torch.Generator().manual_seed(31)
+    probe = torch.randn(3 * 6 * 16 * 16, generator=g)
+    refreshes = []
+    monkeypatch.setattr(m, "update_extra_state", lambda *a, **k: refreshes.append(1))
+
+    def fake_loss(decoder, code, bits, target_rgbs, rays_o, rays_d, dt_gamma=0.0, return_decoder_loss=False, scale_num_ray=1.0, cfg=dict(),
+                  perturb=True, **kw):
+        assert decoder is m.decoder and decoder.training
+        loss = (code.flatten(1) * probe).sum() * 0.01 + code.square().mean() + decoder.base_net[0].weight.sum() * 1e-3
+        return target_rgbs * 0.5, loss, dict(pixel_loss=loss)
+
+    monkeypatch.setattr(m, "loss", fake_loss)
+    data = dict(scene_id=[1, 3], scene_name=["a", "b"], cond_imgs=torch.rand(2, 1, 8, 8, 3, generator=g), cond_poses=torch.eye(4).expand(2, 1, 4, 4),
+                cond_intrinsics=torch.tensor([8.0, 8.0, 4.0, 4.0]).expand(2, 1, 4))
+    opt = dict(diffusion=torch.optim.SGD(m.diffusion.parameters(), lr=0.1), decoder=torch.optim.SGD(m.decoder.parameters(), lr=0.1))
+    torch.manual_seed(3)
+    init = [m.get_init_code_(None) for _ in range(2)]
+    torch.manual_seed(3)                                                      # load_cache draws the same initial codes
+    unet_before = m.diffusion.denoising.out.conv.weight.detach().clone()
+    dec_before = m.decoder.base_net[0].weight.detach().clone()
+    sd = {k: v.clone() for k, v in m.diffusion.denoising.state_dict().items()}
+    norm0 = float(m.diffusion.ddpm_loss.norm_factor)
+    np.random.seed(11)
+    # the draws train_step will make, in its order: init codes (above), timesteps (np.random), noise (torch CPU generator)
+    state = torch.random.get_rng_state()
+    [m.get_init_code_(None) for _ in range(2)]
+    t_exp = m.diffusion.sampler(2)
+    n_exp = torch.randn(2, 18, 16, 16)
+    torch.random.set_rng_state(state); np.random.seed(11)
+    out = m.train_step(data, opt)
+    assert len(refreshes) == 1 + 1                                           # one refresh inside inverse_code (step 0 of E), one before the joint step
+    assert not torch.equal(m.diffusion.denoising.out.conv.weight, unet_before)
+    assert torch.allclose(m.decoder.base_net[0].weight, dec_before - 0.1 * 1e-3, atol=1e-7)        # decoder stepped exactly once
+    for k in ("loss_ddpm_mse", "pixel_loss", "loss_decoder", "train_psnr", "code_rms"):
+        assert k in out["log_vars"]
+    assert out["num_samples"] == 2 and sorted(os.listdir(str(tmp_path / "cache"))) == ["a.pth", "b.pth"]
+    assert m.cache[1] is not None and m.cache[0] is None and m.cache[1]["param"]["code_"].dtype == torch.float32
+    # by hand
+    den = lambda x, t: OD.unet_forward(sd, x, t, image_size=16, base_channels=32, channels_cfg=(1, 2), resblocks_per_downsample=1,
+                                       num_heads=4, attention_res=(8,), norm_groups=8)
+    tables = OD.schedule_tables(1000, "linear")
+    w, _ = OD.snr_timestep_weights(tables, 0.5, "V")
+    cs = [c.detach().clone().requires_grad_(True) for c in init]
+    x0 = (torch.stack(cs).tanh() * 2).reshape(2, 18, 16, 16)
+    norm1 = 0.999 * norm0 + 0.001 * float(x0.detach().square().mean())       # training mode: the running norm moves before it divides
+    prior = OD.prior_loss_v(den, x0, t_exp, n_exp, tables, w, weight_scale=4.0, norm_factor=norm1)
+    pg = torch.autograd.grad(prior, cs)
+    for _ in range(E + 1):
+        code = torch.stack(cs).tanh() * 2
+        rg = torch.autograd.grad((code.flatten(1) * probe).sum() * 0.01 + code.square().mean(), cs)
+        with torch.no_grad():
+            for c, a, b in zip(cs, pg, rg):
+                c -= lr_c * (a + b)
+    for i, sid in enumerate((1, 3)):
+        np.testing.assert_allclose(m.cache[sid]["param"]["code_"].numpy(), cs[i].detach().numpy(), rtol=0, atol=2e-6)
+
+    # MultiSceneNeRF: no prior; E code-only iterations, then the joint one
+    ms = MODELS.build(dict(type="MultiSceneNeRF", code_size=(3, 6, 16, 16), code_activation=dict(type="TanhCode", scale=2), grid_size=16,
+                           decoder=cfg["decoder"], pixel_loss=cfg["pixel_loss"], cache_size=4,
+                           train_cfg=dict(extra_scene_step=E, n_inverse_rays=2 ** 12, optimizer=dict(type="SGD", lr=lr_c)))).train()
+    monkeypatch.setattr(ms, "update_extra_state", lambda *a, **k: None)
+    monkeypatch.setattr(ms, "loss", lambda decoder, code, *a, **k: (a[1] * 0.5, (code.flatten(1) * probe).sum() * 0.01 + code.square().mean(), dict()))
+    torch.manual_seed(5)
+    init = [ms.get_init_code_(None) for _ in range(2)]
+    torch.manual_seed(5)
+    out = ms.train_step(data, dict(decoder=torch.optim.SGD(ms.decoder.parameters(), lr=0.1)))
+    cs = [c.detach().clone().requires_grad_(True) for c in init]
+    for _ in range(E + 1):
+        code = torch.stack(cs).tanh() * 2
+        rg = torch.autograd.grad((code.flatten(1) * probe).sum() * 0.01 + code.square().mean(), cs)
+        with torch.no_grad():
+            for c, b in zip(cs, rg):
+                c -= lr_c * b
+    np.testing.assert_allclose(ms.cache[3]["param"]["code_"].numpy(), cs[1].detach().numpy(), rtol=0, atol=2e-6)
+    assert "loss" in out["log_vars"] and "train_psnr" in out["log_vars"]
