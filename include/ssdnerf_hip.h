@@ -241,6 +241,17 @@ int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C1, int dtyp
                             const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride,
                             float eps, int act, void* workspace, int workspace_state, void* y, void* stream);
 
+/* d/dx of ssdnerf_group_norm_nhwc (single source x, no pre_bias) for frozen gamma / beta and a scale/shift that does not depend on x --
+ * the gradient rendering guidance and the fine-tuning prior push through every norm of the UNet (what autograd assembles from
+ * native_group_norm_backward, silu_backward and the scale/shift mul/add; modules.py:51-110).  x, dy, dx:
+ * [B][HW][C] of `dtype`; fwd_sums: the forward's workspace (sum, sum of squares per sample and group); bwd_workspace: another
+ * ssdnerf_group_norm_workspace(B, G) bytes, zero-filled by the call unless bwd_workspace_is_zero.  Two passes, nothing else saved.
+ * EXPERIMENTAL in round 1: arithmetic checked on the CPU (tests/test_groupnorm_backward_cpu.py), kernels not yet run on hardware. */
+int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
+                                     const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride,
+                                     float eps, int act, const void* fwd_sums, void* bwd_workspace, int bwd_workspace_is_zero,
+                                     void* dx, void* stream);
+
 /* y = x + bias[c] + residual over [B][HW][C] channel-last data (bias fp32 [C] nullable, residual nullable, y may alias x):
  * the epilogue of a bias-less convolution (modules.py:51-110) or the `h + x` closing an attention block (modules.py:47).
  * gn_sums (nullable, fp64 [B][gn_groups][2], pre-zeroed) receives the GroupNorm sums of y for the norm that follows. */

@@ -14,6 +14,7 @@
 // = 2 reads + 1 write of the activation, 16-byte vector accesses, HBM-bound.  Statistics and the affine fold are fp32/fp64
 // whatever the storage type, so the bf16/fp16 paths are *more* accurate than the eager chain they replace.
 #include "common.h"
+#include "gn_bwd_math.h"
 
 #include <hip/hip_fp16.h>
 
@@ -231,6 +232,110 @@ __global__ __launch_bounds__(GN_TPB) void k_bias_residual(const void* __restrict
     }
 }
 
+// ---- input gradient (frozen gamma / beta, time embedding independent of x): the arithmetic of gn_bwd_math.h over the same
+// [row-in-flight][channel vector] thread layout as the forward.  A thread owns one channel vector for the whole slab, so its
+// V x {A, O, k, mean, rstd} coefficients live in registers (no LDS table).
+//   k_gn_bwd_stats : per (sample, group)  sum p,  sum p * xhat   (p = dy * silu'(v) * gamma (1 + scale)), fp64 atomics across blocks
+//   k_gn_bwd_apply : dx = rstd * (p - mean(p) - xhat * mean(p * xhat))
+// = 4 reads + 1 write of the activation for what eager autograd does with ~10 kernels (native_group_norm_backward, silu_backward,
+// the scale/shift mul/add pair, and an NHWC <-> NCHW copy on either side).
+template <int DT, int V>
+__device__ __forceinline__ void gn_bwd_coeffs(uint32_t b, uint32_t cv, uint32_t HW, uint32_t C, uint32_t G, const double* __restrict__ fsums,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale_shift,
+                                              uint32_t ss_stride, float eps, float* A, float* O, float* K, float* M, float* R) {
+    const uint32_t cpg = C / G;
+    const double inv_n = 1.0 / ((double)HW * (double)cpg);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const uint32_t c = cv * V + i, g = c / cpg;
+        ssdg_coeffs(fsums[((size_t)b * G + g) * 2 + 0], fsums[((size_t)b * G + g) * 2 + 1], inv_n, eps, gamma[c], beta[c], scale_shift != nullptr,
+                    scale_shift ? scale_shift[(size_t)b * ss_stride + c] : 0.f, scale_shift ? scale_shift[(size_t)b * ss_stride + C + c] : 0.f,
+                    &A[i], &O[i], &K[i], &M[i], &R[i]);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(GN_TPB) void k_gn_bwd_stats(const void* __restrict__ x, const void* __restrict__ dy, uint32_t HW, uint32_t C, uint32_t G,
+                                                          uint32_t rows_per_block, const double* __restrict__ fsums, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ scale_shift, uint32_t ss_stride, float eps,
+                                                          int act, double* __restrict__ bsums) {
+    constexpr int V = GnVec<DT>::V;
+    __shared__ float part_s[GN_TPB * V], part_q[GN_TPB * V];
+    const uint32_t tpr = C / V, rif = GN_TPB / tpr;
+    const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
+    const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
+    if (lane_row < rif) {
+        float A[V], O[V], K[V], M[V], R[V], s[V], q[V];
+        gn_bwd_coeffs<DT, V>(b, cv, HW, C, G, fsums, gamma, beta, scale_shift, ss_stride, eps, A, O, K, M, R);
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; }
+        const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+        for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
+            float f[V], d[V];
+            GnVec<DT>::load(x, base + (size_t)r * tpr, f);
+            GnVec<DT>::load(dy, base + (size_t)r * tpr, d);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float p, xh;
+                ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act, &p, &xh);
+                s[i] += p;
+                q[i] = __builtin_fmaf(p, xh, q[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) { part_s[lane_row * C + cv * V + i] = s[i]; part_q[lane_row * C + cv * V + i] = q[i]; }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < C; c += GN_TPB) {
+        float ss = 0.f, qq = 0.f;
+        for (uint32_t r = 0; r < rif; ++r) { ss += part_s[r * C + c]; qq += part_q[r * C + c]; }
+        part_s[c] = ss; part_q[c] = qq;
+    }
+    __syncthreads();
+    const uint32_t cpg = C / G;
+    for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
+        double ds = 0.0, dq = 0.0;
+        for (uint32_t i = 0; i < cpg; ++i) { ds += (double)part_s[g * cpg + i]; dq += (double)part_q[g * cpg + i]; }
+        atomicAdd(&bsums[((size_t)b * G + g) * 2 + 0], ds);
+        atomicAdd(&bsums[((size_t)b * G + g) * 2 + 1], dq);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict__ x, const void* __restrict__ dy, uint32_t HW, uint32_t C, uint32_t G,
+                                                          uint32_t rows_per_block, const double* __restrict__ fsums, const double* __restrict__ bsums,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale_shift,
+                                                          uint32_t ss_stride, float eps, int act, void* __restrict__ dx) {
+    constexpr int V = GnVec<DT>::V;
+    const uint32_t tpr = C / V, rif = GN_TPB / tpr;
+    const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
+    const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
+    if (lane_row >= rif) return;
+    float A[V], O[V], K[V], M[V], R[V], m1[V], m2[V];
+    gn_bwd_coeffs<DT, V>(b, cv, HW, C, G, fsums, gamma, beta, scale_shift, ss_stride, eps, A, O, K, M, R);
+    const uint32_t cpg = C / G;
+    const double inv_n = 1.0 / ((double)HW * (double)cpg);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const uint32_t g = (cv * V + i) / cpg;
+        m1[i] = (float)(bsums[((size_t)b * G + g) * 2 + 0] * inv_n);
+        m2[i] = (float)(bsums[((size_t)b * G + g) * 2 + 1] * inv_n);
+    }
+    const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+    for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
+        float f[V], d[V];
+        GnVec<DT>::load(x, base + (size_t)r * tpr, f);
+        GnVec<DT>::load(dy, base + (size_t)r * tpr, d);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float p, xh;
+            ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act, &p, &xh);
+            f[i] = ssdg_dx(p, xh, R[i], m1[i], m2[i]);
+        }
+        GnVec<DT>::store(dx, base + (size_t)r * tpr, f);
+    }
+}
+
 uint32_t gn_rows_per_block(uint32_t B, uint32_t HW, uint32_t min_blocks, uint32_t min_rows) {
     uint32_t rows = HW;                                 // largest power-of-two split of HW that still leaves >= min_blocks blocks
     while (rows > min_rows && (rows % 2 == 0) && (uint64_t)B * (HW / rows) < min_blocks) rows /= 2;
@@ -268,6 +373,35 @@ extern "C" int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C
     if (dtype == GN_F32) { SSD_GN_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_GN_LAUNCH(GN_F16) } else { SSD_GN_LAUNCH(GN_BF16) }
 #undef SSD_GN_LAUNCH
     SSD_CHECK_LAUNCH("group_norm_nhwc");
+    return SSDNERF_OK;
+}
+
+// d/dx of ssdnerf_group_norm_nhwc (single source, no pre_bias) given dy; `fwd_sums` is the forward's workspace (per sample and group:
+// sum, sum of squares of x), `bwd_workspace` another ssdnerf_group_norm_workspace(B, G) bytes, zero-filled here unless
+// `bwd_workspace_is_zero` (stream capture: let the caller zero it with a kernel).
+extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* gamma,
+                                                const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act,
+                                                const void* fwd_sums, void* bwd_workspace, int bwd_workspace_is_zero, void* dx, void* stream) {
+    if (B == 0 || HW == 0 || C == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x && dy && dx && gamma && beta && fwd_sums && bwd_workspace, "group_norm_nhwc_backward: null pointer");
+    SSD_REQUIRE(dtype == GN_F32 || dtype == GN_F16 || dtype == GN_BF16, "group_norm_nhwc_backward: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    const uint32_t V = dtype == GN_F32 ? 4 : 8;
+    SSD_REQUIRE(G > 0 && C % G == 0, "group_norm_nhwc_backward: channels must be divisible by groups");
+    SSD_REQUIRE(!scale_shift || scale_shift_stride >= 2 * C, "group_norm_nhwc_backward: scale_shift_stride must be >= 2*C");
+    SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc_backward: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t rows_s = gn_rows_per_block(B, HW, 1024, 64), rows_a = gn_rows_per_block(B, HW, 2048, 16);
+    const dim3 grid_s(HW / rows_s, B), grid_a(HW / rows_a, B), block(GN_TPB);
+    if (!bwd_workspace_is_zero && hipMemsetAsync(bwd_workspace, 0, ssdnerf_group_norm_workspace(B, G), st) != hipSuccess)
+        return ssdnerf_fail(SSDNERF_E_LAUNCH, "group_norm_nhwc_backward: memset failed");
+#define SSD_GNB_LAUNCH(DT)                                                                                                                              \
+    hipLaunchKernelGGL(k_gn_bwd_stats<DT>, grid_s, block, 0, st, x, dy, HW, C, G, rows_s, (const double*)fwd_sums, gamma, beta, scale_shift, scale_shift_stride, \
+                       eps, act, (double*)bwd_workspace);                                                                                              \
+    hipLaunchKernelGGL(k_gn_bwd_apply<DT>, grid_a, block, 0, st, x, dy, HW, C, G, rows_a, (const double*)fwd_sums, (const double*)bwd_workspace, gamma, beta,   \
+                       scale_shift, scale_shift_stride, eps, act, dx);
+    if (dtype == GN_F32) { SSD_GNB_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_GNB_LAUNCH(GN_F16) } else { SSD_GNB_LAUNCH(GN_BF16) }
+#undef SSD_GNB_LAUNCH
+    SSD_CHECK_LAUNCH("group_norm_nhwc_backward");
     return SSDNERF_OK;
 }
 

@@ -84,6 +84,45 @@ class _Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class _GroupNormActFn(torch.autograd.Function):
+    """y = [silu]( GroupNorm(x) [* (1 + scale) + shift] ) over channel-last activations with FROZEN affine parameters, differentiable
+    w.r.t. x only: forward ``ssdnerf_group_norm_nhwc``, backward ``ssdnerf_group_norm_nhwc_backward`` (two passes, recomputing from x and the
+    forward's per-group sums).  Keeps the whole residual block channel-last between the matrix-core convolutions, which removes the
+    NCHW <-> NHWC copies eager GroupNorm forces around each of them."""
+
+    @staticmethod
+    def forward(ctx, x, norm, scale_shift, act):
+        from . import unet_fast as UF
+        xc = x.contiguous(memory_format=torch.channels_last)
+        sums = torch.zeros(x.size(0) * norm.num_groups * 2, dtype=torch.float64, device=x.device)
+        ss = None if scale_shift is None else scale_shift.detach().float().contiguous()
+        y = UF.group_norm_nhwc(xc, norm.num_groups, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, sums, workspace_is_zero=True)
+        ctx.save_for_backward(xc, sums)
+        ctx.norm, ctx.ss, ctx.act = norm, ss, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import unet_fast as UF
+        xc, sums = ctx.saved_tensors
+        norm = ctx.norm
+        dx = UF.group_norm_nhwc_backward(xc, dy.contiguous(memory_format=torch.channels_last), norm.num_groups, norm.weight.detach(), norm.bias.detach(),
+                                         ctx.ss, norm.eps, ctx.act, sums)
+        return dx, None, None, None
+
+
+#: SSDNERF_UNET_GRAD_GN=1 routes the norms of the input-gradient path through ``_GroupNormActFn``.  Off by default in round 1: the
+#: backward kernels' arithmetic is checked on the CPU, the kernels themselves have not run on hardware yet.
+GRAD_GN = os.environ.get("SSDNERF_UNET_GRAD_GN", "0") == "1"
+
+
+def _gn_act_eligible(x, norm, scale_shift=None):
+    return (GRAD_GN and torch.is_grad_enabled() and x.requires_grad and x.dim() == 4 and _device_ok(x) and x.dtype == torch.float32
+            and not torch.is_autocast_enabled(x.device.type) and isinstance(norm, nn.GroupNorm) and norm.affine
+            and not norm.weight.requires_grad and not norm.bias.requires_grad and norm.num_channels % 4 == 0 and norm.num_channels <= 1024
+            and (scale_shift is None or not scale_shift.requires_grad))
+
+
 def _build_norm(norm_cfg, channels):
     cfg = dict(norm_cfg)
     typ = cfg.pop("type")
@@ -143,12 +182,19 @@ class NormWithEmbedding(nn.Module):
         out = in_channels * 2 if use_scale_shift else in_channels
         self.embedding_layer = nn.Sequential(_build_act(act_cfg), nn.Linear(embedding_channels, out))
 
-    def forward(self, x, y):
-        e = self.embedding_layer(y)[:, :, None, None]
+    def forward(self, x, y, fuse_silu=False):
+        """``fuse_silu`` (extra): also apply the SiLU that follows in the residual block (only honoured on the fused path; returns
+        (tensor, whether the activation was applied))."""
+        e = self.embedding_layer(y)
+        if self.use_scale_shift and fuse_silu and _gn_act_eligible(x, self.norm, e):
+            return _GroupNormActFn.apply(x, self.norm, e, True), True
+        e = e[:, :, None, None]
         if self.use_scale_shift:
             scale, shift = torch.chunk(e, 2, dim=1)
-            return self.norm(x) * (1 + scale) + shift
-        return self.norm(x + e)
+            out = self.norm(x) * (1 + scale) + shift
+        else:
+            out = self.norm(x + e)
+        return (out, False) if fuse_silu else out
 
 
 @MODULES.register_module()
@@ -178,6 +224,13 @@ class DenoisingResBlockMod(nn.Module):
 
     def forward(self, x, y):
         s = self.shortcut(x) if self.learnable_shortcut else x
+        if _gn_act_eligible(x, self.conv_1[0]) and isinstance(self.conv_1[1], nn.SiLU) and isinstance(self.conv_2[0], nn.SiLU) \
+                and not (self.training and len(self.conv_2) > 2):
+            # input-gradient path: GroupNorm + SiLU (and the scale/shift norm + SiLU) as one fused, channel-last op each
+            h = self.conv_1[-1](_GroupNormActFn.apply(x, self.conv_1[0], None, True))
+            h, activated = self.norm_with_embedding(h, y, fuse_silu=True)
+            h = self.conv_2[-1](h if activated else self.conv_2[0](h))
+            return h + s
         h = self.conv_1(x)
         h = self.norm_with_embedding(h, y)
         h = self.conv_2(h)
@@ -254,6 +307,8 @@ class _NormActConv(nn.Module):
         self.activate = _build_act(act_cfg)
 
     def forward(self, x):
+        if _gn_act_eligible(x, self.gn) and isinstance(self.activate, nn.SiLU):
+            return self.conv(_GroupNormActFn.apply(x, self.gn, None, True))
         return self.conv(self.activate(self.gn(x)))
 
 

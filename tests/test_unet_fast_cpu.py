@@ -163,3 +163,59 @@ def test_tiled_triplane_unet_shapes_module_oracle_and_executor():
     assert want.shape == (2, 6, 16, 48)
     assert torch.allclose(want, ref, atol=2e-5, rtol=1e-4), (want - ref).abs().max()
     assert torch.allclose(got, want, atol=2e-4, rtol=2e-4), (got - want).abs().max()
+
+
+def _gn_backward_standin(x, dy, groups, gamma, beta, scale_shift, eps, act, fwd_sums):
+    assert x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last) and fwd_sums.dtype == torch.float64
+    with torch.enable_grad():
+        xx = x.detach().clone().requires_grad_(True)
+        y = F.group_norm(xx, groups, gamma, beta, eps)
+        if scale_shift is not None:
+            c = xx.size(1)
+            y = y * (1 + scale_shift[:, :c, None, None]) + scale_shift[:, c:, None, None]
+        if act:
+            y = F.silu(y)
+        (gx,) = torch.autograd.grad((y * dy).sum(), xx)
+    return gx.contiguous(memory_format=torch.channels_last)
+
+
+def test_input_gradient_norms_fused_channel_last(monkeypatch):
+    """SSDNERF_UNET_GRAD_GN=1 wiring: in the input-gradient path every residual block runs GN+SiLU -> conv -> GN*(1+scale)+shift+SiLU -> conv
+    through _GroupNormActFn (forward group_norm_nhwc, backward group_norm_nhwc_backward; torch stand-ins here) and stays channel-last
+    between the matrix-core convolutions; output and input gradient equal the plain module's."""
+    from ssdnerf_amd import unet
+    net = MODULES.build(dict(type="DenoisingUnetMod", image_size=16, in_channels=6, base_channels=64, channels_cfg=[1, 2], resblocks_per_downsample=1,
+                             dropout=0.1, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4, attention_res=[8])).eval()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    net.requires_grad_(False)
+    x0 = torch.randn(2, 6, 16, 16, generator=g)
+    t = torch.tensor([400, 990])
+    probe = torch.randn(2, 6, 16, 16, generator=g)
+
+    def grad_of():
+        x = x0.clone().requires_grad_(True)
+        y = net(x, t)
+        return y.detach(), torch.autograd.grad((y * probe).sum(), x)[0]
+
+    y_ref, g_ref = grad_of()
+    fwd, bwd, layouts = [], [], []
+    monkeypatch.setattr(unet, "_device_ok", lambda x: True)
+    monkeypatch.setattr(unet, "GRAD_GN", True)
+    monkeypatch.setattr(unet_fast, "conv2d_nhwc_f32x2", lambda *a, **k: (layouts.append(a[0].is_contiguous(memory_format=torch.channels_last)), _conv_f32x2_standin(*a, **k))[1])
+    monkeypatch.setattr(unet_fast, "group_norm_nhwc", lambda *a, **k: (fwd.append(a[6]), _gn_standin(*a, **k))[1])
+    monkeypatch.setattr(unet_fast, "group_norm_nhwc_backward", lambda *a, **k: (bwd.append(1), _gn_backward_standin(*a, **k))[1])
+    y, gx = grad_of()
+    n_res = sum(1 for m in net.modules() if isinstance(m, unet.DenoisingResBlockMod))
+    assert len(fwd) == 2 * n_res + 1 and all(fwd) and len(bwd) == len(fwd)       # two fused norms per residual block + the output head, all with SiLU
+    assert all(layouts)
+    assert torch.allclose(y, y_ref, atol=1e-4, rtol=1e-4), (y - y_ref).abs().max()
+    assert float((gx - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
+    # dropout active (training mode) keeps the eager block
+    del fwd[:]
+    net.train()
+    net(x0.clone().requires_grad_(True), t)
+    net.eval()
+    assert len(fwd) == 1                                                       # only the output head (no dropout there)
