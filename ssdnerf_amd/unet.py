@@ -111,8 +111,8 @@ class _GroupNormActFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-#: SSDNERF_UNET_GRAD_GN=1 routes the norms of the input-gradient path through ``_GroupNormActFn``.  Off by default in round 1: the
-#: backward kernels' arithmetic is checked on the CPU, the kernels themselves have not run on hardware yet.
+#: SSDNERF_UNET_GRAD_GN=1 routes the norms of the input-gradient path through ``_GroupNormActFn``.  Parity-checked on the GPU
+#: (tests/test_unet_fast_gpu.py) but off by default until its effect on the guided step has been timed.
 GRAD_GN = os.environ.get("SSDNERF_UNET_GRAD_GN", "0") == "1"
 
 
