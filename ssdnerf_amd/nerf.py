@@ -111,3 +111,49 @@ def eval_psnr(img1: torch.Tensor, img2: torch.Tensor, max_val: float = 1.0, eps:
     import math
     mse = (img1 - img2).square().flatten(1).mean(dim=-1)
     return 10 * (2 * math.log10(max_val) - torch.log10(mse + eps))
+
+
+# ---------------------------------------------------------------------------------------------- density volume / mesh
+@torch.no_grad()
+def extract_fields(bound_min, bound_max, resolution: int, query_func, S: int = 128, device=None) -> torch.Tensor:
+    """Sample ``query_func`` on the ``resolution``^3 lattice spanning [bound_min, bound_max] (x-major, ``custom_meshgrid`` order) in
+    S^3 chunks (lib/core/utils/nerf_utils.py:64-79).  The volume is assembled ON THE DEVICE and returned as a tensor - the reference
+    copies every chunk to the host; callers that want numpy call ``.cpu().numpy()`` once."""
+    xs_all = [torch.linspace(float(bound_min[a]), float(bound_max[a]), resolution, device=device) for a in range(3)]
+    u = torch.zeros(resolution, resolution, resolution, dtype=torch.float32, device=device)
+    for xi, xs in enumerate(xs_all[0].split(S)):
+        for yi, ys in enumerate(xs_all[1].split(S)):
+            for zi, zs in enumerate(xs_all[2].split(S)):
+                xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+                u[xi * S: xi * S + len(xs), yi * S: yi * S + len(ys), zi * S: zi * S + len(zs)] = query_func(pts).reshape(len(xs), len(ys), len(zs))
+    return u
+
+
+@torch.no_grad()
+def extract_density_volume(decoder: TriPlaneDecoder, code_single: torch.Tensor, resolution: int = 256) -> torch.Tensor:
+    """Density on the lattice ``extract_geometry`` marches over: the box grown by 0.1 on every side, sigma forced to 0 outside the AABB
+    (nerf_utils.py:98-112).  One fused density decode per 128^3 chunk on the GPU."""
+    aabb = decoder.aabb.to(code_single.device)
+
+    def query(pts):
+        sigma = decoder.point_density_decode(pts[None], code_single[None])[0].flatten()
+        out = (pts < aabb[:3]).any(dim=-1) | (pts > aabb[3:]).any(dim=-1)
+        return sigma.masked_fill(out, 0)
+
+    return extract_fields(aabb[:3] - 0.1, aabb[3:] + 0.1, resolution, query, device=code_single.device)
+
+
+def extract_geometry(decoder: TriPlaneDecoder, code_single: torch.Tensor, resolution: int = 256, threshold: float = 10):
+    """``vertices, triangles`` of the density iso-surface (nerf_utils.py:82-112).  The marching-cubes step is PyMCubes in the reference;
+    it is imported on use - the package is an optional dependency, everything up to the density volume is native."""
+    try:
+        import mcubes
+    except ImportError as e:
+        raise ImportError("extract_geometry needs PyMCubes (`mcubes`) for the marching-cubes step; `extract_density_volume` provides the "
+                          "volume it runs on") from e
+    u = extract_density_volume(decoder, code_single, resolution)
+    vertices, triangles = mcubes.marching_cubes(u.cpu().numpy(), threshold)
+    b_min = (decoder.aabb[:3] - 0.1).cpu().numpy()
+    b_max = (decoder.aabb[3:] + 0.1).cpu().numpy()
+    return vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :], triangles

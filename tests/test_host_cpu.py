@@ -228,3 +228,35 @@ def test_multiscene_cache_roundtrip_ram_and_files(tmp_path):
     m2 = build(False, cache_load_from=save_dir)
     c5, _, _, _ = m2.load_cache(dict(scene_id=[2], scene_name=["s2"]))
     assert m2.cache_loaded and m2.cache[3] is not None and torch.equal(c5[0].detach(), m.cache[2]["param"]["code_"].float())
+
+
+def test_density_volume_for_mesh_extraction_matches_oracle_decode():
+    """extract_density_volume (the lattice extract_geometry marches over, lib/core/utils/nerf_utils.py:64-112): lattice order, chunking, the 0.1
+    margin and the zero fill outside the box, against the oracle's density decode on the same points."""
+    import numpy as np
+    import torch
+    from oracle.decoder import point_decode
+    from ssdnerf_amd import nerf, synthetic as S
+    from ssdnerf_amd.decoders import TriPlaneDecoder
+    dec = TriPlaneDecoder(base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], dir_layers=[16, 64])
+    params = S.make_decoder_params()
+    dec.load_state_dict(params, strict=False)
+    dec.eval()
+    code = S.make_triplane(5)
+    res = 20
+    calls = []
+    vol = nerf.extract_fields(dec.aabb[:3] - 0.1, dec.aabb[3:] + 0.1, res, lambda p: (calls.append(len(p)), p[:, 0] * 100 + p[:, 1] * 10 + p[:, 2])[1], S=8)
+    assert calls == [512, 512, 256, 512, 512, 256, 256, 256, 128] * 2 + [256, 256, 128, 256, 256, 128, 128, 128, 64]      # 8,8,4 splits per axis
+    lin = torch.linspace(-1.1, 1.1, res)
+    assert torch.allclose(vol[3, 7, 11], lin[3] * 100 + lin[7] * 10 + lin[11], atol=1e-5)
+    u = nerf.extract_density_volume(dec, code, resolution=res)
+    assert u.shape == (res, res, res)
+    xx, yy, zz = torch.meshgrid(lin, lin, lin, indexing="ij")
+    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+    sig, _ = point_decode(params, code, pts, None, density_only=True)
+    sig = sig.reshape(res, res, res).clone()
+    sig[((pts.abs() > 1).any(dim=-1)).reshape(res, res, res)] = 0
+    np.testing.assert_allclose(u.numpy(), sig.numpy(), rtol=2e-5, atol=1e-6)
+    assert float(u[0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u.max()) > 1.0
+    with pytest.raises(ImportError):
+        nerf.extract_geometry(dec, code, resolution=res)
