@@ -6,7 +6,7 @@ On the hot path: ``prepare_diffusion_vars`` (numpy
 Section 8(f) rank 1 (the fine-tuning half of ``cond_mode='guide_optim'``) adds the diffusion prior loss that
 ``val_optim`` back-propagates into the code: ``q_sample`` (:165-178), ``loss`` (:389-405), ``forward_train`` (:407-433)
 with the timestep samplers (lib/models/diffusions/sampler.py) and ``DDPMMSELossMod`` (lib/models/losses/ddpm_loss.py).
-The DDPM ancestral sampler is out of scope.
+The DDPM ancestral sampler (``p_sample_ddpm`` / ``ddpm_sample``, :333-385; ``sample_method='ddpm'``) is carried for API parity.
 
 The per-step latent update (V-prediction -> x0, clamp, eps, x_prev) is one fused HIP kernel when no guidance closure is
 active (``ssdnerf_ddim_step_v``); the guided path keeps the reference's exact PyTorch expression order because autograd
@@ -371,6 +371,41 @@ class GaussianDiffusion(nn.Module):
                 x_0_x_t_list.append(x_0_pred)
                 x_0_x_t_list.append(x_t)
         return x_0_x_t_list if save_intermediates else x_t
+
+    # ------------------------------------------------------------------------------------------ ancestral sampler
+    def q_posterior_mean(self, x_0, x_t, t):
+        """mean of q(x_{t-1} | x_t, x_0) (:154-163)"""
+        t_host = torch.as_tensor(t).cpu().reshape(-1).numpy()
+        c1 = x_0.new_tensor(self.tilde_mu_t_coef1[t_host], dtype=torch.float32).reshape(-1, 1, 1, 1)
+        c2 = x_0.new_tensor(self.tilde_mu_t_coef2[t_host], dtype=torch.float32).reshape(-1, 1, 1, 1)
+        return c1 * x_0 + c2 * x_t
+
+    def p_sample_ddpm(self, x_t, t, noise=None, cfg=dict(), grad_guide_fn=None, **kwargs):
+        """One ancestral step with the fixed-large / fixed-small variance (:333-365)."""
+        t_host = torch.as_tensor(t).cpu().reshape(-1).numpy()
+        mode = self.denoising_var_mode.upper()
+        if mode == "FIXED_LARGE":
+            table = np.append(self.tilde_betas_t[1], self.betas)
+        elif mode == "FIXED_SMALL":
+            table = self.tilde_betas_t
+        else:
+            raise AttributeError(f"Unknown denoising var output type [{self.denoising_var_mode}].")
+        var_pred = x_t.new_tensor(table[t_host], dtype=torch.float32).reshape(-1, 1, 1, 1)
+        x_0_pred, _ = self.pred_x_0(x_t, t, grad_guide_fn=grad_guide_fn, cfg=cfg, **kwargs)
+        mean_pred = self.q_posterior_mean(x_0_pred, x_t, t)
+        if noise is None:
+            noise = _noise_like(x_t)
+        nonzero = float(int(t_host[0]) != 0) if t_host.size == 1 else x_t.new_tensor((t_host != 0).astype(np.float32)).reshape(-1, 1, 1, 1)
+        return mean_pred + nonzero * torch.sqrt(var_pred) * noise, x_0_pred
+
+    def ddpm_sample(self, noise, show_pbar=False, concat_cond=None, **kwargs):
+        x_t = noise
+        cond_step = 0
+        for t in self.ddim_timesteps():
+            x_t, _ = self.p_sample_ddpm(x_t, t, concat_cond=concat_cond[:, cond_step % concat_cond.size(1)] if concat_cond is not None else None,
+                                        cfg=self.test_cfg, **kwargs)
+            cond_step += 1
+        return x_t
 
     def sample_from_noise(self, noise, **kwargs):
         name = f"{self.sample_method.lower()}_sample"

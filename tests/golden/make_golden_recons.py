@@ -152,6 +152,15 @@ def main():
         lv_g = diff.ddim_sample(noise.clone(), grad_guide_fn=lambda x0_: ((x0_ - target) ** 2).mean() * 5.0)
     out.update(noise=noise.numpy(), target=target.numpy(), langevin_final=lv.numpy(), langevin_guided_final=lv_g.detach().numpy())
 
+    # ---- DDPM ancestral sampler (sample_method='ddpm'), 5 steps, both variance modes ----
+    diff.test_cfg.update(num_timesteps=5, langevin_steps=0)
+    diff.test_cfg.pop("guidance_gain")
+    for mode in ("FIXED_LARGE", "FIXED_SMALL"):
+        diff.denoising_var_mode = mode
+        torch.manual_seed(91)
+        with torch.no_grad():
+            out[f"ddpm_{mode.lower()}"] = diff.ddpm_sample(noise.clone()).numpy()
+
     # ---- code activations ----
     ns = dict(torch=torch, nn=nn, reduce_mean=lambda t: t, MODULES=MODULES)
     exec(_segments("lib/models/autodecoders/base_nerf.py", ["TanhCode", "NormalizedTanhCode"]), ns)

@@ -332,3 +332,17 @@ def test_scene_cache_casting_rules_match_reference_helpers():
     assert float(s["step"]) == float(fx["restored"]["step"]) == 5.0 and opt.param_groups[0]["lr"] == fx["restored"]["lr"] == 0.5
     opt.zero_grad(); (code_b ** 2).sum().backward(); opt.step()                 # and the optimizer keeps stepping from there
     assert float(opt.state[code_b]["step"]) == 6.0
+
+
+def test_ddpm_ancestral_sampler_matches_reference():
+    f = load("recons.npz")
+    d = _toy_recons_diffusion(f)
+    d.test_cfg.update(num_timesteps=5, langevin_steps=0)
+    noise0 = torch.from_numpy(f["noise"])
+    for mode in ("FIXED_LARGE", "FIXED_SMALL"):
+        d.denoising_var_mode = mode
+        d.sample_method = "ddpm"
+        torch.manual_seed(91)
+        with torch.no_grad():
+            got = d(noise0.clone(), return_loss=False)
+        np.testing.assert_allclose(got.numpy(), f[f"ddpm_{mode.lower()}"], rtol=0, atol=5e-6)
