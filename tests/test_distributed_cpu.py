@@ -59,3 +59,44 @@ def test_shard_matches_reference_partition():
     # round(linspace(0, n, ws+1)) as in the reference's sampler / code cache split
     assert shard_bounds(704, 8).tolist() == [0, 88, 176, 264, 352, 440, 528, 616, 704]
     assert shard_bounds(10, 4).tolist() == [0, 2, 5, 8, 10]
+
+
+def _worker_train_state(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.registry import MODELS
+    from ssdnerf_amd.diffusion import DDPMMSELossMod
+    from ssdnerf_amd.models import NormalizedTanhCode
+    m = MODELS.build(dict(type="MultiSceneNeRF", code_size=(3, 6, 8, 8), grid_size=16, cache_size=7,
+                          decoder=dict(type="TriPlaneDecoder", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], dir_layers=[16, 64]),
+                          train_cfg=dict(optimizer=dict(type="Adam", lr=0.01))))
+    # training-time statistics are averaged over ranks: the prior loss' running norm and the code activation's running moments
+    loss = DDPMMSELossMod(rescale_mode=None, data_info=dict(pred="v_t_pred", target="v_t"), scale_norm=True, momentum=0.5).train()
+    x0 = torch.full((2, 4, 2, 2), float(rank + 1))
+    loss(dict(v_t_pred=x0, v_t=x0 * 0, x_0=x0, timesteps=torch.tensor([1, 2])))
+    act = NormalizedTanhCode(std=0.5, momentum=0.5).train()
+    act(torch.full((2, 3), float(rank)) + torch.tensor([[-1.0, 0.0, 1.0]]), update_stats=True)
+    q.put((rank, sorted(m.cache), float(loss.norm_factor), float(act.running_mean), float(act.running_var)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_cache_shards_and_averaged_training_statistics():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_train_state, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 1, 2, 3] and res[1][1] == [4, 5, 6]              # round(linspace(0, 7, 3)) = 0, 4, 7: the reference's cache split
+    # norm_factor: 0.5 * 1 + 0.5 * mean_ranks(mean(x0^2)) = 0.5 + 0.5 * (1 + 4) / 2, identical on both ranks
+    assert res[0][2] == pytest.approx(1.75) and res[1][2] == pytest.approx(1.75)
+    # running_mean: 0.5 * mean_ranks(rank) = 0.25; running_var: 0.5 * 0.25 + 0.5 * mean_ranks(var) with var = 0.8 on both ranks
+    assert res[0][3] == pytest.approx(0.25) and res[1][3] == pytest.approx(0.25)
+    assert res[0][4] == pytest.approx(0.5 * 0.25 + 0.5 * 0.8) and res[1][4] == pytest.approx(res[0][4])
