@@ -13,6 +13,7 @@ casting helpers lib/core/utils/misc.py:43-128):
 ACTIVATED ``code`` instead of ``code_``; ``load_cache`` inverts the activation for those, ``load_scene`` uses them as they are."""
 from __future__ import annotations
 
+import atexit
 import os
 import queue
 import threading
@@ -125,6 +126,7 @@ class _FileWriters:
         self.threads = [threading.Thread(target=self._run, args=(q,), daemon=True) for q in self.queues]
         for t in self.threads:
             t.start()
+        atexit.register(self.flush)          # daemon threads: make sure queued scenes reach the disk before the interpreter goes away
 
     def _run(self, q):
         while True:
