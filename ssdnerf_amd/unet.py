@@ -114,6 +114,9 @@ class _GroupNormActFn(torch.autograd.Function):
 #: SSDNERF_UNET_GRAD_GN=1 routes the norms of the input-gradient path through ``_GroupNormActFn``.  Parity-checked on the GPU
 #: (tests/test_unet_fast_gpu.py) but off by default until its effect on the guided step has been timed.
 GRAD_GN = os.environ.get("SSDNERF_UNET_GRAD_GN", "0") == "1"
+#: SSDNERF_UNET_GRAD_ATT=1 (with GRAD_GN) also runs the attention blocks of that path channel-last (``_forward_channel_last``).  Wiring
+#: checked on the CPU only so far; the same projection + scaled_dot_product_attention form runs in the inference executor on the GPU.
+GRAD_ATT = os.environ.get("SSDNERF_UNET_GRAD_ATT", "0") == "1"
 
 
 def _gn_act_eligible(x, norm, scale_shift=None):
@@ -262,7 +265,25 @@ class MultiHeadAttentionMod(nn.Module):
         w = torch.softmax(w.float(), dim=-1).type(w.dtype)
         return torch.einsum("bts,bcs->bct", w, v)
 
+    def _forward_channel_last(self, x):
+        """Input-gradient path with the fused norm: the block on (B, T, C) views of the channel-last activation -- GroupNorm through
+        ``_GroupNormActFn``, the two 1x1 projections as GEMMs on the last axis, softmax(QK^T)V through ``scaled_dot_product_attention``
+        (fp32 here, so its softmax is the reference's fp32 softmax) -- no NCHW copy, same per-head [q | k | v] channel order as ``forward``."""
+        b, c, h, w = x.shape
+        t, heads = h * w, self.num_heads
+        ch = c // heads
+        xc = x.contiguous(memory_format=torch.channels_last)
+        xn = _GroupNormActFn.apply(xc, self.norm, None, False)
+        qkv = F.linear(xn.permute(0, 2, 3, 1).reshape(b, t, c), self.qkv.weight[:, :, 0], self.qkv.bias)      # channel = head*3ch + {q,k,v}*ch + i
+        q, k, v = qkv.view(b, t, heads, 3, ch).permute(3, 0, 2, 1, 4)                                         # each (b, heads, t, ch)
+        a = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(b, t, c)
+        out = F.linear(a, self.proj.weight[:, :, 0], self.proj.bias) + xc.permute(0, 2, 3, 1).reshape(b, t, c)
+        return out.view(b, h, w, c).permute(0, 3, 1, 2)                                                       # a channels_last (B, C, H, W) view
+
     def forward(self, x):
+        if GRAD_ATT and x.dim() == 4 and self.groups == 1 and _gn_act_eligible(x, self.norm) and not self.qkv.weight.requires_grad \
+                and not self.proj.weight.requires_grad:
+            return self._forward_channel_last(x)
         b, c, *spatial = x.shape
         x = x.reshape(b, c, -1)
         t = x.size(-1)

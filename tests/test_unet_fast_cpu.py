@@ -204,12 +204,15 @@ def test_input_gradient_norms_fused_channel_last(monkeypatch):
     fwd, bwd, layouts = [], [], []
     monkeypatch.setattr(unet, "_device_ok", lambda x: True)
     monkeypatch.setattr(unet, "GRAD_GN", True)
+    monkeypatch.setattr(unet, "GRAD_ATT", True)
     monkeypatch.setattr(unet_fast, "conv2d_nhwc_f32x2", lambda *a, **k: (layouts.append(a[0].is_contiguous(memory_format=torch.channels_last)), _conv_f32x2_standin(*a, **k))[1])
     monkeypatch.setattr(unet_fast, "group_norm_nhwc", lambda *a, **k: (fwd.append(a[6]), _gn_standin(*a, **k))[1])
     monkeypatch.setattr(unet_fast, "group_norm_nhwc_backward", lambda *a, **k: (bwd.append(1), _gn_backward_standin(*a, **k))[1])
     y, gx = grad_of()
     n_res = sum(1 for m in net.modules() if isinstance(m, unet.DenoisingResBlockMod))
-    assert len(fwd) == 2 * n_res + 1 and all(fwd) and len(bwd) == len(fwd)       # two fused norms per residual block + the output head, all with SiLU
+    n_att = sum(1 for m in net.modules() if isinstance(m, unet.MultiHeadAttentionMod))
+    # two fused norms per residual block + the output head (with SiLU), one plain norm per attention block (channel-last attention path)
+    assert n_att >= 2 and len(fwd) == 2 * n_res + 1 + n_att and sum(fwd) == 2 * n_res + 1 and len(bwd) == len(fwd)
     assert all(layouts)
     assert torch.allclose(y, y_ref, atol=1e-4, rtol=1e-4), (y - y_ref).abs().max()
     assert float((gx - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
@@ -218,4 +221,4 @@ def test_input_gradient_norms_fused_channel_last(monkeypatch):
     net.train()
     net(x0.clone().requires_grad_(True), t)
     net.eval()
-    assert len(fwd) == 1                                                       # only the output head (no dropout there)
+    assert len(fwd) == 1 + n_att                                               # the output head and the attention blocks (no dropout there)
