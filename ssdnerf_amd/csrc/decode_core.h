@@ -22,6 +22,12 @@
 #include "common.h"
 #include "sh_basis.h"
 
+// SSD_GATHER_PAIRS=1: packed form of the bilinear interpolation (see ssd_gather18).  Experimental: identical arithmetic by construction,
+// off until it has been parity-run and timed on hardware.
+#ifndef SSD_GATHER_PAIRS
+#define SSD_GATHER_PAIRS 0
+#endif
+
 #define MLP_OFF_WD (64 * 24)
 #define MLP_OFF_BD (64 * 24 + 64 * 16)
 #define MLP_OFF_TAIL (64 * 24 + 64 * 16 + 64)
@@ -78,9 +84,25 @@ SSD_DEV void ssd_gather18(const PT* __restrict__ planes, const PlaneGeom& g, flo
         Texel<PT>::load6(base + ((uint64_t)y1 * g.Wp + x0) * 8, t10);
         Texel<PT>::load6(base + ((uint64_t)y1 * g.Wp + x1) * 8, t11);
         const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+#if SSD_GATHER_PAIRS
+        // the same four-term chain per channel, written on channel PAIRS of one texel (adjacent registers of the load, one shared weight)
+        // so that it maps onto v_pk_mul/v_pk_fma without operand assembly; element-wise identical arithmetic, bit-identical results
+        typedef float ssd_f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+            const ssd_f2 a00 = {t00[c], t00[c + 1]}, a01 = {t01[c], t01[c + 1]}, a10 = {t10[c], t10[c + 1]}, a11 = {t11[c], t11[c + 1]};
+            ssd_f2 r = a00 * ssd_f2{w00, w00};
+            r = __builtin_elementwise_fma(a01, ssd_f2{w01, w01}, r);
+            r = __builtin_elementwise_fma(a10, ssd_f2{w10, w10}, r);
+            r = __builtin_elementwise_fma(a11, ssd_f2{w11, w11}, r);
+            f[c * 3 + p] = r.x;
+            f[(c + 1) * 3 + p] = r.y;
+        }
+#else
 #pragma unroll
         for (int c = 0; c < 6; ++c)
             f[c * 3 + p] = ssd_fma(t11[c], w11, ssd_fma(t10[c], w10, ssd_fma(t01[c], w01, t00[c] * w00)));
+#endif
         if (PLANE_BY_PLANE) __builtin_amdgcn_sched_barrier(0);
     }
 }
