@@ -82,7 +82,7 @@ template <int VAR> struct SmGeo {
     static constexpr unsigned MARCH_W = POOL / 2;              // rays advanced by one march pass
     static constexpr unsigned STAGE = VAR == 3 ? 32 : 64;      // prepared rays per wave
     static constexpr unsigned WLDS = VAR == 3 ? (2 * 10 + 2 * 9) * 64 : 0;   // floats of A-operand weights in LDS
-    static constexpr unsigned SHF = VAR == 4 ? 1536 : 1024;    // floats of per-ray SH operands per wave (VAR 4: three bf16 terms x 64 rays x 16)
+    static constexpr unsigned SHF = (VAR == 4 || VAR == 6) ? 1536 : 1024;    // floats of per-ray SH operands per wave (VAR 4: three bf16 terms x 64 rays x 16)
     static constexpr unsigned LDS_FLOATS = 512 + WLDS + (SM_TPB / 64) * (2 * POOL * 8 + SHF + STAGE * 16);
 };
 
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
     // ---- A operands: lane l holds W[mt*32 + (l&31)][2s + (l>>5)] for every k-step s ----
     // VAR 4: pre-split A operands.  wa1[mt][ks][term] / wa2[mt][ks][term]: lane l holds the 8 bf16 terms of W[mt*32 + (l&31)][16 ks + 8 (l>>5) + e]
     sm_bf16x8 wa1[2][2][3], wa2[2][2][3];
-    if constexpr (VAR == 4) {
+    if constexpr (VAR == 4 || VAR == 6) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int row = mt * 32 + (lane & 31);
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
         sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
         float sh[16];
         shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
-        if constexpr (VAR == 4) {                      // three bf16 terms per value, in MFMA B-operand form: [term][sample][k 0-7 | k 8-15]
+        if constexpr (VAR == 4 || VAR == 6) {          // three bf16 terms per value, in MFMA B-operand form: [term][sample][k 0-7 | k 8-15]
             uint32_t tm[3][16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) sm_split3(sh[k], tm[0][k], tm[1][k], tm[2][k]);
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                 ws = dep = cr = cg = cb = 0.f; cnt = 0;
                 float sh[16];
                 shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
-                if constexpr (VAR == 4) {
+                if constexpr (VAR == 4 || VAR == 6) {
                     uint32_t tm[3][16];
 #pragma unroll
                     for (int k = 0; k < 16; ++k) sm_split3(sh[k], tm[0][k], tm[1][k], tm[2][k]);
@@ -575,6 +575,113 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                 res[nt][0] = ps.x + ps.y; res[nt][1] = pr.x + pr.y; res[nt][2] = pg.x + pg.y; res[nt][3] = pb.x + pb.y;
             }
             ps0 = res[0][0]; ps1 = res[1][0]; pr0 = res[0][1]; pr1 = res[1][1]; pg0 = res[0][2]; pg1 = res[1][2]; pb0 = res[0][3]; pb1 = res[1][3];
+        } else if constexpr (VAR == 6) {
+            // ---- variant 4's operands (bf16 x 3 on the matrix cores, same products in the same order per accumulator: bit-identical
+            // results) in variant 2's schedule: both sample tiles hold their accumulators (64 registers instead of 32), and every MFMA
+            // group has SiLU pairs of the OTHER tile behind it in program order, so the wave keeps issuing VALU work while its own MFMAs
+            // run (variant 4 leaves that to the second wave of the SIMD).  Needs the register headroom of SSD_GATHER_PAIRS=1.
+            //   A: layer 1, tile 0 (24 MFMA)   B: layer 1, tile 1 (24) || density head 0   C: dir term 0 (18) || density head 1
+            //   D: dir term 1 (18) || colour head 0   E: colour head 1
+            uint32_t T[3][9], Z[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int p2 = 0; p2 < 9; ++p2) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                sm_split3(f[2 * p2], h0, m0, l0);
+                sm_split3(f[2 * p2 + 1], h1, m1, l1);
+                T[0][p2] = sm_pack2(h0, h1); T[1][p2] = sm_pack2(m0, m1); T[2][p2] = sm_pack2(l0, l1);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sm_swap_u(T[t][k], T[t][4 + k]);
+                sm_swap_u(T[t][8], Z[t]);
+            }
+            const uint32_t bias_pair = half == 0 ? 0x00003F80u : 0u;
+            const sm_bf16x8 b_bias = sm_op(bias_pair, 0u, 0u, 0u);
+            floatx16 acc[2][2];                                              // [tile][mt]
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.0f;
+            constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};
+            auto layer1 = [&](int nt, int pr_i) {                            // 4 MFMA: products (weight term i) x (feature term j) of both row tiles
+                const int i = TI[pr_i], j = TJ[pr_i];
+                const sm_bf16x8 b0 = sm_op(T[j][4 * nt], T[j][4 * nt + 1], T[j][4 * nt + 2], T[j][4 * nt + 3]);
+                const sm_bf16x8 b1 = sm_op(nt == 0 ? T[j][8] : Z[j], j == 0 ? bias_pair : 0u, 0u, 0u);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0, acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][1][i], b1, acc[nt][mt], 0, 0, 0);
+                }
+            };
+            sm_bf16x8 sb[3];
+            auto load_sh = [&](int nt) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) sb[t] = *reinterpret_cast<const sm_bf16x8*>(reinterpret_cast<const uint4*>(sh_lds) + t * 128 + (nt * 32 + (lane & 31)) * 2 + half);
+            };
+            auto dir_term = [&](int nt, int pr_i) {                          // 2 or 4 MFMA: h += Wd [SH(d); 1]
+                const int i = TI[pr_i], j = TJ[pr_i];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][0][i], sb[j], acc[nt][mt], 0, 0, 0);
+                    if (j == 0) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][1][i], b_bias, acc[nt][mt], 0, 0, 0);
+                }
+            };
+            floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+            floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+            auto density_pair = [&](int nt, int q) {
+                const int mt = q >> 3, p2 = q & 7;
+                const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
+                ps_[nt] = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]}), ps_[nt]);
+            };
+            auto colour_pair = [&](int nt, int q) {
+                const int mt = q >> 3, p2 = q & 7;
+                const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+                const floatx2 cc = sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]});
+                pr_[nt] = sm_fma2(floatx2{w0.z, w0.w}, cc, pr_[nt]);
+                pg_[nt] = sm_fma2(floatx2{w1.x, w1.y}, cc, pg_[nt]);
+                pb_[nt] = sm_fma2(floatx2{w1.z, w1.w}, cc, pb_[nt]);
+            };
+            constexpr int QB[7] = {0, 3, 6, 9, 12, 14, 16};                 // 16 SiLU pairs spread over the 6 MFMA groups of a phase
+            // ---- A
+#pragma unroll
+            for (int g = 0; g < 6; ++g) layer1(0, g);
+            // ---- B
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                layer1(1, g);
+#pragma unroll
+                for (int q = QB[g]; q < QB[g + 1]; ++q) density_pair(0, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- C
+            load_sh(0);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                dir_term(0, g);
+#pragma unroll
+                for (int q = QB[g]; q < QB[g + 1]; ++q) density_pair(1, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- D
+            load_sh(1);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                dir_term(1, g);
+#pragma unroll
+                for (int q = QB[g]; q < QB[g + 1]; ++q) colour_pair(0, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- E
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                colour_pair(1, q);
+                if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);
+            }
+            ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y; pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y;
+            pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         } else if constexpr (VAR == 3) {
             // ---- three waves per SIMD: the tiles are shaded one after the other, A operands come from LDS, B operands are built in place ----
             // after the swaps f[2s] feeds tile 0 (the samples of lanes 0-31) and f[2s+1] tile 1, k-step s; the SH operands sit in LDS in that form
@@ -816,16 +923,17 @@ extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dt
     }
     const uint32_t slices = 0;   // (kept in the kernel signature; slices are ticketed dynamically)
     // residency: WPS workgroups x 4 waves per CU, persistent.  SSDNERF_SHADE_WPS=2|3 picks the variant (default below).
-    static int var = 0;                                  // 2: f32 MFMA, 2 waves/SIMD; 3: f32 MFMA, 3 waves/SIMD; 4: bf16 x 3 on the matrix cores
+    static int var = 0;                                  // 2: f32 MFMA, 2 waves/SIMD; 3: f32 MFMA, 3 waves/SIMD; 4: bf16 x 3 on the matrix cores;
+                                                         // 6: variant 4's arithmetic in variant 2's interleaved schedule (experimental: not yet run on hardware)
     if (var == 0) {
         const char* e = getenv("SSDNERF_SHADE_VARIANT");
-        var = (e && e[0] >= '2' && e[0] <= '4') ? e[0] - '0' : SM_DEFAULT_VARIANT;
+        var = (e && ((e[0] >= '2' && e[0] <= '4') || e[0] == '6')) ? e[0] - '0' : SM_DEFAULT_VARIANT;
     }
     dim3 g((unsigned)n_cu * (var == 3 ? 3u : 2u)), b(SM_TPB);
     hipStream_t s = (hipStream_t)stream;
 #define SM_LAUNCH(PT, V) hipLaunchKernelGGL((k_shade_mfma<PT, V>), g, b, 0, s, c, slices, (const PT*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag)
-    if (planes_dtype == 0) { if (var == 4) SM_LAUNCH(float, 4); else if (var == 3) SM_LAUNCH(float, 3); else SM_LAUNCH(float, 2); }
-    else { if (var == 4) SM_LAUNCH(__half, 4); else if (var == 3) SM_LAUNCH(__half, 3); else SM_LAUNCH(__half, 2); }
+    if (planes_dtype == 0) { if (var == 4) SM_LAUNCH(float, 4); else if (var == 6) SM_LAUNCH(float, 6); else if (var == 3) SM_LAUNCH(float, 3); else SM_LAUNCH(float, 2); }
+    else { if (var == 4) SM_LAUNCH(__half, 4); else if (var == 6) SM_LAUNCH(__half, 6); else if (var == 3) SM_LAUNCH(__half, 3); else SM_LAUNCH(__half, 2); }
 #undef SM_LAUNCH
     SSD_CHECK_LAUNCH("render_shade_queue_mfma");
     return SSDNERF_OK;
