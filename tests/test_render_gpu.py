@@ -359,3 +359,23 @@ def test_fused_decode_backward_matches_autograd_through_the_eager_decode():
     sig, rgb, _ = dec.point_decode(xyzs, dirs, c)
     gw = torch.autograd.grad(sig.sum() + rgb.sum(), dec.base_net[0].weight)[0]
     assert bool(torch.isfinite(gw).all()) and float(gw.abs().max()) > 0
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SSDNERF_TEST_EXPERIMENTAL", "0") != "1",
+                    reason="variant 6 of the shade kernel has not run on hardware yet (set SSDNERF_TEST_EXPERIMENTAL=1)")
+def test_shade_variants_are_bit_identical(tmp_path):
+    """Variant 6 keeps variant 4's operands and product order and only re-schedules them: every output must be bit-identical.  The variant is
+    read once per process (SSDNERF_SHADE_VARIANT), so each runs in its own interpreter on the same two-scene, three-view workload."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for var in ("4", "6"):
+        path = str(tmp_path / f"v{var}.npz")
+        env = dict(os.environ, SSDNERF_SHADE_VARIANT=var, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        subprocess.run([sys.executable, os.path.join(root, "tests", "_render_variant.py"), path], check=True, env=env, cwd=root, timeout=300)
+        outs[var] = np.load(path)
+    assert int(outs["4"]["counts"].sum()) > 100000
+    for k in ("counts", "image", "depth", "weights_sum"):
+        assert np.array_equal(outs["4"][k], outs["6"][k]), k
