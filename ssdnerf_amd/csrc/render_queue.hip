@@ -214,6 +214,122 @@ __global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage A, compacting form (SSDNERF_FIRST_HIT_COMPACT=1; experimental -- written against k_first_hit's counters, not yet run on hardware).
+// k_first_hit is VALU-bound at ~100 % issue (r01 PMC: 2 520 VALU instructions per wave of 64 rays) and most of that is the exact march
+// of the ~35 % of rays that survive the pre-test, executed by whole waves in which the other lanes idle.  Here a 1024-thread block
+// runs the pre-test for its rays (same arithmetic, same background writes), appends the survivors (ray, near, bounded far, tail) to an LDS
+// list with one LDS atomic per wave, and then marches the list densely: 64 live lanes per wave instead of ~22.  Per-ray arithmetic, and
+// therefore every output, is unchanged; only the order of the hit queue differs (it is unordered already).
+static constexpr unsigned RQC_TPB = 1024;
+
+__global__ void __launch_bounds__(RQC_TPB) k_first_hit_compact(QueueCfg c, const uint8_t* __restrict__ lin_bits, const uint8_t* __restrict__ coarse_bits,
+                                                                const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
+                                                                int32_t* __restrict__ sample_counts, uint2* __restrict__ queue, uint32_t* __restrict__ queue_count) {
+    const uint32_t scene = blockIdx.y;
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t ray0 = (uint64_t)scene * c.N;
+    lin_bits += (uint64_t)scene * c.bitfield_stride;
+    if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
+    __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
+    __shared__ uint32_t list_n[RQC_TPB], list_tail[RQC_TPB];
+    __shared__ float list_t[RQC_TPB], list_far[RQC_TPB];
+    __shared__ uint32_t list_count;
+    const uint32_t Hc = c.m.H >> RQ_COARSE_LOG2B, log2Hc = c.m.log2H - RQ_COARSE_LOG2B, coarse_bytes = (Hc * Hc * Hc) >> 3;
+    const bool use_coarse = coarse_bits != nullptr && coarse_bytes <= RQ_COARSE_MAX_BYTES && coarse_bytes % 16 == 0;
+    if (threadIdx.x == 0) list_count = 0;
+    if (use_coarse) {
+        const uint4* src = reinterpret_cast<const uint4*>(coarse_bits + (uint64_t)scene * coarse_bytes);
+        for (uint32_t i = threadIdx.x; i < coarse_bytes / 16; i += RQC_TPB) reinterpret_cast<uint4*>(coarse_lds)[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // ---- phase 1: near/far + coarse pre-test (the arithmetic of k_first_hit, line for line)
+    bool need = false;
+    float t = 0.f, far_ = 0.f;
+    uint32_t tail = SSD_TAIL_NONE;
+    if (n < c.N) {
+        const uint64_t gi = ray0 + n;
+        const RayGeom r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
+        ssd_near_far(c.aabb, r, c.min_near, t, far_);
+        if (use_coarse && t < far_) {
+            const float len = sqrtf(ssd_fma(r.dx, r.dx, ssd_fma(r.dy, r.dy, r.dz * r.dz)));
+            const float step_t = (RQ_COARSE_STEP * c.m.two_rH * c.m.mip_bound) / fmaxf(len, 1e-20f);
+            int j_last = -1, j = 0;
+            float t_last = 0.f;
+            for (float tc = t; ; tc += step_t, ++j) {
+                const float u = fminf(tc, far_);
+                const int bx = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
+                const int by = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
+                const int bz = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
+                const uint32_t ci = ((((uint32_t)bz << log2Hc) + (uint32_t)by) << log2Hc) + (uint32_t)bx;
+                if ((coarse_lds[ci >> 3] >> (ci & 7u)) & 1u) { j_last = j; t_last = tc; }
+                if (!(tc < far_)) break;
+            }
+            if (j_last < 0) t = far_;
+            else {
+                far_ = fminf(far_, t_last + step_t);
+                if (c.N <= SSD_RAY_ID_MASK + 1u && j_last < (int)SSD_TAIL_NONE) tail = (uint32_t)j_last;
+            }
+        }
+        need = t < far_;
+        if (!need) {                                                         // misses the box, or nothing within a cell of the ray: background only
+            image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
+            depth[gi] = 0.f; weights_sum[gi] = 0.f;
+            if (sample_counts) sample_counts[gi] = 0;
+        }
+    }
+    {   // survivors -> LDS list, one LDS atomic per wave
+        const uint64_t m = __ballot(need);
+        if (m != 0) {
+            uint32_t base = 0;
+            if (lane == __builtin_ctzll(m)) base = atomicAdd(&list_count, (uint32_t)__popcll(m));
+            base = __shfl(base, __builtin_ctzll(m), 64);
+            if (need) {
+                const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                list_n[slot] = n; list_tail[slot] = tail; list_t[slot] = t; list_far[slot] = far_;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = list_count;
+    // ---- phase 2: dense exact march of the survivors (whole waves stay in the loop for the ballot)
+    for (uint32_t wbase = threadIdx.x & ~63u; wbase < cnt; wbase += RQC_TPB) {
+        const uint32_t i = wbase + lane;
+        bool hit = false;
+        uint32_t nn = 0, tl = SSD_TAIL_NONE;
+        float tt = 0.f;
+        if (i < cnt) {
+            nn = list_n[i]; tl = list_tail[i]; tt = list_t[i];
+            const float ff = list_far[i];
+            const uint64_t gi = ray0 + nn;
+            const RayGeom r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
+            const float sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f), sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f), sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
+            while (tt < ff) {
+                const FastProbe p = rq_probe(c.m, lin_bits, r, tt);
+                if (p.occ) { hit = true; break; }
+                tt = rq_skip(c.m, r, p, sgx, sgy, sgz, tt);
+            }
+            if (!hit) {
+                image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
+                depth[gi] = 0.f; weights_sum[gi] = 0.f;
+                if (sample_counts) sample_counts[gi] = 0;
+            }
+        }
+        const uint64_t hits = __ballot(hit);
+        if (hits != 0) {
+            uint32_t base = 0;
+            if (lane == __builtin_ctzll(hits)) base = atomicAdd(queue_count + scene, (uint32_t)__popcll(hits));
+            base = __shfl(base, __builtin_ctzll(hits), 64);
+            if (hit) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                queue[ray0 + base + rank] = make_uint2(c.N <= SSD_RAY_ID_MASK + 1u ? (nn | (tl << 24)) : nn, __float_as_uint(tt));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stage B: shade the hit queue.
 template <typename PT>
 __global__ void __launch_bounds__(RQ_TPB) k_shade_queue(QueueCfg c, uint32_t slices_per_scene, const PT* __restrict__ planes,
@@ -426,8 +542,13 @@ extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_s
     const bool coarse_ok = hc >= 8 && (hc * hc * hc / 8) <= RQ_COARSE_MAX_BYTES && (hc * hc * hc / 8) % 16 == 0 && bound <= 1.0f && getenv("SSDNERF_NO_COARSE") == nullptr;
     if (coarse_ok)
         hipLaunchKernelGGL(k_bitfield_coarsen, dim3(ssd_blocks(hc * hc * hc, RQ_TPB), S), dim3(RQ_TPB), 0, s, w.lin_bits, grid_size, c.m.log2H, c.bitfield_stride, w.coarse);
-    hipLaunchKernelGGL(k_first_hit, dim3(ssd_blocks(N, RQ_TPB), S), dim3(RQ_TPB), 0, s, c, w.lin_bits, coarse_ok ? w.coarse : (const uint8_t*)nullptr, rays_o, rays_d, image,
-                       depth, weights_sum, sample_counts, w.queue, w.counters);
+    static const bool compact = getenv("SSDNERF_FIRST_HIT_COMPACT") != nullptr;      // experimental compacting form (see k_first_hit_compact)
+    if (compact)
+        hipLaunchKernelGGL(k_first_hit_compact, dim3(ssd_blocks(N, RQC_TPB), S), dim3(RQC_TPB), 0, s, c, w.lin_bits, coarse_ok ? w.coarse : (const uint8_t*)nullptr, rays_o,
+                           rays_d, image, depth, weights_sum, sample_counts, w.queue, w.counters);
+    else
+        hipLaunchKernelGGL(k_first_hit, dim3(ssd_blocks(N, RQ_TPB), S), dim3(RQ_TPB), 0, s, c, w.lin_bits, coarse_ok ? w.coarse : (const uint8_t*)nullptr, rays_o, rays_d, image,
+                           depth, weights_sum, sample_counts, w.queue, w.counters);
     SSD_CHECK_LAUNCH("render_first_hit");
     return SSDNERF_OK;
 }

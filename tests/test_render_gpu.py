@@ -362,20 +362,25 @@ def test_fused_decode_backward_matches_autograd_through_the_eager_decode():
 
 
 @pytest.mark.skipif(__import__("os").environ.get("SSDNERF_TEST_EXPERIMENTAL", "0") != "1",
-                    reason="variant 6 of the shade kernel has not run on hardware yet (set SSDNERF_TEST_EXPERIMENTAL=1)")
-def test_shade_variants_are_bit_identical(tmp_path):
-    """Variant 6 keeps variant 4's operands and product order and only re-schedules them: every output must be bit-identical.  The variant is
-    read once per process (SSDNERF_SHADE_VARIANT), so each runs in its own interpreter on the same two-scene, three-view workload."""
+                    reason="re-scheduled kernel forms that have not run on hardware yet (set SSDNERF_TEST_EXPERIMENTAL=1)")
+def test_rescheduled_kernel_forms_are_bit_identical(tmp_path):
+    """Shade variant 6 (variant 4's operands and product order, tile-interleaved schedule) and the compacting first-hit kernel
+    (SSDNERF_FIRST_HIT_COMPACT=1: same per-ray arithmetic, survivors of the pre-test marched densely) only re-order work: every output must be
+    bit-identical to the default.  Both switches are read once per process, so each form runs in its own interpreter on one workload."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    forms = {"default": {"SSDNERF_SHADE_VARIANT": "4"}, "variant6": {"SSDNERF_SHADE_VARIANT": "6"},
+             "compact": {"SSDNERF_SHADE_VARIANT": "4", "SSDNERF_FIRST_HIT_COMPACT": "1"}}
     outs = {}
-    for var in ("4", "6"):
-        path = str(tmp_path / f"v{var}.npz")
-        env = dict(os.environ, SSDNERF_SHADE_VARIANT=var, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for name, extra in forms.items():
+        path = str(tmp_path / f"{name}.npz")
+        env = {k: v for k, v in os.environ.items() if k not in ("SSDNERF_SHADE_VARIANT", "SSDNERF_FIRST_HIT_COMPACT")}
+        env.update(extra, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
         subprocess.run([sys.executable, os.path.join(root, "tests", "_render_variant.py"), path], check=True, env=env, cwd=root, timeout=300)
-        outs[var] = np.load(path)
-    assert int(outs["4"]["counts"].sum()) > 100000
-    for k in ("counts", "image", "depth", "weights_sum"):
-        assert np.array_equal(outs["4"][k], outs["6"][k]), k
+        outs[name] = np.load(path)
+    assert int(outs["default"]["counts"].sum()) > 100000
+    for name in ("variant6", "compact"):
+        for k in ("counts", "image", "depth", "weights_sum"):
+            assert np.array_equal(outs["default"][k], outs[name][k]), (name, k)
