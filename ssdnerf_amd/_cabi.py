@@ -12,7 +12,8 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssdnerf_hip.so")
+# SSDNERF_HIP_LIB: another build of the SAME library (e.g. one compiled with experimental -D flags into .variants/) for A/B runs
+_LIB_PATH = os.environ.get("SSDNERF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssdnerf_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
 ABI_VERSION = 1

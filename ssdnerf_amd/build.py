@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_DIR = os.path.join(HERE, "lib")
+LIB_DIR = os.environ.get("SSDNERF_LIB_DIR") or os.path.join(HERE, "lib")     # SSDNERF_LIB_DIR + SSDNERF_EXTRA_FLAGS: side builds for A/B runs
 LIB_PATH = os.path.join(LIB_DIR, "libssdnerf_hip.so")
 SOURCES = ["raymarching_ops.hip", "shencoder.hip", "decode.hip", "render_fused.hip", "render_queue.hip", "shade_mfma.hip", "ddim.hip", "groupnorm.hip", "conv_igemm.hip", "attention.hip", "raygen.hip"]
 HEADERS = ["common.h", "sh_basis.h", "decode_core.h", "decode_bwd_math.h", "gn_bwd_math.h", os.path.join("..", "..", "include", "ssdnerf_hip.h")]
