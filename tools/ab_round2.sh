@@ -30,6 +30,8 @@ for s in $SECTIONS; do
       T=150 run finetune_default python tools/bench_finetune.py
       T=150 run finetune_grad_gn env SSDNERF_UNET_GRAD_GN=1 python tools/bench_finetune.py
       T=150 run finetune_grad_gn_att env SSDNERF_UNET_GRAD_GN=1 SSDNERF_UNET_GRAD_ATT=1 python tools/bench_finetune.py
+      T=150 run finetune_bf16_default python tools/bench_finetune.py --dtype bf16
+      T=150 run finetune_bf16_grad_conv env SSDNERF_UNET_GRAD_CONV_BF16=1 python tools/bench_finetune.py --dtype bf16
       ;;
     ubench)
       [ -x .variants/trans_rate ] && T=60 run ubench_trans_rate .variants/trans_rate
