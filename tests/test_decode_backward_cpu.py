@@ -90,3 +90,40 @@ def test_truncated_exp_gradient_clamp(host):
     sig0, _ = point_decode(params, code, torch.from_numpy(xyz), None, density_only=True)
     ratio = gp_big.sum() / gp_ref.sum()
     assert ratio == pytest.approx(1e6 / float(sig0[0]), rel=1e-4)
+
+
+def test_host_build_reproduces_the_reference_train_branch_gradient(host):
+    """The reference's own train-branch render (its Python + its kernels on the CPU, tests/golden/render_train_64.npz): upstream gradients from
+    the oracle's composite backward, pushed through the host build of the decode-backward arithmetic, land on the fixture's d loss / d code."""
+    from oracle import guidance as OG, ops as _ops, render as R
+    from oracle.decoder import sh_encode
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.decoders import pack_mlp_params
+    gold = os.path.join(ROOT, "tests", "golden")
+    f, rays = np.load(os.path.join(gold, "render_train_64.npz")), np.load(os.path.join(gold, "cam_rays_64.npz"))
+    params, code = S.make_decoder_params(), S.make_triplane()
+    g = torch.Generator().manual_seed(7)
+    jit = [torch.rand(64 ** 3, 3, generator=g).numpy() for _ in range(2)]
+    _, bits, _ = R.get_density(params, code, jit, density_thresh=0.1)
+    sub = f["ray_subset"]
+    ro = np.ascontiguousarray(rays["rays_o"][:, sub].reshape(-1, 3), np.float32)
+    rd = np.ascontiguousarray(rays["rays_d"][:, sub].reshape(-1, 3), np.float32)
+    o = _ops()
+    nears, fars = o.near_far_from_aabb(ro, rd, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
+    xyzs, dirs, deltas, rec, counter = o.march_rays_train(ro, rd, bits, 1.0, 0.0038095, 256, 1, 64, nears, fars, np.zeros(ro.shape[0], np.float32))
+    m = int(counter[0])
+    mp = m + 128 - m % 128
+    xyzs, dirs, deltas = np.ascontiguousarray(xyzs[:mp]), np.ascontiguousarray(dirs[:mp]), deltas[:mp]
+    with torch.no_grad():
+        sig, rgb = OG.decode_autograd(params, code, torch.from_numpy(xyzs), torch.from_numpy(dirs))
+    sig, rgb = sig.requires_grad_(True), rgb.requires_grad_(True)
+    ws, _, image = OG._CompositeTrain.apply(sig, rgb, deltas, rec, 1e-4)
+    loss = ((image + (1 - ws.unsqueeze(-1)) - torch.from_numpy(f["target"])) ** 2).mean() * 20.0
+    assert abs(float(loss.detach()) - float(f["loss"])) < 1e-5
+    gs, gc = torch.autograd.grad(loss, [sig, rgb])
+    planes = np.zeros((3, 128, 128, 8), np.float32)
+    planes[..., :6] = code.permute(0, 2, 3, 1).numpy()
+    gp, _ = _run(host, planes, pack_mlp_params(params, "cpu").numpy(), xyzs, sh_encode(torch.from_numpy(dirs)).numpy().astype(np.float32),
+                 np.ascontiguousarray(gs.numpy()), np.ascontiguousarray(gc.numpy()))
+    got = torch.from_numpy(gp[..., :6]).permute(0, 3, 1, 2)[:, :, ::16, ::16].numpy()
+    assert float(np.abs(got - f["grad_code_sample"]).max()) <= 1e-5 * float(f["grad_code_absmax"])
