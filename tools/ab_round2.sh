@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
 # tools/ab_round2.sh [section ...] -- run on the GPU box (gpurun): the A/B measurements DESIGN.md section 6 lists as the first calls of the
-# next round.  Every step has its own timeout and reads no stdin; results go to gpurun_out/ab/.  Sections: parity bench finetune ubench (default: all).
+# next round.  Every step has its own timeout and reads no stdin; results go to gpurun_out/ab/.  Sections: parity bench finetune sample ubench (default: all).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R"
 OUT=$R/gpurun_out/ab
 mkdir -p "$OUT"
-SECTIONS="${@:-parity bench finetune ubench}"
+SECTIONS="${@:-parity bench finetune sample ubench}"
 GP=$R/.variants/gather_pairs/libssdnerf_hip.so
 run() { name=$1; shift; echo "== $name" | tee -a "$OUT/log.txt"; ( timeout "${T:-120}" "$@" ) > "$OUT/$name.out" 2> "$OUT/$name.err" < /dev/null; echo "rc=$? $(tail -n 1 "$OUT/$name.out" | cut -c1-300)" | tee -a "$OUT/log.txt"; }
 for s in $SECTIONS; do
@@ -32,6 +32,10 @@ for s in $SECTIONS; do
       T=150 run finetune_grad_gn_att env SSDNERF_UNET_GRAD_GN=1 SSDNERF_UNET_GRAD_ATT=1 python tools/bench_finetune.py
       T=150 run finetune_bf16_default python tools/bench_finetune.py --dtype bf16
       T=150 run finetune_bf16_grad_conv env SSDNERF_UNET_GRAD_CONV_BF16=1 python tools/bench_finetune.py --dtype bf16
+      ;;
+    sample)
+      T=150 run sample_bf16 python tools/bench_sample.py --dtype bf16
+      T=150 run sample_fp32 python tools/bench_sample.py --dtype fp32
       ;;
     ubench)
       [ -x .variants/trans_rate ] && T=60 run ubench_trans_rate .variants/trans_rate
