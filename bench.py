@@ -3,20 +3,33 @@
 ssdnerf_cars_uncond, 128x128 novel-view render of cached triplanes, 251 views/scene, 8 scenes/GPU/batch).
 
 One "step" = BaseNeRF.render of one batch: S scenes x V views x 128x128 rays through
-AABB -> bitfield-guided march -> triplane gather -> tiny MLP -> composite -> background blend -> uint8 quantise
+camera -> ray -> AABB -> bitfield-guided march -> triplane gather -> tiny MLP -> composite -> background blend -> uint8 quantise
 (and, for N > 1 GPUs, the RCCL all-gather of the rendered uint8 views).  Inputs (packed triplanes, bitfields, MLP
-weights, ray arrays) are resident in HBM before the timed region.  Scenes shard over ranks (weak scaling: S scenes
-per rank); there is no collective inside the render.
+weights, camera poses + intrinsics) are resident in HBM before the timed region; rays are generated inside the kernels
+(`--ray-arrays` feeds pre-materialised (S,N,3) arrays instead, the reference API's form).  Scenes shard over ranks (weak
+scaling: S scenes per rank); there is no collective inside the render.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     : the fused render kernel's ALGORITHMIC bytes (44 B/ray + 288 B/sample) / its mean
-                 launch time measured with HIP events on the launch stream, against the 8 TB/s HBM peak.
-  cpu_baseline : the CPU oracle (reference-shaped loop over the C restatement + PyTorch-CPU decode) timed on the
-                 host cores on a bounded sample of the same workload (rank 0, N == 1 only).
+`python bench.py --gpus N` without a torchrun environment spawns its own N ranks (torch.distributed.run, 127.0.0.1).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      : the shading kernel's ALGORITHMIC bytes (288 B/sample + per-hitting-ray bytes) / its mean launch
+                  time measured with HIP events on the launch stream, against the 8 TB/s HBM peak.
+  cpu_baseline  : the CPU oracle (reference-shaped loop over the C restatement + PyTorch-CPU decode) timed on the
+                  host cores on a bounded sample of the same workload (rank 0, N == 1 only).
+  gpu_baseline  : "B1" of BASELINE.md -- the reference-shaped path on this GPU: the <=256-iteration alive-ray loop of
+                  base_volume_renderer.py:79-123 over the UNFUSED operators with the eager PyTorch decode (grid_sample + nn.Linear) and a
+                  device->host sync per iteration, on a bounded sample of the same workload; value / gpu_baseline.value is the speed-up.
+  ddim          : the DDIM leg of the same config (50 steps over 8 scenes' triplane latents, cars UNet, V-prediction): ms per step,
+                  TFLOP/s and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak, for the config's fp32 executor and the bf16 one.
+  boundary_rays : termination tests that landed within 2e-6 of T_thresh in one step (the only rays whose integer sample count may
+                  differ from the reference's), and the exact sample total, so a drift between kernel builds is visible.
+  uniform_variant: the same render on the worst-case fog scenes (every ray marches through occupied space).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,16 +37,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-BYTES_PER_RAY = 44             # 24 B in (o, d) + 20 B out (rgb, depth, weights_sum)
+MFMA_PEAK_TFLOPS = 2500.0      # same guide: dense bf16 MFMA peak (no sparsity)
 BYTES_PER_SAMPLE = 288         # 3 planes x 4 corners x 6 channels x 4 B
+UNET_FLOP_PER_SCENE = 2.18e11  # cars UNet forward
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -43,20 +53,45 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--variant", default="object", choices=["object", "uniform"])
     ap.add_argument("--plane-dtype", default="float32", choices=["float32", "float16"])
+    ap.add_argument("--ray-arrays", action="store_true", help="feed materialised (S,N,3) ray arrays instead of cameras")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip gpu_baseline / ddim / uniform_variant (profiling runs)")
     ap.add_argument("--cpu-views", type=int, default=64, help="views of scene 0 rendered by the CPU oracle")
-    args = ap.parse_args()
+    ap.add_argument("--b1-views", type=int, default=32, help="views of scene 0 rendered by the reference-shaped eager GPU path")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    return ap.parse_args()
+
+
+def self_spawn(args):
+    """--gpus N outside a torchrun environment: launch N ranks of this script (one process per GPU over RCCL) and relay their output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ssdnerf_amd import synthetic as S
     from ssdnerf_amd import nerf
@@ -69,43 +104,49 @@ def main():
     def log(msg):
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
     params = S.make_decoder_params(2021)
     dec = TriPlaneDecoder(base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], dir_layers=[16, 64], max_steps=256,
                           plane_dtype=args.plane_dtype)
     dec.load_state_dict(params, strict=False)
     dec = dec.to(dev).eval()
-
-    # ---- resident inputs -----------------------------------------------------------------------------------
-    seeds = [2021 + rank * ns + s for s in range(ns)]               # mirrors --diff_seed: distinct scenes per rank
-    code_cpu = torch.stack([S.make_triplane(sd, args.variant) for sd in seeds], dim=0)
-    code = code_cpu.to(dev)
-    log('synthetic scenes built')
     g = torch.Generator().manual_seed(7)
     jit_cpu = [torch.rand(64 ** 3, 3, generator=g) for _ in range(8)]
-    grid, bits = get_density(dec, code, 64, density_thresh=0.1, density_step=8, jitters=[j.to(dev) for j in jit_cpu])
-    planes = pack_triplanes(code, dec.plane_dtype)
-    torch.cuda.synchronize(); log('density grids + packed planes ready')
     poses = S.spiral_poses(nv).to(dev)[None].expand(ns, -1, -1, -1).contiguous()
     intr = S.cars_intrinsics(hw, hw).to(dev)[None, None].expand(ns, nv, -1).contiguous()
-    t0 = time.perf_counter()
-    rays_o, rays_d = nerf.get_cam_rays(poses, intr, hw, hw)
-    rays_o = rays_o.reshape(ns, nv * hw * hw, 3).contiguous()
-    rays_d = rays_d.reshape(ns, nv * hw * hw, 3).contiguous()
-    torch.cuda.synchronize()
-    ms_raygen = (time.perf_counter() - t0) * 1e3
-    log(f'rays generated ({ms_raygen:.0f} ms)')
     n_rays = ns * nv * hw * hw
+    bytes_per_hit_ray = 8 + 20 + (24 if args.ray_arrays else 0)     # queue entry + outputs (+ the ray, when it is read instead of generated)
+
+    def build_scenes(variant):
+        seeds = [2021 + rank * ns + s for s in range(ns)]           # mirrors --diff_seed: distinct scenes per rank
+        code_cpu = torch.stack([S.make_triplane(sd, variant) for sd in seeds], dim=0)
+        code = code_cpu.to(dev)
+        _, bits = get_density(dec, code, 64, density_thresh=0.1, density_step=8, jitters=[j.to(dev) for j in jit_cpu])
+        return code_cpu, pack_triplanes(code, dec.plane_dtype), bits
+
+    code_cpu, planes, bits = build_scenes(args.variant)
+    torch.cuda.synchronize(); log("synthetic scenes, density grids, packed planes ready")
+    rays = None
+    if args.ray_arrays:
+        ro, rd = nerf.get_cam_rays(poses, intr, hw, hw)
+        rays = (ro.reshape(ns, -1, 3).contiguous(), rd.reshape(ns, -1, 3).contiguous())
+        del ro, rd
+
+    def render(planes_, bits_, **kw):
+        if rays is not None:
+            return dec.render_packed(planes_, rays[0], rays[1], bits_, 64, [0.0] * ns, 1e-4, bg_color=1.0, check_overflow=False, **kw)
+        return dec.render_packed(planes_, None, None, bits_, 64, [0.0] * ns, 1e-4, bg_color=1.0, check_overflow=False, cams=(poses, intr, hw, hw), **kw)
+
     # N > 1: every rank ends up with every rank's quantised views (RCCL all-gather over xGMI).  The collective of step i runs on RCCL's
     # stream while step i+1 renders (two landing buffers); the compute stream only waits for it before issuing the next collective.
     gathered = [torch.empty(world * ns, nv, hw, hw, 3, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
     pending = {"work": None, "i": 0, "keep": None}
-    kernel_events = []
 
-    def step(record=False):
-        dec.stage_events = [] if record else None      # HIP events on the launch stream: [before A, between A and B, after B]
-        out = dec.render_packed(planes, rays_o, rays_d, bits, 64, [0.0] * ns, 1e-4, bg_color=1.0, check_overflow=False)
-        if record:
-            kernel_events.append(dec.stage_events)
+    def step(planes_, bits_, events=None):
+        dec.stage_events = [] if events is not None else None      # HIP events on the launch stream: [before A, between A and B, after B]
+        out = render(planes_, bits_)
+        if events is not None:
+            events.append(dec.stage_events)
             dec.stage_events = None
         img_u8 = nerf.quantize_u8(out["image"]).reshape(ns, nv, hw, hw, 3)
         if world > 1:
@@ -114,60 +155,69 @@ def main():
             pending["keep"] = img_u8                     # the source must stay alive until the collective has run
             pending["work"] = dist.all_gather_into_tensor(gathered[pending["i"] & 1], img_u8, async_op=True)
             pending["i"] += 1
-        return out, img_u8
+        return out
 
     def drain():
         if pending["work"] is not None:
             pending["work"].wait()
             pending["work"] = None
 
-    # one untimed pass for the integer statistics the roofline needs (exact sample count of this workload)
-    out = dec.render_packed(planes, rays_o, rays_d, bits, 64, [0.0] * ns, 1e-4, bg_color=1.0, want_counts=True, check_overflow=False)
-    counts = dec.last_render_stats["sample_counts"]
-    n_samples = int(counts.sum().item())
-    counts_gt0 = int((counts > 0).sum().item())
-    overflow = int(dec.last_render_stats["overflow"].item())
-    del counts
-    log(f'stat pass done: {n_samples} samples, overflow {overflow}')
+    def stat_pass(planes_, bits_):
+        """one untimed pass for the integer statistics (exact sample count of this workload, hitting rays, boundary tests)"""
+        render(planes_, bits_, want_counts=True)
+        st = dec.last_render_stats
+        counts = st["sample_counts"]
+        res = dict(n_samples=int(counts.sum().item()), n_hit=int((counts > 0).sum().item()), overflow=int(st["overflow"].item()),
+                   boundary=None if st.get("boundary_tests") is None else int(st["boundary_tests"].sum().item()))
+        del counts
+        return res
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
+    def timed(planes_, bits_, warmup, steps):
+        events = []
+        for _ in range(warmup):
+            step(planes_, bits_)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step(planes_, bits_, events)
+        drain()                                              # the last step's collective is inside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, events, out
+
+    stats = stat_pass(planes, bits)
+    log(f"stat pass done: {stats['n_samples']} samples, overflow {stats['overflow']}, boundary tests {stats['boundary']}")
+    elapsed, kernel_events, out = timed(planes, bits, args.warmup, args.steps)
+    n_samples = stats["n_samples"]
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, img_u8 = step(record=True)
-    drain()                                              # the last step's collective is inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         tot = torch.tensor([n_samples], dtype=torch.float64, device=dev)
         dist.all_reduce(tot)
         n_samples_all = int(tot.item())
     else:
         n_samples_all = n_samples
     ms_per_step = elapsed / args.steps * 1e3
-    log(f'timed region done: {ms_per_step:.2f} ms/step')
+    log(f"timed region done: {ms_per_step:.2f} ms/step")
     rays_per_s = world * n_rays / (elapsed / args.steps)
 
     first_hit_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in kernel_events]))
     shade_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in kernel_events]))
-    kern_ms = shade_ms
-    # dominant kernel = k_shade_queue (gather + MLP + composite).  Its algorithmic bytes: 288 B per sample it shades plus,
-    # per hitting ray, 8 B queue entry + 24 B ray + 20 B outputs.
-    n_hit = int((counts_gt0))
-    algo_bytes = n_samples * BYTES_PER_SAMPLE + n_hit * (8 + BYTES_PER_RAY)
-    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    first_hit_bytes = n_rays * 24 + (n_rays - n_hit) * 20 + n_hit * 8
+    # dominant kernel = k_shade_mfma (gather + MLP + composite).  Its algorithmic bytes: 288 B per sample it shades plus,
+    # per hitting ray, 8 B queue entry + 20 B outputs (+ 24 B ray when ray arrays are read).
+    n_hit = stats["n_hit"]
+    algo_bytes = n_samples * BYTES_PER_SAMPLE + n_hit * bytes_per_hit_ray
+    achieved = algo_bytes / (shade_ms * 1e-3) / 1e9
+    first_hit_bytes = n_rays * (24 if args.ray_arrays else 0) + (n_rays - n_hit) * 20 + n_hit * 8
 
     traffic = None          # HBM bytes per launch from the PMC counters: measured offline (separate rocprofv3 passes), valid for the default workload only
     try:
@@ -185,30 +235,144 @@ def main():
         "config": {"workload": "ssdnerf_cars_uncond render of cached triplanes (BASELINE.json configs[1])", "scenes_per_gpu": ns,
                    "views_per_scene": nv, "image": f"{hw}x{hw}", "rays_per_step_per_gpu": n_rays, "grid_size": 64, "max_steps": 256,
                    "T_thresh": 1e-4, "dt_gamma": 0.0, "scene_variant": args.variant, "parallelism": f"scene-parallel x{world}",
+                   "ray_source": "(S,N,3) ray arrays" if args.ray_arrays else "cameras (rays generated in the kernels)",
                    "collective": "all_gather(uint8 views), overlapped with the next step's render" if world > 1 else "none"},
-        "views_per_s": rays_per_s / (hw * hw), "samples_per_s": world * n_samples / (elapsed / args.steps) if world == 1 else n_samples_all / (elapsed / args.steps),
-        "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": overflow, "ms_raygen_untimed": ms_raygen,
+        "views_per_s": rays_per_s / (hw * hw), "samples_per_s": n_samples_all / (elapsed / args.steps),
+        "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": stats["overflow"],
         "roofline": {"bound": "hbm", "kernel": "k_shade_mfma", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
-                     "launch_ms": kern_ms, "launches_per_step": 1,
-                     "note": "algorithmic = 288 B/sample + 52 B per hitting ray; planes (1.5 MiB/scene) are L2-resident, so real HBM "
+                     "launch_ms": shade_ms, "launches_per_step": 1,
+                     "note": f"algorithmic = 288 B/sample + {bytes_per_hit_ray} B per hitting ray; planes (1.5 MiB/scene) are L2-resident, so real HBM "
                              "traffic is far below this (PMC numbers in DESIGN.md / profiles/)",
-                     "other_kernels": {"k_first_hit": {"launch_ms": first_hit_ms, "algorithmic_bytes_per_launch": first_hit_bytes,
-                                                       "achieved_GBs": first_hit_bytes / (first_hit_ms * 1e-3) / 1e9}}},
+                     "other_kernels": {"first_hit (k_ray_cull + k_survivor_march)": {
+                         "launch_ms": first_hit_ms, "algorithmic_bytes_per_launch": first_hit_bytes,
+                         "achieved_GBs": first_hit_bytes / (first_hit_ms * 1e-3) / 1e9}}},
         "hit_rays_per_step_per_gpu": n_hit,
+        "boundary_rays": {"termination_tests_within_2e-6_of_T_thresh": stats["boundary"], "samples_per_step_per_gpu": n_samples},
     }
 
+    extras = rank == 0 and world == 1 and not args.no_extras
+    if extras:
+        try:
+            result["gpu_baseline"] = gpu_baseline_b1(dec, code_cpu[0].to(dev), bits[0], min(args.b1_views, nv), hw, out, nv, rays_per_s)
+            log(f"gpu_baseline done: {result['gpu_baseline']['value']:.3g} rays/s")
+        except Exception as e:                               # an extra must never cost the headline line
+            result["gpu_baseline"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(params, code_cpu[0], bits[0].cpu().numpy(), min(args.cpu_views, nv), hw, out, nv)
+        log("cpu_baseline done")
+    del out
+    if extras and args.variant == "object":
+        try:
+            _, planes_u, bits_u = build_scenes("uniform")
+            st_u = stat_pass(planes_u, bits_u)
+            el_u, ev_u, _ = timed(planes_u, bits_u, 1, 3)
+            result["uniform_variant"] = {"ms_per_step": el_u / 3 * 1e3, "rays_per_s": n_rays / (el_u / 3), "samples_per_s": st_u["n_samples"] / (el_u / 3),
+                                         "mean_samples_per_ray": st_u["n_samples"] / n_rays,
+                                         "shade_launch_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in ev_u])),
+                                         "shade_algorithmic_GBs": (st_u["n_samples"] * BYTES_PER_SAMPLE + st_u["n_hit"] * bytes_per_hit_ray)
+                                         / (float(np.mean([e[1].elapsed_time(e[2]) for e in ev_u])) * 1e-3) / 1e9,
+                                         "boundary_tests": st_u["boundary"], "rays_at_step_cap": st_u["overflow"]}
+            del planes_u, bits_u
+            log("uniform variant done")
+        except Exception as e:
+            result["uniform_variant"] = {"error": repr(e)}
+    if extras:
+        del planes
+        torch.cuda.empty_cache()
+        try:
+            result["ddim"] = ddim_leg(dev, ns, args.ddim_steps, log)
+        except Exception as e:
+            result["ddim"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
 
 
+def gpu_baseline_b1(dec, code0, bits0, n_views, hw, gpu_out, nv, fused_rays_per_s):
+    """the reference-shaped render on THIS GPU -- alive-ray loop, unfused march / composite operators, eager PyTorch decode,
+    a host sync per iteration -- for `n_views` views of scene 0 as one ray batch (the reference batches all views of a scene)."""
+    import numpy as np
+    import torch
+    from ssdnerf_amd import nerf, synthetic as S
+    dev = code0.device
+    poses = S.spiral_poses(nv)[:n_views].to(dev)[None]
+    intr = S.cars_intrinsics(hw, hw).to(dev)[None, None].expand(1, n_views, -1)
+    ro, rd = nerf.get_cam_rays(poses, intr, hw, hw)
+    ro, rd = ro.reshape(1, -1, 3), rd.reshape(1, -1, 3)
+    dec.render_mode, dec.eager_decode = "stepwise", True
+    try:
+        with torch.no_grad():
+            for rep in range(2):                             # rep 0 warms the allocator / library kernel caches
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = dec(ro, rd, code0[None], bits0[None], 64, dt_gamma=0.0, perturb=False)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+        iters = len(dec.last_render_stats["iterations"][0])
+    finally:
+        dec.render_mode, dec.eager_decode = "fused", False
+    ws = res["weights_sum"][0]
+    rgb = res["image"][0] + 1.0 * (1 - ws.unsqueeze(-1))
+    got = gpu_out["image"][0].reshape(nv, hw * hw, 3)[:n_views].reshape(-1, 3)
+    n = n_views * hw * hw
+    return {"value": n / dt, "unit": "rays/s", "kind": "reference-shaped eager path on the same MI355X (B1)",
+            "sample": f"scene 0, {n_views} views of {hw}x{hw} as one batch ({n} rays), {dt * 1e3:.0f} ms, {iters} loop iterations "
+                      "(march_rays -> grid_sample + nn.Linear decode -> composite_rays -> compaction with a host sync each)",
+            "speedup_of_fused_path": fused_rays_per_s / (n / dt), "max_abs_rgb_diff_vs_fused": float((rgb - got).abs().max().item())}
+
+
+def ddim_leg(dev, ns, n_steps, log):
+    """50-step DDIM (eta 0, V-prediction, clip [-2, 2]) over `ns` scenes' (18,128,128) latents with the cars UNet (122 M parameters, random
+    weights -- timing only), through the product's sampler: fp32 (what ssdnerf_cars_uncond runs: no autocast) and bf16 (config 5)."""
+    import torch
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.registry import MODULES
+    diff = MODULES.build(dict(
+        type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"), denoising_mean_mode="V",
+        denoising=dict(type="DenoisingUnetMod", image_size=128, in_channels=18, base_channels=128, channels_cfg=[1, 2, 2, 4, 4],
+                       resblocks_per_downsample=2, dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True,
+                       num_heads=4, attention_res=[32, 16, 8]),
+        timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+        ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight", log_cfgs=None, data_info=dict(pred="v_t_pred", target="v_t"),
+                       weight_scale=4.0, scale_norm=True),
+        test_cfg=dict(num_timesteps=n_steps, clip_range=[-2, 2])))
+    diff = diff.to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for p in diff.denoising.parameters():
+            p.copy_(torch.randn(p.shape, generator=g, device=dev) * 0.02)
+    out = {"scenes": ns, "steps": n_steps, "unet": "DenoisingUnetMod cars (122.4 M parameters, 218 GFLOP forward per scene)", "weights": "random"}
+    noise = torch.randn(ns, 18, 128, 128, generator=g, device=dev)
+    for name, dt in (("fp32", None), ("bf16", torch.bfloat16)):
+        best = None
+        with torch.no_grad(), torch.autocast("cuda", enabled=dt is not None, dtype=dt):
+            for rep in range(3):                             # rep 0: graph capture / library kernel selection
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                x0 = diff(noise, return_loss=False)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                if rep and (best is None or el < best):
+                    best = el
+        ms = best / n_steps * 1e3
+        tflops = ns * UNET_FLOP_PER_SCENE / (ms * 1e-3) / 1e12
+        ex = getattr(diff.denoising, "_fast_cache", {}).get(torch.float32 if dt is None else dt)
+        out[name] = {"ms_per_step": ms, "dtype": "f32 activations, bf16x2-split products on the matrix cores" if dt is None else "bf16",
+                     "tflops": tflops, "mfma_frac_of_2.5PF": tflops / MFMA_PEAK_TFLOPS, "scenes_per_s": ns / best,
+                     "library_fallback_ops": None if ex is None else getattr(ex, "library_fallbacks", None), "finite": bool(torch.isfinite(x0).all())}
+        log(f"ddim {name}: {ms:.2f} ms/step, {tflops:.0f} TFLOP/s")
+    out.update(ms_per_step=out["fp32"]["ms_per_step"], dtype="fp32 config (ssdnerf_cars_uncond runs the UNet without autocast); bf16 beside it",
+               tflops=out["fp32"]["tflops"], **{"mfma_frac_of_2.5PF": out["fp32"]["mfma_frac_of_2.5PF"]}, scenes_per_s=out["fp32"]["scenes_per_s"])
+    return out
+
+
 def cpu_baseline(params, code0, bits0, n_views, hw, gpu_out, nv):
     """Oracle on the host cores: scene 0, `n_views` views, same triplane / bitfield / rays as the GPU run.
     Also reports the GPU-vs-oracle error on that sample."""
+    import numpy as np
+    import torch
     import oracle
     from oracle import render as R
     from ssdnerf_amd import synthetic as S

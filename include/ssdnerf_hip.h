@@ -165,8 +165,9 @@ int ssdnerf_render_rays_fused_batch(const void* planes, int planes_dtype, uint32
                                     void* stream);
 
 /* The same render as two stages (the fast path for power-of-two grids; csrc/render_queue.hip):
- *   first_hit   : every ray marched to its first occupied sample; rays without one are finished here (background written),
- *                 the others are appended to a per-scene hit queue inside `workspace`;
+ *   first_hit   : a conservative empty-space pre-test finishes the rays that cannot meet an occupied cell (background written)
+ *                 and lists the others; the listed rays are marched, densely, to their first occupied sample; rays without one
+ *                 are finished too, the others are appended to a per-scene hit queue inside `workspace`;
  *   shade_queue : persistent waves shade the queued rays (gather + MLP + composite + onward march).
  * Both take the SAME workspace (ssdnerf_render_queue_workspace(S, N, grid_size) bytes, caller-owned) and must be issued
  * in this order on one stream.  Results are bit-identical to ssdnerf_render_rays_fused_batch. */
@@ -182,15 +183,32 @@ int ssdnerf_render_shade_queue(const void* planes, int planes_dtype, uint32_t Hp
                                int32_t* sample_counts, int32_t* overflow_flag, void* workspace, size_t workspace_bytes,
                                void* stream);
 
-/* Stage B with the 18->64 and 16->64 MLP layers on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) and wave-local LDS
- * pools that turn long empty-space searches into full-width march passes (csrc/shade_mfma.hip).  Same arguments and
- * workspace as ssdnerf_render_shade_queue; integer outputs identical, floats within fp32 rounding. */
+/* Stage B with the 18->64 and 16->64 MLP layers on the bf16 matrix cores in fp32-class arithmetic (every operand split exactly into
+ * three bf16 terms) and wave-local LDS pools that turn long empty-space searches into full-width march passes
+ * (csrc/shade_mfma.hip).  Same arguments and workspace as ssdnerf_render_shade_queue; integer outputs identical, floats within
+ * fp32 rounding. */
 int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
                                     uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N,
                                     float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps,
                                     float T_thresh, float bg_color, float sigmoid_saturation, float* image, float* depth,
                                     float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag, void* workspace,
                                     size_t workspace_bytes, void* stream);
+
+/* The same two stages fed with CAMERAS instead of ray arrays: c2w [S][V][4][4] row-major, intrinsics [S][V][4] = {fx, fy, cx, cy};
+ * ray n = pixel (n % (h*w)) of view n / (h*w), N = V*h*w rays per scene, generated in the kernels by the arithmetic of
+ * ssdnerf_cam_rays (get_cam_rays, lib/core/utils/nerf_utils.py:17-61; a generated ray is bit-identical to the stored one), so
+ * BaseNeRF.render (base_nerf.py:494-533) never materialises its (S,V,h,w,3) ray arrays: 80 B per view instead of 24 B per ray.
+ * Workspace: ssdnerf_render_queue_workspace(S, V*h*w, grid_size).  Outputs as above, (S, V*h*w, ...). */
+int ssdnerf_render_first_hit_cams(const uint8_t* bitfield, uint32_t grid_size, const float* c2w, const float* intrinsics, uint32_t S,
+                                  uint32_t V, uint32_t h, uint32_t w, float bound, float min_near, float dt_gamma,
+                                  const float* dt_gammas, uint32_t max_steps, float bg_color, float* image, float* depth,
+                                  float* weights_sum, int32_t* sample_counts, void* workspace, size_t workspace_bytes, void* stream);
+int ssdnerf_render_shade_queue_mfma_cams(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                         uint32_t grid_size, const float* c2w, const float* intrinsics, uint32_t S, uint32_t V,
+                                         uint32_t h, uint32_t w, float bound, float min_near, float dt_gamma, const float* dt_gammas,
+                                         uint32_t max_steps, float T_thresh, float bg_color, float sigmoid_saturation, float* image,
+                                         float* depth, float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag,
+                                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused full-refresh branch of BaseNeRF.update_extra_state (base_nerf.py:328-351,377-387) for S scenes:
  * for every cell of the H^3 grid (x-major order like custom_meshgrid) decode sigma at the jittered cell centre
@@ -298,8 +316,13 @@ int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, cons
 /* Self-attention of MultiHeadAttentionMod (modules.py:12-48; mmgen QKVAttention) over the qkv projection of a channel-last
  * activation: qkv bf16 [B][T][3*heads*ch] with the reference's channel order [head][q | k | v][ch], out bf16 [B][T][heads*ch]
  * (channel = head*ch + i):  out = softmax(q k^T / sqrt(ch)) v  per (sample, head), softmax statistics and accumulation in fp32,
- * probabilities rounded to bf16 before the PV product (as the reference's `.type(weight.dtype)`).  ch in {64, 128}, T % 32 == 0. */
+ * probabilities rounded to bf16 before the PV product (as the reference's `.type(weight.dtype)`).  Any T >= 1; ch a multiple of 8 in
+ * [8, 128] (keys / channels past the tensor are masked). */
 int ssdnerf_attention_qkv_bf16(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
+/* The same for the fp32 configs (the UNet runs without autocast in every paper config but the fp16 one): qkv, out fp32; q, k, v and the
+ * probabilities are each split into a bf16 pair and every product is hi*hi + hi*lo + lo*hi in fp32 on the matrix cores (the arithmetic
+ * class of ssdnerf_conv2d_nhwc_f32x2), softmax in fp32. */
+int ssdnerf_attention_qkv_f32(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,9 @@
 // ssdnerf_amd/csrc/attention.hip -- the denoising UNet's self-attention (MultiHeadAttentionMod.QKVAttention,
 // lib/models/architecture/ddpm/modules.py:12-48 + mmgen's QKVAttention) on the bf16 matrix cores.
 //
-// Input is the qkv projection of the channel-last activation, [B][T][3C] bf16 with the reference's per-head channel order
-// [head][q | k | v][ch]; output is [B][T][C] bf16, channel = head*ch + i (what the proj GEMM consumes).  16 sites per forward:
-// T = 1024 (ch 64), 256 and 64 (ch 128), B*heads = 32 independent problems each.
+// Input is the qkv projection of the channel-last activation, [B][T][3C] with the reference's per-head channel order
+// [head][q | k | v][ch]; output is [B][T][C], channel = head*ch + i (what the proj GEMM consumes).  Cars layout: 16 sites per forward,
+// T = 1024 (ch 64), 256 and 64 (ch 128), B*heads = 32 independent problems each; tiled layout: T = 768 / 192 / 48, ch = 40 / 80.
 //
 // Flash-style, one pass over the keys, nothing T x T ever leaves the registers:
 //   * a wave owns 32 queries; per block of 32 keys it computes  S^T = K Q^T  with v_mfma_f32_32x32x16_bf16 -- transposed on
@@ -13,8 +13,16 @@
 //     C-layout's key order per lane half ({0-3, 8-11} / {4-7, 12-15} of every 16) is simply adopted as the k-slot order, and the
 //     V tile is written to LDS transposed in that same order, so no permute or LDS round trip of P is needed;
 //   * K fragments come straight from L2 into registers (each lane's 16 bytes are contiguous in the qkv row), V goes through LDS
-//     because it needs the transpose; both are prefetched one key block ahead; one barrier per key block;
+//     because it needs the transpose; one barrier per key block;
 //   * softmax statistics in fp32, O accumulated in fp32, divided by the row sum at the end.
+//
+// Two element types share the kernel (template F32):
+//   bf16 : operands as stored; P rounded to bf16 (the reference's `.type(weight.dtype)` under autocast).
+//   fp32 : the fp32 configs (no autocast).  q, k, v and P are each split into a bf16 pair (hi = bf16(x), lo = bf16(x - hi)) and every product
+//          is hi*hi + hi*lo + lo*hi accumulated in fp32 -- >= 16 significand bits per factor, the arithmetic class of the fp32 convolutions
+//          (k_conv_igemm_f32x2); three MFMAs where the bf16 form has one, still < 3 % of the UNet's matrix work.
+// Shapes: any T >= 1 (keys past T are masked to -inf / zero V rows, queries past T are not stored) and any head width ch that is a
+// multiple of 8 up to 128 (the kernel is instantiated for the padded widths 32 / 64 / 96 / 128; channels past ch read as zeros).
 #include "common.h"
 
 namespace {
@@ -28,6 +36,22 @@ SSD_DEV uint32_t at_bf16_rne(float x) {
     const uint32_t u = __float_as_uint(x);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+SSD_DEV float at_bf16_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// 8 fp32 values -> bf16 hi and lo operand vectors (x ~= hi + lo to >= 16 significand bits)
+SSD_DEV void at_split8(const float4& a, const float4& b, bf16x8& hi, bf16x8& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = at_bf16_rne(v[e]);
+        l[e] = at_bf16_rne(v[e] - at_bf16_to_f32(h[e]));
+    }
+    const uint4 uh = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    const uint4 ul = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    hi = *reinterpret_cast<const bf16x8*>(&uh);
+    lo = *reinterpret_cast<const bf16x8*>(&ul);
+}
 
 // position of key kk (0..31) inside a V^T row: per 16 keys, lane half 0 owns {0-3, 8-11}, half 1 owns {4-7, 12-15} (MFMA C layout)
 SSD_DEV uint32_t at_key_pos(uint32_t kk) {
@@ -35,53 +59,82 @@ SSD_DEV uint32_t at_key_pos(uint32_t kk) {
     return (kk & 16u) + ((w >> 2) & 1u) * 8u + (w & 3u) + 4u * (w >> 3);
 }
 
-template <int CH>
-__global__ __launch_bounds__(256) void k_attn_fwd_bf16(const unsigned char* __restrict__ qkv, unsigned char* __restrict__ out, uint32_t T, uint32_t heads,
-                                                       float scale_log2e) {
-    constexpr int KS = CH / 16;            // k-steps of the QK^T product
-    constexpr int CT = CH / 32;            // 32-channel tiles of O
-    constexpr int VCH = (32 * CH / 8) / 256;   // 16-byte V chunks per thread per key block
-    __shared__ __attribute__((aligned(16))) unsigned char vt[2][CH * AT_ROW];
+template <int CHP, bool F32>
+__global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restrict__ qkv, unsigned char* __restrict__ out, uint32_t T, uint32_t heads,
+                                                  uint32_t ch, float scale_log2e) {
+    constexpr int KS = CHP / 16;           // k-steps of the QK^T product
+    constexpr int CT = CHP / 32;           // 32-channel tiles of O
+    constexpr int VTOT = 32 * CHP / 8;     // 8-channel V chunks per key block
+    constexpr int VCH = (VTOT + 255) / 256; // ... per thread
+    constexpr int ES = F32 ? 4 : 2;        // bytes per stored element
+    constexpr int NT = F32 ? 2 : 1;        // operand terms (hi, lo)
+    __shared__ __attribute__((aligned(16))) unsigned char vt[2][NT][CHP * AT_ROW];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
-    const uint32_t b = blockIdx.y / heads, h = blockIdx.y % heads, C = heads * CH;
-    const size_t row_bytes = (size_t)3 * C * 2;
-    const unsigned char* base = qkv + (size_t)b * T * row_bytes + (size_t)h * 3 * CH * 2;       // q of this head; k at +CH, v at +2CH elements
+    const uint32_t b = blockIdx.y / heads, h = blockIdx.y % heads, C = heads * ch;
+    const size_t row_bytes = (size_t)3 * C * ES;
+    const unsigned char* base = qkv + (size_t)b * T * row_bytes + (size_t)h * 3 * ch * ES;      // q of this head; k at +ch, v at +2ch elements
     const uint32_t q0 = blockIdx.x * 128 + wave * 32;
-    const bool active = q0 < T;
+    const bool active = q0 < T;                          // wave-uniform
+    const uint32_t nchunk = ch / 8;                      // valid 8-channel chunks per row
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    bf16x8 qf[KS];
+    // 8 channels [c8*8, c8*8+8) of row `row` of q (which = 0), k (1) or v (2) as operand terms; zeros outside the tensor
+    auto load8 = [&](uint32_t row, uint32_t which, uint32_t c8, bf16x8& hi, bf16x8& lo) {
+        hi = zero8; lo = zero8;
+        if (row < T && c8 < nchunk) {
+            const unsigned char* p = base + (size_t)row * row_bytes + ((size_t)which * ch + c8 * 8) * ES;
+            if constexpr (F32) at_split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 16), hi, lo);
+            else hi = *reinterpret_cast<const bf16x8*>(p);
+        }
+    };
+
+    bf16x8 qf[NT][KS];
     if (active) {
-        const unsigned char* qp = base + (size_t)(q0 + l31) * row_bytes + hf * 16;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 32);
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 hi, lo;
+            load8(q0 + l31, 0, 2 * s + hf, hi, lo);
+            qf[0][s] = hi;
+            if constexpr (F32) qf[1][s] = lo;
+        }
     }
 
     // V staging: chunk id = tid + 256*i -> (key, 8-channel chunk)
-    uint4 vreg[VCH];
+    bf16x8 vreg[NT][VCH];
     auto v_load = [&](uint32_t kb) {
 #pragma unroll
         for (int i = 0; i < VCH; ++i) {
-            const uint32_t id = tid + 256 * i, key = id / (CH / 8), cc = id % (CH / 8);
-            vreg[i] = *reinterpret_cast<const uint4*>(base + (size_t)(kb * 32 + key) * row_bytes + (2 * CH + cc * 8) * 2);
+            const uint32_t id = tid + 256 * i, key = id / (CHP / 8), cc = id % (CHP / 8);
+            bf16x8 hi, lo;
+            load8(id < VTOT ? kb * 32 + key : T, 2, cc, hi, lo);
+            vreg[0][i] = hi;
+            if constexpr (F32) vreg[1][i] = lo;
         }
     };
     auto v_store = [&](uint32_t buf) {
 #pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            const uint32_t id = tid + 256 * i, key = id / (CH / 8), cc = id % (CH / 8);
-            const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
-            unsigned char* dst = vt[buf] + (cc * 8) * AT_ROW + at_key_pos(key) * 2;
+        for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<uint16_t*>(dst + e * AT_ROW) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
-        }
+            for (int i = 0; i < VCH; ++i) {
+                const uint32_t id = tid + 256 * i, key = id / (CHP / 8), cc = id % (CHP / 8);
+                if (id >= VTOT) continue;
+                const uint4 u = *reinterpret_cast<const uint4*>(&vreg[tm][i]);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+                unsigned char* dst = vt[buf][tm] + (cc * 8) * AT_ROW + at_key_pos(key) * 2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<uint16_t*>(dst + e * AT_ROW) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+            }
     };
-    bf16x8 kf[KS];
-    auto k_load = [&](uint32_t kb) {
-        const unsigned char* kp = base + (size_t)(kb * 32 + l31) * row_bytes + (CH + hf * 8) * 2;
+    // bf16: K fragments are prefetched one key block ahead (16 B per lane per k-step); fp32: loaded and split at their use (the split pair of a
+    // whole block would not fit the register file next to Q and O)
+    bf16x8 kf[F32 ? 1 : KS];
+    auto k_prefetch = [&](uint32_t kb) {
+        if constexpr (!F32) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kp + s * 32);
+            for (int s = 0; s < KS; ++s) { bf16x8 lo; load8(kb * 32 + l31, 1, 2 * s + hf, kf[s], lo); }
+        }
     };
 
     f32x16 o[CT];
@@ -91,26 +144,45 @@ __global__ __launch_bounds__(256) void k_attn_fwd_bf16(const unsigned char* __re
         for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    const uint32_t nkb = T / 32;
+    const uint32_t nkb = (T + 31) / 32;
     v_load(0);
     v_store(0);
-    if (active) k_load(0);
+    if (active) k_prefetch(0);
     __syncthreads();
     for (uint32_t kb = 0; kb < nkb; ++kb) {
         const uint32_t buf = kb & 1;
-        bf16x8 kcur[KS];
+        bf16x8 kcur[F32 ? 1 : KS];
+        if constexpr (!F32) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) kcur[s] = kf[s];
+            for (int s = 0; s < KS; ++s) kcur[s] = kf[s];
+        }
         if (kb + 1 < nkb) {                                                  // prefetch the next key block (K -> registers, V -> registers)
             v_load(kb + 1);
-            if (active) k_load(kb + 1);
+            if (active) k_prefetch(kb + 1);
         }
         if (active) {
             f32x16 sacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[s], qf[s], sacc, 0, 0, 0);   // S^T[key][query]
+            for (int s = 0; s < KS; ++s) {                                   // S^T[key][query]
+                if constexpr (F32) {
+                    bf16x8 khi, klo;
+                    load8(kb * 32 + l31, 1, 2 * s + hf, khi, klo);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qf[0][s], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[1][s], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[0][s], sacc, 0, 0, 0);
+                } else {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[s], qf[0][s], sacc, 0, 0, 0);
+                }
+            }
+            if ((kb + 1) * 32 > T) {                                         // last, partial key block: keys past T never win the softmax
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf;       // C layout: register e of lane half hf
+                    if (key >= T) sacc[e] = -1e30f;
+                }
+            }
             float mx = sacc[0];
 #pragma unroll
             for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sacc[e]);
@@ -126,52 +198,85 @@ __global__ __launch_bounds__(256) void k_attn_fwd_bf16(const unsigned char* __re
             for (int c = 0; c < CT; ++c)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[c][e] *= alpha;
-            bf16x8 pb[2];
+            bf16x8 pb[NT][2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                uint32_t w[4];
+                uint32_t wh[4], wl[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = at_bf16_rne(p[8 * s + 2 * k]) | (at_bf16_rne(p[8 * s + 2 * k + 1]) << 16);
-                const uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
-                pb[s] = *reinterpret_cast<const bf16x8*>(&u);
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t h0 = at_bf16_rne(p[8 * s + 2 * k]), h1 = at_bf16_rne(p[8 * s + 2 * k + 1]);
+                    wh[k] = h0 | (h1 << 16);
+                    if constexpr (F32)
+                        wl[k] = at_bf16_rne(p[8 * s + 2 * k] - at_bf16_to_f32(h0)) | (at_bf16_rne(p[8 * s + 2 * k + 1] - at_bf16_to_f32(h1)) << 16);
+                }
+                const uint4 u = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+                pb[0][s] = *reinterpret_cast<const bf16x8*>(&u);
+                if constexpr (F32) {
+                    const uint4 ul = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+                    pb[1][s] = *reinterpret_cast<const bf16x8*>(&ul);
+                }
             }
-            const unsigned char* vrow = vt[buf] + l31 * AT_ROW + hf * 16;
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vrow + c * 32 * AT_ROW + s * 32);   // V^T[channel][8 keys of this half]
-                    o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s], o[c], 0, 0, 0);              // O^T[channel][query]
+                for (int s = 0; s < 2; ++s) {                                // O^T[channel][query] += V^T[channel][8 keys of this half] P
+                    const size_t off = (size_t)(c * 32 + l31) * AT_ROW + s * 32 + hf * 16;
+                    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vt[buf][0] + off);
+                    if constexpr (F32) {
+                        const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vt[buf][1] + off);
+                        o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, pb[0][s], o[c], 0, 0, 0);
+                        o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pb[1][s], o[c], 0, 0, 0);
+                    }
+                    o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pb[0][s], o[c], 0, 0, 0);
                 }
         }
         if (kb + 1 < nkb) v_store(buf ^ 1);
         __syncthreads();
     }
-    if (!active) return;
+    if (!active || q0 + l31 >= T) return;
     const float inv_l = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
-    unsigned char* op = out + ((size_t)(b * T + q0 + l31) * C + h * CH) * 2;
+    unsigned char* op = out + ((size_t)(b * T + q0 + l31) * C + h * ch) * ES;
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                                        // registers 4g..4g+3 = channels c*32 + 8g + 4hf + {0..3}
-            const uint32_t w0 = at_bf16_rne(o[c][4 * g] * inv_l) | (at_bf16_rne(o[c][4 * g + 1] * inv_l) << 16);
-            const uint32_t w1 = at_bf16_rne(o[c][4 * g + 2] * inv_l) | (at_bf16_rne(o[c][4 * g + 3] * inv_l) << 16);
-            *reinterpret_cast<uint2*>(op + (c * 32 + 8 * g + 4 * hf) * 2) = make_uint2(w0, w1);
+            const uint32_t c0 = c * 32 + 8 * g + 4 * hf;
+            if (c0 >= ch) continue;                                          // (ch % 8 == 0: a group of 4 is inside or outside as a whole)
+            if constexpr (F32) {
+                *reinterpret_cast<float4*>(op + c0 * 4) = make_float4(o[c][4 * g] * inv_l, o[c][4 * g + 1] * inv_l, o[c][4 * g + 2] * inv_l, o[c][4 * g + 3] * inv_l);
+            } else {
+                const uint32_t w0 = at_bf16_rne(o[c][4 * g] * inv_l) | (at_bf16_rne(o[c][4 * g + 1] * inv_l) << 16);
+                const uint32_t w1 = at_bf16_rne(o[c][4 * g + 2] * inv_l) | (at_bf16_rne(o[c][4 * g + 3] * inv_l) << 16);
+                *reinterpret_cast<uint2*>(op + c0 * 2) = make_uint2(w0, w1);
+            }
         }
+}
+
+template <bool F32>
+int at_launch(const char* who, const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream) {
+    if (B == 0 || T == 0) return SSDNERF_OK;
+    SSD_REQUIRE(qkv && out, "%s: null pointer", who);
+    SSD_REQUIRE(ch >= 8 && ch <= 128 && ch % 8 == 0, "%s: head width must be a multiple of 8 in [8, 128]", who);
+    SSD_REQUIRE(heads > 0 && (uint64_t)B * heads <= 65535, "%s: B*heads <= 65535", who);
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)ch);       // softmax(q.k / sqrt(ch)) == softmax((q s)(k s)), s = ch^-1/4
+    const dim3 grid((T + 127) / 128, B * heads), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char* in = (const unsigned char*)qkv;
+    unsigned char* o = (unsigned char*)out;
+    if (ch <= 32) hipLaunchKernelGGL((k_attn_fwd<32, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e);
+    else if (ch <= 64) hipLaunchKernelGGL((k_attn_fwd<64, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e);
+    else if (ch <= 96) hipLaunchKernelGGL((k_attn_fwd<96, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e);
+    else hipLaunchKernelGGL((k_attn_fwd<128, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e);
+    SSD_CHECK_LAUNCH(who);
+    return SSDNERF_OK;
 }
 
 }  // namespace
 
 extern "C" int ssdnerf_attention_qkv_bf16(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream) {
-    if (B == 0 || T == 0) return SSDNERF_OK;
-    SSD_REQUIRE(qkv && out, "attention_qkv_bf16: null pointer");
-    SSD_REQUIRE(ch == 64 || ch == 128, "attention_qkv_bf16: head width must be 64 or 128");
-    SSD_REQUIRE(T % 32 == 0 && heads > 0 && B * heads <= 65535, "attention_qkv_bf16: T must be a multiple of 32, B*heads <= 65535");
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)ch);       // softmax(q.k / sqrt(ch)) == softmax((q s)(k s)), s = ch^-1/4
-    const dim3 grid((T + 127) / 128, B * heads), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (ch == 64) hipLaunchKernelGGL(k_attn_fwd_bf16<64>, grid, block, 0, st, (const unsigned char*)qkv, (unsigned char*)out, T, heads, scale_log2e);
-    else hipLaunchKernelGGL(k_attn_fwd_bf16<128>, grid, block, 0, st, (const unsigned char*)qkv, (unsigned char*)out, T, heads, scale_log2e);
-    SSD_CHECK_LAUNCH("attention_qkv_bf16");
-    return SSDNERF_OK;
+    return at_launch<false>("attention_qkv_bf16", qkv, out, B, T, heads, ch, stream);
+}
+
+extern "C" int ssdnerf_attention_qkv_f32(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream) {
+    return at_launch<true>("attention_qkv_f32", qkv, out, B, T, heads, ch, stream);
 }

@@ -154,6 +154,101 @@ SSD_DEV float ssd_skip_empty(const MarchCfg& c, const RayGeom& r, const Probe& p
     return t;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Camera rays (reference: get_ray_directions / get_rays / get_cam_rays, lib/core/utils/nerf_utils.py:17-61).  ONE statement of the arithmetic,
+// shared by k_cam_rays (raygen.hip, materialises the arrays the reference API hands around) and by the render kernels when they are given
+// cameras instead of ray arrays -- so a ray generated in a kernel is bit-identical to the one k_cam_rays would have stored.
+//     d_cam = ((x + 0.5 - cx) / fx, (y + 0.5 - cy) / fy, 1);  d = R d_cam / max(|R d_cam|, 1e-12);  o = c2w[:3, 3]
+SSD_DEV void ssd_cam_ray(const float* __restrict__ M /* c2w, 16 floats row-major */, const float* __restrict__ K /* fx fy cx cy */, uint32_t px_i,
+                         uint32_t py_i, float o[3], float d[3]) {
+    const float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
+    const float dx = (px - K[2]) / K[0], dy = (py - K[3]) / K[1];
+    const float vx = ssd_fma(dx, M[0], ssd_fma(dy, M[1], M[2]));
+    const float vy = ssd_fma(dx, M[4], ssd_fma(dy, M[5], M[6]));
+    const float vz = ssd_fma(dx, M[8], ssd_fma(dy, M[9], M[10]));
+    const float inv = 1.0f / fmaxf(sqrtf(ssd_fma(vx, vx, ssd_fma(vy, vy, vz * vz))), 1e-12f);
+    d[0] = vx * inv; d[1] = vy * inv; d[2] = vz * inv;
+    o[0] = M[3]; o[1] = M[7]; o[2] = M[11];
+}
+
+// Where a render kernel gets ray n of a scene from: the (S, N, 3) arrays of the reference API, or -- c2w != NULL -- the cameras themselves
+// (c2w [S][V][16], intr [S][V][4], N = V * hw rays per scene, ray n = pixel n % hw of view n / hw): 80 B per VIEW instead of 24 B per RAY.
+struct RaySrc {
+    const float* rays_o; const float* rays_d;
+    const float* c2w; const float* intr;
+    uint32_t V, hw, w;
+    int hw_shift, w_shift;        // log2 when hw / w are powers of two (the 128 x 128 views of the hot path), else -1
+};
+static inline RaySrc ssd_ray_src_arrays(const float* o, const float* d) { RaySrc s = {}; s.rays_o = o; s.rays_d = d; s.hw_shift = s.w_shift = -1; return s; }
+static inline RaySrc ssd_ray_src_cams(const float* c2w, const float* intr, uint32_t V, uint32_t h, uint32_t w) {
+    RaySrc s = {};
+    s.c2w = c2w; s.intr = intr; s.V = V; s.hw = h * w; s.w = w;
+    s.hw_shift = (s.hw & (s.hw - 1)) == 0 ? __builtin_ctz(s.hw) : -1;
+    s.w_shift = (w & (w - 1)) == 0 ? __builtin_ctz(w) : -1;
+    return s;
+}
+SSD_DEV RayGeom ssd_ray_geom(float ox, float oy, float oz, float dx, float dy, float dz) {
+    RayGeom r;
+    r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+    r.rdx = 1.0f / dx; r.rdy = 1.0f / dy; r.rdz = 1.0f / dz;
+    return r;
+}
+// ray n of scene `scene` (N rays per scene)
+SSD_DEV RayGeom ssd_fetch_ray(const RaySrc& s, uint32_t scene, uint32_t N, uint32_t n) {
+    if (s.c2w == nullptr) {
+        const uint64_t gi = (uint64_t)scene * N + n;
+        return ssd_load_ray(s.rays_o + 3 * gi, s.rays_d + 3 * gi);
+    }
+    const uint32_t view = s.hw_shift >= 0 ? n >> s.hw_shift : n / s.hw;
+    const uint32_t pix = n - view * s.hw;
+    const uint32_t py = s.w_shift >= 0 ? pix >> s.w_shift : pix / s.w;
+    const uint32_t px = pix - py * s.w;
+    const uint64_t cam = (uint64_t)scene * s.V + view;
+    float o[3], d[3];
+    ssd_cam_ray(s.c2w + cam * 16, s.intr + cam * 4, px, py, o, d);
+    return ssd_ray_geom(o[0], o[1], o[2], d[0], d[1], d[2]);
+}
+
+// Tail bound of a ray that passed the coarse pre-test (render_queue.hip, k_ray_cull): its list / queue word carries, above the 24-bit ray
+// index, the index j_last of the last coarse test point that was not clear; past near + (j_last + 1) coarse steps no occupied cell can be
+// met, + 0.5 step of slack for the difference between the scan's accumulated test parameters and this product form.
+SSD_DEV float ssd_coarse_step_t(const RayGeom& q, float cell_world /* 2 / H * mip_bound */) {
+    const float len = sqrtf(ssd_fma(q.dx, q.dx, ssd_fma(q.dy, q.dy, q.dz * q.dz)));
+    return (SSD_COARSE_STEP * cell_world) / fmaxf(len, 1e-20f);
+}
+SSD_DEV float ssd_tail_far(const RayGeom& q, float cell_world, float near_, float far_, uint32_t packed, bool packing) {
+    const uint32_t jl = packed >> 24;
+    if (!packing || jl >= SSD_TAIL_NONE) return far_;
+    return fminf(far_, ssd_fma((float)jl + 1.5f, ssd_coarse_step_t(q, cell_world), near_));
+}
+
+// Workspace of the two-stage renderer (caller-owned, ssdnerf_render_queue_workspace bytes), shared by render_queue.hip and shade_mfma.hip:
+//   counters : 4 kinds x S scenes, ONE 128-BYTE LINE EACH (ssd_counter): hits per scene | slice tickets | survivors per scene | termination
+//              tests within 2e-6 of T_thresh (diagnostic).  Device-scope atomics on one address are resolved one after the other at the memory
+//              side; r02 measured 2.7 ms for ~250 k wave-level appends that all landed in ONE cache line (profiles/r02/a_kernel_stats_*.csv),
+//              so every counter has its own line and the producers reserve per BLOCK, not per wave.
+//   lin_bits [S][H^3/8]: the bitfield in linear z/y/x order         coarse [S][(H/2)^3/8] (room for the finest block size)
+//   queue [S][N] uint2 {ray | tail << 24, t_first}                    survivors [S][N] u32 {ray | tail << 24}
+#define SSD_COUNTER_STRIDE 32u     // u32 words per counter (128 B)
+enum { SSD_CNT_HITS = 0, SSD_CNT_TICKETS = 1, SSD_CNT_SURVIVORS = 2, SSD_CNT_BOUNDARY = 3, SSD_CNT_KINDS = 4 };
+__host__ __device__ static inline uint32_t ssd_counter(uint32_t kind, uint32_t S, uint32_t scene) { return (kind * S + scene) * SSD_COUNTER_STRIDE; }
+struct RenderWs { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; uint32_t* survivors; size_t counter_bytes, bytes; };
+static inline RenderWs ssd_render_ws(void* base, uint32_t S, uint32_t N, uint32_t grid_size) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t counters = up((size_t)SSD_CNT_KINDS * S * SSD_COUNTER_STRIDE * 4), bits = up((size_t)S * grid_size * grid_size * grid_size / 8);
+    const size_t hc = grid_size / 2, coarse = up((size_t)S * (hc * hc * hc / 8)), queue = up((size_t)S * N * sizeof(uint2));
+    RenderWs w;
+    uint8_t* b = (uint8_t*)base;
+    w.counters = (uint32_t*)b;
+    w.lin_bits = b + counters;
+    w.coarse = b + counters + bits;
+    w.queue = (uint2*)(b + counters + bits + coarse);
+    w.survivors = (uint32_t*)(b + counters + bits + coarse + queue);
+    w.counter_bytes = counters;
+    w.bytes = counters + bits + coarse + queue + (size_t)S * N * sizeof(uint32_t);
+    return w;
+}
+
 // Slab test of one ray against the scene box.  Returns false on a miss (near = far = FLT_MAX).
 SSD_DEV bool ssd_near_far(const float* __restrict__ aabb, const RayGeom& r, float min_near, float& near_, float& far_) {
     float lo = (aabb[0] - r.ox) * r.rdx, hi = (aabb[3] - r.ox) * r.rdx;

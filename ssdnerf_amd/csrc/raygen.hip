@@ -16,19 +16,11 @@ __global__ void __launch_bounds__(256) k_cam_rays(const float* __restrict__ c2w,
     const uint32_t view = blockIdx.y, hw = h * w;
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= hw) return;
-    const float* M = c2w + (size_t)view * 16;
-    const float* K = intrinsics + (size_t)view * 4;
-    const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
-    const float px = (float)(pix % w) + 0.5f, py = (float)(pix / w) + 0.5f;
-    const float dx = (px - cx) / fx, dy = (py - cy) / fy;
-    // rays_d = d_cam @ R^T: component k = dx R[k][0] + dy R[k][1] + R[k][2]
-    const float vx = ssd_fma(dx, M[0], ssd_fma(dy, M[1], M[2]));
-    const float vy = ssd_fma(dx, M[4], ssd_fma(dy, M[5], M[6]));
-    const float vz = ssd_fma(dx, M[8], ssd_fma(dy, M[9], M[10]));
-    const float inv = 1.0f / fmaxf(sqrtf(ssd_fma(vx, vx, ssd_fma(vy, vy, vz * vz))), 1e-12f);
+    float o3[3], d3[3];
+    ssd_cam_ray(c2w + (size_t)view * 16, intrinsics + (size_t)view * 4, pix % w, pix / w, o3, d3);       // common.h: the one statement of the arithmetic
     const size_t o = ((size_t)view * hw + pix) * 3;
-    rays_d[o + 0] = vx * inv; rays_d[o + 1] = vy * inv; rays_d[o + 2] = vz * inv;
-    rays_o[o + 0] = M[3]; rays_o[o + 1] = M[7]; rays_o[o + 2] = M[11];
+    rays_d[o + 0] = d3[0]; rays_d[o + 1] = d3[1]; rays_d[o + 2] = d3[2];
+    rays_o[o + 0] = o3[0]; rays_o[o + 1] = o3[1]; rays_o[o + 2] = o3[2];
 }
 
 extern "C" int ssdnerf_cam_rays(const float* c2w, const float* intrinsics, uint32_t n_views, uint32_t h, uint32_t w, float* rays_o, float* rays_d,

@@ -28,7 +28,7 @@
 
 static constexpr unsigned RQ_TPB = 256;
 static constexpr unsigned RQ_SLICE = 256;        // hit-queue entries per shading wave
-static constexpr unsigned RQ_COARSE_MAX_BYTES = 4096; // coarse occupancy ((H >> RQ_COARSE_LOG2B)^3 bits) staged in LDS by k_first_hit
+static constexpr unsigned RQ_COARSE_MAX_BYTES = 4096; // coarse occupancy ((H >> RQ_COARSE_LOG2B)^3 bits) staged in LDS by k_ray_cull
 static constexpr unsigned RQ_HD_STRIDE = 68;     // floats per LDS row of the per-ray direction term (64 + 4 pad)
 
 struct FastMarch {
@@ -132,201 +132,155 @@ __global__ void __launch_bounds__(RQ_TPB) k_bitfield_coarsen(const uint8_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage A: first occupied sample of every ray.
+// Stage A: first occupied sample of every ray, as two dense passes.
 //
-// Empty-space pre-test (exact by construction): the reference's march only ever tests the cell that contains a point o + t d of the
-// ray (t in [near, far)), in fp32, i.e. a cell within one cell of the true segment.  Before marching, the lane samples the segment every
-// RQ_COARSE_STEP cells and looks each sample up in the dilated coarse bitfield; if all samples are clear, every cell the march could
-// test is empty, the ray has zero samples whatever its stepping sequence, and the background is written at once.  Otherwise the exact
-// march runs from `near` as before -- the pre-test never moves a ray along, so the stepping sequence of a marched ray is untouched.
-__global__ void __launch_bounds__(RQ_TPB) k_first_hit(QueueCfg c, const uint8_t* __restrict__ lin_bits, const uint8_t* __restrict__ coarse_bits,
-                                                       const float* __restrict__ rays_o,
-                                                       const float* __restrict__ rays_d, float* __restrict__ image, float* __restrict__ depth,
-                                                       float* __restrict__ weights_sum, int32_t* __restrict__ sample_counts,
-                                                       uint2* __restrict__ queue, uint32_t* __restrict__ queue_count) {
-    const uint32_t scene = blockIdx.y;
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t gi = (uint64_t)scene * c.N + n;
-    lin_bits += (uint64_t)scene * c.bitfield_stride;
-    if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
-    // this scene's coarse bitfield -> LDS ((H/2)^3 bits; 4 KiB for H = 64)
-    __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
-    const uint32_t Hc = c.m.H >> RQ_COARSE_LOG2B, log2Hc = c.m.log2H - RQ_COARSE_LOG2B, coarse_bytes = (Hc * Hc * Hc) >> 3;
-    const bool use_coarse = coarse_bits != nullptr && coarse_bytes <= RQ_COARSE_MAX_BYTES && coarse_bytes % 16 == 0;
-    if (use_coarse) {
-        const uint4* src = reinterpret_cast<const uint4*>(coarse_bits + (uint64_t)scene * coarse_bytes);
-        for (uint32_t i = threadIdx.x; i < coarse_bytes / 16; i += RQ_TPB) reinterpret_cast<uint4*>(coarse_lds)[i] = src[i];
-        __syncthreads();
-    }
-    bool hit = false;
-    float t = 0.f;
-    uint32_t tail = SSD_TAIL_NONE;
-    if (n < c.N) {
-        const RayGeom r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
-        float far_;
-        ssd_near_far(c.aabb, r, c.min_near, t, far_);
-        const float sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f), sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f), sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
-        if (use_coarse && t < far_) {
-            const float len = sqrtf(ssd_fma(r.dx, r.dx, ssd_fma(r.dy, r.dy, r.dz * r.dz)));
-            const float step_t = (RQ_COARSE_STEP * c.m.two_rH * c.m.mip_bound) / fmaxf(len, 1e-20f);   // RQ_COARSE_STEP cells of world length, in t
-            int j_last = -1, j = 0;
-            float t_last = 0.f;
-            for (float tc = t; ; tc += step_t, ++j) {                        // test points from near to (at least) far
-                const float u = fminf(tc, far_);
-                const int bx = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;   // block of the point's exact cell
-                const int by = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
-                const int bz = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
-                const uint32_t ci = ((((uint32_t)bz << log2Hc) + (uint32_t)by) << log2Hc) + (uint32_t)bx;
-                if ((coarse_lds[ci >> 3] >> (ci & 7u)) & 1u) { j_last = j; t_last = tc; }
-                if (!(tc < far_)) break;
-            }
-            if (j_last < 0) t = far_;                                        // nothing within a cell of this ray: skip the march
-            else {
-                // every test point after j_last is clear: past t_last + step no cell the march could test is occupied, so the march (here and
-                // in the shading kernel, which gets j_last with the queue entry) may stop there; it still starts at `near`
-                far_ = fminf(far_, t_last + step_t);
-                if (c.N <= SSD_RAY_ID_MASK + 1u && j_last < (int)SSD_TAIL_NONE) tail = (uint32_t)j_last;
-            }
-        }
-        while (t < far_) {
-            const FastProbe p = rq_probe(c.m, lin_bits, r, t);
-            if (p.occ) { hit = true; break; }
-            t = rq_skip(c.m, r, p, sgx, sgy, sgz, t);
-        }
-        if (!hit) {  // the ray left the box without a sample: background only
-            image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
-            depth[gi] = 0.f; weights_sum[gi] = 0.f;
-            if (sample_counts) sample_counts[gi] = 0;
-        }
-    }
-    // wave-aggregated append: one atomic per wave
-    const uint64_t hits = __ballot(hit);
-    if (hits != 0) {
-        const int lane = threadIdx.x & 63;
-        uint32_t base = 0;
-        if (lane == __builtin_ctzll(hits)) base = atomicAdd(queue_count + scene, (uint32_t)__popcll(hits));
-        base = __shfl(base, __builtin_ctzll(hits), 64);
-        if (hit) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-            queue[(uint64_t)scene * c.N + base + rank] = make_uint2(c.N <= SSD_RAY_ID_MASK + 1u ? (n | (tail << 24)) : n, __float_as_uint(t));
-        }
-    }
+//   k_ray_cull        one lane per ray.  Ray from the arrays or generated from the view's camera (RaySrc), slab test, then the conservative
+//                     EMPTY-SPACE PRE-TEST: the reference's march only ever tests the cell that contains a point o + t d of the ray
+//                     (t in [near, far)), in fp32, i.e. a cell within one cell of the true segment.  The lane samples the segment every
+//                     RQ_COARSE_STEP cells and looks each sample up in the dilated coarse bitfield (LDS); if all samples are clear, every
+//                     cell the march could test is empty, the ray has zero samples whatever its stepping sequence, and the background is
+//                     written at once (65 % of the bench's rays).  Otherwise the ray is appended -- one atomic per wave -- to the scene's
+//                     SURVIVOR list as (ray id | tail bound << 24): past the last non-clear test point no occupied cell can be met.
+//   k_survivor_march  one lane per SURVIVOR: the exact march from `near` to the first occupied probe (hit -> the scene's hit queue) or to
+//                     the tail bound (background).  The pre-test never advances a ray, so a marched ray keeps the reference's stepping
+//                     sequence.  r01 ran both phases in one kernel, where the march executed at ~22 live lanes of 64 (survivors are the
+//                     silhouette band of each view) and was 2/3 of the kernel's VALU issue; compacted through the list it runs full waves.
+struct CullGrid { uint32_t group; };   // rays per blockIdx.y group: hw (one view per y, cameras) or N (arrays, gridDim.y == 1)
+static constexpr unsigned RQ_CHUNKS = 8;       // 256-ray chunks per block: the block stages its list in LDS and reserves global slots ONCE
+
+// Appends `item` of every lane with `take` to the block's LDS list (one LDS atomic per wave).
+template <typename T>
+SSD_DEV void rq_lds_append(bool take, const T& item, T* list, uint32_t* list_count) {
+    const uint64_t m = __ballot(take);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) base = atomicAdd(list_count, (uint32_t)__popcll(m));
+    base = __shfl(base, __builtin_ctzll(m), 64);
+    if (take) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = item;
+}
+// Copies the block's LDS list to its global array behind ONE atomic reservation (coalesced stores).  Ends with every thread past the barrier.
+template <typename T>
+SSD_DEV void rq_flush(const T* list, const uint32_t* list_count, uint32_t* slot /* LDS */, uint32_t* global_counter, T* global_list) {
+    __syncthreads();
+    const uint32_t n = *list_count;
+    if (threadIdx.x == 0 && n != 0) *slot = atomicAdd(global_counter, n);
+    __syncthreads();
+    const uint32_t base = *slot;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) global_list[base + i] = list[i];
 }
 
-// ------------------------------------------------------------------------------------------------
-// Stage A, compacting form (SSDNERF_FIRST_HIT_COMPACT=1; experimental -- written against k_first_hit's counters, not yet run on hardware).
-// k_first_hit is VALU-bound at ~100 % issue (r01 PMC: 2 520 VALU instructions per wave of 64 rays) and most of that is the exact march
-// of the ~35 % of rays that survive the pre-test, executed by whole waves in which the other lanes idle.  Here a 1024-thread block
-// runs the pre-test for its rays (same arithmetic, same background writes), appends the survivors (ray, near, bounded far, tail) to an LDS
-// list with one LDS atomic per wave, and then marches the list densely: 64 live lanes per wave instead of ~22.  Per-ray arithmetic, and
-// therefore every output, is unchanged; only the order of the hit queue differs (it is unordered already).
-static constexpr unsigned RQC_TPB = 1024;
-
-__global__ void __launch_bounds__(RQC_TPB) k_first_hit_compact(QueueCfg c, const uint8_t* __restrict__ lin_bits, const uint8_t* __restrict__ coarse_bits,
-                                                                const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                                float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
-                                                                int32_t* __restrict__ sample_counts, uint2* __restrict__ queue, uint32_t* __restrict__ queue_count) {
-    const uint32_t scene = blockIdx.y;
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t ray0 = (uint64_t)scene * c.N;
-    lin_bits += (uint64_t)scene * c.bitfield_stride;
-    if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
+__global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, CullGrid cg, const uint8_t* __restrict__ coarse_bits,
+                                                      float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
+                                                      int32_t* __restrict__ sample_counts, uint32_t* __restrict__ survivors,
+                                                      uint32_t* __restrict__ counters) {
+    const uint32_t scene = blockIdx.z;
+    // this scene's coarse bitfield -> LDS ((H/4)^3 bits; 512 B for H = 64)
     __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
-    __shared__ uint32_t list_n[RQC_TPB], list_tail[RQC_TPB];
-    __shared__ float list_t[RQC_TPB], list_far[RQC_TPB];
-    __shared__ uint32_t list_count;
+    __shared__ uint32_t list[RQ_CHUNKS * RQ_TPB];
+    __shared__ uint32_t list_count, slot;
     const uint32_t Hc = c.m.H >> RQ_COARSE_LOG2B, log2Hc = c.m.log2H - RQ_COARSE_LOG2B, coarse_bytes = (Hc * Hc * Hc) >> 3;
-    const bool use_coarse = coarse_bits != nullptr && coarse_bytes <= RQ_COARSE_MAX_BYTES && coarse_bytes % 16 == 0;
+    const bool use_coarse = coarse_bits != nullptr;
     if (threadIdx.x == 0) list_count = 0;
     if (use_coarse) {
-        const uint4* src = reinterpret_cast<const uint4*>(coarse_bits + (uint64_t)scene * coarse_bytes);
-        for (uint32_t i = threadIdx.x; i < coarse_bytes / 16; i += RQC_TPB) reinterpret_cast<uint4*>(coarse_lds)[i] = src[i];
+        const uint4* cb = reinterpret_cast<const uint4*>(coarse_bits + (uint64_t)scene * coarse_bytes);
+        for (uint32_t i = threadIdx.x; i < coarse_bytes / 16; i += RQ_TPB) reinterpret_cast<uint4*>(coarse_lds)[i] = cb[i];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    // ---- phase 1: near/far + coarse pre-test (the arithmetic of k_first_hit, line for line)
-    bool need = false;
-    float t = 0.f, far_ = 0.f;
-    uint32_t tail = SSD_TAIL_NONE;
-    if (n < c.N) {
-        const uint64_t gi = ray0 + n;
-        const RayGeom r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
-        ssd_near_far(c.aabb, r, c.min_near, t, far_);
-        if (use_coarse && t < far_) {
-            const float len = sqrtf(ssd_fma(r.dx, r.dx, ssd_fma(r.dy, r.dy, r.dz * r.dz)));
-            const float step_t = (RQ_COARSE_STEP * c.m.two_rH * c.m.mip_bound) / fmaxf(len, 1e-20f);
-            int j_last = -1, j = 0;
-            float t_last = 0.f;
-            for (float tc = t; ; tc += step_t, ++j) {
-                const float u = fminf(tc, far_);
-                const int bx = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
-                const int by = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
-                const int bz = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
-                const uint32_t ci = ((((uint32_t)bz << log2Hc) + (uint32_t)by) << log2Hc) + (uint32_t)bx;
-                if ((coarse_lds[ci >> 3] >> (ci & 7u)) & 1u) { j_last = j; t_last = tc; }
-                if (!(tc < far_)) break;
+    const bool packing = c.N <= SSD_RAY_ID_MASK + 1u;
+#pragma unroll 1
+    for (uint32_t chunk = 0; chunk < RQ_CHUNKS; ++chunk) {
+        const uint32_t in_group = (blockIdx.x * RQ_CHUNKS + chunk) * RQ_TPB + threadIdx.x;
+        const uint32_t n = blockIdx.y * cg.group + in_group;
+        const uint64_t gi = (uint64_t)scene * c.N + n;
+        bool alive = false;
+        uint32_t tail = SSD_TAIL_NONE;
+        if (in_group < cg.group && n < c.N) {
+            RayGeom r;
+            if (src.c2w != nullptr) {       // the view is uniform over the block (blockIdx.y): pose and intrinsics are scalar loads
+                const uint64_t cam = (uint64_t)scene * src.V + blockIdx.y;
+                const uint32_t py = src.w_shift >= 0 ? in_group >> src.w_shift : in_group / src.w;
+                float o[3], d[3];
+                ssd_cam_ray(src.c2w + cam * 16, src.intr + cam * 4, in_group - py * src.w, py, o, d);
+                r = ssd_ray_geom(o[0], o[1], o[2], d[0], d[1], d[2]);
+            } else {
+                r = ssd_load_ray(src.rays_o + 3 * gi, src.rays_d + 3 * gi);
             }
-            if (j_last < 0) t = far_;
-            else {
-                far_ = fminf(far_, t_last + step_t);
-                if (c.N <= SSD_RAY_ID_MASK + 1u && j_last < (int)SSD_TAIL_NONE) tail = (uint32_t)j_last;
+            float t, far_;
+            ssd_near_far(c.aabb, r, c.min_near, t, far_);
+            alive = t < far_;
+            if (use_coarse && alive) {
+                const float step_t = ssd_coarse_step_t(r, c.m.two_rH * c.m.mip_bound);          // RQ_COARSE_STEP cells of world length, in t
+                int j_last = -1, j = 0;
+                for (float tc = t; ; tc += step_t, ++j) {                        // test points from near to (at least) far
+                    const float u = fminf(tc, far_);
+                    const int bx = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;   // block of the point's exact cell
+                    const int by = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
+                    const int bz = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
+                    const uint32_t ci = ((((uint32_t)bz << log2Hc) + (uint32_t)by) << log2Hc) + (uint32_t)bx;
+                    if ((coarse_lds[ci >> 3] >> (ci & 7u)) & 1u) j_last = j;
+                    if (!(tc < far_)) break;
+                }
+                alive = j_last >= 0;                                             // nothing within a cell of this ray: no march
+                // every test point after j_last is clear: past near + (j_last + 1) steps no cell the march could test is occupied, so the
+                // march (k_survivor_march and the shading kernel, via ssd_tail_far) may stop there; it still starts at `near`
+                if (alive && packing && j_last < (int)SSD_TAIL_NONE) tail = (uint32_t)j_last;
             }
-        }
-        need = t < far_;
-        if (!need) {                                                         // misses the box, or nothing within a cell of the ray: background only
-            image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
-            depth[gi] = 0.f; weights_sum[gi] = 0.f;
-            if (sample_counts) sample_counts[gi] = 0;
-        }
-    }
-    {   // survivors -> LDS list, one LDS atomic per wave
-        const uint64_t m = __ballot(need);
-        if (m != 0) {
-            uint32_t base = 0;
-            if (lane == __builtin_ctzll(m)) base = atomicAdd(&list_count, (uint32_t)__popcll(m));
-            base = __shfl(base, __builtin_ctzll(m), 64);
-            if (need) {
-                const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                list_n[slot] = n; list_tail[slot] = tail; list_t[slot] = t; list_far[slot] = far_;
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t cnt = list_count;
-    // ---- phase 2: dense exact march of the survivors (whole waves stay in the loop for the ballot)
-    for (uint32_t wbase = threadIdx.x & ~63u; wbase < cnt; wbase += RQC_TPB) {
-        const uint32_t i = wbase + lane;
-        bool hit = false;
-        uint32_t nn = 0, tl = SSD_TAIL_NONE;
-        float tt = 0.f;
-        if (i < cnt) {
-            nn = list_n[i]; tl = list_tail[i]; tt = list_t[i];
-            const float ff = list_far[i];
-            const uint64_t gi = ray0 + nn;
-            const RayGeom r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
-            const float sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f), sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f), sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
-            while (tt < ff) {
-                const FastProbe p = rq_probe(c.m, lin_bits, r, tt);
-                if (p.occ) { hit = true; break; }
-                tt = rq_skip(c.m, r, p, sgx, sgy, sgz, tt);
-            }
-            if (!hit) {
+            if (!alive) {  // misses the box, or nothing within a cell of the ray: background only
                 image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
                 depth[gi] = 0.f; weights_sum[gi] = 0.f;
                 if (sample_counts) sample_counts[gi] = 0;
             }
         }
-        const uint64_t hits = __ballot(hit);
-        if (hits != 0) {
-            uint32_t base = 0;
-            if (lane == __builtin_ctzll(hits)) base = atomicAdd(queue_count + scene, (uint32_t)__popcll(hits));
-            base = __shfl(base, __builtin_ctzll(hits), 64);
-            if (hit) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-                queue[ray0 + base + rank] = make_uint2(c.N <= SSD_RAY_ID_MASK + 1u ? (nn | (tl << 24)) : nn, __float_as_uint(tt));
+        rq_lds_append(alive, packing ? (n | (tail << 24)) : n, list, &list_count);
+    }
+    rq_flush(list, &list_count, &slot, counters + ssd_counter(SSD_CNT_SURVIVORS, c.S, scene), survivors + (uint64_t)scene * c.N);
+}
+
+__global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc src, const uint8_t* __restrict__ lin_bits,
+                                                            const uint32_t* __restrict__ survivors, float* __restrict__ image,
+                                                            float* __restrict__ depth, float* __restrict__ weights_sum,
+                                                            int32_t* __restrict__ sample_counts, uint2* __restrict__ queue,
+                                                            uint32_t* __restrict__ counters) {
+    const uint32_t scene = blockIdx.y;
+    const uint32_t count = counters[ssd_counter(SSD_CNT_SURVIVORS, c.S, scene)];
+    if (blockIdx.x * (RQ_CHUNKS * RQ_TPB) >= count) return;                  // the grid covers the worst case (every ray survives)
+    __shared__ uint2 list[RQ_CHUNKS * RQ_TPB];
+    __shared__ uint32_t list_count, slot;
+    if (threadIdx.x == 0) list_count = 0;
+    __syncthreads();
+    lin_bits += (uint64_t)scene * c.bitfield_stride;
+    if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
+    const bool packing = c.N <= SSD_RAY_ID_MASK + 1u;
+#pragma unroll 1
+    for (uint32_t chunk = 0; chunk < RQ_CHUNKS; ++chunk) {
+        const uint32_t i = (blockIdx.x * RQ_CHUNKS + chunk) * RQ_TPB + threadIdx.x;
+        bool hit = false;
+        uint32_t e = 0;
+        float t = 0.f;
+        if (i < count) {
+            e = survivors[(uint64_t)scene * c.N + i];
+            const uint32_t n = packing ? (e & SSD_RAY_ID_MASK) : e;
+            const uint64_t gi = (uint64_t)scene * c.N + n;
+            const RayGeom r = ssd_fetch_ray(src, scene, c.N, n);
+            float near_, far_;
+            ssd_near_far(c.aabb, r, c.min_near, near_, far_);
+            far_ = ssd_tail_far(r, c.m.two_rH * c.m.mip_bound, near_, far_, e, packing);
+            const float sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f), sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f), sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
+            t = near_;
+            while (t < far_) {
+                const FastProbe p = rq_probe(c.m, lin_bits, r, t);
+                if (p.occ) { hit = true; break; }
+                t = rq_skip(c.m, r, p, sgx, sgy, sgz, t);
+            }
+            if (!hit) {  // the ray left the object's neighbourhood without a sample: background only
+                image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
+                depth[gi] = 0.f; weights_sum[gi] = 0.f;
+                if (sample_counts) sample_counts[gi] = 0;
             }
         }
+        rq_lds_append(hit, make_uint2(e, __float_as_uint(t)), list, &list_count);
     }
+    rq_flush(list, &list_count, &slot, counters + ssd_counter(SSD_CNT_HITS, c.S, scene), queue + (uint64_t)scene * c.N);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,7 +309,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_shade_queue(QueueCfg c, uint32_t sli
         wg = b % wg_per_scene;
     }
     if (scene >= c.S) return;
-    const uint32_t count = queue_count[scene];
+    const uint32_t count = queue_count[ssd_counter(SSD_CNT_HITS, c.S, scene)];
     uint32_t next = __builtin_amdgcn_readfirstlane((wg * (RQ_TPB / 64) + wave) * RQ_SLICE);
     if (next >= count) return;
     const uint32_t end = min(next + RQ_SLICE, count);
@@ -498,36 +452,26 @@ static int rq_make_cfg(QueueCfg& c, uint32_t Hp, uint32_t Wp, uint32_t grid_size
     return SSDNERF_OK;
 }
 
-// workspace layout: [ S x u32 queue counters, S x u32 slice tickets (padded to 256 B) | S x H^3/8 linear bitfields | S x N x uint2 queue ]
-static size_t rq_coarse_bytes(uint32_t S, uint32_t grid_size) {
-    const size_t hc = grid_size / 2;
-    return ((size_t)S * (hc * hc * hc / 8) + 255) / 256 * 256;
+extern "C" size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size) { return ssd_render_ws(nullptr, S, N, grid_size).bytes; }
+
+// Rays come from the (S, N, 3) arrays, or -- c2w != NULL -- from S x V cameras of h x w pixels (N == V * h * w).
+static int rq_ray_src(RaySrc& src, const char* who, const float* rays_o, const float* rays_d, const float* c2w, const float* intrinsics, uint32_t V,
+                      uint32_t h, uint32_t w, uint32_t N) {
+    if (c2w != nullptr) {
+        SSD_REQUIRE(intrinsics && V > 0 && h > 0 && w > 0 && (uint64_t)V * h * w == N, "%s: cameras need intrinsics and N == V * h * w", who);
+        SSD_REQUIRE(V <= 65535, "%s: at most 65535 views per scene", who);
+        src = ssd_ray_src_cams(c2w, intrinsics, V, h, w);
+    } else {
+        SSD_REQUIRE(rays_o && rays_d, "%s: null ray arrays", who);
+        src = ssd_ray_src_arrays(rays_o, rays_d);
+    }
+    return SSDNERF_OK;
 }
 
-extern "C" size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size) {
-    const size_t counters = ((size_t)S * 8 + 255) / 256 * 256;
-    const size_t bits = ((size_t)S * grid_size * grid_size * grid_size / 8 + 255) / 256 * 256;
-    return counters + bits + rq_coarse_bytes(S, grid_size) + (size_t)S * N * sizeof(uint2);
-}
-
-struct RqWorkspace { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; };
-static RqWorkspace rq_carve(void* ws, uint32_t S, uint32_t grid_size) {
-    RqWorkspace w;
-    const size_t counters = ((size_t)S * 8 + 255) / 256 * 256;
-    const size_t bits = ((size_t)S * grid_size * grid_size * grid_size / 8 + 255) / 256 * 256;
-    w.counters = (uint32_t*)ws;
-    w.lin_bits = (uint8_t*)ws + counters;
-    w.coarse = (uint8_t*)ws + counters + bits;
-    w.queue = (uint2*)((uint8_t*)ws + counters + bits + rq_coarse_bytes(S, grid_size));
-    return w;
-}
-
-extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N,
-                                        float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps, float bg_color,
-                                        float* image, float* depth, float* weights_sum, int32_t* sample_counts, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
-    if (N == 0 || S == 0) return SSDNERF_OK;
-    SSD_REQUIRE(bitfield && rays_o && rays_d && image && depth && weights_sum && workspace, "render_first_hit: null pointer");
+static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySrc& src, uint32_t S, uint32_t N, float bound, float min_near,
+                        float dt_gamma, const float* dt_gammas, uint32_t max_steps, float bg_color, float* image, float* depth, float* weights_sum,
+                        int32_t* sample_counts, void* workspace, size_t workspace_bytes, void* stream) {
+    SSD_REQUIRE(bitfield && image && depth && weights_sum && workspace, "render_first_hit: null pointer");
     if (workspace_bytes < ssdnerf_render_queue_workspace(S, N, grid_size))
         return ssdnerf_fail(SSDNERF_E_WORKSPACE, "render_first_hit: workspace %zu < %zu bytes", workspace_bytes, ssdnerf_render_queue_workspace(S, N, grid_size));
     SSD_REQUIRE(S <= 65535, "render_first_hit: at most 65535 scenes per launch");
@@ -535,22 +479,47 @@ extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_s
     int rc = rq_make_cfg(c, 1, 1, grid_size, S, N, bound, min_near, dt_gamma, dt_gammas, max_steps, 0.f, bg_color, 0.f);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const RqWorkspace w = rq_carve(workspace, S, grid_size);
-    if (hipMemsetAsync(w.counters, 0, (size_t)S * 8, s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "render_first_hit: memset failed");   // hit counts + slice tickets
+    const RenderWs w = ssd_render_ws(workspace, S, N, grid_size);
+    if (hipMemsetAsync(w.counters, 0, w.counter_bytes, s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "render_first_hit: memset failed");   // hit counts, slice tickets, survivor counts, boundary tests
     hipLaunchKernelGGL(k_bitfield_linearize, dim3(ssd_blocks(c.bitfield_stride, RQ_TPB), S), dim3(RQ_TPB), 0, s, bitfield, grid_size, c.m.log2H, c.bitfield_stride, w.lin_bits);
     const uint32_t hc = grid_size >> RQ_COARSE_LOG2B;    // (the workspace reserves room for the finest block size, 2 cells)
     const bool coarse_ok = hc >= 8 && (hc * hc * hc / 8) <= RQ_COARSE_MAX_BYTES && (hc * hc * hc / 8) % 16 == 0 && bound <= 1.0f && getenv("SSDNERF_NO_COARSE") == nullptr;
     if (coarse_ok)
         hipLaunchKernelGGL(k_bitfield_coarsen, dim3(ssd_blocks(hc * hc * hc, RQ_TPB), S), dim3(RQ_TPB), 0, s, w.lin_bits, grid_size, c.m.log2H, c.bitfield_stride, w.coarse);
-    static const bool compact = getenv("SSDNERF_FIRST_HIT_COMPACT") != nullptr;      // experimental compacting form (see k_first_hit_compact)
-    if (compact)
-        hipLaunchKernelGGL(k_first_hit_compact, dim3(ssd_blocks(N, RQC_TPB), S), dim3(RQC_TPB), 0, s, c, w.lin_bits, coarse_ok ? w.coarse : (const uint8_t*)nullptr, rays_o,
-                           rays_d, image, depth, weights_sum, sample_counts, w.queue, w.counters);
-    else
-        hipLaunchKernelGGL(k_first_hit, dim3(ssd_blocks(N, RQ_TPB), S), dim3(RQ_TPB), 0, s, c, w.lin_bits, coarse_ok ? w.coarse : (const uint8_t*)nullptr, rays_o, rays_d, image,
-                           depth, weights_sum, sample_counts, w.queue, w.counters);
+    CullGrid cg;
+    dim3 grid;
+    if (src.c2w != nullptr) { cg.group = src.hw; grid = dim3(ssd_blocks(src.hw, RQ_TPB * RQ_CHUNKS), src.V, S); }      // one view per blockIdx.y: camera loads are scalar
+    else { cg.group = N; grid = dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), 1, S); }
+    hipLaunchKernelGGL(k_ray_cull, grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
+                       w.survivors, w.counters);
+    hipLaunchKernelGGL(k_survivor_march, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum, sample_counts,
+                       w.queue, w.counters);
     SSD_CHECK_LAUNCH("render_first_hit");
     return SSDNERF_OK;
+}
+
+extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N,
+                                        float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps, float bg_color,
+                                        float* image, float* depth, float* weights_sum, int32_t* sample_counts, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    if (N == 0 || S == 0) return SSDNERF_OK;
+    RaySrc src;
+    if (int rc = rq_ray_src(src, "render_first_hit", rays_o, rays_d, nullptr, nullptr, 0, 0, 0, N)) return rc;
+    return rq_first_hit(bitfield, grid_size, src, S, N, bound, min_near, dt_gamma, dt_gammas, max_steps, bg_color, image, depth, weights_sum, sample_counts,
+                        workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssdnerf_render_first_hit_cams(const uint8_t* bitfield, uint32_t grid_size, const float* c2w, const float* intrinsics, uint32_t S, uint32_t V,
+                                             uint32_t h, uint32_t w, float bound, float min_near, float dt_gamma, const float* dt_gammas,
+                                             uint32_t max_steps, float bg_color, float* image, float* depth, float* weights_sum,
+                                             int32_t* sample_counts, void* workspace, size_t workspace_bytes, void* stream) {
+    const uint64_t N64 = (uint64_t)V * h * w;
+    if (N64 == 0 || S == 0) return SSDNERF_OK;
+    SSD_REQUIRE(N64 <= 0xffffffffull, "render_first_hit_cams: more than 2^32 rays per scene");
+    RaySrc src;
+    if (int rc = rq_ray_src(src, "render_first_hit_cams", nullptr, nullptr, c2w, intrinsics, V, h, w, (uint32_t)N64)) return rc;
+    return rq_first_hit(bitfield, grid_size, src, S, (uint32_t)N64, bound, min_near, dt_gamma, dt_gammas, max_steps, bg_color, image, depth, weights_sum,
+                        sample_counts, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ssdnerf_render_shade_queue(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params, uint32_t grid_size,
@@ -567,7 +536,7 @@ extern "C" int ssdnerf_render_shade_queue(const void* planes, int planes_dtype, 
     int rc = rq_make_cfg(c, Hp, Wp, grid_size, S, N, bound, min_near, dt_gamma, dt_gammas, max_steps, T_thresh, bg_color, sigmoid_saturation);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const RqWorkspace w = rq_carve(workspace, S, grid_size);
+    const RenderWs w = ssd_render_ws(workspace, S, N, grid_size);
     const uint32_t slices = ssd_blocks(N, RQ_SLICE);                       // worst case: every ray hits
     const uint32_t wg_per_scene = ssd_blocks(slices, RQ_TPB / 64);
     dim3 g(S * wg_per_scene), b(RQ_TPB);

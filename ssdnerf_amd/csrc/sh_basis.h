@@ -45,6 +45,8 @@ constexpr Tables make_tables() {
     return t;
 }
 
+constexpr float C0 = make_tables().norm[0];   // SH_0 of every direction (exactly what eval() returns in out[0])
+
 // Evaluates the C*C basis values (and optionally the three Jacobian rows) of one direction.
 template <int C, bool GRAD>
 SSD_DEV void eval(float x, float y, float z, float* __restrict__ out, float* __restrict__ gx, float* __restrict__ gy, float* __restrict__ gz) {

@@ -1,29 +1,33 @@
-// ssdnerf_amd/csrc/shade_mfma.hip -- stage B of the fused renderer, MFMA form (the default shading kernel).
+// ssdnerf_amd/csrc/shade_mfma.hip -- stage B of the fused renderer (the default shading kernel).
 //
-// Same contract as k_shade_queue (render_queue.hip): persistent waves shade the per-scene hit queues written by
-// k_first_hit.  Two changes, both driven by the r01 profiles (k_shade_queue was ISSUE-bound: ~5600 VALU instructions
-// per 64-sample iteration at ~50 % lane utilisation):
+// Same contract as k_shade_queue (render_queue.hip): persistent waves shade the per-scene hit queues written by stage A
+// (k_ray_cull + k_survivor_march).  What differs, all of it driven by the r01 / r02 profiles (k_shade_queue was ISSUE-bound: ~5600 VALU
+// instructions per 64-sample iteration at ~50 % lane utilisation):
 //
-// (The numbered points describe the f32-MFMA form, variants 2 and 3; the default, variant 4, keeps the structure and runs the same two layers on
-//  the bf16 matrix cores with exact three-term operand splitting -- see the variant list above SmGeo below.)
+// 1. The two wide layers of the tiny MLP run on the bf16 matrix cores in fp32-class arithmetic:
+//        h      = W1 . [f ; 1]        64 x (18+1)
+//        h_col  = h + Wd' . SH'(d)    64 x 16, accumulated IN PLACE on top of h
+//    every fp32 operand is split exactly into three bf16 terms (x = hi + mid + lo, 8 + 8 + 8 significand bits) and the six products whose
+//    weight is >= 2^-16 accumulate in fp32 (dropped terms <= 2^-24 relative: the accuracy class of the fp32 chain).  v_mfma_f32_32x32x16_bf16
+//    runs beside the VALU stream, which the f32-input MFMA does not (it executes on the VALU's own FMA lanes: tools/ubench/mfma_valu_overlap.hip,
+//    2 MFMA + 32 v_fma = 126 ns = 59 + 70 with f32 MFMA, 77 ns with bf16 MFMA; the f32-MFMA forms of r01, 9.4-9.7 ms, are gone).
+//    One lane = one sample = one MFMA "column": lane l supplies the B operand of column l with ONE v_permlane32_swap per packed feature
+//    pair for both 32-sample tiles, and after a second swap+add every lane ends up with the four outputs (sigma, r, g, b) of ITS OWN sample.
+//    Weights live in registers as pre-split A operands (loaded once per wave).  The bias b1 rides as a constant-1 input row; the direction
+//    layer's bias is folded into its first column -- SH_0 is the constant 0.2820948, so Wd'[:,0] = fl32(Wd[:,0] * SH_0 + bd) (one rounding,
+//    computed in fp64 in the prologue) against the input 1.0 replaces (Wd[:,0], bd) against (SH_0, 1): six MFMAs per tile and 24 registers
+//    less, and one rounding instead of two in that term.
+//    The 64->{1,3} output layer and the 128 SiLUs per sample stay on the VALU (4 outputs cannot fill an MFMA tile); output weights sit in
+//    1 KiB of LDS and are read as broadcast ds_read_b128.
 //
-// 1. The two wide layers of the tiny MLP run on the matrix pipe in exact fp32:
-//        h      = W1 . [f ; 1]        64 x (18+1)   -> v_mfma_f32_32x32x2_f32, 10 k-steps x (2 M-tiles x 2 N-tiles)
-//        h_col  = h + Wd . [SH(d); 1] 64 x (16+1)   ->  9 k-steps, accumulated IN PLACE on top of h
-//    (biases ride along as a constant-1 input row, so the accumulator starts from the inline constant 0).
-//    One lane = one sample = one MFMA "column": lane l supplies the B operand of column l with ONE v_permlane32_swap per
-//    k-step for both 32-sample tiles, and after a second swap+add every lane ends up with the four outputs (sigma, r, g, b)
-//    of ITS OWN sample.  Weights live in 38 VGPRs as A operands (loaded once per wave) - no per-iteration scalar loads, and
-//    the per-ray LDS cache of the direction term disappears (it is recomputed on the otherwise idle matrix pipe).
-//    The 64->{1,3} output layer and the 128 SiLUs per sample stay on the VALU (4 outputs cannot fill an MFMA tile);
-//    output weights sit in 1 KiB of LDS and are read as broadcast ds_read_b128.
-//    f32-input MFMA is a k-ordered fp32 FMA chain (MI355X guide), i.e. the same arithmetic class as the VALU kernel.
-//
-// 2. A lane never searches more than SEARCH_PROBES empty voxels for its next sample.  A ray that needs a longer search
+// 2. A lane never searches more than SM_SEARCH_PROBES empty voxels for its next sample.  A ray that needs a longer search
 //    (typically: it left the object and must cross the rest of the box) is parked - state and all - in a wave-local
 //    LDS pool; when 64 of them have collected (or nothing else is left) the wave runs a MARCH PASS in which every lane
 //    marches one parked ray to its next hit (-> "ready" pool, picked up by the next refill) or to the end of the box
 //    (-> finished).  Shading iterations therefore stay full, and marching runs at full lane utilisation too.
+//
+// 3. Rays are prepared 64 at a time by the whole wave (queue entry -> ray from the arrays or from the view's camera (RaySrc) -> near/far, tail
+//    bound, first sample -> LDS stage); idle lanes refill from LDS by ballot/mbcnt rank.
 //
 // Results are bit-identical in the integer outputs and within fp32 rounding of k_shade_queue for the floats (the MFMA
 // accumulates the same products in a different, fixed order); tests/test_render_gpu.py checks both against the oracle.
@@ -64,26 +68,21 @@ SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_el
 
 static constexpr unsigned SM_TPB = 256;
 static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
-static constexpr unsigned SM_SEARCH_PROBES = 4;    // in-lane search budget after each sample
-// Variants of the same kernel (template parameter VAR):
-//   VAR 2: weights as MFMA A operands in 38 VGPRs, both 32-sample tiles in flight (64 accumulator registers), 253 VGPRs, 66 KiB LDS per block.
-//   VAR 3: weights as A operands read from LDS right before each MFMA, the two tiles shaded one after the other (32 accumulator registers),
-//          B operands built in place; <= 168 VGPRs and <= 53 KiB LDS per block, so THREE waves share a SIMD: the r01 counters showed the
-//          2-wave form waiting (SQ_WAIT_INST_ANY ~ 43 % of wave time) with both pipes half idle -- a third wave is what fills those gaps.
-//   VAR 4: the two wide layers on the REAL matrix cores (v_mfma_f32_32x32x16_bf16) with every fp32 operand split exactly into three
-//          bf16 terms (x = hi + mid + lo, 8 + 8 + 8 significand bits) and the six products whose weight is >= 2^-16 accumulated in
-//          fp32: the same accuracy class as the fp32 chain (dropped terms <= 2^-24 relative), but -- unlike the f32-input MFMA, which
-//          executes on the VALU's own FMA lanes and therefore cannot overlap with VALU work at all (tools/ubench/mfma_valu_overlap.hip:
-//          2 MFMA + 32 v_fma take 126 ns = 59 + 70 with f32 MFMA, 77 ns with bf16 MFMA) -- it runs beside the SiLU / gather / marching VALU
-//          stream.  Two waves per SIMD, weights as 96 VGPRs of pre-split A operands, tiles shaded in sequence, SH operands pre-split in LDS.
+#ifndef SM_PROBES
+#define SM_PROBES 4
+#endif
+static constexpr unsigned SM_SEARCH_PROBES = SM_PROBES;   // in-lane search budget after each sample
+// Schedules of the same arithmetic (template parameter VAR; identical products in identical order per accumulator -> bit-identical results):
+//   VAR 4: the two sample tiles are shaded one after the other (32 accumulator registers); MFMA bursts overlap with the OTHER wave's VALU work.
+//   VAR 6: both tiles hold their accumulators (64 registers) and every MFMA group is followed, in program order, by SiLU pairs of the other
+//          tile, so a wave also overlaps its own matrix-pipe time (r02 A/B on the bench scene: 7.72 vs 7.88 ms).  Default.
 template <int VAR> struct SmGeo {
-    static constexpr int WPS = VAR == 3 ? 3 : 2;
-    static constexpr unsigned POOL = VAR == 3 ? 64 : 128;      // entries per wave-local pool (two pools per wave)
-    static constexpr unsigned MARCH_W = POOL / 2;              // rays advanced by one march pass
-    static constexpr unsigned STAGE = VAR == 3 ? 32 : 64;      // prepared rays per wave
-    static constexpr unsigned WLDS = VAR == 3 ? (2 * 10 + 2 * 9) * 64 : 0;   // floats of A-operand weights in LDS
-    static constexpr unsigned SHF = (VAR == 4 || VAR == 6) ? 1536 : 1024;    // floats of per-ray SH operands per wave (VAR 4: three bf16 terms x 64 rays x 16)
-    static constexpr unsigned LDS_FLOATS = 512 + WLDS + (SM_TPB / 64) * (2 * POOL * 8 + SHF + STAGE * 16);
+    static constexpr int WPS = 2;
+    static constexpr unsigned POOL = 128;                       // entries per wave-local pool (two pools per wave)
+    static constexpr unsigned MARCH_W = POOL / 2;               // rays advanced by one march pass
+    static constexpr unsigned STAGE = 64;                       // prepared rays per wave
+    static constexpr unsigned SHF = 1536;                       // floats of per-ray SH operands per wave (three bf16 terms x 64 rays x 16)
+    static constexpr unsigned LDS_FLOATS = 512 + (SM_TPB / 64) * (2 * POOL * 8 + SHF + STAGE * 16);
 };
 
 typedef __bf16 sm_bf16x8 __attribute__((ext_vector_type(8)));
@@ -104,13 +103,13 @@ SSD_DEV void sm_swap_u(uint32_t& a, uint32_t& b) {
     a = r[0]; b = r[1];
 }
 #ifndef SM_DEFAULT_VARIANT
-#define SM_DEFAULT_VARIANT 4                       // measured r01 (bench scene / fog scene): variant 2 9.66 / 29.2 ms, 3 9.36 / 28.1 ms, 4 8.10 / 26.0 ms
+#define SM_DEFAULT_VARIANT 6
 #endif
 #ifndef SM_HEAD_GROUP
 #define SM_HEAD_GROUP 3                            // variant 4: SiLU pairs per scheduling group minus one (3 = four pairs)
 #endif
-#ifndef SM_REFILL_MIN
-#define SM_REFILL_MIN 1                            // refill only when this many lanes are idle (the divergent refill code then runs every few iterations instead of every iteration)
+#ifndef SM_GATHER_BY_PLANE
+#define SM_GATHER_BY_PLANE 1                       // gather one plane at a time (24 texel registers in flight instead of 72)
 #endif
 
 struct FastMarchB {
@@ -152,16 +151,6 @@ SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, fl
     return t;
 }
 
-// Tail bound of a queued ray (common.h): past near + (j_last + 1) coarse steps no occupied cell can be met; + 0.5 step of slack for the
-// difference between k_first_hit's accumulated test parameters and this product form.
-SSD_DEV float sm_tail_far(const FastMarchB& m, const RayGeom& q, float near_, float far_, uint32_t packed, bool packing) {
-    const uint32_t jl = packed >> 24;
-    if (!packing || jl >= SSD_TAIL_NONE) return far_;
-    const float len = sqrtf(ssd_fma(q.dx, q.dx, ssd_fma(q.dy, q.dy, q.dz * q.dz)));
-    const float step_t = (SSD_COARSE_STEP * m.two_rH * m.mip_bound) / fmaxf(len, 1e-20f);
-    return fminf(far_, ssd_fma((float)jl + 1.5f, step_t, near_));
-}
-
 // v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.
 SSD_DEV void sm_swap(float& a, float& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -170,19 +159,17 @@ SSD_DEV void sm_swap(float& a, float& b) {
 }
 
 template <typename PT, int VAR>
-__global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg c, uint32_t slices_per_scene, const PT* __restrict__ planes,
+__global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg c, RaySrc src, const PT* __restrict__ planes,
                                                            const float* __restrict__ P, const uint8_t* __restrict__ lin_bits,
-                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                            const uint2* __restrict__ queue, uint32_t* __restrict__ queue_count,
                                                            float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
                                                            int32_t* __restrict__ sample_counts, int32_t* __restrict__ overflow_flag) {
     // LDS: [0,1 KiB) output-layer weights per accumulator slot; then per wave two pools of SM_POOL x 8 dwords.
     // wout2: 64 entries x 8 floats; per (mt, pair p of adjacent accumulator registers, half): {ws_a, ws_b, wr_a, wr_b, wg_a, wg_b, wb_a, wb_b}
-    // sh  : per wave 64 lanes x 16 floats as [k/4][lane][k%4] (lane-contiguous 16-byte slots: conflict-free ds_read_b128)
-    // stage: per wave 64 PREPARED rays x 16 dwords {ray, t, far, dt | o | d | 1/d | sample xyz}: queue entries and ray geometry are fetched from
-    //        HBM 64 at a time by the whole wave (coalesced, full lane utilisation) instead of one lane at a time inside the divergent refill
-    constexpr int WPS = SmGeo<VAR>::WPS;
-    constexpr unsigned SM_POOL = SmGeo<VAR>::POOL, SM_MARCH_W = SmGeo<VAR>::MARCH_W, SM_STAGE = SmGeo<VAR>::STAGE, SM_WLDS = SmGeo<VAR>::WLDS, SM_SHF = SmGeo<VAR>::SHF;
+    // sh   : per wave 64 rays x 16 SH' values as three bf16 terms in MFMA B-operand form, [term][sample][k 0-7 | k 8-15] (SH'_0 = 1, see the header)
+    // stage: per wave 64 PREPARED rays x 16 dwords {ray, t, far, dt | o | d | 1/d | sample xyz}: queue entries and ray geometry are fetched
+    //        64 at a time by the whole wave (coalesced, full lane utilisation) instead of one lane at a time inside the divergent refill
+    constexpr unsigned SM_POOL = SmGeo<VAR>::POOL, SM_MARCH_W = SmGeo<VAR>::MARCH_W, SM_STAGE = SmGeo<VAR>::STAGE, SM_SHF = SmGeo<VAR>::SHF;
     __shared__ __attribute__((aligned(16))) float lds[SmGeo<VAR>::LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -204,84 +191,54 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
     }
     __syncthreads();
     const float4* wout2 = reinterpret_cast<const float4*>(lds);     // index ((mt*8 + pair)*2 + half)*2 + {0: sigma|r, 1: g|b}
-    float* w_lds = lds + 512;                                       // WPS 3: A operands [layer-1: mt][s][lane] then [dir: mt][s][lane]
-    uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 512 + SM_WLDS) + wave * 2 * SM_POOL * 8;
+    uint32_t* pool_search = reinterpret_cast<uint32_t*>(lds + 512) + wave * 2 * SM_POOL * 8;
     uint32_t* pool_ready = pool_search + SM_POOL * 8;
-    float4* sh_lds = reinterpret_cast<float4*>(lds + 512 + SM_WLDS + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * SM_SHF);   // [kq][lane]  (VAR 4: [term][sample][2 x 16 B])
-    float4* stage = reinterpret_cast<float4*>(lds + 512 + SM_WLDS + (SM_TPB / 64) * (2 * SM_POOL * 8 + SM_SHF) + wave * SM_STAGE * 16);   // [slot][4]
+    uint4* sh_lds = reinterpret_cast<uint4*>(lds + 512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * SM_SHF);   // [term][sample][2 x 16 B]
+    float4* stage = reinterpret_cast<float4*>(lds + 512 + (SM_TPB / 64) * (2 * SM_POOL * 8 + SM_SHF) + wave * SM_STAGE * 16);   // [slot][4]
 
     // ---- persistent grid: every wave pulls 512-ray slices of a scene's hit queue with one atomic ticket per slice.  Waves of
     // XCD x (workgroups are dispatched round-robin over the 8 XCDs, b % 8) start on scene x so that the scene's 1.5 MiB of
     // planes stay in that XCD's L2, and move on to the next scene when theirs has no slices left (work stealing: a wrong
-    // placement guess only costs L2 misses).  queue_count[0..S) = hits per scene, queue_count[S..2S) = slice tickets. ----
-    uint32_t* tickets = queue_count + c.S;
+    // placement guess only costs L2 misses).  Counters (hits per scene, slice tickets): common.h, ssd_counter. ----
     const uint32_t start_scene = (blockIdx.x & 7u) % c.S;
     const PT* planes_base = planes;
     const uint8_t* bits_base = lin_bits;
     const uint2* queue_base = queue;
     const float dt_gamma_default = c.m.dt_gamma;
-    // ---- A operands: lane l holds W[mt*32 + (l&31)][2s + (l>>5)] for every k-step s ----
-    // VAR 4: pre-split A operands.  wa1[mt][ks][term] / wa2[mt][ks][term]: lane l holds the 8 bf16 terms of W[mt*32 + (l&31)][16 ks + 8 (l>>5) + e]
-    sm_bf16x8 wa1[2][2][3], wa2[2][2][3];
-    if constexpr (VAR == 4 || VAR == 6) {
+    const float cell_world = c.m.two_rH * c.m.mip_bound;
+    // ---- pre-split A operands.  wa1[mt][ks][term]: lane l holds the 8 bf16 terms of [W1 | b1 | 0][mt*32 + (l&31)][16 ks + 8 (l>>5) + e];
+    // wa2[mt][term]: the same for Wd' (16 columns, one k-step; column 0 = fl32(Wd[:,0] * SH_0 + bd), the folded bias) ----
+    sm_bf16x8 wa1[2][2][3], wa2[2][3];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = mt * 32 + (lane & 31);
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 32 + (lane & 31);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint32_t t1[3][8], t2[3][8];
+        for (int ks = 0; ks < 2; ++ks) {
+            uint32_t t1[3][8], t2[3][8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = 16 * ks + 8 * half + e;
-                    const float w1 = k < 19 ? P[row * 24 + k] : 0.0f;                                                        // W1 | b1 | 0
-                    const float w2 = k < 16 ? P[MLP_OFF_WD + row * 16 + k] : (k == 16 ? P[MLP_OFF_BD + row] : 0.0f);           // Wd | bd | 0
-                    sm_split3(w1, t1[0][e], t1[1][e], t1[2][e]);
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * ks + 8 * half + e;
+                const float w1 = k < 19 ? P[row * 24 + k] : 0.0f;                                                        // W1 | b1 | 0
+                sm_split3(w1, t1[0][e], t1[1][e], t1[2][e]);
+                if (ks == 0) {
+                    float w2 = P[MLP_OFF_WD + row * 16 + k];
+                    if (k == 0) w2 = (float)((double)w2 * (double)shb::C0 + (double)P[MLP_OFF_BD + row]);
                     sm_split3(w2, t2[0][e], t2[1][e], t2[2][e]);
                 }
+            }
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    wa1[mt][ks][t] = sm_op(sm_pack2(t1[t][0], t1[t][1]), sm_pack2(t1[t][2], t1[t][3]), sm_pack2(t1[t][4], t1[t][5]), sm_pack2(t1[t][6], t1[t][7]));
-                    wa2[mt][ks][t] = sm_op(sm_pack2(t2[t][0], t2[t][1]), sm_pack2(t2[t][2], t2[t][3]), sm_pack2(t2[t][4], t2[t][5]), sm_pack2(t2[t][6], t2[t][7]));
-                }
+            for (int t = 0; t < 3; ++t) {
+                wa1[mt][ks][t] = sm_op(sm_pack2(t1[t][0], t1[t][1]), sm_pack2(t1[t][2], t1[t][3]), sm_pack2(t1[t][4], t1[t][5]), sm_pack2(t1[t][6], t1[t][7]));
+                if (ks == 0) wa2[mt][t] = sm_op(sm_pack2(t2[t][0], t2[t][1]), sm_pack2(t2[t][2], t2[t][3]), sm_pack2(t2[t][4], t2[t][5]), sm_pack2(t2[t][6], t2[t][7]));
             }
         }
     }
-    float a1[2][10], a2[2][9];
-    if (VAR == 2 || (VAR == 3 && wave == 0)) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = mt * 32 + (lane & 31);
-#pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                const int k = 2 * s + half;                       // W1 | b1 | 0
-                a1[mt][s] = k < 19 ? P[row * 24 + k] : 0.0f;      // rec[row][0..17] = W1, rec[row][18] = b1
-            }
-#pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const int k = 2 * s + half;                       // Wd | bd | 0
-                a2[mt][s] = k < 16 ? P[MLP_OFF_WD + row * 16 + k] : (k == 16 ? P[MLP_OFF_BD + row] : 0.0f);
-            }
-        }
-    }
-    if constexpr (VAR == 3) {                                 // park the A operands in LDS (one copy per block), lane-contiguous: conflict-free ds_read_b32
-        if (wave == 0) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-                for (int s = 0; s < 10; ++s) w_lds[(mt * 10 + s) * 64 + lane] = a1[mt][s];
-#pragma unroll
-                for (int s = 0; s < 9; ++s) w_lds[1280 + (mt * 9 + s) * 64 + lane] = a2[mt][s];
-            }
-        }
-        __syncthreads();
-    }
-    const float b_const = half == 0 ? 1.0f : 0.0f;            // B operand of the (1, 0) bias/pad k-step, both tiles
     const float b_sigma = P[MLP_OFF_TAIL + 0], bc0 = P[MLP_OFF_TAIL + 1], bc1 = P[MLP_OFF_TAIL + 2], bc2 = P[MLP_OFF_TAIL + 3];
     const float sat_k = ssd_fma(c.sat, 2.0f, 1.0f);
 
   for (uint32_t sk = 0; sk < c.S; ++sk) {
     const uint32_t scene = (start_scene + sk) % c.S;
-    const uint32_t count = queue_count[scene];
+    const uint32_t count = queue_count[ssd_counter(SSD_CNT_HITS, c.S, scene)];
     const uint32_t n_slices = (count + SM_SLICE - 1) / SM_SLICE;
     const uint64_t ray0 = (uint64_t)scene * c.N;
     planes = planes_base + scene * c.plane_stride;
@@ -313,44 +270,28 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
         weights_sum[gi] = ws_;
         if (sample_counts) sample_counts[gi] = (int32_t)cnt_;
     };
-    auto load_geometry = [&](uint32_t rid) {
-        const uint64_t gi = ray0 + (rid & id_mask);
-        r = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
-        float near_;
-        ssd_near_far(c.aabb, r, c.min_near, near_, far_);
-        far_ = sm_tail_far(c.m, r, near_, far_, rid, packing);
+    auto set_signs = [&]() {
         sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f); sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f); sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
     };
-    auto begin_ray = [&]() {   // geometry is loaded and t points at an occupied probe
-        const ProbeB p = sm_probe(c.m, lin_bits, r, t);
-        sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
+    auto store_sh = [&]() {    // SH'(d) of this lane's ray as three bf16 terms per value, in MFMA B-operand form: [term][sample][k 0-7 | k 8-15]
         float sh[16];
         shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
-        if constexpr (VAR == 4 || VAR == 6) {          // three bf16 terms per value, in MFMA B-operand form: [term][sample][k 0-7 | k 8-15]
-            uint32_t tm[3][16];
+        sh[0] = 1.0f;                                            // SH_0 is constant: its weight column carries Wd[:,0] * SH_0 + bd
+        uint32_t tm[3][16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) sm_split3(sh[k], tm[0][k], tm[1][k], tm[2][k]);
+        for (int k = 0; k < 16; ++k) sm_split3(sh[k], tm[0][k], tm[1][k], tm[2][k]);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                uint4* dst = reinterpret_cast<uint4*>(sh_lds) + t * 128 + lane * 2;
-                dst[0] = make_uint4(sm_pack2(tm[t][0], tm[t][1]), sm_pack2(tm[t][2], tm[t][3]), sm_pack2(tm[t][4], tm[t][5]), sm_pack2(tm[t][6], tm[t][7]));
-                dst[1] = make_uint4(sm_pack2(tm[t][8], tm[t][9]), sm_pack2(tm[t][10], tm[t][11]), sm_pack2(tm[t][12], tm[t][13]), sm_pack2(tm[t][14], tm[t][15]));
-            }
-        } else if constexpr (VAR == 3) {               // operand form [k][sample]: the dir-term MFMAs read their B operands straight from LDS
-#pragma unroll
-            for (int k = 0; k < 16; ++k) reinterpret_cast<float*>(sh_lds)[k * 64 + lane] = sh[k];
-        } else {
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) sh_lds[kq * 64 + lane] = make_float4(sh[4 * kq], sh[4 * kq + 1], sh[4 * kq + 2], sh[4 * kq + 3]);
+        for (int tt = 0; tt < 3; ++tt) {
+            uint4* dst = sh_lds + tt * 128 + lane * 2;
+            dst[0] = make_uint4(sm_pack2(tm[tt][0], tm[tt][1]), sm_pack2(tm[tt][2], tm[tt][3]), sm_pack2(tm[tt][4], tm[tt][5]), sm_pack2(tm[tt][6], tm[tt][7]));
+            dst[1] = make_uint4(sm_pack2(tm[tt][8], tm[tt][9]), sm_pack2(tm[tt][10], tm[tt][11]), sm_pack2(tm[tt][12], tm[tt][13]), sm_pack2(tm[tt][14], tm[tt][15]));
         }
     };
 
     for (;;) {
         // ================= refill idle lanes: parked-and-found rays first, then the global hit queue =================
-        const uint64_t idle_now = __ballot(ray < 0);
-        const bool do_refill = (uint32_t)__popcll(idle_now) >= SM_REFILL_MIN || idle_now == ~0ull;
-        if (do_refill) {
-            const uint64_t idle = idle_now;
+        {
+            const uint64_t idle = __ballot(ray < 0);
             if (idle != 0 && rp_count != 0) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t take = min((uint32_t)__popcll(idle), rp_count);
@@ -359,8 +300,14 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                     const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + 4);
                     ray = (int)e0.x; t = __uint_as_float(e0.y); ws = __uint_as_float(e0.z); dep = __uint_as_float(e0.w);
                     cr = __uint_as_float(e1.x); cg = __uint_as_float(e1.y); cb = __uint_as_float(e1.z); cnt = e1.w;
-                    load_geometry(e0.x);
-                    begin_ray();
+                    r = ssd_fetch_ray(src, scene, c.N, e0.x & id_mask);
+                    float near_;
+                    ssd_near_far(c.aabb, r, c.min_near, near_, far_);
+                    far_ = ssd_tail_far(r, cell_world, near_, far_, e0.x, packing);
+                    set_signs();
+                    const ProbeB p = sm_probe(c.m, lin_bits, r, t);      // t points at an occupied probe
+                    sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
+                    store_sh();
                 }
                 rp_head = (rp_head + take) % SM_POOL;
                 rp_count -= take;
@@ -374,7 +321,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             if (st_count == 0) {
                 if (next >= end && !scene_done) {            // current slice used up: take a ticket for the next one
                     uint32_t sl = 0;
-                    if (lane == 0) sl = atomicAdd(tickets + scene, 1u);
+                    if (lane == 0) sl = atomicAdd(queue_count + ssd_counter(SSD_CNT_TICKETS, c.S, scene), 1u);
                     sl = __builtin_amdgcn_readfirstlane(sl);
                     if (sl < n_slices) { next = sl * SM_SLICE; end = min(next + SM_SLICE, count); }
                     else scene_done = true;
@@ -383,11 +330,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                 const uint32_t n = min(end - next, SM_STAGE);
                 if ((uint32_t)lane < n) {                    // stage fill: one queue entry per lane, all lanes busy
                     const uint2 e = queue[next + lane];
-                    const uint64_t gi = ray0 + (e.x & id_mask);
-                    const RayGeom q = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
+                    const RayGeom q = ssd_fetch_ray(src, scene, c.N, e.x & id_mask);
                     float qn, qf;
                     ssd_near_far(c.aabb, q, c.min_near, qn, qf);
-                    qf = sm_tail_far(c.m, q, qn, qf, e.x, packing);
+                    qf = ssd_tail_far(q, cell_world, qn, qf, e.x, packing);
                     const float qt = __uint_as_float(e.y);
                     const ProbeB p = sm_probe(c.m, lin_bits, q, qt);      // the queued t is an occupied probe by construction
                     float4* dst = stage + lane * 4;
@@ -405,32 +351,14 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t take = min((uint32_t)__popcll(idle), st_count);
             if (ray < 0 && rank < take) {
-                const float4* src = stage + (st_head + rank) * 4;
-                const float4 g0 = src[0], g1 = src[1], g2 = src[2], g3 = src[3];
+                const float4* sp = stage + (st_head + rank) * 4;
+                const float4 g0 = sp[0], g1 = sp[1], g2 = sp[2], g3 = sp[3];
                 ray = (int)__float_as_uint(g0.x); t = g0.y; far_ = g0.z; sdt = g0.w;
                 r.ox = g1.x; r.oy = g1.y; r.oz = g1.z; r.dx = g1.w; r.dy = g2.x; r.dz = g2.y; r.rdx = g2.z; r.rdy = g2.w; r.rdz = g3.x;
                 sx = g3.y; sy = g3.z; sz = g3.w;
-                sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f); sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f); sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
+                set_signs();
                 ws = dep = cr = cg = cb = 0.f; cnt = 0;
-                float sh[16];
-                shb::eval<4, false>(r.dx, r.dy, r.dz, sh, nullptr, nullptr, nullptr);
-                if constexpr (VAR == 4 || VAR == 6) {
-                    uint32_t tm[3][16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) sm_split3(sh[k], tm[0][k], tm[1][k], tm[2][k]);
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        uint4* dst = reinterpret_cast<uint4*>(sh_lds) + t * 128 + lane * 2;
-                        dst[0] = make_uint4(sm_pack2(tm[t][0], tm[t][1]), sm_pack2(tm[t][2], tm[t][3]), sm_pack2(tm[t][4], tm[t][5]), sm_pack2(tm[t][6], tm[t][7]));
-                        dst[1] = make_uint4(sm_pack2(tm[t][8], tm[t][9]), sm_pack2(tm[t][10], tm[t][11]), sm_pack2(tm[t][12], tm[t][13]), sm_pack2(tm[t][14], tm[t][15]));
-                    }
-                } else if constexpr (VAR == 3) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) reinterpret_cast<float*>(sh_lds)[k * 64 + lane] = sh[k];
-                } else {
-#pragma unroll
-                    for (int kq = 0; kq < 4; ++kq) sh_lds[kq * 64 + lane] = make_float4(sh[4 * kq], sh[4 * kq + 1], sh[4 * kq + 2], sh[4 * kq + 3]);
-                }
+                store_sh();
             }
             st_head += take; st_count -= take;
         }
@@ -444,11 +372,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             if (mine) {
                 const uint32_t* e = pool_search + ((sp_head + lane) % SM_POOL) * 8;
                 e0 = *reinterpret_cast<const uint4*>(e); e1 = *reinterpret_cast<const uint4*>(e + 4);
-                const uint64_t gi = ray0 + (e0.x & id_mask);
-                const RayGeom q = ssd_load_ray(rays_o + 3 * gi, rays_d + 3 * gi);
+                const RayGeom q = ssd_fetch_ray(src, scene, c.N, e0.x & id_mask);
                 float qn, qf;
                 ssd_near_far(c.aabb, q, c.min_near, qn, qf);
-                qf = sm_tail_far(c.m, q, qn, qf, e0.x, packing);
+                qf = ssd_tail_far(q, cell_world, qn, qf, e0.x, packing);
                 const float qx = ssd_fma(0.5f, ssd_sign1(q.dx), 0.5f), qy = ssd_fma(0.5f, ssd_sign1(q.dy), 0.5f), qz = ssd_fma(0.5f, ssd_sign1(q.dz), 0.5f);
                 float qt = __uint_as_float(e0.y);
                 while (qt < qf) {
@@ -480,40 +407,32 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
 
         // ================= shade: gather -> MFMA layers -> output layer -> composite =================
         float f[18];
-        if (ray >= 0) ssd_gather18<PT, VAR != 2>(planes, c.g, sx, sy, sz, f);
+        if (ray >= 0) ssd_gather18<PT, SM_GATHER_BY_PLANE != 0>(planes, c.g, sx, sy, sz, f);
         else {
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
         }
-        // Software-pipelined by sample tile so that (almost) every MFMA has independent VALU work to hide under, inside this
-        // wave: the f32 MFMA occupies the matrix pipe for 64 cycles, and an in-order wave that issues MFMAs back to back just
-        // waits (r01 counters: SQ_WAIT_INST_ANY = 2.4x the MFMA time, both waves of a SIMD colliding in their MFMA bursts).
-        //   A: layer-1 tile 0            (20 MFMA)
-        //   B: layer-1 tile 1            (20 MFMA)  ||  density head of tile 0   (16 SiLU pairs)
-        //   C: direction term tile 0     (18 MFMA)  ||  density head of tile 1
-        //   D: direction term tile 1     (18 MFMA)  ||  colour head of tile 0
-        //   E: colour head of tile 1
+        // Split every feature into three bf16 terms, pack feature pairs, and trade halves so that T[t][0..3] is tile 0's k-step-0 operand
+        // (features 0-15 of the samples of lanes 0-31) and T[t][4..7] tile 1's; T[t][8] / Z[t] carry features 16, 17 for k-step 1 (their other
+        // k slots are the bias row and zeros).
+        uint32_t T[3][9], Z[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int p2 = 0; p2 < 9; ++p2) {
+            uint32_t h0, m0, l0, h1, m1, l1;
+            sm_split3(f[2 * p2], h0, m0, l0);
+            sm_split3(f[2 * p2 + 1], h1, m1, l1);
+            T[0][p2] = sm_pack2(h0, h1); T[1][p2] = sm_pack2(m0, m1); T[2][p2] = sm_pack2(l0, l1);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm_swap_u(T[tt][k], T[tt][4 + k]);
+            sm_swap_u(T[tt][8], Z[tt]);
+        }
+        const uint32_t bias_pair = half == 0 ? 0x00003F80u : 0u;          // {bf16(1.0), 0}: the bias row of layer 1's k-step 1 (k = 18), lane half 0 only
+        constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};   // products (weight term i) x (input term j), i + j <= 2, smallest first
         float ps0, ps1, pr0, pr1, pg0, pg1, pb0, pb1;            // per tile: this lane half's share of (sigma, r, g, b) pre-activations
         if constexpr (VAR == 4) {
-            // ---- bf16 x 3 on the matrix cores.  Split every feature into three bf16 terms, pack feature pairs, and trade halves so that
-            // T[t][0..3] is tile 0's k-step-0 operand (features 0-15 of the samples of lanes 0-31) and T[t][4..7] tile 1's; T[t][8] / Z[t]
-            // carry features 16, 17 for k-step 1 (their other k slots are the bias row and zeros)
-            uint32_t T[3][9], Z[3] = {0u, 0u, 0u};
-#pragma unroll
-            for (int p2 = 0; p2 < 9; ++p2) {
-                uint32_t h0, m0, l0, h1, m1, l1;
-                sm_split3(f[2 * p2], h0, m0, l0);
-                sm_split3(f[2 * p2 + 1], h1, m1, l1);
-                T[0][p2] = sm_pack2(h0, h1); T[1][p2] = sm_pack2(m0, m1); T[2][p2] = sm_pack2(l0, l1);
-            }
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sm_swap_u(T[t][k], T[t][4 + k]);
-                sm_swap_u(T[t][8], Z[t]);
-            }
-            const uint32_t bias_pair = half == 0 ? 0x00003F80u : 0u;          // {bf16(1.0), 0}: the bias row of k-step 1 (k = 18 resp. 16), lane half 0 only
-            const sm_bf16x8 b_bias = sm_op(bias_pair, 0u, 0u, 0u);            // dir layer, k-step 1: [1, 0, ...]
             float res[2][4];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -524,14 +443,12 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                     for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
                 sm_bf16x8 b0[3], b1[3];                                      // B operands of k-step 0 / 1, terms hi, mid, lo
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    b0[t] = sm_op(T[t][4 * nt], T[t][4 * nt + 1], T[t][4 * nt + 2], T[t][4 * nt + 3]);
-                    b1[t] = sm_op(nt == 0 ? T[t][8] : Z[t], t == 0 ? bias_pair : 0u, 0u, 0u);
+                for (int tt = 0; tt < 3; ++tt) {
+                    b0[tt] = sm_op(T[tt][4 * nt], T[tt][4 * nt + 1], T[tt][4 * nt + 2], T[tt][4 * nt + 3]);
+                    b1[tt] = sm_op(nt == 0 ? T[tt][8] : Z[tt], tt == 0 ? bias_pair : 0u, 0u, 0u);
                 }
-                // h = W1 [f; 1]: products (weight term i) x (feature term j), i + j <= 2, smallest first
 #pragma unroll
-                for (int pr_i = 0; pr_i < 6; ++pr_i) {
-                    constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};
+                for (int pr_i = 0; pr_i < 6; ++pr_i) {                       // h = W1 [f; 1]
                     const int i = TI[pr_i], j = TJ[pr_i];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
@@ -545,21 +462,16 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                     const int mt = q >> 3, p2 = q & 7;
                     const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
                     ps = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]}), ps);
-                    if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);    // four pairs at a time (see VAR 3)
+                    if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);    // four pairs at a time: the scheduler otherwise batches all 32 exp/rcp and spills their results
                 }
-                // h += Wd [SH(d); 1]: SH operands pre-split per ray in LDS, [term][sample][k 0-7 | k 8-15]
-                sm_bf16x8 sb[3];
+                sm_bf16x8 sb[3];                                             // h += Wd' SH'(d): operands pre-split per ray in LDS
 #pragma unroll
-                for (int t = 0; t < 3; ++t) sb[t] = *reinterpret_cast<const sm_bf16x8*>(reinterpret_cast<const uint4*>(sh_lds) + t * 128 + (nt * 32 + (lane & 31)) * 2 + half);
+                for (int tt = 0; tt < 3; ++tt) sb[tt] = *reinterpret_cast<const sm_bf16x8*>(sh_lds + tt * 128 + (nt * 32 + (lane & 31)) * 2 + half);
 #pragma unroll
                 for (int pr_i = 0; pr_i < 6; ++pr_i) {
-                    constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};
                     const int i = TI[pr_i], j = TJ[pr_i];
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][0][i], sb[j], acc[mt], 0, 0, 0);
-                        if (j == 0) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][1][i], b_bias, acc[mt], 0, 0, 0);   // + bd (exactly: 1.0 has one term)
-                    }
+                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][i], sb[j], acc[mt], 0, 0, 0);
                 }
                 floatx2 pr = {0.f, 0.f}, pg = {0.f, 0.f}, pb = {0.f, 0.f};
 #pragma unroll
@@ -575,29 +487,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                 res[nt][0] = ps.x + ps.y; res[nt][1] = pr.x + pr.y; res[nt][2] = pg.x + pg.y; res[nt][3] = pb.x + pb.y;
             }
             ps0 = res[0][0]; ps1 = res[1][0]; pr0 = res[0][1]; pr1 = res[1][1]; pg0 = res[0][2]; pg1 = res[1][2]; pb0 = res[0][3]; pb1 = res[1][3];
-        } else if constexpr (VAR == 6) {
-            // ---- variant 4's operands (bf16 x 3 on the matrix cores, same products in the same order per accumulator: bit-identical
-            // results) in variant 2's schedule: both sample tiles hold their accumulators (64 registers instead of 32), and every MFMA
-            // group has SiLU pairs of the OTHER tile behind it in program order, so the wave keeps issuing VALU work while its own MFMAs
-            // run (variant 4 leaves that to the second wave of the SIMD).  Needs the register headroom of SSD_GATHER_PAIRS=1.
-            //   A: layer 1, tile 0 (24 MFMA)   B: layer 1, tile 1 (24) || density head 0   C: dir term 0 (18) || density head 1
-            //   D: dir term 1 (18) || colour head 0   E: colour head 1
-            uint32_t T[3][9], Z[3] = {0u, 0u, 0u};
-#pragma unroll
-            for (int p2 = 0; p2 < 9; ++p2) {
-                uint32_t h0, m0, l0, h1, m1, l1;
-                sm_split3(f[2 * p2], h0, m0, l0);
-                sm_split3(f[2 * p2 + 1], h1, m1, l1);
-                T[0][p2] = sm_pack2(h0, h1); T[1][p2] = sm_pack2(m0, m1); T[2][p2] = sm_pack2(l0, l1);
-            }
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sm_swap_u(T[t][k], T[t][4 + k]);
-                sm_swap_u(T[t][8], Z[t]);
-            }
-            const uint32_t bias_pair = half == 0 ? 0x00003F80u : 0u;
-            const sm_bf16x8 b_bias = sm_op(bias_pair, 0u, 0u, 0u);
+        } else {
+            // ---- VAR 6: the same products in the same order per accumulator, tile-interleaved:
+            //   A: layer 1, tile 0 (24 MFMA)   B: layer 1, tile 1 (24) || density head 0   C: dir term 0 (12) || density head 1
+            //   D: dir term 1 (12) || colour head 0   E: colour head 1
             floatx16 acc[2][2];                                              // [tile][mt]
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -605,7 +498,6 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.0f;
-            constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};
             auto layer1 = [&](int nt, int pr_i) {                            // 4 MFMA: products (weight term i) x (feature term j) of both row tiles
                 const int i = TI[pr_i], j = TJ[pr_i];
                 const sm_bf16x8 b0 = sm_op(T[j][4 * nt], T[j][4 * nt + 1], T[j][4 * nt + 2], T[j][4 * nt + 3]);
@@ -619,15 +511,12 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             sm_bf16x8 sb[3];
             auto load_sh = [&](int nt) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) sb[t] = *reinterpret_cast<const sm_bf16x8*>(reinterpret_cast<const uint4*>(sh_lds) + t * 128 + (nt * 32 + (lane & 31)) * 2 + half);
+                for (int tt = 0; tt < 3; ++tt) sb[tt] = *reinterpret_cast<const sm_bf16x8*>(sh_lds + tt * 128 + (nt * 32 + (lane & 31)) * 2 + half);
             };
-            auto dir_term = [&](int nt, int pr_i) {                          // 2 or 4 MFMA: h += Wd [SH(d); 1]
+            auto dir_term = [&](int nt, int pr_i) {                          // 2 MFMA: h += Wd' SH'(d)
                 const int i = TI[pr_i], j = TJ[pr_i];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][0][i], sb[j], acc[nt][mt], 0, 0, 0);
-                    if (j == 0) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][1][i], b_bias, acc[nt][mt], 0, 0, 0);
-                }
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][i], sb[j], acc[nt][mt], 0, 0, 0);
             };
             floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
             floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
@@ -682,157 +571,30 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             }
             ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y; pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y;
             pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
-        } else if constexpr (VAR == 3) {
-            // ---- three waves per SIMD: the tiles are shaded one after the other, A operands come from LDS, B operands are built in place ----
-            // after the swaps f[2s] feeds tile 0 (the samples of lanes 0-31) and f[2s+1] tile 1, k-step s; the SH operands sit in LDS in that form
-#pragma unroll
-            for (int s = 0; s < 9; ++s) sm_swap(f[2 * s], f[2 * s + 1]);
-            const float* sh_op = reinterpret_cast<const float*>(sh_lds) + half * 64 + (lane & 31);   // + (2s)*64 + nt*32: SH_{2s+half} of sample nt*32 + (lane & 31)
-            float res[2][4];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                // the A operands are the same for both tiles; the laundered lane offset keeps the compiler from loading them once and holding
-                // all 38 of them in registers across the two tiles (which is exactly the register budget this variant exists to avoid)
-                uint32_t wl = (uint32_t)lane;
-                asm volatile("" : "+v"(wl));
-                const float* wA = w_lds + wl;
-                floatx16 acc[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
-#pragma unroll
-                for (int s = 0; s < 10; ++s) {                              // h = W1 [f; 1]
-                    const float bop = s < 9 ? f[2 * s + nt] : b_const;
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[(0 * 10 + s) * 64], bop, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[(1 * 10 + s) * 64], bop, acc[1], 0, 0, 0);
-                }
-                floatx2 ps = {0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {                              // density head on silu(h)
-                    const int mt = q >> 3, p2 = q & 7;
-                    const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
-                    ps = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]}), ps);
-                    if (q & 1) __builtin_amdgcn_sched_barrier(0);           // two pairs at a time: the scheduler otherwise batches all 32 exp/rcp and spills their results
-                }
-#pragma unroll
-                for (int s = 0; s < 9; ++s) {                               // h += Wd [SH(d); 1], in place
-                    const float bop = s < 8 ? sh_op[2 * s * 64 + nt * 32] : b_const;
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[1280 + (0 * 9 + s) * 64], bop, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[1280 + (1 * 9 + s) * 64], bop, acc[1], 0, 0, 0);
-                }
-                floatx2 pr = {0.f, 0.f}, pg = {0.f, 0.f}, pb = {0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {                              // colour head on silu(h + hd)
-                    const int mt = q >> 3, p2 = q & 7;
-                    const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
-                    const floatx2 cc = sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]});
-                    pr = sm_fma2(floatx2{w0.z, w0.w}, cc, pr);
-                    pg = sm_fma2(floatx2{w1.x, w1.y}, cc, pg);
-                    pb = sm_fma2(floatx2{w1.z, w1.w}, cc, pb);
-                    if (q & 1) __builtin_amdgcn_sched_barrier(0);
-                }
-                res[nt][0] = ps.x + ps.y; res[nt][1] = pr.x + pr.y; res[nt][2] = pg.x + pg.y; res[nt][3] = pb.x + pb.y;
-            }
-            ps0 = res[0][0]; ps1 = res[1][0]; pr0 = res[0][1]; pr1 = res[1][1]; pg0 = res[0][2]; pg1 = res[1][2]; pb0 = res[0][3]; pb1 = res[1][3];
-        } else {
-            floatx16 acc[2][2];
-    #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-    #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-    #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
-            float fb0[10], fb1[10];                 // B operands of layer 1 for tile 0 / tile 1
-    #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                fb0[s] = f[2 * s]; fb1[s] = f[2 * s + 1];
-                sm_swap(fb0[s], fb1[s]);
-            }
-            fb0[9] = fb1[9] = b_const;
-            floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
-            floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
-            auto density_pair = [&](int nt, int q) {     // q in [0,16): accumulator pair (mt = q / 8, registers 2*(q%8), 2*(q%8)+1)
-                const int mt = q >> 3, p2 = q & 7;
-                const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
-                const floatx2 wS = {w.x, w.y};
-                ps_[nt] = sm_fma2(wS, sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]}), ps_[nt]);
-            };
-            auto colour_pair = [&](int nt, int q) {
-                const int mt = q >> 3, p2 = q & 7;
-                const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
-                const floatx2 wR = {w0.z, w0.w}, wG = {w1.x, w1.y}, wB = {w1.z, w1.w};
-                const floatx2 cc = sm_silu2(floatx2{acc[mt][nt][2 * p2], acc[mt][nt][2 * p2 + 1]});
-                pr_[nt] = sm_fma2(wR, cc, pr_[nt]);
-                pg_[nt] = sm_fma2(wG, cc, pg_[nt]);
-                pb_[nt] = sm_fma2(wB, cc, pb_[nt]);
-            };
-            // ---- A
-    #pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][s], fb0[s], acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][s], fb0[s], acc[1][0], 0, 0, 0);
-            }
-            // SH operands (per-ray constants parked in LDS)
-            float4 shq[4];
-    #pragma unroll
-            for (int kq = 0; kq < 4; ++kq) shq[kq] = sh_lds[kq * 64 + lane];
-            const float* sh = reinterpret_cast<const float*>(shq);
-            float sb0[9], sb1[9];
-    #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                sb0[s] = sh[2 * s]; sb1[s] = sh[2 * s + 1];
-                sm_swap(sb0[s], sb1[s]);
-            }
-            sb0[8] = sb1[8] = b_const;
-            // ---- B
-    #pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][s], fb1[s], acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][s], fb1[s], acc[1][1], 0, 0, 0);
-                if (s < 8) { density_pair(0, 2 * s); density_pair(0, 2 * s + 1); }
-            }
-            // ---- C
-    #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][s], sb0[s], acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][s], sb0[s], acc[1][0], 0, 0, 0);
-                if (s < 8) { density_pair(1, 2 * s); density_pair(1, 2 * s + 1); }
-            }
-            // ---- D
-    #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][s], sb1[s], acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][s], sb1[s], acc[1][1], 0, 0, 0);
-                if (s < 8) { colour_pair(0, 2 * s); colour_pair(0, 2 * s + 1); }
-            }
-            // ---- E
-    #pragma unroll
-            for (int q = 0; q < 16; ++q) colour_pair(1, q);
-            ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y;
-            pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y; pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y;
-            pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         }
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
         sm_swap(ps0, ps1); sm_swap(pr0, pr1); sm_swap(pg0, pg1); sm_swap(pb0, pb1);
         const float sigma = ssd_exp(ps0 + ps1 + b_sigma);
         const float sr = ssd_fma(ssd_sigmoid(pr0 + pr1 + bc0), sat_k, -c.sat);
         const float sg = ssd_fma(ssd_sigmoid(pg0 + pg1 + bc1), sat_k, -c.sat);
-        const float sb = ssd_fma(ssd_sigmoid(pb0 + pb1 + bc2), sat_k, -c.sat);
+        const float sb_ = ssd_fma(ssd_sigmoid(pb0 + pb1 + bc2), sat_k, -c.sat);
 
         bool park = false;
         if (ray >= 0) {
             const float alpha = 1.0f - __expf(-sigma * sdt);
-            const float T = 1.0f - ws;
-            const float w = alpha * T;
+            const float Tr = 1.0f - ws;
+            const float w = alpha * Tr;
+            // diagnostic: termination tests that land within float noise of the threshold (the only rays whose sample count may differ from
+            // the reference's, whose exp is CUDA's __expf: DESIGN.md "arithmetic contract"); ~1 ray in 5000, so the atomic is free
+            if (fabsf(Tr - c.T_thresh) < 2e-6f) atomicAdd(queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, scene), 1u);
             ws += w;
             dep = ssd_fma(w, t, dep);
             cr = ssd_fma(w, sr, cr);
             cg = ssd_fma(w, sg, cg);
-            cb = ssd_fma(w, sb, cb);
+            cb = ssd_fma(w, sb_, cb);
             t += sdt;
             ++cnt;
-            if (T < c.T_thresh) {
+            if (Tr < c.T_thresh) {
                 write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1;
             } else {
                 uint32_t probes = 0;
@@ -880,16 +642,13 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
 }
 
 // ------------------------------------------------------------------------------------------------
-size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size);   // render_queue.hip (same workspace layout)
+extern "C" size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size);   // render_queue.hip (same workspace layout)
 
-extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
-                                               uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N, float bound,
-                                               float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps, float T_thresh,
-                                               float bg_color, float sigmoid_saturation, float* image, float* depth, float* weights_sum,
-                                               int32_t* sample_counts, int32_t* overflow_flag, void* workspace, size_t workspace_bytes,
-                                               void* stream) {
-    if (N == 0 || S == 0) return SSDNERF_OK;
-    SSD_REQUIRE(planes && mlp_params && rays_o && rays_d && image && depth && weights_sum && workspace, "render_shade_queue_mfma: null pointer");
+static int sm_shade(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params, uint32_t grid_size, const RaySrc& src,
+                    uint32_t S, uint32_t N, float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps, float T_thresh,
+                    float bg_color, float sigmoid_saturation, float* image, float* depth, float* weights_sum, int32_t* sample_counts,
+                    int32_t* overflow_flag, void* workspace, size_t workspace_bytes, void* stream) {
+    SSD_REQUIRE(planes && mlp_params && image && depth && weights_sum && workspace, "render_shade_queue_mfma: null pointer");
     SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "render_shade_queue_mfma: unsupported plane dtype");
     SSD_REQUIRE(grid_size >= 8 && grid_size <= 512 && (grid_size & (grid_size - 1)) == 0, "render_shade_queue_mfma: grid_size must be a power of two in [8, 512]");
     if (workspace_bytes < ssdnerf_render_queue_workspace(S, N, grid_size))
@@ -907,13 +666,7 @@ extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dt
     c.plane_stride = (uint64_t)3 * Hp * Wp * 8;
     c.bitfield_stride = (grid_size * grid_size * grid_size) / 8;
     c.dt_gammas = dt_gammas;
-    // workspace carve (must match render_queue.hip)
-    const size_t counters = ((size_t)S * 8 + 255) / 256 * 256;
-    const size_t bits = ((size_t)S * c.bitfield_stride + 255) / 256 * 256;
-    uint32_t* q_count = (uint32_t*)workspace;
-    const uint8_t* lin_bits = (const uint8_t*)workspace + counters;
-    const size_t hc = grid_size / 2, coarse = ((size_t)S * (hc * hc * hc / 8) + 255) / 256 * 256;   // k_first_hit's coarse occupancy
-    const uint2* queue = (const uint2*)((const uint8_t*)workspace + counters + bits + coarse);
+    const RenderWs w = ssd_render_ws(workspace, S, N, grid_size);
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -921,20 +674,44 @@ extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dt
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    const uint32_t slices = 0;   // (kept in the kernel signature; slices are ticketed dynamically)
-    // residency: WPS workgroups x 4 waves per CU, persistent.  SSDNERF_SHADE_WPS=2|3 picks the variant (default below).
-    static int var = 0;                                  // 2: f32 MFMA, 2 waves/SIMD; 3: f32 MFMA, 3 waves/SIMD; 4: bf16 x 3 on the matrix cores;
-                                                         // 6: variant 4's arithmetic in variant 2's interleaved schedule (experimental: not yet run on hardware)
+    // residency: 2 workgroups x 4 waves per CU, persistent.  SSDNERF_SHADE_VARIANT=4|6 picks the schedule (results are bit-identical).
+    static int var = 0;
     if (var == 0) {
         const char* e = getenv("SSDNERF_SHADE_VARIANT");
-        var = (e && ((e[0] >= '2' && e[0] <= '4') || e[0] == '6')) ? e[0] - '0' : SM_DEFAULT_VARIANT;
+        var = (e && (e[0] == '4' || e[0] == '6')) ? e[0] - '0' : SM_DEFAULT_VARIANT;
     }
-    dim3 g((unsigned)n_cu * (var == 3 ? 3u : 2u)), b(SM_TPB);
+    dim3 g((unsigned)n_cu * 2u), b(SM_TPB);
     hipStream_t s = (hipStream_t)stream;
-#define SM_LAUNCH(PT, V) hipLaunchKernelGGL((k_shade_mfma<PT, V>), g, b, 0, s, c, slices, (const PT*)planes, mlp_params, lin_bits, rays_o, rays_d, queue, q_count, image, depth, weights_sum, sample_counts, overflow_flag)
-    if (planes_dtype == 0) { if (var == 4) SM_LAUNCH(float, 4); else if (var == 6) SM_LAUNCH(float, 6); else if (var == 3) SM_LAUNCH(float, 3); else SM_LAUNCH(float, 2); }
-    else { if (var == 4) SM_LAUNCH(__half, 4); else if (var == 6) SM_LAUNCH(__half, 6); else if (var == 3) SM_LAUNCH(__half, 3); else SM_LAUNCH(__half, 2); }
+#define SM_LAUNCH(PT, V) hipLaunchKernelGGL((k_shade_mfma<PT, V>), g, b, 0, s, c, src, (const PT*)planes, mlp_params, (const uint8_t*)w.lin_bits, (const uint2*)w.queue, w.counters, image, depth, weights_sum, sample_counts, overflow_flag)
+    if (planes_dtype == 0) { if (var == 4) SM_LAUNCH(float, 4); else SM_LAUNCH(float, 6); }
+    else { if (var == 4) SM_LAUNCH(__half, 4); else SM_LAUNCH(__half, 6); }
 #undef SM_LAUNCH
     SSD_CHECK_LAUNCH("render_shade_queue_mfma");
     return SSDNERF_OK;
+}
+
+extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                               uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N, float bound,
+                                               float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps, float T_thresh,
+                                               float bg_color, float sigmoid_saturation, float* image, float* depth, float* weights_sum,
+                                               int32_t* sample_counts, int32_t* overflow_flag, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+    if (N == 0 || S == 0) return SSDNERF_OK;
+    SSD_REQUIRE(rays_o && rays_d, "render_shade_queue_mfma: null ray arrays");
+    return sm_shade(planes, planes_dtype, Hp, Wp, mlp_params, grid_size, ssd_ray_src_arrays(rays_o, rays_d), S, N, bound, min_near, dt_gamma, dt_gammas,
+                    max_steps, T_thresh, bg_color, sigmoid_saturation, image, depth, weights_sum, sample_counts, overflow_flag, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssdnerf_render_shade_queue_mfma_cams(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                                    uint32_t grid_size, const float* c2w, const float* intrinsics, uint32_t S, uint32_t V, uint32_t h,
+                                                    uint32_t w, float bound, float min_near, float dt_gamma, const float* dt_gammas,
+                                                    uint32_t max_steps, float T_thresh, float bg_color, float sigmoid_saturation, float* image,
+                                                    float* depth, float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag,
+                                                    void* workspace, size_t workspace_bytes, void* stream) {
+    const uint64_t N64 = (uint64_t)V * h * w;
+    if (N64 == 0 || S == 0) return SSDNERF_OK;
+    SSD_REQUIRE(c2w && intrinsics && N64 <= 0xffffffffull && V <= 65535, "render_shade_queue_mfma_cams: bad camera arguments");
+    return sm_shade(planes, planes_dtype, Hp, Wp, mlp_params, grid_size, ssd_ray_src_cams(c2w, intrinsics, V, h, w), S, (uint32_t)N64, bound, min_near,
+                    dt_gamma, dt_gammas, max_steps, T_thresh, bg_color, sigmoid_saturation, image, depth, weights_sum, sample_counts, overflow_flag, workspace,
+                    workspace_bytes, stream);
 }

@@ -319,6 +319,8 @@ class TriPlaneDecoder(VolumeRenderer):
         num_points (reference: triplane_decoder.py:119-179).  Uses the fused HIP decode when no gradient is required."""
         params_need_grad = any(p.requires_grad for p in self.parameters())
         need_grad = torch.is_grad_enabled() and (code.requires_grad or params_need_grad)
+        if self.eager_decode:                                   # the reference-shaped baseline (bench.py gpu_baseline): grid_sample + nn.Linear
+            return self.point_decode_eager(xyzs, dirs, code, density_only)
         if not need_grad and self.fused_supported(code):
             return self._point_decode_hip(xyzs, dirs, code, density_only)
         if (self.fused_code_grad and not params_need_grad and not density_only and dirs is not None and code.is_cuda
@@ -329,6 +331,9 @@ class TriPlaneDecoder(VolumeRenderer):
             sigmas, rgbs = _PointDecodeFn.apply(code, self, xyzs, dirs)
             return sigmas, rgbs, [int(x.size(-2)) for x in xyzs]
         return self.point_decode_eager(xyzs, dirs, code, density_only)
+
+    #: True forces ``point_decode`` through the eager PyTorch statement (measurement of the reference-shaped path only)
+    eager_decode = False
 
     #: SSDNERF_DECODE_GRAD=0 sends the code-gradient decode through PyTorch autograd (grid_sample + nn.Linear) instead of the fused kernels
     fused_code_grad = os.environ.get("SSDNERF_DECODE_GRAD", "1") != "0"
@@ -419,13 +424,18 @@ class TriPlaneDecoder(VolumeRenderer):
         return out
 
     def render_packed(self, planes, rays_o, rays_d, density_bitfield, grid_size, dt_gamma, T_thresh=1e-4, bg_color=None,
-                      want_counts=False, check_overflow=True):
+                      want_counts=False, check_overflow=True, cams=None):
         """Fused render of S scenes from already-packed planes (S,3,h,w,8).
 
         rays_o/rays_d: a dense (S,N,3) tensor -> ONE launch for the whole batch (outputs are (S,N,3)/(S,N) tensors, indexable
         per scene like the reference's lists); or per-scene lists of (N_s,3) -> one launch per scene.
+        cams=(c2w (S,V,4,4), intrinsics (S,V,4), h, w) instead of ray arrays (rays_o = rays_d = None): the kernels generate ray n =
+        pixel n % (h*w) of view n // (h*w) themselves (the arithmetic of ``nerf.get_cam_rays``), N = V*h*w.
         dt_gamma: per-scene list of floats, or a DEVICE tensor (S,) (no host sync)."""
         params = self.packed_params()
+        if cams is not None:
+            assert rays_o is None and rays_d is None, "render_packed: give ray arrays or cameras, not both"
+            return self._render_packed_cams(planes, cams, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color, want_counts, check_overflow)
         num_scenes = len(rays_o)
         dev = planes.device
         _, _, hp, wp, _ = planes.shape
@@ -435,6 +445,7 @@ class TriPlaneDecoder(VolumeRenderer):
         if not isinstance(grid_size, int):
             assert all(g == gs for g in grid_size), "one grid size per batch"
         dense = isinstance(rays_o, torch.Tensor) and rays_o.dim() == 3
+        boundary = None
         if isinstance(dt_gamma, torch.Tensor):
             dtg_dev, dtg_host = dt_gamma.float().contiguous(), None
         else:
@@ -474,6 +485,7 @@ class TriPlaneDecoder(VolumeRenderer):
             if ev is not None:
                 ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
             weights_sum, depth, image, counts = ws, dp, im, cn
+            boundary = self._boundary_tests(wsp, num_scenes) if want_counts and self.fused_pipeline == "queue_mfma" else None
         elif dense:
             C.check(C.lib().ssdnerf_render_rays_fused_batch(
                 C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(bits), C.u32(gs), C.ptr(o), C.ptr(d),
@@ -498,7 +510,65 @@ class TriPlaneDecoder(VolumeRenderer):
                     C.f32(blend), C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.stream()),
                     "render_rays_fused")
                 weights_sum.append(ws); depth.append(dp); image.append(im); counts.append(cn)
-        self.last_render_stats = dict(mode="fused", overflow=overflow, sample_counts=counts if want_counts else None)
+        self.last_render_stats = dict(mode="fused", overflow=overflow, sample_counts=counts if want_counts else None,
+                                      boundary_tests=boundary if dense and want_counts else None)
         if check_overflow and int(overflow.item()) != 0:
             raise RuntimeError("render_rays_fused: a ray hit the max_steps cap; use render_mode='stepwise' for this batch")
         return dict(weights_sum=weights_sum, depth=depth, image=image, blended=bg_color is not None)
+
+    @staticmethod
+    def _boundary_tests(wsp, num_scenes):
+        """per-scene count of termination tests that landed within 2e-6 of T_thresh (diagnostic counters at the head of the workspace)"""
+        return wsp[:4 * num_scenes * 128].view(torch.int32).view(4, num_scenes, 32)[3, :, 0].clone()        # csrc/common.h: ssd_counter(SSD_CNT_BOUNDARY, ...)
+
+    def _render_packed_cams(self, planes, cams, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color, want_counts, check_overflow):
+        c2w, intr, h, w = cams
+        dev = planes.device
+        num_scenes, nv = int(c2w.shape[0]), int(c2w.shape[1])
+        gs = grid_size if isinstance(grid_size, int) else grid_size[0]
+        if self.fused_pipeline != "queue_mfma" or gs < 8 or (gs & (gs - 1)) != 0:
+            from .nerf import get_cam_rays                                   # forms without in-kernel ray generation: materialise the arrays
+            o, d = get_cam_rays(c2w, intr, h, w)
+            return self.render_packed(planes, o.reshape(num_scenes, -1, 3), d.reshape(num_scenes, -1, 3), density_bitfield, grid_size, dt_gamma,
+                                      T_thresh, bg_color, want_counts, check_overflow)
+        params = self.packed_params()
+        _, _, hp, wp, _ = planes.shape
+        pose = c2w.detach().to(torch.float32).reshape(num_scenes, nv, 16).contiguous()
+        k = intr.detach().to(torch.float32).expand(num_scenes, nv, 4).contiguous()
+        n = nv * h * w
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        blend = 0.0 if bg_color is None else float(bg_color)
+        if isinstance(dt_gamma, torch.Tensor):
+            dtg_dev, g0 = dt_gamma.float().contiguous(), 0.0
+        else:
+            host = [float(g) for g in dt_gamma]
+            g0 = host[0]
+            dtg_dev = None if all(g == g0 for g in host) else torch.tensor(host, dtype=torch.float32, device=dev)
+        bits = density_bitfield if isinstance(density_bitfield, torch.Tensor) else torch.stack(list(density_bitfield), dim=0)
+        bits = bits.contiguous()
+        im = torch.empty(num_scenes, n, 3, dtype=torch.float32, device=dev)
+        dp = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
+        ws = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
+        cn = torch.empty(num_scenes, n, dtype=torch.int32, device=dev) if want_counts else None
+        wsp = self._workspace(C.lib().ssdnerf_render_queue_workspace(num_scenes, n, gs), dev)
+        ev = self.stage_events
+        if ev is not None:
+            ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+        C.check(C.lib().ssdnerf_render_first_hit_cams(
+            C.ptr(bits), C.u32(gs), C.ptr(pose), C.ptr(k), C.u32(num_scenes), C.u32(nv), C.u32(h), C.u32(w), C.f32(self.bound), C.f32(self.min_near),
+            C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(blend), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(wsp),
+            C.ctypes.c_size_t(wsp.numel()), C.stream()), "render_first_hit_cams")
+        if ev is not None:
+            ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+        C.check(C.lib().ssdnerf_render_shade_queue_mfma_cams(
+            C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.u32(gs), C.ptr(pose), C.ptr(k), C.u32(num_scenes), C.u32(nv),
+            C.u32(h), C.u32(w), C.f32(self.bound), C.f32(self.min_near), C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(T_thresh), C.f32(blend),
+            C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.ptr(wsp), C.ctypes.c_size_t(wsp.numel()),
+            C.stream()), "render_shade_queue_mfma_cams")
+        if ev is not None:
+            ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+        self.last_render_stats = dict(mode="fused", overflow=overflow, sample_counts=cn if want_counts else None,
+                                      boundary_tests=self._boundary_tests(wsp, num_scenes) if want_counts else None)
+        if check_overflow and int(overflow.item()) != 0:
+            raise RuntimeError("render_rays_fused: a ray hit the max_steps cap; use render_mode='stepwise' for this batch")
+        return dict(weights_sum=ws, depth=dp, image=im, blended=bg_color is not None)

@@ -62,35 +62,55 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
     decoder.train(False)
     dt_gamma_scale = cfg.get("dt_gamma_scale", 0.0)
     dt_gamma = dt_gamma_scale * 2 / (intrinsics[..., 0] + intrinsics[..., 1]).mean(dim=-1)      # (S,)
-    if rays is None:
-        rays_o, rays_d = get_cam_rays(poses, intrinsics, h, w)
-    else:
-        rays_o, rays_d = rays
     s, v = poses.shape[:2]
-    rays_o = rays_o.reshape(s, v * h * w, 3)
-    rays_d = rays_d.reshape(s, v * h * w, 3)
     max_render_rays = cfg.get("max_render_rays", -1)
-    chunks_o = rays_o.split(max_render_rays, dim=1) if 0 < max_render_rays < rays_o.size(1) else [rays_o]
-    chunks_d = rays_d.split(max_render_rays, dim=1) if 0 < max_render_rays < rays_d.size(1) else [rays_d]
+    chunked = 0 < max_render_rays < v * h * w
     if planes is None and decoder.render_mode == "fused" and decoder.fused_supported(code):
         planes = pack_triplanes(code, decoder.plane_dtype)
-    images, depths = [], []
-    gammas = None
-    for o, d in zip(chunks_o, chunks_d):
-        if planes is not None:
-            # dt_gamma stays on the device (the reference calls .item() per scene, base_volume_renderer.py:112)
-            out = decoder.render_packed(planes, o, d, density_bitfield, grid_size, dt_gamma.reshape(-1), 1e-4, bg_color=bg_color,
-                                        check_overflow=False)
-            rgb = out["image"]                                    # already a dense (S,N,3) tensor: no stack copy
-        else:
-            gammas = gammas or [float(g) for g in dt_gamma.reshape(-1).tolist()]
-            out = decoder(o, d, code, density_bitfield, grid_size, dt_gamma=gammas, perturb=False)
-            ws = torch.stack(out["weights_sum"], dim=0)
-            rgb = torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1))
-        images.append(rgb)
-        depths.append(out["depth"] if isinstance(out["depth"], torch.Tensor) else torch.stack(out["depth"], dim=0))
-    image = (torch.cat(images, dim=1) if len(images) > 1 else images[0]).reshape(s, v, h, w, 3)
-    depth = (torch.cat(depths, dim=1) if len(depths) > 1 else depths[0]).reshape(s, v, h, w)
+    overflow = []                                                     # device flags of the fused launches: ONE host read after the last chunk
+    if planes is not None and rays is None and not chunked:
+        # the whole batch in one fused launch pair, rays generated in the kernels from (poses, intrinsics): no (S,V,h,w,3) arrays at all
+        out = decoder.render_packed(planes, None, None, density_bitfield, grid_size, dt_gamma.reshape(-1), 1e-4, bg_color=bg_color,
+                                    check_overflow=False, cams=(poses, intrinsics.expand(s, v, 4), h, w))
+        overflow.append(decoder.last_render_stats["overflow"])
+        image, depth = out["image"], out["depth"]
+    else:
+        rays_o, rays_d = get_cam_rays(poses, intrinsics, h, w) if rays is None else rays
+        rays_o = rays_o.reshape(s, v * h * w, 3)
+        rays_d = rays_d.reshape(s, v * h * w, 3)
+        chunks_o = rays_o.split(max_render_rays, dim=1) if chunked else [rays_o]
+        chunks_d = rays_d.split(max_render_rays, dim=1) if chunked else [rays_d]
+        images, depths = [], []
+        gammas = None
+        for o, d in zip(chunks_o, chunks_d):
+            if planes is not None:
+                # dt_gamma stays on the device (the reference calls .item() per scene, base_volume_renderer.py:112)
+                out = decoder.render_packed(planes, o, d, density_bitfield, grid_size, dt_gamma.reshape(-1), 1e-4, bg_color=bg_color,
+                                            check_overflow=False)
+                overflow.append(decoder.last_render_stats["overflow"])
+                rgb = out["image"]                                    # already a dense (S,N,3) tensor: no stack copy
+            else:
+                gammas = gammas or [float(g) for g in dt_gamma.reshape(-1).tolist()]
+                out = decoder(o, d, code, density_bitfield, grid_size, dt_gamma=gammas, perturb=False)
+                ws = torch.stack(out["weights_sum"], dim=0)
+                rgb = torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1))
+            images.append(rgb)
+            depths.append(out["depth"] if isinstance(out["depth"], torch.Tensor) else torch.stack(out["depth"], dim=0))
+        image = torch.cat(images, dim=1) if len(images) > 1 else images[0]
+        depth = torch.cat(depths, dim=1) if len(depths) > 1 else depths[0]
+    if overflow and int(torch.stack([f.reshape(()) for f in overflow]).sum().item()) != 0:
+        # a ray reached the reference loop's global step cap (max_steps occupied samples), where the reference's answer depends on its n_step
+        # schedule: redo the batch through the reference-shaped stepwise path, which is exact by construction (same rule as
+        # TriPlaneDecoder._forward_eval_fused).  One sync per render call; the reference syncs once per loop iteration.
+        rays_o, rays_d = get_cam_rays(poses, intrinsics, h, w) if rays is None else rays
+        gammas = [float(g) for g in dt_gamma.reshape(-1).tolist()]
+        out = decoder._forward_eval_stepwise(list(rays_o.reshape(s, -1, 3)), list(rays_d.reshape(s, -1, 3)), code, density_bitfield,
+                                             [grid_size] * s if isinstance(grid_size, int) else grid_size, gammas, False, 1e-4)
+        ws = torch.stack(out["weights_sum"], dim=0)
+        image = torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1))
+        depth = torch.stack(out["depth"], dim=0)
+    image = image.reshape(s, v, h, w, 3)
+    depth = depth.reshape(s, v, h, w)
     decoder.train(was_training)
     return image, depth
 

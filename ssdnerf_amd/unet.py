@@ -50,27 +50,6 @@ class _ConvF32x2Fn(torch.autograd.Function):
         return UF.conv2d_nhwc_f32x2(gy.contiguous(memory_format=torch.channels_last), hi, lo), None
 
 
-class _ConvBf16Fn(torch.autograd.Function):
-    """The bf16-autocast counterpart of ``_ConvF32x2Fn`` (config 5 runs the UNet under ``autocast_dtype='bfloat16'``): forward and
-    backward-data through ``ssdnerf_conv2d_nhwc_bf16`` -- bf16 operands, fp32 accumulation, one rounding of the result, like the library
-    convolution it replaces.  Opt-in (``SSDNERF_UNET_GRAD_CONV_BF16=1``): kernel validated by the inference executor, this wiring only on the CPU."""
-
-    @staticmethod
-    def forward(ctx, x, conv):
-        from . import unet_fast as UF
-        ctx.conv, ctx.in_dtype = conv, x.dtype
-        w = conv._bf16_weight(False)
-        bias = None if conv.bias is None else conv.bias.detach().float()
-        return UF.conv2d_nhwc_bf16(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), w, bias=bias)
-
-    @staticmethod
-    def backward(ctx, gy):
-        from . import unet_fast as UF
-        w = ctx.conv._bf16_weight(True)
-        gx = UF.conv2d_nhwc_bf16(gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), w)
-        return gx.to(ctx.in_dtype), None
-
-
 class _Conv2d(nn.Conv2d):
     """``nn.Conv2d`` (same parameters and state-dict keys) that routes input-gradient-only fp32 GPU calls through ``_ConvF32x2Fn``."""
 
@@ -99,36 +78,9 @@ class _Conv2d(nn.Conv2d):
             cache[transposed] = tuple(t.contiguous(memory_format=torch.channels_last) for t in split_bf16x2(wt.contiguous()))
         return cache[transposed]
 
-    #: SSDNERF_UNET_GRAD_CONV_BF16=1: under bf16 autocast, route the same convolutions through the bf16 matrix-core kernel
-    grad_conv_bf16 = os.environ.get("SSDNERF_UNET_GRAD_CONV_BF16", "0") == "1"
-
-    def _eligible_bf16(self, x):
-        k = self.kernel_size[0]
-        return (self.grad_conv_bf16 and torch.is_grad_enabled() and x.requires_grad and not self.weight.requires_grad and _device_ok(x)
-                and torch.is_autocast_enabled(x.device.type) and torch.get_autocast_dtype(x.device.type) == torch.bfloat16
-                and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4 and self.groups == 1
-                and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.dilation == (1, 1) and self.padding == (k // 2, k // 2)
-                and self.padding_mode == "zeros" and self.in_channels % 64 == 0 and self.out_channels % 64 == 0
-                and (self.bias is None or not self.bias.requires_grad))
-
-    def _bf16_weight(self, transposed):
-        w = self.weight
-        cache = self.__dict__.setdefault("_bf16_cache", {})
-        key = (w._version, w.data_ptr(), str(w.device))
-        if cache.get("key") != key:
-            cache.clear()
-            cache["key"] = key
-        if transposed not in cache:
-            wt = w.detach().flip(2, 3).transpose(0, 1) if transposed else w.detach()
-            cache[transposed] = wt.to(torch.bfloat16).contiguous().contiguous(memory_format=torch.channels_last)
-        return cache[transposed]
-
     def forward(self, x):
         if self._eligible(x):
             return _ConvF32x2Fn.apply(x, self)
-        if self._eligible_bf16(x):
-            with torch.autocast(x.device.type, enabled=False):
-                return _ConvBf16Fn.apply(x, self)
         return super().forward(x)
 
 
@@ -159,12 +111,11 @@ class _GroupNormActFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-#: SSDNERF_UNET_GRAD_GN=1 routes the norms of the input-gradient path through ``_GroupNormActFn``.  Parity-checked on the GPU
-#: (tests/test_unet_fast_gpu.py) but off by default until its effect on the guided step has been timed.
-GRAD_GN = os.environ.get("SSDNERF_UNET_GRAD_GN", "0") == "1"
-#: SSDNERF_UNET_GRAD_ATT=1 (with GRAD_GN) also runs the attention blocks of that path channel-last (``_forward_channel_last``).  Wiring
-#: checked on the CPU only so far; the same projection + scaled_dot_product_attention form runs in the inference executor on the GPU.
-GRAD_ATT = os.environ.get("SSDNERF_UNET_GRAD_ATT", "0") == "1"
+#: The norms of the input-gradient path go through ``_GroupNormActFn`` and its attention blocks run channel-last (``_forward_channel_last``):
+#: r02 A/B on the MI355X (profiles/r02): guided DDIM step 77.8 -> 69.0 (norms) -> 63.9 ms (+ attention), fine-tuning iteration 71.9 -> 64.2 ->
+#: 56.6 ms for 8 scenes.  SSDNERF_UNET_GRAD_GN=0 / SSDNERF_UNET_GRAD_ATT=0 restore the eager module path (A/B runs only).
+GRAD_GN = os.environ.get("SSDNERF_UNET_GRAD_GN", "1") != "0"
+GRAD_ATT = os.environ.get("SSDNERF_UNET_GRAD_ATT", "1") != "0"
 
 
 def _gn_act_eligible(x, norm, scale_shift=None):

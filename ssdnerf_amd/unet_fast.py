@@ -31,6 +31,16 @@ from . import _cabi as C
 
 _GN_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
+#: while an executor traces its first forward this is a list that every LIBRARY call inside the block functions (MIOpen convolution, library
+#: GEMM for a 1x1 projection, scaled_dot_product_attention) appends its name to; ``FastUnet.library_fallbacks`` is its length (0 = every
+#: convolution / projection / attention of the forward ran on the hand-written kernels)
+_FALLBACK_LOG: Optional[list] = None
+
+
+def _lib_call(what: str):
+    if _FALLBACK_LOG is not None:
+        _FALLBACK_LOG.append(what)
+
 
 def group_norm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, scale_shift: Optional[torch.Tensor], eps: float,
                     act: bool, workspace: torch.Tensor, out: Optional[torch.Tensor] = None, pre_bias: Optional[torch.Tensor] = None,
@@ -196,31 +206,71 @@ def attention_qkv_bf16(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     return out
 
 
+def attention_qkv_f32(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """fp32 form of the same kernel: ``qkv`` (B, T, 3C) fp32, fp32-class products on the bf16 matrix cores (q, k, v and the probabilities each
+    split into a bf16 pair, hi*hi + hi*lo + lo*hi accumulated in fp32 -- the arithmetic class of the fp32 convolutions); returns (B, T, C) fp32."""
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    if qkv.dtype != torch.float32 or not qkv.is_contiguous():
+        raise RuntimeError("attention_qkv_f32: contiguous fp32 input only")
+    out = torch.empty((B, T, Cc), dtype=torch.float32, device=qkv.device)
+    C.check(C.lib().ssdnerf_attention_qkv_f32(C.ptr(qkv), C.ptr(out), C.u32(B), C.u32(T), C.u32(heads), C.u32(Cc // heads), C.stream()), "attention_qkv_f32")
+    return out
+
+
+def attention_supported(dtype, T: int, ch: int) -> bool:
+    """shapes the hand-written attention kernels take (csrc/attention.hip): any T, head width a multiple of 8 up to 128"""
+    return dtype in (torch.bfloat16, torch.float32) and ch % 8 == 0 and 8 <= ch <= 128 and T >= 1
+
+
+def attention_qkv(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    return attention_qkv_bf16(qkv, heads) if qkv.dtype == torch.bfloat16 else attention_qkv_f32(qkv, heads)
+
+
 class _Conv:
     """A convolution split into its bias-less GEMM part (``mm``) and an fp32 bias that the *consumer* folds in: the following
-    GroupNorm (``pre_bias``) or the residual epilogue -- the library convolution would spend a pass of its own on it."""
-    __slots__ = ("w", "w_lo", "bias", "stride", "padding", "fold", "own")
+    GroupNorm (``pre_bias``) or the residual epilogue -- the library convolution would spend a pass of its own on it.
+
+    ``pad_in`` / ``pad_out``: zero-pad the input / output channels of the weights up to a multiple of 64 so that the two edge layers of the UNet
+    (18 -> 128 stem, 128 -> 18 head; denoising.py:116-118,178-187) run on the hand-written implicit GEMM as well: the executor hands the stem
+    a zero-padded input and slices the head's output (the extra products are exact zeros)."""
+    __slots__ = ("w", "w_lo", "bias", "stride", "padding", "fold", "own", "cin", "cout")
     SPLITK_BYTES = 16 << 20
 
-    def __init__(self, conv: torch.nn.Conv2d, dtype):
-        assert conv.groups == 1
-        self.w = conv.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last)
-        self.bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-        self.stride, self.padding = conv.stride, conv.padding
-        self.fold = conv.out_channels % 8 == 0                      # the 16-byte vector kernels need C % 8 == 0 (the 18-channel head does not)
-        k = conv.kernel_size
-        # the hand-written MFMA implicit GEMM (csrc/conv_igemm.hip) takes every layer whose channel counts are multiples of 64: bf16 as is,
-        # fp32 with fp32-class products (weights pre-split into a bf16 pair; the library's fp32 convolution is kept for everything else)
-        self.own = bool(dtype in (torch.bfloat16, torch.float32) and self.w.is_cuda and k[0] == k[1] and conv.stride[0] == conv.stride[1]
-                        and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and tuple(conv.dilation) == (1, 1)
-                        and C.lib().ssdnerf_conv2d_nhwc_bf16_supported(conv.in_channels, conv.out_channels, k[0], conv.stride[0], 0))
+    def __init__(self, conv, dtype, pad_in: bool = False, pad_out: bool = False):
+        weight = conv.weight.detach()
+        if weight.dim() == 3:                                        # nn.Conv1d 1x1 projection (attention qkv / proj) == a 1x1 convolution
+            weight = weight[..., None]
+            stride, padding, dilation, k, groups = (1, 1), (0, 0), (1, 1), (1, 1), conv.groups
+        else:
+            stride, padding, dilation, k, groups = conv.stride, conv.padding, conv.dilation, conv.kernel_size, conv.groups
+        assert groups == 1
+        self.cout, self.cin = int(weight.shape[0]), int(weight.shape[1])
+        bias = conv.bias.detach().float() if conv.bias is not None else None
+        pin = (-self.cin) % 64 if pad_in else 0
+        pout = (-self.cout) % 64 if pad_out else 0
+        if pin or pout:
+            weight = F.pad(weight, (0, 0, 0, 0, 0, pin, 0, pout))
+            if bias is not None and pout:
+                bias = F.pad(bias, (0, pout))
+        self.w = weight.to(dtype).contiguous(memory_format=torch.channels_last)
+        self.bias = bias.contiguous() if bias is not None else None
+        self.stride, self.padding = tuple(stride), tuple(padding)
+        self.fold = weight.shape[0] % 8 == 0                          # the 16-byte vector kernels need C % 8 == 0
+        # the hand-written MFMA implicit GEMM (csrc/conv_igemm.hip) takes every layer whose (padded) channel counts are multiples of 64: bf16 as
+        # is, fp32 with fp32-class products (weights pre-split into a bf16 pair; the library's fp32 convolution is kept for everything else)
+        self.own = bool(dtype in (torch.bfloat16, torch.float32) and self.w.is_cuda and k[0] == k[1] and stride[0] == stride[1]
+                        and tuple(padding) == (k[0] // 2, k[0] // 2) and tuple(dilation) == (1, 1)
+                        and C.lib().ssdnerf_conv2d_nhwc_bf16_supported(int(weight.shape[1]), int(weight.shape[0]), k[0], stride[0], 0))
         self.w_lo = None
         if self.own and dtype == torch.float32 and _Conv.F32X2:
-            hi, lo = split_bf16x2(conv.weight.detach().float())
+            hi, lo = split_bf16x2(weight.float())
             self.w_lo = (hi.contiguous(memory_format=torch.channels_last), lo.contiguous(memory_format=torch.channels_last))
             self.w = self.w_lo[0]                                   # (the fp32 copy is not needed; shape queries go through the hi term)
         elif dtype == torch.float32:
             self.own = False
+        if not self.own and (pin or pout):                          # no kernel for it after all: keep the layer's true shape for the library
+            self.__init__(conv, dtype)
 
     splitk_ws: Optional[torch.Tensor] = None        # shared all-zero fp32 scratch for the small layers' split-K (set by the executor)
     F32X2 = os.environ.get("SSDNERF_UNET_F32X2", "1") != "0"      # fp32 executor: own bf16 x 2 convolution (default) or the library's fp32 one
@@ -234,6 +284,7 @@ class _Conv:
         return self.w if self.w_lo is None else (self.w_lo[0].float() + self.w_lo[1].float()).contiguous(memory_format=torch.channels_last)
 
     def mm(self, x):
+        _lib_call(f"conv2d {tuple(self.w.shape)}")
         return F.conv2d(x, self._w_lib(), None, self.stride, self.padding)
 
     def __call__(self, x):
@@ -242,6 +293,7 @@ class _Conv:
         if self.bias is None:
             return self.mm(x)
         if not self.fold:
+            _lib_call(f"conv2d {tuple(self.w.shape)}")
             return F.conv2d(x, self.w, self.bias.to(self.w.dtype), self.stride, self.padding)
         return bias_residual_nhwc(self.mm(x), self.bias, None)
 
@@ -268,6 +320,8 @@ class FastUnet:
         self.device = next(net.parameters()).device
         self._types = (DenoisingResBlockMod, MultiHeadAttentionMod, DenoisingDownsampleMod, DenoisingUpsampleMod)
         self._graphs: Dict[Tuple[int, int, int], tuple] = {}
+        self.fallback_log: Optional[list] = None
+        self.library_fallbacks: Optional[int] = None
         self._pack()
 
     # ------------------------------------------------------------------------------------------------ weights
@@ -302,8 +356,7 @@ class FastUnet:
         def att(m):
             assert m.groups == 1
             self._n_gn += 1
-            return ("att", _GN(m.norm), m.num_heads, m.qkv.weight.detach()[:, :, 0].to(dt).contiguous(), m.qkv.bias.detach().to(dt),
-                    m.proj.weight.detach()[:, :, 0].to(dt).contiguous(), m.proj.bias.detach().to(dt))
+            return ("att", _GN(m.norm), m.num_heads, _Conv(m.qkv, dt), _Conv(m.proj, dt))
 
         def seq(block):
             ops = []
@@ -324,9 +377,13 @@ class FastUnet:
             return ops
 
         self.in_ops = [seq(b) for b in net.in_blocks]
+        stem = net.in_blocks[0][0]
+        if len(net.in_blocks[0]) == 1 and isinstance(stem, torch.nn.Conv2d):     # 18 -> 128: input channels zero-padded to 64 (see _Conv)
+            self.in_ops[0] = [("conv", _Conv(stem, dt, pad_in=True))]
+        self.stem_cin = self.in_ops[0][0][1].w.shape[1] if self.in_ops[0][0][0] == "conv" and self.in_ops[0][0][1].own else None
         self.mid_ops = seq(net.mid_blocks)
         self.out_ops = [seq(b) for b in net.out_blocks]
-        self.head = (_GN(net.out.gn), _Conv(net.out.conv, dt))
+        self.head = (_GN(net.out.gn), _Conv(net.out.conv, dt, pad_out=True))
         self.emb_w, self.emb_b = torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous()
         if dt == torch.bfloat16 and self.device.type == "cuda" and _Conv.splitk_ws is None:
             _Conv.splitk_ws = torch.zeros(_Conv.SPLITK_BYTES // 4, dtype=torch.float32, device=self.device)
@@ -385,18 +442,30 @@ class FastUnet:
         return bias_residual_nhwc(h, out_bias, shortcut.mm(x) if shortcut is not None else x), None   # + b_conv2 (+ b_shortcut) + skip
 
     def _att(self, x, stats, op):
-        _, gn, heads, wqkv, bqkv, wproj, bproj = op
+        _, gn, heads, qkv_conv, proj_conv = op
         B, Cc, H, W = x.shape
         T, ch = H * W, Cc // heads
         xt = x.permute(0, 2, 3, 1).reshape(B, T, Cc)                       # a view: channels_last storage is already [B][T][C]
-        qkv = F.linear(self._gn(xt, gn, None, False, stats=stats), wqkv, bqkv)           # (B, T, 3C), channel = head*3ch + {q,k,v}*ch + i
-        if qkv.dtype == torch.bfloat16 and qkv.is_cuda and ch in (64, 128) and T % 32 == 0:
-            a = attention_qkv_bf16(qkv, heads)                                # hand-written MFMA flash attention, (B, T, C)
+        xn = self._gn(xt, gn, None, False, stats=stats)                     # (B, T, C)
+        own = qkv_conv.own and proj_conv.own and attention_supported(self.dtype, T, ch)
+        if own:
+            # the whole block on the hand-written kernels: 1x1 projections on the implicit GEMM (bias, residual and the next norm's statistics in
+            # its epilogue), softmax(QK^T)V on the MFMA flash-attention kernel
+            qkv = qkv_conv.igemm(xn.view(B, H, W, Cc).permute(0, 3, 1, 2), qkv_conv.bias)           # (B, 3C, H, W) channels_last
+            a = attention_qkv(qkv.permute(0, 2, 3, 1).reshape(B, T, 3 * Cc), heads)                  # (B, T, C)
+            st = self._stats_slice(B) if self._can_fuse_stats(proj_conv, x, gn) else None
+            h = proj_conv.igemm(a.view(B, H, W, Cc).permute(0, 3, 1, 2), proj_conv.bias, x, gn_sums=st, gn_groups=gn.groups)
+            return h, st
+        _lib_call(f"attention block C={Cc} T={T} (linear, sdpa, linear)")
+        wqkv, wproj = qkv_conv._w_lib()[:, :, 0, 0], proj_conv._w_lib()[:, :, 0, 0]
+        qkv = F.linear(xn, wqkv.to(xn.dtype), qkv_conv.bias.to(xn.dtype))   # (B, T, 3C), channel = head*3ch + {q,k,v}*ch + i
+        if qkv.is_cuda and attention_supported(self.dtype, T, ch):
+            a = attention_qkv(qkv, heads)
         else:
             q, k, v = qkv.view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)   # each (B, heads, T, ch)
             a = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(B, T, Cc)
         st = self._stats_slice(B)                                            # h + x, and the sums the next block's norm needs, in one pass
-        h = bias_residual_nhwc(F.linear(a, wproj, bproj), None, xt, gn_sums=st, gn_groups=gn.groups)
+        h = bias_residual_nhwc(F.linear(a, wproj.to(a.dtype), proj_conv.bias.to(a.dtype)), None, xt, gn_sums=st, gn_groups=gn.groups)
         return h.view(B, H, W, Cc).permute(0, 3, 1, 2), st                  # back to a channels_last (B, C, H, W) view
 
     def _run(self, ops, h, ss_all, stats=None, x2=None):
@@ -413,6 +482,7 @@ class FastUnet:
                 if op[1] is not None and op[1].own:
                     h = op[1].igemm(h, op[1].bias, upsample=True)           # the upsampled tensor is never built
                 else:
+                    _lib_call("interpolate (+ library convolution)")
                     h = F.interpolate(h, scale_factor=2, mode="nearest")
                     if op[1] is not None:
                         h = op[1](h)
@@ -437,7 +507,11 @@ class FastUnet:
         self._ws_next = 0
         emb = self._time_embedding(t)
         ss_all = F.linear(F.silu(emb), self.emb_w, self.emb_b)             # every block's [scale | shift], fp32, one GEMM
-        h = x_t.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        if self.stem_cin is not None and self.stem_cin != x_t.size(1):      # stem on the own kernel: hand it a zero-padded channel-last input
+            h = torch.zeros((x_t.size(0), self.stem_cin) + tuple(x_t.shape[2:]), dtype=self.dtype, device=x_t.device).contiguous(memory_format=torch.channels_last)
+            h[:, :x_t.size(1)] = x_t
+        else:
+            h = x_t.to(self.dtype).contiguous(memory_format=torch.channels_last)
         hs, stats = [], None
         for ops in self.in_ops:
             h, stats = self._run(ops, h, ss_all, stats)
@@ -448,7 +522,7 @@ class FastUnet:
             h, stats = self._run(ops, h, ss_all, x2=hs.pop())                # torch.cat([h, skip]) happens inside the block's kernels
         gn, conv = self.head
         out = conv(self._gn(h, gn, None, True, stats=stats))
-        return out.float().contiguous()                                     # NCHW fp32, what the DDIM update consumes
+        return out[:, :net.out_channels].float().contiguous()               # NCHW fp32, what the DDIM update consumes (drops the head's padding)
 
     # ------------------------------------------------------------------------------------------------ entry
     def _ensure_ws(self, B):
@@ -464,6 +538,16 @@ class FastUnet:
             self._pack()
             self._graphs.clear()
         self._ensure_ws(x_t.size(0))
+        if self.fallback_log is None:                                       # first forward: record which ops (if any) went to a library
+            global _FALLBACK_LOG
+            _FALLBACK_LOG = []
+            try:
+                y = self._forward(x_t, t)
+            finally:
+                self.fallback_log, _FALLBACK_LOG = _FALLBACK_LOG, None
+            self.library_fallbacks = len(self.fallback_log)
+            if not self.use_graph:
+                return y
         if not self.use_graph:
             return self._forward(x_t, t)
         key = tuple(x_t.shape)

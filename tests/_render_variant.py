@@ -1,6 +1,5 @@
-"""Helper of tests/test_render_gpu.py::test_rescheduled_kernel_forms_are_bit_identical: renders a fixed workload with the kernel forms named by
-SSDNERF_SHADE_VARIANT / SSDNERF_FIRST_HIT_COMPACT (read once per process by the library, hence one process per form) and writes the outputs
-to the given .npz."""
+"""Helper of tests/test_render_gpu.py::test_shade_schedules_are_bit_identical: renders a fixed workload with the shading schedule named by
+SSDNERF_SHADE_VARIANT (read once per process by the library, hence one process per form) and writes the outputs to the given .npz."""
 import sys
 
 import numpy as np

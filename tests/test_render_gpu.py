@@ -361,26 +361,46 @@ def test_fused_decode_backward_matches_autograd_through_the_eager_decode():
     assert bool(torch.isfinite(gw).all()) and float(gw.abs().max()) > 0
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SSDNERF_TEST_EXPERIMENTAL", "0") != "1",
-                    reason="re-scheduled kernel forms that have not run on hardware yet (set SSDNERF_TEST_EXPERIMENTAL=1)")
-def test_rescheduled_kernel_forms_are_bit_identical(tmp_path):
-    """Shade variant 6 (variant 4's operands and product order, tile-interleaved schedule) and the compacting first-hit kernel
-    (SSDNERF_FIRST_HIT_COMPACT=1: same per-ray arithmetic, survivors of the pre-test marched densely) only re-order work: every output must be
-    bit-identical to the default.  Both switches are read once per process, so each form runs in its own interpreter on one workload."""
+def test_shade_schedules_are_bit_identical(tmp_path):
+    """The two schedules of the shading kernel (SSDNERF_SHADE_VARIANT=6, tile-interleaved, the default; 4, tile after tile) issue the same
+    products in the same order per accumulator: every output must be bit-identical.  The switch is read once per process, so each form runs
+    in its own interpreter on one workload."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    forms = {"default": {"SSDNERF_SHADE_VARIANT": "4"}, "variant6": {"SSDNERF_SHADE_VARIANT": "6"},
-             "compact": {"SSDNERF_SHADE_VARIANT": "4", "SSDNERF_FIRST_HIT_COMPACT": "1"}}
+    forms = {"default": {}, "variant4": {"SSDNERF_SHADE_VARIANT": "4"}}
     outs = {}
     for name, extra in forms.items():
         path = str(tmp_path / f"{name}.npz")
-        env = {k: v for k, v in os.environ.items() if k not in ("SSDNERF_SHADE_VARIANT", "SSDNERF_FIRST_HIT_COMPACT")}
+        env = {k: v for k, v in os.environ.items() if k != "SSDNERF_SHADE_VARIANT"}
         env.update(extra, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
         subprocess.run([sys.executable, os.path.join(root, "tests", "_render_variant.py"), path], check=True, env=env, cwd=root, timeout=300)
         outs[name] = np.load(path)
     assert int(outs["default"]["counts"].sum()) > 100000
-    for name in ("variant6", "compact"):
-        for k in ("counts", "image", "depth", "weights_sum"):
-            assert np.array_equal(outs["default"][k], outs[name][k]), (name, k)
+    for k in ("counts", "image", "depth", "weights_sum"):
+        assert np.array_equal(outs["default"][k], outs["variant4"][k]), k
+
+
+def test_camera_fed_render_is_bit_identical_to_ray_arrays(decoder, scene):
+    """ssdnerf_render_*_cams generate every ray in the kernels (pose + intrinsics -> o, d in registers) with the arithmetic of ssdnerf_cam_rays:
+    all outputs, per-ray sample counts included, equal the render of the materialised ray arrays bit for bit (two scenes, different cone
+    angles, non-square views whose pixel count is not a power of two, and the 128 x 128 hot-path shape)."""
+    from ssdnerf_amd import nerf, synthetic as S
+    from ssdnerf_amd.decoders import pack_triplanes
+    code = torch.stack([scene["code"], S.make_triplane(12, "uniform")]).cuda()
+    bits = torch.from_numpy(scene["bits"]).cuda()[None].expand(2, -1).contiguous()
+    planes = pack_triplanes(code, decoder.plane_dtype)
+    for (h, w, views) in ((128, 128, [3, 64, 180]), (40, 56, [10, 200])):
+        poses = S.spiral_poses()[views].cuda()[None].expand(2, -1, -1, -1).contiguous()
+        intr = S.cars_intrinsics(w, h).cuda()[None, None].expand(2, len(views), -1).contiguous()
+        ro, rd = nerf.get_cam_rays(poses, intr, h, w)
+        a = decoder.render_packed(planes, ro.reshape(2, -1, 3), rd.reshape(2, -1, 3), bits, 64, [0.0, 0.0038095], 1e-4, bg_color=1.0, want_counts=True,
+                                  check_overflow=False)
+        ca = decoder.last_render_stats["sample_counts"].clone()
+        b = decoder.render_packed(planes, None, None, bits, 64, [0.0, 0.0038095], 1e-4, bg_color=1.0, want_counts=True, check_overflow=False,
+                                  cams=(poses, intr, h, w))
+        cb = decoder.last_render_stats["sample_counts"]
+        assert int(ca.sum()) > 10000 and torch.equal(ca, cb)
+        for k in ("image", "depth", "weights_sum"):
+            assert torch.equal(a[k], b[k]), (h, w, k)

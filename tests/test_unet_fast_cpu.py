@@ -117,6 +117,8 @@ def test_input_gradient_convs_use_the_same_kernel_forward_and_backward(monkeypat
     y_ref, g_ref = grad_of(x0)                                            # CPU tensors: every conv is nn.Conv2d's own forward
     calls = []
     monkeypatch.setattr(unet, "_device_ok", lambda x: True)
+    monkeypatch.setattr(unet, "GRAD_GN", False)                     # this test is about the convolutions only (the fused norms have their own below)
+    monkeypatch.setattr(unet, "GRAD_ATT", False)
     monkeypatch.setattr(unet_fast, "conv2d_nhwc_f32x2", lambda *a, **k: (calls.append(a[1].shape), _conv_f32x2_standin(*a, **k))[1])
     y, gx = grad_of(x0)
     n_fwd = sum(1 for m in net.modules() if isinstance(m, unet._Conv2d) and m.in_channels % 64 == 0 and m.out_channels % 64 == 0)
@@ -180,7 +182,7 @@ def _gn_backward_standin(x, dy, groups, gamma, beta, scale_shift, eps, act, fwd_
 
 
 def test_input_gradient_norms_fused_channel_last(monkeypatch):
-    """SSDNERF_UNET_GRAD_GN=1 wiring: in the input-gradient path every residual block runs GN+SiLU -> conv -> GN*(1+scale)+shift+SiLU -> conv
+    """Input-gradient path wiring (the default; SSDNERF_UNET_GRAD_GN / _ATT=0 switch it off): in it every residual block runs GN+SiLU -> conv -> GN*(1+scale)+shift+SiLU -> conv
     through _GroupNormActFn (forward group_norm_nhwc, backward group_norm_nhwc_backward; torch stand-ins here) and stays channel-last
     between the matrix-core convolutions; output and input gradient equal the plain module's."""
     from ssdnerf_amd import unet
@@ -222,49 +224,3 @@ def test_input_gradient_norms_fused_channel_last(monkeypatch):
     net(x0.clone().requires_grad_(True), t)
     net.eval()
     assert len(fwd) == 1 + n_att                                               # the output head and the attention blocks (no dropout there)
-
-
-def test_bf16_autocast_input_gradient_convs(monkeypatch):
-    """SSDNERF_UNET_GRAD_CONV_BF16=1 wiring (config 5 runs the UNet under bf16 autocast): eligible convolutions run forward and backward-data
-    through conv2d_nhwc_bf16 (torch stand-in: bf16 operands, fp32 accumulate, bf16 result); output and input gradient stay within bf16
-    tolerance of the autocast module."""
-    from ssdnerf_amd import unet
-    net = MODULES.build(dict(type="DenoisingUnetMod", image_size=16, in_channels=6, base_channels=64, channels_cfg=[1, 2], resblocks_per_downsample=1,
-                             dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4, attention_res=[8])).eval()
-    g = torch.Generator().manual_seed(8)
-    with torch.no_grad():
-        for p in net.parameters():
-            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
-    net.requires_grad_(False)
-    x0 = torch.randn(2, 6, 16, 16, generator=g)
-    t = torch.tensor([300, 800])
-    probe = torch.randn(2, 6, 16, 16, generator=g)
-
-    def grad_of():
-        x = x0.clone().requires_grad_(True)
-        with torch.autocast("cpu", dtype=torch.bfloat16):
-            y = net(x, t)
-        return y.detach().float(), torch.autograd.grad((y.float() * probe).sum(), x)[0]
-
-    y_ref, g_ref = grad_of()
-    calls = []
-
-    def standin(x, w, bias=None, **k):
-        assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
-        calls.append(tuple(w.shape))
-        return F.conv2d(x.float(), w.float(), bias, padding=w.shape[-1] // 2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-
-    monkeypatch.setattr(unet, "_device_ok", lambda x: True)
-    monkeypatch.setattr(unet._Conv2d, "grad_conv_bf16", True)
-    monkeypatch.setattr(unet_fast, "conv2d_nhwc_bf16", standin)
-    y, gx = grad_of()
-    n = sum(1 for m in net.modules() if isinstance(m, unet._Conv2d) and m.in_channels % 64 == 0 and m.out_channels % 64 == 0)
-    assert len(calls) == 2 * n and n >= 8
-    assert float((y - y_ref).abs().max()) <= 0.03 * float(y_ref.abs().max())
-    assert float((gx - g_ref).abs().max()) <= 0.05 * float(g_ref.abs().max())
-    # fp32 (no autocast) calls are not routed to the bf16 kernel
-    del calls[:]
-    monkeypatch.setattr(unet._Conv2d, "grad_conv", False)            # (the fp32 path has its own kernel and its own test above)
-    x = x0.clone().requires_grad_(True)
-    net(x, t).sum().backward()
-    assert calls == []

@@ -229,6 +229,27 @@ def test_attention_kernel_peaked_softmax():
     assert ((got - want).norm() / want.norm()).item() < 8e-3
 
 
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 1024, 4, 64), (2, 256, 4, 128), (1, 64, 4, 128), (2, 768, 4, 40), (1, 192, 4, 80), (2, 48, 4, 80),
+                                           (1, 12, 4, 24), (1, 3, 2, 48), (1, 33, 1, 8)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_kernel_general_shapes_and_fp32(B, T, heads, ch, dtype):
+    """Every shape of the cars and tiled layouts (T = 768 / 192 / 48 with head widths 40 / 80: ragged key blocks, widths that are not a power of
+    two) plus tiny ones; the fp32 form (bf16-pair products) must be fp32-class, the bf16 form within bf16 rounding."""
+    g = torch.Generator().manual_seed(T * 131 + ch)
+    C = heads * ch
+    qkv = (torch.randn(B, T, 3 * C, generator=g) * 1.3).cuda().to(dtype)
+    got = unet_fast.attention_qkv(qkv, heads).float()
+    q, k, v = qkv.double().view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)
+    want = (torch.softmax(q @ k.transpose(-1, -2) / ch ** 0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, T, C).float()
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    rel = ((got - want).norm() / want.norm()).item()
+    if dtype == torch.float32:
+        assert rel < 2e-5, rel                                                        # >= 16 significand bits per factor
+        assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    else:
+        assert rel < 6e-3, rel
+
+
 # ------------------------------------------------------------------------------------------------ fused skip concatenation / statistics
 @pytest.mark.parametrize("C1,C2,H", [(256, 128, 16), (512, 512, 8), (128, 128, 32)])
 def test_concat_is_fused_into_norm_and_shortcut(C1, C2, H):
@@ -444,8 +465,8 @@ def test_group_norm_backward_kernel_matches_autograd(C, G, HW, scale_shift, act)
 
 
 def test_input_gradient_norms_fused_on_the_gpu():
-    """SSDNERF_UNET_GRAD_GN=1 path (off by default until it has been timed): fused channel-last GroupNorm(+scale-shift)+SiLU forward and
-    input gradient inside the module graph, against the library path."""
+    """The input-gradient path (default): fused channel-last GroupNorm(+scale-shift)+SiLU forward and input gradient and channel-last attention
+    blocks inside the module graph, against the eager library path."""
     from ssdnerf_amd import unet
     from ssdnerf_amd.registry import MODULES
     net = MODULES.build(dict(type="DenoisingUnetMod", image_size=32, in_channels=18, base_channels=64, channels_cfg=[1, 2, 2], resblocks_per_downsample=1,
@@ -464,11 +485,13 @@ def test_input_gradient_norms_fused_on_the_gpu():
         y = net(x, t)
         return y.detach(), torch.autograd.grad((y * probe).sum(), x)[0]
 
-    y_ref, g_ref = grad_of()
-    unet.GRAD_GN = True
+    gn, att = unet.GRAD_GN, unet.GRAD_ATT
+    unet.GRAD_GN = unet.GRAD_ATT = False
     try:
-        y, gx = grad_of()
+        y_ref, g_ref = grad_of()                                    # eager module graph (library GroupNorm / attention)
     finally:
-        unet.GRAD_GN = False
+        unet.GRAD_GN, unet.GRAD_ATT = gn, att
+    assert unet.GRAD_GN and unet.GRAD_ATT                          # the fused, channel-last path is the default
+    y, gx = grad_of()
     assert float((y - y_ref).abs().max()) <= 1e-4 * float(y_ref.abs().max())
     assert float((gx - g_ref).abs().max()) <= 1e-4 * float(g_ref.abs().max())
