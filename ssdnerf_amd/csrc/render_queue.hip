@@ -51,32 +51,39 @@ struct QueueCfg {
     const float* dt_gammas;     // [S] on device or null
 };
 
-SSD_DEV int rq_cell(const FastMarch& m, float v) { return (int)ssd_clamp(v * m.half_H, 0.0f, m.Hm1f); }
+// cell index of v = p * rb + 1: only the upper clamp can bind (v > -1 always, and (int) truncates (-1, 0) to 0 exactly like a clamp at 0)
+SSD_DEV int rq_cell(const FastMarch& m, float v) { return (int)fminf(v * m.half_H, m.Hm1f); }
 
 struct FastProbe { float x, y, z, dt; int nx, ny, nz; bool occ; };
 
+// DTG0: dt_gamma == 0 (the uncond render), where clamp(t * 0, dt_min, dt_max) == dt_min: the march step is a constant
+template <bool DTG0>
+SSD_DEV float rq_dt(const FastMarch& m, float t) { return DTG0 ? m.dt_min : ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max); }
+
+template <bool DTG0 = false>
 SSD_DEV FastProbe rq_probe(const FastMarch& m, const uint8_t* __restrict__ lin_bits, const RayGeom& r, float t) {
     FastProbe p;
-    p.x = ssd_clamp(ssd_fma(t, r.dx, r.ox), -m.bound, m.bound);
-    p.y = ssd_clamp(ssd_fma(t, r.dy, r.oy), -m.bound, m.bound);
-    p.z = ssd_clamp(ssd_fma(t, r.dz, r.oz), -m.bound, m.bound);
-    p.dt = ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max);
+    p.x = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dx, r.ox), -m.bound, m.bound);      // == min(bound, max(-bound, v)) for the finite values that occur
+    p.y = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dy, r.oy), -m.bound, m.bound);
+    p.z = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dz, r.oz), -m.bound, m.bound);
+    p.dt = rq_dt<DTG0>(m, t);
     p.nx = rq_cell(m, ssd_fma(p.x, m.rb, 1.0f));
     p.ny = rq_cell(m, ssd_fma(p.y, m.rb, 1.0f));
     p.nz = rq_cell(m, ssd_fma(p.z, m.rb, 1.0f));
-    const uint32_t idx = (((uint32_t)p.nz << m.log2H) + (uint32_t)p.ny << m.log2H) + (uint32_t)p.nx;
+    const uint32_t idx = ((((uint32_t)p.nz << m.log2H) + (uint32_t)p.ny) << m.log2H) + (uint32_t)p.nx;
     p.occ = (lin_bits[idx >> 3] >> (idx & 7u)) & 1u;
     return p;
 }
 
 // sgn{x,y,z} = 0.5 + 0.5*sign(d): 0 or 1, so  nx + 0.5 + 0.5*sign(dx) == (float)(nx + sgn)  exactly.
+template <bool DTG0 = false>
 SSD_DEV float rq_skip(const FastMarch& m, const RayGeom& r, const FastProbe& p, float sgx, float sgy, float sgz, float t) {
     const float tx = ssd_fma(ssd_fma((float)p.nx + sgx, m.two_rH, -1.0f), m.mip_bound, -p.x) * r.rdx;
     const float ty = ssd_fma(ssd_fma((float)p.ny + sgy, m.two_rH, -1.0f), m.mip_bound, -p.y) * r.rdy;
     const float tz = ssd_fma(ssd_fma((float)p.nz + sgz, m.two_rH, -1.0f), m.mip_bound, -p.z) * r.rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     do {
-        t += ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max);
+        t += rq_dt<DTG0>(m, t);
     } while (t < tt);
     return t;
 }
@@ -236,6 +243,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
     rq_flush(list, &list_count, &slot, counters + ssd_counter(SSD_CNT_SURVIVORS, c.S, scene), survivors + (uint64_t)scene * c.N);
 }
 
+template <bool DTG0>
 __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc src, const uint8_t* __restrict__ lin_bits,
                                                             const uint32_t* __restrict__ survivors, float* __restrict__ image,
                                                             float* __restrict__ depth, float* __restrict__ weights_sum,
@@ -268,9 +276,9 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
             const float sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f), sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f), sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
             t = near_;
             while (t < far_) {
-                const FastProbe p = rq_probe(c.m, lin_bits, r, t);
+                const FastProbe p = rq_probe<DTG0>(c.m, lin_bits, r, t);
                 if (p.occ) { hit = true; break; }
-                t = rq_skip(c.m, r, p, sgx, sgy, sgz, t);
+                t = rq_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
             }
             if (!hit) {  // the ray left the object's neighbourhood without a sample: background only
                 image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
@@ -492,8 +500,12 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     else { cg.group = N; grid = dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), 1, S); }
     hipLaunchKernelGGL(k_ray_cull, grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
                        w.survivors, w.counters);
-    hipLaunchKernelGGL(k_survivor_march, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum, sample_counts,
-                       w.queue, w.counters);
+    if (dt_gammas == nullptr && dt_gamma == 0.0f)
+        hipLaunchKernelGGL(k_survivor_march<true>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum,
+                           sample_counts, w.queue, w.counters);
+    else
+        hipLaunchKernelGGL(k_survivor_march<false>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum,
+                           sample_counts, w.queue, w.counters);
     SSD_CHECK_LAUNCH("render_first_hit");
     return SSDNERF_OK;
 }

@@ -69,14 +69,18 @@ SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_el
 static constexpr unsigned SM_TPB = 256;
 static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
 #ifndef SM_PROBES
-#define SM_PROBES 4
+#define SM_PROBES 2                                // r02 A/B (bench scene, shade kernel): 1: 7.58, 2: 7.29, 3: 7.51, 4: 7.58, 8: 8.31 ms
 #endif
 static constexpr unsigned SM_SEARCH_PROBES = SM_PROBES;   // in-lane search budget after each sample
-// Schedules of the same arithmetic (template parameter VAR; identical products in identical order per accumulator -> bit-identical results):
-//   VAR 4: the two sample tiles are shaded one after the other (32 accumulator registers); MFMA bursts overlap with the OTHER wave's VALU work.
-//   VAR 6: both tiles hold their accumulators (64 registers) and every MFMA group is followed, in program order, by SiLU pairs of the other
-//          tile, so a wave also overlaps its own matrix-pipe time (r02 A/B on the bench scene: 7.72 vs 7.88 ms).  Default.
-template <int VAR> struct SmGeo {
+// Kernel forms (template parameter MODE):
+//   0: any power-of-two grid, any plane size, per-scene cone angle.
+//   1: the hot-path geometry as compile-time constants -- 64^3 grid, 128 x 128 planes, bound 1, 256 steps (configs/paper_cfgs/ssdnerf_*.py) --
+//      so that march / plane constants are immediates instead of ~25 SGPRs (the generic form spills 76 of them to VGPR lanes and pays
+//      a v_readlane per use, ~130 in the composite / search section alone).
+//   2: MODE 1 with dt_gamma == 0 (the uncond render of cached triplanes): the march step is a constant.
+// The MLP schedule is the tile-interleaved one (r01 "variant 6"): both 32-sample tiles hold their accumulators and every MFMA group is followed, in
+// program order, by SiLU pairs of the other tile, so a wave overlaps its own matrix-pipe time (7.72 vs 7.88 ms for tile-after-tile, r02 A/B).
+struct SmGeo {
     static constexpr int WPS = 2;
     static constexpr unsigned POOL = 128;                       // entries per wave-local pool (two pools per wave)
     static constexpr unsigned MARCH_W = POOL / 2;               // rays advanced by one march pass
@@ -102,11 +106,8 @@ SSD_DEV void sm_swap_u(uint32_t& a, uint32_t& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0]; b = r[1];
 }
-#ifndef SM_DEFAULT_VARIANT
-#define SM_DEFAULT_VARIANT 6
-#endif
 #ifndef SM_HEAD_GROUP
-#define SM_HEAD_GROUP 3                            // variant 4: SiLU pairs per scheduling group minus one (3 = four pairs)
+#define SM_HEAD_GROUP 1                            // SiLU pairs per scheduling group minus one (r02 A/B: 1 -> 7.29, 3 -> 7.44, 7 -> 7.64 ms)
 #endif
 #ifndef SM_GATHER_BY_PLANE
 #define SM_GATHER_BY_PLANE 1                       // gather one plane at a time (24 texel registers in flight instead of 72)
@@ -129,25 +130,34 @@ struct ShadeCfg {
 
 struct ProbeB { float x, y, z, dt; int nx, ny, nz; bool occ; };
 
+// One probe of the reference's march (common.h ssd_probe, cascade 0, power-of-two grid), trimmed to the instructions that can change a result:
+//   * position clamp as ONE v_med3_f32 (== min(hi, max(lo, v)) for the finite values that occur);
+//   * the cell index needs only its upper clamp: v = p * rb + 1 > -1 always, and (int) truncates (-1, 0) to 0 like the clamp at 0 would;
+//   * DTG0 (dt_gamma == 0, the uncond render): clamp(t * 0, dt_min, dt_max) == dt_min, so the step is a constant.
+template <bool DTG0>
+SSD_DEV float sm_dt(const FastMarchB& m, float t) { return DTG0 ? m.dt_min : ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max); }
+
+template <bool DTG0>
 SSD_DEV ProbeB sm_probe(const FastMarchB& m, const uint8_t* __restrict__ lin_bits, const RayGeom& r, float t) {
     ProbeB p;
-    p.x = ssd_clamp(ssd_fma(t, r.dx, r.ox), -m.bound, m.bound);
-    p.y = ssd_clamp(ssd_fma(t, r.dy, r.oy), -m.bound, m.bound);
-    p.z = ssd_clamp(ssd_fma(t, r.dz, r.oz), -m.bound, m.bound);
-    p.dt = ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max);
-    p.nx = (int)ssd_clamp(ssd_fma(p.x, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
-    p.ny = (int)ssd_clamp(ssd_fma(p.y, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
-    p.nz = (int)ssd_clamp(ssd_fma(p.z, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
-    const uint32_t idx = (((uint32_t)p.nz << m.log2H) + (uint32_t)p.ny << m.log2H) + (uint32_t)p.nx;
+    p.x = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dx, r.ox), -m.bound, m.bound);
+    p.y = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dy, r.oy), -m.bound, m.bound);
+    p.z = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dz, r.oz), -m.bound, m.bound);
+    p.dt = sm_dt<DTG0>(m, t);
+    p.nx = (int)fminf(ssd_fma(p.x, m.rb, 1.0f) * m.half_H, m.Hm1f);
+    p.ny = (int)fminf(ssd_fma(p.y, m.rb, 1.0f) * m.half_H, m.Hm1f);
+    p.nz = (int)fminf(ssd_fma(p.z, m.rb, 1.0f) * m.half_H, m.Hm1f);
+    const uint32_t idx = ((((uint32_t)p.nz << m.log2H) + (uint32_t)p.ny) << m.log2H) + (uint32_t)p.nx;
     p.occ = (lin_bits[idx >> 3] >> (idx & 7u)) & 1u;
     return p;
 }
+template <bool DTG0>
 SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, float sgx, float sgy, float sgz, float t) {
     const float tx = ssd_fma(ssd_fma((float)p.nx + sgx, m.two_rH, -1.0f), m.mip_bound, -p.x) * r.rdx;
     const float ty = ssd_fma(ssd_fma((float)p.ny + sgy, m.two_rH, -1.0f), m.mip_bound, -p.y) * r.rdy;
     const float tz = ssd_fma(ssd_fma((float)p.nz + sgz, m.two_rH, -1.0f), m.mip_bound, -p.z) * r.rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-    do { t += ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max); } while (t < tt);
+    do { t += sm_dt<DTG0>(m, t); } while (t < tt);
     return t;
 }
 
@@ -158,8 +168,8 @@ SSD_DEV void sm_swap(float& a, float& b) {
     b = __uint_as_float(r[1]);
 }
 
-template <typename PT, int VAR>
-__global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg c, RaySrc src, const PT* __restrict__ planes,
+template <typename PT, int MODE>
+__global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, RaySrc src, const PT* __restrict__ planes,
                                                            const float* __restrict__ P, const uint8_t* __restrict__ lin_bits,
                                                            const uint2* __restrict__ queue, uint32_t* __restrict__ queue_count,
                                                            float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
@@ -169,8 +179,19 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
     // sh   : per wave 64 rays x 16 SH' values as three bf16 terms in MFMA B-operand form, [term][sample][k 0-7 | k 8-15] (SH'_0 = 1, see the header)
     // stage: per wave 64 PREPARED rays x 16 dwords {ray, t, far, dt | o | d | 1/d | sample xyz}: queue entries and ray geometry are fetched
     //        64 at a time by the whole wave (coalesced, full lane utilisation) instead of one lane at a time inside the divergent refill
-    constexpr unsigned SM_POOL = SmGeo<VAR>::POOL, SM_MARCH_W = SmGeo<VAR>::MARCH_W, SM_STAGE = SmGeo<VAR>::STAGE, SM_SHF = SmGeo<VAR>::SHF;
-    __shared__ __attribute__((aligned(16))) float lds[SmGeo<VAR>::LDS_FLOATS];
+    constexpr unsigned SM_POOL = SmGeo::POOL, SM_MARCH_W = SmGeo::MARCH_W, SM_STAGE = SmGeo::STAGE, SM_SHF = SmGeo::SHF;
+    constexpr bool DTG0 = MODE == 2;
+    if constexpr (MODE != 0) {       // the hot-path geometry as literals (the host dispatches here only when the arguments say exactly this)
+        c.m.bound = 1.0f; c.m.mip_bound = 1.0f; c.m.rb = 1.0f;
+        c.m.dt_min = 2.0f * SSD_SQRT3 / 256.0f; c.m.dt_max = 2.0f * SSD_SQRT3 / 64.0f;        // ssd_make_march_cfg's expressions, evaluated at compile time
+        c.m.half_H = 32.0f; c.m.two_rH = 2.0f / 64.0f; c.m.Hm1f = 63.0f; c.m.H = 64u; c.m.log2H = 6u;
+        c.g.Hp = c.g.Wp = 128u; c.g.Hf = c.g.Wf = 128.0f;
+        c.aabb[0] = c.aabb[1] = c.aabb[2] = -1.0f; c.aabb[3] = c.aabb[4] = c.aabb[5] = 1.0f;
+        c.cap = 256u;
+        c.plane_stride = (uint64_t)3 * 128 * 128 * 8;
+        c.bitfield_stride = 64u * 64u * 64u / 8u;
+    }
+    __shared__ __attribute__((aligned(16))) float lds[SmGeo::LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -233,6 +254,17 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             }
         }
     }
+#ifdef SM_SIGMA_REGS     // experiment: the density head's 32 weights of this lane half in registers instead of LDS broadcast reads
+    floatx2 wsig[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float4 w = wout2[(((q >> 3) * 8 + (q & 7)) * 2 + half) * 2];
+        wsig[q] = floatx2{w.x, w.y};
+    }
+#define SM_WSIG(q, w) wsig[q]
+#else
+#define SM_WSIG(q, w) floatx2{(w).x, (w).y}
+#endif
     const float b_sigma = P[MLP_OFF_TAIL + 0], bc0 = P[MLP_OFF_TAIL + 1], bc1 = P[MLP_OFF_TAIL + 2], bc2 = P[MLP_OFF_TAIL + 3];
     const float sat_k = ssd_fma(c.sat, 2.0f, 1.0f);
 
@@ -244,7 +276,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
     planes = planes_base + scene * c.plane_stride;
     lin_bits = bits_base + (uint64_t)scene * c.bitfield_stride;
     queue = queue_base + ray0;
-    c.m.dt_gamma = c.dt_gammas ? c.dt_gammas[scene] : dt_gamma_default;
+    c.m.dt_gamma = DTG0 ? 0.0f : (c.dt_gammas ? c.dt_gammas[scene] : dt_gamma_default);
     uint32_t next = 0, end = 0;
     bool scene_done = n_slices == 0;
 
@@ -257,6 +289,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
     float sx = 0.f, sy = 0.f, sz = 0.f, sdt = 0.f;
     uint32_t sp_head = 0, sp_count = 0, rp_head = 0, rp_count = 0;    // wave-uniform pool cursors
     uint32_t st_head = 0, st_count = 0;                                // staged (prepared) rays
+    bool fresh = false;                                                // this lane took a new ray in the refill above: its SH operands are due
 
     const bool packing = c.N <= SSD_RAY_ID_MASK + 1u;           // queue / pool ray words carry the tail bound in their upper 8 bits
     const uint32_t id_mask = packing ? SSD_RAY_ID_MASK : 0xffffffffu;
@@ -305,9 +338,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                     ssd_near_far(c.aabb, r, c.min_near, near_, far_);
                     far_ = ssd_tail_far(r, cell_world, near_, far_, e0.x, packing);
                     set_signs();
-                    const ProbeB p = sm_probe(c.m, lin_bits, r, t);      // t points at an occupied probe
+                    const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, r, t);      // t points at an occupied probe
                     sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
-                    store_sh();
+                    fresh = true;
                 }
                 rp_head = (rp_head + take) % SM_POOL;
                 rp_count -= take;
@@ -335,7 +368,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                     ssd_near_far(c.aabb, q, c.min_near, qn, qf);
                     qf = ssd_tail_far(q, cell_world, qn, qf, e.x, packing);
                     const float qt = __uint_as_float(e.y);
-                    const ProbeB p = sm_probe(c.m, lin_bits, q, qt);      // the queued t is an occupied probe by construction
+                    const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, q, qt);      // the queued t is an occupied probe by construction
                     float4* dst = stage + lane * 4;
                     dst[0] = make_float4(__uint_as_float(e.x), qt, qf, p.dt);
                     dst[1] = make_float4(q.ox, q.oy, q.oz, q.dx);
@@ -358,10 +391,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                 sx = g3.y; sy = g3.z; sz = g3.w;
                 set_signs();
                 ws = dep = cr = cg = cb = 0.f; cnt = 0;
-                store_sh();
+                fresh = true;
             }
             st_head += take; st_count -= take;
         }
+        if (fresh) { store_sh(); fresh = false; }               // (one copy of the SH evaluation + operand split for both refill sources)
         const uint64_t live = __ballot(ray >= 0);
 
         // ================= march pass: every lane takes one parked ray to its next hit or to the end of the box =================
@@ -379,9 +413,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
                 const float qx = ssd_fma(0.5f, ssd_sign1(q.dx), 0.5f), qy = ssd_fma(0.5f, ssd_sign1(q.dy), 0.5f), qz = ssd_fma(0.5f, ssd_sign1(q.dz), 0.5f);
                 float qt = __uint_as_float(e0.y);
                 while (qt < qf) {
-                    const ProbeB p = sm_probe(c.m, lin_bits, q, qt);
+                    const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, q, qt);
                     if (p.occ) { found = true; break; }
-                    qt = sm_skip(c.m, q, p, qx, qy, qz, qt);
+                    qt = sm_skip<DTG0>(c.m, q, p, qx, qy, qz, qt);
                 }
                 if (found) e0.y = __float_as_uint(qt);
                 else write_out(e0.x, __uint_as_float(e0.z), __uint_as_float(e0.w), __uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z), e1.w);
@@ -412,6 +446,16 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
         }
+#ifdef SM_DUP_GATHER      // in-situ cost probe (tools/ab_shade.sh): a second gather at a nearby position, folded in with weight 0 (results unchanged)
+        {
+            float f2[18];
+            if (ray >= 0) {
+                ssd_gather18<PT, SM_GATHER_BY_PLANE != 0>(planes, c.g, sy, sz, sx, f2);
+#pragma unroll
+                for (int i = 0; i < 18; ++i) f[i] = ssd_fma(0.0f, f2[i], f[i]);
+            }
+        }
+#endif
         // Split every feature into three bf16 terms, pack feature pairs, and trade halves so that T[t][0..3] is tile 0's k-step-0 operand
         // (features 0-15 of the samples of lanes 0-31) and T[t][4..7] tile 1's; T[t][8] / Z[t] carry features 16, 17 for k-step 1 (their other
         // k slots are the bias row and zeros).
@@ -432,146 +476,91 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
         const uint32_t bias_pair = half == 0 ? 0x00003F80u : 0u;          // {bf16(1.0), 0}: the bias row of layer 1's k-step 1 (k = 18), lane half 0 only
         constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};   // products (weight term i) x (input term j), i + j <= 2, smallest first
         float ps0, ps1, pr0, pr1, pg0, pg1, pb0, pb1;            // per tile: this lane half's share of (sigma, r, g, b) pre-activations
-        if constexpr (VAR == 4) {
-            float res[2][4];
+        // ---- tile-interleaved schedule:
+        //   A: layer 1, tile 0 (24 MFMA)   B: layer 1, tile 1 (24) || density head 0   C: dir term 0 (12) || density head 1
+        //   D: dir term 1 (12) || colour head 0   E: colour head 1
+        floatx16 acc[2][2];                                              // [tile][mt]
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                floatx16 acc[2];
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
-                sm_bf16x8 b0[3], b1[3];                                      // B operands of k-step 0 / 1, terms hi, mid, lo
+                for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.0f;
+        auto layer1 = [&](int nt, int pr_i) {                            // 4 MFMA: products (weight term i) x (feature term j) of both row tiles
+            const int i = TI[pr_i], j = TJ[pr_i];
+            const sm_bf16x8 b0 = sm_op(T[j][4 * nt], T[j][4 * nt + 1], T[j][4 * nt + 2], T[j][4 * nt + 3]);
+            const sm_bf16x8 b1 = sm_op(nt == 0 ? T[j][8] : Z[j], j == 0 ? bias_pair : 0u, 0u, 0u);
 #pragma unroll
-                for (int tt = 0; tt < 3; ++tt) {
-                    b0[tt] = sm_op(T[tt][4 * nt], T[tt][4 * nt + 1], T[tt][4 * nt + 2], T[tt][4 * nt + 3]);
-                    b1[tt] = sm_op(nt == 0 ? T[tt][8] : Z[tt], tt == 0 ? bias_pair : 0u, 0u, 0u);
-                }
-#pragma unroll
-                for (int pr_i = 0; pr_i < 6; ++pr_i) {                       // h = W1 [f; 1]
-                    const int i = TI[pr_i], j = TJ[pr_i];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0[j], acc[mt], 0, 0, 0);
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][1][i], b1[j], acc[mt], 0, 0, 0);
-                    }
-                }
-                floatx2 ps = {0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {                              // density head on silu(h)
-                    const int mt = q >> 3, p2 = q & 7;
-                    const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
-                    ps = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]}), ps);
-                    if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);    // four pairs at a time: the scheduler otherwise batches all 32 exp/rcp and spills their results
-                }
-                sm_bf16x8 sb[3];                                             // h += Wd' SH'(d): operands pre-split per ray in LDS
-#pragma unroll
-                for (int tt = 0; tt < 3; ++tt) sb[tt] = *reinterpret_cast<const sm_bf16x8*>(sh_lds + tt * 128 + (nt * 32 + (lane & 31)) * 2 + half);
-#pragma unroll
-                for (int pr_i = 0; pr_i < 6; ++pr_i) {
-                    const int i = TI[pr_i], j = TJ[pr_i];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][i], sb[j], acc[mt], 0, 0, 0);
-                }
-                floatx2 pr = {0.f, 0.f}, pg = {0.f, 0.f}, pb = {0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {                              // colour head on silu(h + hd)
-                    const int mt = q >> 3, p2 = q & 7;
-                    const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
-                    const floatx2 cc = sm_silu2(floatx2{acc[mt][2 * p2], acc[mt][2 * p2 + 1]});
-                    pr = sm_fma2(floatx2{w0.z, w0.w}, cc, pr);
-                    pg = sm_fma2(floatx2{w1.x, w1.y}, cc, pg);
-                    pb = sm_fma2(floatx2{w1.z, w1.w}, cc, pb);
-                    if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);
-                }
-                res[nt][0] = ps.x + ps.y; res[nt][1] = pr.x + pr.y; res[nt][2] = pg.x + pg.y; res[nt][3] = pb.x + pb.y;
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0, acc[nt][mt], 0, 0, 0);
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][1][i], b1, acc[nt][mt], 0, 0, 0);
             }
-            ps0 = res[0][0]; ps1 = res[1][0]; pr0 = res[0][1]; pr1 = res[1][1]; pg0 = res[0][2]; pg1 = res[1][2]; pb0 = res[0][3]; pb1 = res[1][3];
-        } else {
-            // ---- VAR 6: the same products in the same order per accumulator, tile-interleaved:
-            //   A: layer 1, tile 0 (24 MFMA)   B: layer 1, tile 1 (24) || density head 0   C: dir term 0 (12) || density head 1
-            //   D: dir term 1 (12) || colour head 0   E: colour head 1
-            floatx16 acc[2][2];                                              // [tile][mt]
+        };
+        sm_bf16x8 sb[3];
+        auto load_sh = [&](int nt) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int tt = 0; tt < 3; ++tt) sb[tt] = *reinterpret_cast<const sm_bf16x8*>(sh_lds + tt * 128 + (nt * 32 + (lane & 31)) * 2 + half);
+        };
+        auto dir_term = [&](int nt, int pr_i) {                          // 2 MFMA: h += Wd' SH'(d)
+            const int i = TI[pr_i], j = TJ[pr_i];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][i], sb[j], acc[nt][mt], 0, 0, 0);
+        };
+        floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+        floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
+        auto density_pair = [&](int nt, int q) {
+            const int mt = q >> 3, p2 = q & 7;
+#ifndef SM_SIGMA_REGS
+            const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
+#endif
+            ps_[nt] = sm_fma2(SM_WSIG(q, w), sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]}), ps_[nt]);
+        };
+        auto colour_pair = [&](int nt, int q) {
+            const int mt = q >> 3, p2 = q & 7;
+            const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+            const floatx2 cc = sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]});
+            pr_[nt] = sm_fma2(floatx2{w0.z, w0.w}, cc, pr_[nt]);
+            pg_[nt] = sm_fma2(floatx2{w1.x, w1.y}, cc, pg_[nt]);
+            pb_[nt] = sm_fma2(floatx2{w1.z, w1.w}, cc, pb_[nt]);
+        };
+        constexpr int QB[7] = {0, 3, 6, 9, 12, 14, 16};                 // 16 SiLU pairs spread over the 6 MFMA groups of a phase
+        // ---- A
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.0f;
-            auto layer1 = [&](int nt, int pr_i) {                            // 4 MFMA: products (weight term i) x (feature term j) of both row tiles
-                const int i = TI[pr_i], j = TJ[pr_i];
-                const sm_bf16x8 b0 = sm_op(T[j][4 * nt], T[j][4 * nt + 1], T[j][4 * nt + 2], T[j][4 * nt + 3]);
-                const sm_bf16x8 b1 = sm_op(nt == 0 ? T[j][8] : Z[j], j == 0 ? bias_pair : 0u, 0u, 0u);
+        for (int g = 0; g < 6; ++g) layer1(0, g);
+        // ---- B
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0, acc[nt][mt], 0, 0, 0);
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][1][i], b1, acc[nt][mt], 0, 0, 0);
-                }
-            };
-            sm_bf16x8 sb[3];
-            auto load_sh = [&](int nt) {
+        for (int g = 0; g < 6; ++g) {
+            layer1(1, g);
 #pragma unroll
-                for (int tt = 0; tt < 3; ++tt) sb[tt] = *reinterpret_cast<const sm_bf16x8*>(sh_lds + tt * 128 + (nt * 32 + (lane & 31)) * 2 + half);
-            };
-            auto dir_term = [&](int nt, int pr_i) {                          // 2 MFMA: h += Wd' SH'(d)
-                const int i = TI[pr_i], j = TJ[pr_i];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][i], sb[j], acc[nt][mt], 0, 0, 0);
-            };
-            floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
-            floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
-            auto density_pair = [&](int nt, int q) {
-                const int mt = q >> 3, p2 = q & 7;
-                const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
-                ps_[nt] = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]}), ps_[nt]);
-            };
-            auto colour_pair = [&](int nt, int q) {
-                const int mt = q >> 3, p2 = q & 7;
-                const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
-                const floatx2 cc = sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]});
-                pr_[nt] = sm_fma2(floatx2{w0.z, w0.w}, cc, pr_[nt]);
-                pg_[nt] = sm_fma2(floatx2{w1.x, w1.y}, cc, pg_[nt]);
-                pb_[nt] = sm_fma2(floatx2{w1.z, w1.w}, cc, pb_[nt]);
-            };
-            constexpr int QB[7] = {0, 3, 6, 9, 12, 14, 16};                 // 16 SiLU pairs spread over the 6 MFMA groups of a phase
-            // ---- A
-#pragma unroll
-            for (int g = 0; g < 6; ++g) layer1(0, g);
-            // ---- B
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                layer1(1, g);
-#pragma unroll
-                for (int q = QB[g]; q < QB[g + 1]; ++q) density_pair(0, q);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- C
-            load_sh(0);
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                dir_term(0, g);
-#pragma unroll
-                for (int q = QB[g]; q < QB[g + 1]; ++q) density_pair(1, q);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- D
-            load_sh(1);
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                dir_term(1, g);
-#pragma unroll
-                for (int q = QB[g]; q < QB[g + 1]; ++q) colour_pair(0, q);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- E
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                colour_pair(1, q);
-                if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);
-            }
-            ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y; pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y;
-            pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
+            for (int q = QB[g]; q < QB[g + 1]; ++q) density_pair(0, q);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- C
+        load_sh(0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            dir_term(0, g);
+#pragma unroll
+            for (int q = QB[g]; q < QB[g + 1]; ++q) density_pair(1, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- D
+        load_sh(1);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            dir_term(1, g);
+#pragma unroll
+            for (int q = QB[g]; q < QB[g + 1]; ++q) colour_pair(0, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- E
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            colour_pair(1, q);
+            if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);
+        }
+        ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y; pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y;
+        pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
         sm_swap(ps0, ps1); sm_swap(pr0, pr1); sm_swap(pg0, pg1); sm_swap(pb0, pb1);
         const float sigma = ssd_exp(ps0 + ps1 + b_sigma);
@@ -579,13 +568,13 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
         const float sg = ssd_fma(ssd_sigmoid(pg0 + pg1 + bc1), sat_k, -c.sat);
         const float sb_ = ssd_fma(ssd_sigmoid(pb0 + pb1 + bc2), sat_k, -c.sat);
 
-        bool park = false;
+        bool park = false, finish = false;
         if (ray >= 0) {
             const float alpha = 1.0f - __expf(-sigma * sdt);
             const float Tr = 1.0f - ws;
             const float w = alpha * Tr;
             // diagnostic: termination tests that land within float noise of the threshold (the only rays whose sample count may differ from
-            // the reference's, whose exp is CUDA's __expf: DESIGN.md "arithmetic contract"); ~1 ray in 5000, so the atomic is free
+            // the reference's, whose exp is CUDA's __expf: DESIGN.md "arithmetic contract"); a few % of the hitting rays, once each
             if (fabsf(Tr - c.T_thresh) < 2e-6f) atomicAdd(queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, scene), 1u);
             ws += w;
             dep = ssd_fma(w, t, dep);
@@ -594,24 +583,24 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             cb = ssd_fma(w, sb_, cb);
             t += sdt;
             ++cnt;
-            if (Tr < c.T_thresh) {
-                write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1;
-            } else {
+            finish = Tr < c.T_thresh;
+            if (!finish) {
                 uint32_t probes = 0;
                 for (;;) {
-                    if (!(t < far_)) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break; }
+                    if (!(t < far_)) { finish = true; break; }
                     if (cnt >= c.cap) {
                         if (overflow_flag) atomicAdd(overflow_flag, 1);
-                        write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break;
+                        finish = true; break;
                     }
                     if (probes == SM_SEARCH_PROBES) { park = true; break; }
-                    const ProbeB p = sm_probe(c.m, lin_bits, r, t);
+                    const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, r, t);
                     if (p.occ) { sx = p.x; sy = p.y; sz = p.z; sdt = p.dt; break; }
-                    t = sm_skip(c.m, r, p, sgx, sgy, sgz, t);
+                    t = sm_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
                     ++probes;
                 }
             }
         }
+        if (finish) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; }      // the ONE store sequence of the loop body
         // ---- park rays that need a long search (state -> LDS search pool) ----
         const uint64_t pm = __ballot(park);
         if (pm != 0) {
@@ -628,9 +617,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo<VAR>::WPS) k_shade_mfma(ShadeCfg
             if (park) {   // pool full (cannot happen with the trigger above, kept as a guard): finish the search in the lane
                 for (;;) {
                     if (!(t < far_)) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break; }
-                    const ProbeB p = sm_probe(c.m, lin_bits, r, t);
+                    const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, r, t);
                     if (p.occ) { sx = p.x; sy = p.y; sz = p.z; sdt = p.dt; break; }
-                    t = sm_skip(c.m, r, p, sgx, sgy, sgz, t);
+                    t = sm_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -674,17 +663,22 @@ static int sm_shade(const void* planes, int planes_dtype, uint32_t Hp, uint32_t 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    // residency: 2 workgroups x 4 waves per CU, persistent.  SSDNERF_SHADE_VARIANT=4|6 picks the schedule (results are bit-identical).
-    static int var = 0;
-    if (var == 0) {
-        const char* e = getenv("SSDNERF_SHADE_VARIANT");
-        var = (e && (e[0] == '4' || e[0] == '6')) ? e[0] - '0' : SM_DEFAULT_VARIANT;
+    // residency: 2 workgroups x 4 waves per CU, persistent.
+    static int blocks_per_cu = 0;                                  // SSDNERF_SHADE_BLOCKS_PER_CU=1: one wave per SIMD (occupancy experiments only)
+    static int force_generic = -1;                                 // SSDNERF_SHADE_GENERIC=1: never take the specialised forms (bit-identity test)
+    if (blocks_per_cu == 0) {
+        const char* e = getenv("SSDNERF_SHADE_BLOCKS_PER_CU");
+        blocks_per_cu = (e && e[0] == '1') ? 1 : 2;
+        force_generic = getenv("SSDNERF_SHADE_GENERIC") != nullptr;
     }
-    dim3 g((unsigned)n_cu * 2u), b(SM_TPB);
+    // MODE 1 / 2: the cars / chairs / tables geometry exactly (the constants of csrc above); anything else runs the generic form
+    const bool hot = !force_generic && grid_size == 64 && Hp == 128 && Wp == 128 && bound == 1.0f && max_steps == 256;
+    const int mode = !hot ? 0 : ((dt_gammas == nullptr && dt_gamma == 0.0f) ? 2 : 1);
+    dim3 g((unsigned)n_cu * (unsigned)blocks_per_cu), b(SM_TPB);
     hipStream_t s = (hipStream_t)stream;
-#define SM_LAUNCH(PT, V) hipLaunchKernelGGL((k_shade_mfma<PT, V>), g, b, 0, s, c, src, (const PT*)planes, mlp_params, (const uint8_t*)w.lin_bits, (const uint2*)w.queue, w.counters, image, depth, weights_sum, sample_counts, overflow_flag)
-    if (planes_dtype == 0) { if (var == 4) SM_LAUNCH(float, 4); else SM_LAUNCH(float, 6); }
-    else { if (var == 4) SM_LAUNCH(__half, 4); else SM_LAUNCH(__half, 6); }
+#define SM_LAUNCH(PT, M) hipLaunchKernelGGL((k_shade_mfma<PT, M>), g, b, 0, s, c, src, (const PT*)planes, mlp_params, (const uint8_t*)w.lin_bits, (const uint2*)w.queue, w.counters, image, depth, weights_sum, sample_counts, overflow_flag)
+    if (planes_dtype == 0) { if (mode == 2) SM_LAUNCH(float, 2); else if (mode == 1) SM_LAUNCH(float, 1); else SM_LAUNCH(float, 0); }
+    else { if (mode == 2) SM_LAUNCH(__half, 2); else if (mode == 1) SM_LAUNCH(__half, 1); else SM_LAUNCH(__half, 0); }
 #undef SM_LAUNCH
     SSD_CHECK_LAUNCH("render_shade_queue_mfma");
     return SSDNERF_OK;

@@ -71,7 +71,7 @@ def test_fast_executor_matches_reference_unet(name, dtype, tol):
     assert err < tol * scale * (10 if dtype == torch.bfloat16 else 1), (err, scale)
     assert rel_rms < tol, rel_rms
     # replays agree to rounding (GroupNorm statistics and split-K partial sums are accumulated with atomics: the order is not fixed)
-    assert float((out - out2).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2) * scale
+    assert float((out - out2).abs().max()) <= (1e-4 if dtype == torch.float32 else 2e-2) * scale
     if name == "cars":
         # every convolution / projection / attention of the cars layout runs on the hand-written kernels: no library fallbacks
         assert ex.library_fallbacks == 0, ex.fallback_log

@@ -1,0 +1,27 @@
+#!/usr/bin/env bash
+# tools/ab_shade.sh <variant names...> -- on the GPU box: bench each .variants/<name> build (and the in-tree library as "base") with both shading
+# schedules; prints ms/step, shade ms, first-hit ms, samples (a changed sample total flags a broken variant).
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/ab
+one() { # label, env...
+  l=$1; shift
+  env "$@" timeout 120 python bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline > gpurun_out/ab/$l.json 2> gpurun_out/ab/$l.err < /dev/null
+  python - "$l" <<'PY'
+import json, sys
+l = sys.argv[1]
+try:
+    d = json.loads([x for x in open(f"gpurun_out/ab/{l}.json") if x.startswith("{")][-1])
+    r = d["roofline"]
+    print(f"{l:28s} step {d['ms_per_step']:.3f}  shade {r['launch_ms']:.3f}  first_hit {list(r['other_kernels'].values())[0]['launch_ms']:.3f}  samples {d['boundary_rays']['samples_per_step_per_gpu']}")
+except Exception as e:
+    print(l, "FAILED", e)
+PY
+}
+one base_v6 SSDNERF_SHADE_VARIANT=6
+one base_v4 SSDNERF_SHADE_VARIANT=4
+for v in "$@"; do
+  [ -f .variants/$v/libssdnerf_hip.so ] || { echo "$v: not built"; continue; }
+  one ${v}_v4 SSDNERF_HIP_LIB=$R/.variants/$v/libssdnerf_hip.so SSDNERF_SHADE_VARIANT=4
+  one ${v}_v6 SSDNERF_HIP_LIB=$R/.variants/$v/libssdnerf_hip.so SSDNERF_SHADE_VARIANT=6
+done
+one base_v6_1wave SSDNERF_SHADE_VARIANT=6 SSDNERF_SHADE_BLOCKS_PER_CU=1
+one base_v4_1wave SSDNERF_SHADE_VARIANT=4 SSDNERF_SHADE_BLOCKS_PER_CU=1
