@@ -36,22 +36,8 @@
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
-// SiLU of two values at once.  Default: the multiply / add / multiply around the two transcendentals are packed fp32 ops
-// (v_pk_mul_f32 / v_pk_add_f32 process two values per instruction).  -DSM_SCALAR_VALU issues plain v_mul/v_add/v_fma instead
-// (inline asm, so that the SLP vectoriser cannot re-pack them): packed f32 ops issued beside MFMAs cost extra cycles on gfx950
-// (MI355X guide, "price of one filler beside MFMAs"), and phases B-D of the shading loop run VALU work under MFMAs on purpose.
-#ifdef SM_SCALAR_VALU
-SSD_DEV float sm_vmul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-SSD_DEV float sm_vadd(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-SSD_DEV float sm_vfma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-SSD_DEV floatx2 sm_silu2(floatx2 h) {
-    floatx2 o;
-    o.x = sm_vmul(h.x, __builtin_amdgcn_rcpf(sm_vadd(__builtin_amdgcn_exp2f(sm_vmul(h.x, -1.4426950408889634f)), 1.0f)));
-    o.y = sm_vmul(h.y, __builtin_amdgcn_rcpf(sm_vadd(__builtin_amdgcn_exp2f(sm_vmul(h.y, -1.4426950408889634f)), 1.0f)));
-    return o;
-}
-SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return floatx2{sm_vfma(w.x, v.x, acc.x), sm_vfma(w.y, v.y, acc.y)}; }
-#else
+// SiLU of two values at once: the multiply / add / multiply around the two transcendentals are packed fp32 ops (v_pk_mul_f32 / v_pk_add_f32
+// process two values per instruction at the rate of a plain op: tools/ubench/mfma_valu_2wave.hip, 128 v_pk_fma = 278 ns = 128 v_fma).
 SSD_DEV floatx2 sm_silu2(floatx2 h) {
     const floatx2 a = h * floatx2{-1.4426950408889634f, -1.4426950408889634f};
     floatx2 e;
@@ -64,7 +50,6 @@ SSD_DEV floatx2 sm_silu2(floatx2 h) {
     return h * rcp;
 }
 SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_elementwise_fma(w, v, acc); }
-#endif
 
 static constexpr unsigned SM_TPB = 256;
 static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
@@ -254,17 +239,6 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             }
         }
     }
-#ifdef SM_SIGMA_REGS     // experiment: the density head's 32 weights of this lane half in registers instead of LDS broadcast reads
-    floatx2 wsig[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float4 w = wout2[(((q >> 3) * 8 + (q & 7)) * 2 + half) * 2];
-        wsig[q] = floatx2{w.x, w.y};
-    }
-#define SM_WSIG(q, w) wsig[q]
-#else
-#define SM_WSIG(q, w) floatx2{(w).x, (w).y}
-#endif
     const float b_sigma = P[MLP_OFF_TAIL + 0], bc0 = P[MLP_OFF_TAIL + 1], bc1 = P[MLP_OFF_TAIL + 2], bc2 = P[MLP_OFF_TAIL + 3];
     const float sat_k = ssd_fma(c.sat, 2.0f, 1.0f);
 
@@ -446,16 +420,6 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
         }
-#ifdef SM_DUP_GATHER      // in-situ cost probe (tools/ab_shade.sh): a second gather at a nearby position, folded in with weight 0 (results unchanged)
-        {
-            float f2[18];
-            if (ray >= 0) {
-                ssd_gather18<PT, SM_GATHER_BY_PLANE != 0>(planes, c.g, sy, sz, sx, f2);
-#pragma unroll
-                for (int i = 0; i < 18; ++i) f[i] = ssd_fma(0.0f, f2[i], f[i]);
-            }
-        }
-#endif
         // Split every feature into three bf16 terms, pack feature pairs, and trade halves so that T[t][0..3] is tile 0's k-step-0 operand
         // (features 0-15 of the samples of lanes 0-31) and T[t][4..7] tile 1's; T[t][8] / Z[t] carry features 16, 17 for k-step 1 (their other
         // k slots are the bias row and zeros).
@@ -510,10 +474,8 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
         auto density_pair = [&](int nt, int q) {
             const int mt = q >> 3, p2 = q & 7;
-#ifndef SM_SIGMA_REGS
             const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
-#endif
-            ps_[nt] = sm_fma2(SM_WSIG(q, w), sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]}), ps_[nt]);
+            ps_[nt] = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]}), ps_[nt]);
         };
         auto colour_pair = [&](int nt, int q) {
             const int mt = q >> 3, p2 = q & 7;

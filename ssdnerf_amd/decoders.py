@@ -293,7 +293,7 @@ class TriPlaneDecoder(VolumeRenderer):
     def packed_params(self) -> torch.Tensor:
         ps = [self.base_net[0].weight, self.base_net[0].bias, self.density_net[0].weight, self.density_net[0].bias,
               self.dir_net[0].weight, self.dir_net[0].bias, self.color_net[0].weight, self.color_net[0].bias]
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = tuple((p.data_ptr(), p._version, p.device.index, p.dtype) for p in ps)     # (writes through p.data bypass this: call invalidate_packed())
         if self._packed is None or key != self._packed_key:
             sd = {"base_net.0.weight": ps[0].detach(), "base_net.0.bias": ps[1].detach(), "density_net.0.weight": ps[2].detach(),
                   "density_net.0.bias": ps[3].detach(), "dir_net.0.weight": ps[4].detach(), "dir_net.0.bias": ps[5].detach(),
@@ -301,6 +301,21 @@ class TriPlaneDecoder(VolumeRenderer):
             self._packed = pack_mlp_params(sd, ps[0].device)
             self._packed_key = key
         return self._packed
+
+    def invalidate_packed(self):
+        """Forget the packed parameter block (re-packed on the next fused call).  Automatic after ``load_state_dict`` / ``.to()``; needed by hand
+        only after writing weights through ``p.data``, which no version counter sees."""
+        self._packed, self._packed_key = None, None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packed()
+        return out
 
     # ------------------------------------------------------------------------------ decode
     def xyz_transform(self, xyz):

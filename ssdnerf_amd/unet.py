@@ -434,6 +434,24 @@ class DenoisingUnetMod(nn.Module):
     #: activations, hipGraph replay); set to False (or SSDNERF_UNET_FAST=0) to force the eager module forward.
     fast_inference = os.environ.get("SSDNERF_UNET_FAST", "1") != "0"
 
+    def invalidate_fast_cache(self):
+        """Forget every packed copy of the weights (inference executor, split / transposed convolution operands).  Called automatically by
+        ``load_state_dict`` and by ``.to()`` / ``.half()`` / ``.cuda()``; call it yourself after writing weights through ``p.data``."""
+        for ex in self.__dict__.get("_fast_cache", {}).values():
+            ex.invalidate()
+        for m in self.modules():
+            m.__dict__.pop("_f32x2_cache", None)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_fast_cache()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_fast_cache()
+        return out
+
     def _fast_executor(self, dtype):
         from .unet_fast import FastUnet
         cache = self.__dict__.setdefault("_fast_cache", {})
@@ -442,9 +460,22 @@ class DenoisingUnetMod(nn.Module):
             ex = cache[dtype] = FastUnet(self, dtype=dtype)
         return ex
 
+    def _fast_path_ok(self, x_t, label=None):
+        return (self.fast_inference and x_t.is_cuda and not torch.is_grad_enabled() and not self.training and label is None
+                and self.concat_cond_channels == 0 and self.num_classes == 0)
+
+    def inference_session(self, x_t, t):
+        """Static-buffer session on the inference executor for a sampling loop (``unet_fast.FastUnet.session``), or None when this call would
+        not take the executor (gradients enabled, CPU tensors, conditioning inputs ...)."""
+        from .unet_fast import FastUnet
+        if not self._fast_path_ok(x_t) or not FastUnet.capture_by_default:
+            return None
+        dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        with torch.autocast("cuda", enabled=False):
+            return self._fast_executor(dtype).session(x_t.float(), t)
+
     def forward(self, x_t, t, label=None, concat_cond=None, return_noise=False):
-        if (self.fast_inference and x_t.is_cuda and not torch.is_grad_enabled() and not self.training and label is None
-                and self.concat_cond_channels == 0 and self.num_classes == 0):
+        if self._fast_path_ok(x_t, label):
             dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
             with torch.autocast("cuda", enabled=False):
                 return self._fast_executor(dtype)(x_t.float(), t)

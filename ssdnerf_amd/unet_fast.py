@@ -326,8 +326,19 @@ class FastUnet:
 
     # ------------------------------------------------------------------------------------------------ weights
     @staticmethod
-    def param_version(net) -> int:
-        return sum(p._version for p in net.parameters())
+    def param_version(net):
+        """Identity of the weights the packed copies were made from: storage pointer, version counter, device and dtype of every parameter.
+        In-place updates through autograd-visible ops (optimizer steps, ``copy_``, ``load_state_dict``) bump the version; ``module.to()`` /
+        ``.half()`` / ``p.data = ...`` swap the storage; all of these re-pack.  Writes THROUGH ``p.data`` (``p.data.copy_()``, ``p.data.mul_()``)
+        bypass both -- PyTorch gives no hook for them -- so code that updates weights that way (some EMA loops) must call
+        ``DenoisingUnetMod.invalidate_fast_cache()`` afterwards."""
+        return hash(tuple((p.data_ptr(), p._version, p.device.index, p.dtype) for p in net.parameters()))
+
+    def invalidate(self):
+        """Drop the packed weights and captured graphs; the next call re-packs from the module's current parameters."""
+        self.version = None
+        self._graphs.clear()
+        self.fallback_log = None
 
     def _pack(self):
         net, dt = self.net, self.dtype
@@ -532,9 +543,20 @@ class FastUnet:
             ws = self._ws_by_batch[B] = torch.zeros(n, dtype=torch.float64, device=self.device)
         self._ws = ws
 
+    def session(self, x_t: torch.Tensor, t: torch.Tensor) -> "UnetSession":
+        """Static-buffer handle on the captured forward for inputs shaped like ``x_t`` / ``t``: a sampling loop writes the latent into
+        ``session.x`` (in place), the timesteps into ``session.t``, calls ``session.run()`` and reads ``session.y`` -- no per-step copies in or
+        out of the graph's buffers (``__call__`` pays three: x, t and the output clone)."""
+        if not self.use_graph:
+            raise RuntimeError("FastUnet.session needs graph capture")
+        if self.version is None or self.param_version(self.net) != self.version or tuple(x_t.shape) not in self._graphs:
+            self(x_t, t)                                                    # packs / captures (one forward, first use only)
+        g, sx, st, sy = self._graphs[tuple(x_t.shape)]
+        return UnetSession(self, g, sx, st, sy)
+
     @torch.no_grad()
     def __call__(self, x_t: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-        if self.param_version(self.net) != self.version:
+        if self.version is None or self.param_version(self.net) != self.version:
             self._pack()
             self._graphs.clear()
         self._ensure_ws(x_t.size(0))
@@ -568,3 +590,17 @@ class FastUnet:
         sx.copy_(x_t); st.copy_(t)
         g.replay()
         return sy.clone()
+
+
+class UnetSession:
+    """See ``FastUnet.session``.  Valid until the executor re-packs (weights changed); ``run`` checks."""
+    __slots__ = ("ex", "graph", "x", "t", "y", "version")
+
+    def __init__(self, ex: FastUnet, graph, x, t, y):
+        self.ex, self.graph, self.x, self.t, self.y, self.version = ex, graph, x, t, y, ex.version
+
+    def run(self) -> torch.Tensor:
+        if self.ex.version != self.version or self.ex.param_version(self.ex.net) != self.version:
+            raise RuntimeError("UnetSession: the network's weights changed since this session was opened; open a new one")
+        self.graph.replay()
+        return self.y

@@ -80,6 +80,33 @@ def test_executor_repacks_after_parameter_update():
     assert torch.allclose(b, 2 * a, atol=1e-4, rtol=1e-4)
 
 
+def test_executor_repacks_after_storage_swaps_and_explicit_invalidation():
+    """Weight-cache invalidation beyond version counters: ``p.data = ...`` and ``module.to()/.double()`` swap the storage (detected through the
+    storage pointer / dtype), ``load_state_dict`` invalidates explicitly, and a write THROUGH ``p.data`` -- invisible to PyTorch's counters --
+    is picked up after ``invalidate_fast_cache()``."""
+    net = _small_unet(3)
+    x = torch.randn(1, 6, 16, 16, generator=torch.Generator().manual_seed(5))
+    t = torch.tensor([321])
+    with torch.no_grad():
+        net.fast_inference = False
+        ex = net._fast_executor(torch.float32)
+        ex.use_graph = False
+        a = ex(x, t)
+        # 1. storage swap without a version bump
+        net.out.conv.weight.data = net.out.conv.weight.data * 2.0
+        net.out.conv.bias.data = net.out.conv.bias.data * 2.0
+        assert torch.allclose(ex(x, t), 2 * a, atol=1e-4, rtol=1e-4)
+        # 2. load_state_dict
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd["out.conv.weight"] *= 0.5; sd["out.conv.bias"] *= 0.5
+        net.load_state_dict(sd)
+        assert torch.allclose(ex(x, t), a, atol=1e-4, rtol=1e-4)
+        # 3. a write through .data is NOT seen (documented) until the cache is invalidated by hand
+        net.out.conv.weight.data.mul_(3.0); net.out.conv.bias.data.mul_(3.0)
+        net.invalidate_fast_cache()
+        assert torch.allclose(ex(x, t), 3 * a, atol=2e-4, rtol=2e-4)
+
+
 def test_executor_refuses_conditioning():
     net = MODULES.build(dict(type="DenoisingUnetMod", image_size=8, in_channels=4, base_channels=32, channels_cfg=[1], resblocks_per_downsample=1,
                              use_scale_shift_norm=True, num_classes=3, attention_res=[]))
