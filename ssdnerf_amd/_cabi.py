@@ -57,9 +57,16 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+_SYNC_CHECK = os.environ.get("SSDNERF_SYNC_CHECK", "0") == "1"      # debugging aid: synchronise after every library call and name it first
+
+
 def check(status: int, what: str) -> None:
     if status != 0:
         raise RuntimeError(f"{what} failed ({status}): {lib().ssdnerf_last_error().decode()}")
+    if _SYNC_CHECK and not torch.cuda.is_current_stream_capturing():
+        import sys
+        print(f"[ssdnerf sync-check] {what}", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
 
 
 def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:

@@ -4,8 +4,9 @@
 // HBM-bound streaming: 8 B read + 8 B written per element, float4 per lane.
 #include "common.h"
 
-__global__ void k_ddim_step_v(const float4* __restrict__ x_t, const float4* __restrict__ v, uint64_t n4, float a, float b, float inv_b, float c,
-                              float d, float lo, float hi, float4* __restrict__ x0_out, float4* __restrict__ xprev_out) {
+// (no __restrict__: the sampling loop runs this in place, xprev_out == x_t and, when x0 is not kept, x0_out == v; element i is read before it is written)
+__global__ void k_ddim_step_v(const float4* x_t, const float4* v, uint64_t n4, float a, float b, float inv_b, float c,
+                              float d, float lo, float hi, float4* x0_out, float4* xprev_out) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 xt = x_t[i], vv = v[i];

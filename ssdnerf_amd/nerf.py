@@ -3,6 +3,7 @@
 lib/core/utils/nerf_utils.py:17-61 ``get_cam_rays``), host orchestration in Python on PyTorch-ROCm."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -68,7 +69,7 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
     if planes is None and decoder.render_mode == "fused" and decoder.fused_supported(code):
         planes = pack_triplanes(code, decoder.plane_dtype)
     overflow = []                                                     # device flags of the fused launches: ONE host read after the last chunk
-    if planes is not None and rays is None and not chunked:
+    if planes is not None and rays is None and not chunked and os.environ.get("SSDNERF_RENDER_ARRAYS", "0") != "1":   # (=1: debugging aid, materialise the rays)
         # the whole batch in one fused launch pair, rays generated in the kernels from (poses, intrinsics): no (S,V,h,w,3) arrays at all
         out = decoder.render_packed(planes, None, None, density_bitfield, grid_size, dt_gamma.reshape(-1), 1e-4, bg_color=bg_color,
                                     check_overflow=False, cams=(poses, intrinsics.expand(s, v, 4), h, w))
