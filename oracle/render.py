@@ -40,7 +40,8 @@ def get_cam_rays(c2w: torch.Tensor, intrinsics: torch.Tensor, h: int, w: int) ->
 
 def render_eval(params: Dict[str, torch.Tensor], code: torch.Tensor, bitfield: np.ndarray, rays_o: np.ndarray,
                 rays_d: np.ndarray, grid_size: int = 64, bound: float = 1.0, min_near: float = 0.2, max_steps: int = 256,
-                dt_gamma: float = 0.0, T_thresh: float = 1e-4, bg_color: float = 1.0, ops=None, trace: Optional[dict] = None):
+                dt_gamma: float = 0.0, T_thresh: float = 1e-4, bg_color: float = 1.0, ops=None, trace: Optional[dict] = None,
+                near_band: float = 2e-6):
     """One scene.  Returns rgb (N,3), depth (N,), weights_sum (N,).  ``trace`` (if given) is filled with the
     integer history of the loop: n_alive and n_step per iteration and the per-ray sample count."""
     o = ops or _ops()
@@ -55,6 +56,8 @@ def render_eval(params: Dict[str, torch.Tensor], code: torch.Tensor, bitfield: n
     rays_alive = np.arange(N, dtype=np.int32)
     rays_t = nears.copy()
     samples = np.zeros(N, np.int64)
+    composited = np.zeros(N, np.int64)
+    near_cut = np.zeros(N, bool)
     hist: List[Tuple[int, int]] = []
     step = 0
     while step < max_steps:
@@ -68,6 +71,19 @@ def render_eval(params: Dict[str, torch.Tensor], code: torch.Tensor, bitfield: n
             sig, rgb = point_decode(params, code, torch.from_numpy(xyzs), torch.from_numpy(dirs))
         taken = (deltas[: n_alive * n_step, 0].reshape(n_alive, n_step) != 0).sum(1)
         samples[rays_alive] += taken
+        if trace is not None:      # samples that ENTER the composite (a ray cut at T < T_thresh leaves the rest of its batch unused): replay of the
+            dts = deltas[: n_alive * n_step, 0].reshape(n_alive, n_step)          # kernel's per-ray loop (.cu:875-903), vectorised over the rays
+            sg = sig.numpy()[: n_alive * n_step].reshape(n_alive, n_step)
+            w_run = ws[rays_alive].copy()
+            going = np.ones(n_alive, bool)
+            for k in range(n_step):
+                going &= dts[:, k] != 0
+                alpha = (np.float32(1) - np.exp(-sg[:, k] * dts[:, k], dtype=np.float32)).astype(np.float32)
+                T = (np.float32(1) - w_run).astype(np.float32)
+                w_run = np.where(going, (w_run + alpha * T).astype(np.float32), w_run)
+                composited[rays_alive[going]] += 1
+                near_cut[rays_alive[going & (np.abs(T - np.float32(T_thresh)) < near_band)]] = True
+                going &= ~(T < np.float32(T_thresh))
         o.composite_rays(n_alive, n_step, rays_alive, rays_t, sig.numpy(), rgb.numpy(), deltas, ws, depth, image, T_thresh)
         hist.append((n_alive, n_step))
         rays_alive = np.ascontiguousarray(rays_alive[rays_alive >= 0])
@@ -75,6 +91,8 @@ def render_eval(params: Dict[str, torch.Tensor], code: torch.Tensor, bitfield: n
     if trace is not None:
         trace["iterations"] = hist
         trace["samples_marched"] = samples
+        trace["samples_composited"] = composited      # what the fused kernels count per ray
+        trace["near_threshold"] = near_cut            # rays with a termination test within near_band of T_thresh (exp implementations may disagree there)
         trace["nears"], trace["fars"] = nears, fars
     rgb_out = image + bg_color * (1.0 - ws[:, None])
     return rgb_out.astype(np.float32), depth, ws

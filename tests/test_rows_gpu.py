@@ -1,0 +1,258 @@
+"""GPU tests for the SURVEY.md section 8 rows the round-1 verdict left partial:
+
+  item 8   integer sample counts of a FULL bench scene (251 views) against the threaded oracle, object-like and fog scene
+  (f)2     Langevin correction steps and the tiled (6, H, 3H) layout through the sampler on the GPU
+  (f)3     a 16-bit cached ``.pth`` scene (fp16 code, written by ``save_cache``) loaded and rendered through the fused HIP path
+  (f)4     ``MultiSceneNeRF.train_step`` / ``DiffusionNeRF.train_step`` with the real renderer on the GPU
+  N1       config 5's precision mix end to end: bf16 UNet + fp16 planes against the fp32 path, PSNR floor
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEC = dict(type="TriPlaneDecoder", interp_mode="bilinear", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], use_dir_enc=True,
+           dir_layers=[16, 64], activation="silu", sigma_activation="trunc_exp", sigmoid_saturation=0.001, max_steps=256)
+
+
+def _unet(image_size=128, in_channels=18, base=64, cfg=(1, 2), att=(64,), groups=32):
+    return dict(type="DenoisingUnetMod", image_size=image_size, in_channels=in_channels, base_channels=base, channels_cfg=list(cfg),
+                resblocks_per_downsample=1, dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4,
+                attention_res=list(att), norm_cfg=dict(type="GN", num_groups=groups))
+
+
+def _randomize(module, seed, scale=0.2):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (scale / max(1.0, p[0].numel() ** 0.5) if p.dim() > 1 else 0.1))
+
+
+def _decoder():
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.decoders import TriPlaneDecoder
+    dec = TriPlaneDecoder(**{k: v for k, v in DEC.items() if k != "type"})
+    dec.load_state_dict(S.make_decoder_params(), strict=False)
+    return dec.cuda().eval()
+
+
+# ---------------------------------------------------------------------------------------------- item 8: bench-scale integer parity
+@pytest.mark.parametrize("variant,n_views", [("object", 251), ("uniform", 16)])
+def test_full_scene_sample_counts_match_the_oracle(variant, n_views):
+    """Per-ray sample counts of a whole bench scene -- every view of the spiral for the object-like scene, 16 views of the fog scene (33
+    samples per ray) -- from the camera-fed fused path against the reference-shaped oracle loop (C restatement of the reference kernels on all
+    host cores + PyTorch-CPU decode).  Integer contract: equal except on rays with a termination test within 1e-5 of T_thresh -- the
+    transmittance there is 1 - (a sum of ~30 weights near 1), so hardware exp vs expf and the summation order of the MLP move it by a few 1e-6 --
+    and those mismatches must be rarer than 1 ray in 2000."""
+    import oracle
+    from oracle import render as R
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.decoders import pack_triplanes
+    from ssdnerf_amd.density import get_density
+    oracle.set_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    dec = _decoder()
+    params, code = S.make_decoder_params(), S.make_triplane(2021, variant)
+    g = torch.Generator().manual_seed(7)
+    jit = [torch.rand(64 ** 3, 3, generator=g) for _ in range(8)]
+    _, bits = get_density(dec, code.cuda()[None], 64, density_thresh=0.1, density_step=8, jitters=[j.cuda() for j in jit])
+    poses = S.spiral_poses(251)[:n_views]
+    intr = S.cars_intrinsics(128, 128)[None].expand(n_views, -1)
+    dec.render_packed(pack_triplanes(code.cuda()[None]), None, None, bits, 64, [0.0], 1e-4, bg_color=1.0, want_counts=True, check_overflow=False,
+                      cams=(poses.cuda()[None], intr.cuda()[None], 128, 128))
+    got = dec.last_render_stats["sample_counts"][0].cpu().numpy().reshape(n_views, -1)
+    near_thresh = int(dec.last_render_stats["boundary_tests"].sum())
+    assert int(dec.last_render_stats["overflow"].item()) == 0
+    bits_np = bits[0].cpu().numpy()
+    # the oracle marches the SAME rays: the arrays ssdnerf_cam_rays materialises, which the camera-fed kernels reproduce bit for bit
+    # (test_camera_fed_render_is_bit_identical_to_ray_arrays); the CPU tensor-op form differs from them by a few ulp (row a1's tolerance),
+    # which is enough to move a sample across a voxel face on ~1 ray per view
+    from ssdnerf_amd import nerf
+    ro, rd = (t[0].cpu() for t in nerf.get_cam_rays(poses.cuda()[None], intr.cuda()[None], 128, 128))
+    mismatched = unexplained = total = 0
+    for v in range(n_views):
+        tr = {}
+        R.render_eval(params, code, bits_np, ro[v].reshape(-1, 3).numpy(), rd[v].reshape(-1, 3).numpy(), trace=tr, near_band=1e-5)
+        diff = tr["samples_composited"] != got[v]
+        mismatched += int(diff.sum())
+        unexplained += int((diff & ~tr["near_threshold"]).sum())
+        total += int(tr["samples_composited"].sum())
+    n_rays = n_views * 128 * 128
+    assert total > 50 * n_views and abs(int(got.sum()) - total) <= max(8, mismatched * 8)
+    assert unexplained == 0                                                    # only rays sitting at the threshold may differ ...
+    assert mismatched <= max(1, n_rays // 2000), (mismatched, n_rays)          # ... and they are rare
+    assert near_thresh > 0 or mismatched == 0                                  # (the kernel's own diagnostic count of tests within 2e-6)
+
+
+# ---------------------------------------------------------------------------------------------- (f)3: 16-bit scene cache -> fused render
+def test_sixteen_bit_cached_scene_renders_through_the_fused_path(tmp_path):
+    """``MultiSceneNeRF.save_cache`` with ``cache_16bit`` writes fp16 pre-activation codes (+ bf16 optimizer moments); the files are read back
+    (``data['code']`` -> ``load_scene``), rendered by the fused kernels, and must equal the oracle's render of the SAME fp16-rounded code to
+    render tolerance, and stay close to the fp32 original (the quantisation is the only difference)."""
+    from oracle import render as R
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.registry import MODELS
+    m = MODELS.build(dict(type="MultiSceneNeRF", code_size=(3, 6, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64,
+                          decoder=DEC, pixel_loss=dict(type="MSELoss", loss_weight=20.0), cache_size=2, cache_16bit=True,
+                          train_cfg=dict(save_dir=str(tmp_path), optimizer=dict(type="Adam", lr=0.01))))
+    m.decoder.load_state_dict(S.make_decoder_params(), strict=False)
+    m = m.cuda().eval()
+    codes = torch.stack([S.make_triplane(31), S.make_triplane(32)]).cuda()
+    leaves = [m.code_activation.inverse(c).detach().requires_grad_(True) for c in codes]
+    opts = m.build_optimizer(leaves, m.train_cfg)
+    for leaf, opt in zip(leaves, opts):                                        # one step so that the optimizers have state to cast
+        leaf.grad = torch.zeros_like(leaf)
+        opt.step()
+    g = torch.Generator().manual_seed(5)
+    jit = [torch.rand(64 ** 3, 3, generator=g) for _ in range(4)]
+    grid, bits = m.get_density(m.decoder, m.code_activation(torch.stack(leaves)).detach(), cfg=dict(density_thresh=0.1, density_step=4),
+                               jitters=[j.cuda() for j in jit])
+    m.save_cache(leaves, opts, grid, bits, [0, 1], ["scene_a", "scene_b"])
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["scene_a.pth", "scene_b.pth"]
+    entries = [torch.load(os.path.join(tmp_path, f), map_location="cpu") for f in files]
+    assert entries[0]["param"]["code_"].dtype == torch.float16 and entries[0]["param"]["density_grid"].dtype == torch.float16
+    assert all(v.dtype == torch.bfloat16 for k, v in entries[0]["optimizer"]["state"][0].items() if k != "step" and torch.is_tensor(v))
+    code, grid2, bits2 = m.load_scene(dict(code=entries), load_density=True)
+    assert code.dtype in (torch.float16, torch.float32) and torch.equal(bits2.cpu(), bits.cpu())
+    poses = S.spiral_poses()[[64]].cuda()[None].expand(2, -1, -1, -1)
+    intr = S.cars_intrinsics(64, 64).cuda()[None, None].expand(2, 1, -1)
+    image, depth = m.render(m.decoder, code.float(), bits2, 64, 64, intr, poses, cfg=dict())
+    ref, _ = m.render(m.decoder, codes, bits, 64, 64, intr, poses, cfg=dict())
+    assert float((image - ref).abs().max()) < 5e-2 and float(((image - ref) ** 2).mean()) < 1e-5      # fp16 code quantisation only
+    ro, rd = R.get_cam_rays(S.spiral_poses()[[64]], S.cars_intrinsics(64, 64)[None], 64, 64)
+    want, dep0, _ = R.render_eval(S.make_decoder_params(), code[0].float().cpu(), bits2[0].cpu().numpy(), ro.reshape(-1, 3).numpy(),
+                                  rd.reshape(-1, 3).numpy())
+    np.testing.assert_allclose(image[0].reshape(-1, 3).cpu().numpy(), want, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(depth[0].reshape(-1).cpu().numpy(), dep0, rtol=0, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------- N1: config 5's precision mix
+def _sampling_model(autocast_dtype, plane_dtype, test_cfg, code_permute=None, code_reshape=(18, 128, 128), unet=None):
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.registry import MODELS
+    m = MODELS.build(dict(type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=code_reshape, code_permute=code_permute,
+                          code_activation=dict(type="TanhCode", scale=2), grid_size=64, autocast_dtype=autocast_dtype,
+                          diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"), denoising=unet or _unet()),
+                          decoder=dict(DEC, plane_dtype=plane_dtype), decoder_use_ema=True, freeze_decoder=False, bg_color=1,
+                          pixel_loss=dict(type="MSELoss", loss_weight=20.0), cache_size=0, test_cfg=test_cfg))
+    _randomize(m.diffusion_ema.denoising, 17)
+    m.decoder_ema.load_state_dict(S.make_decoder_params(), strict=False)
+    return m.cuda().eval()
+
+
+def test_bf16_unet_fp16_planes_end_to_end_against_fp32():
+    """ssdnerf_chairs_recons1v-style precision (BASELINE.json configs[4]): the UNet under bf16 autocast (inference executor, bf16 matrix-core
+    convolutions and attention) and fp16 triplanes in the renderer, against the all-fp32 path from the same noise and weights: the sampled
+    codes stay within bf16 accumulation error and the rendered views agree to > 35 dB PSNR."""
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd import nerf
+    cfg = dict(img_size=(128, 128), num_timesteps=6, clip_range=[-2, 2], density_thresh=0.1)
+    lo = _sampling_model("bfloat16", "float16", cfg)
+    hi = _sampling_model(None, "float32", cfg)
+    hi.load_state_dict(lo.state_dict())
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(2, 3, 6, 128, 128, generator=g).cuda()
+    jit = [torch.rand(64 ** 3, 3, generator=g).cuda() for _ in range(8)]
+    code_lo, _, _ = lo.val_uncond(dict(scene_id=[0, 1], noise=noise), density_jitters=jit)
+    code_hi, _, bits_hi = hi.val_uncond(dict(scene_id=[0, 1], noise=noise), density_jitters=jit)
+    rel = float((code_lo - code_hi).norm() / code_hi.norm())
+    assert rel < 5e-2, rel
+    ex = lo.diffusion_ema.denoising._fast_cache[torch.bfloat16]
+    assert ex.library_fallbacks == 0, ex.fallback_log                         # the bf16 step ran on the hand-written kernels
+    # render the SAME scene (the fp32 codes; object-like stand-in for visible content) with fp16 and fp32 planes
+    codes = torch.stack([S.make_triplane(41), S.make_triplane(42)]).cuda()
+    _, bits = hi.get_density(hi.decoder_ema, codes, cfg=cfg, jitters=jit)
+    poses = S.spiral_poses()[[20, 140]].cuda()[None].expand(2, -1, -1, -1)
+    intr = S.cars_intrinsics().cuda()[None, None].expand(2, 2, -1)
+    img_lo, _ = lo.render(lo.decoder_ema, codes, bits, 128, 128, intr, poses, cfg=cfg)
+    img_hi, _ = hi.render(hi.decoder_ema, codes, bits, 128, 128, intr, poses, cfg=cfg)
+    psnr = nerf.eval_psnr(img_lo.reshape(4, -1), img_hi.reshape(4, -1))
+    assert float(psnr.min()) > 35.0, psnr
+
+
+# ---------------------------------------------------------------------------------------------- (f)2: Langevin steps, tiled layout
+def test_langevin_sampling_and_tiled_layout_on_the_gpu():
+    """``langevin_steps`` correction evaluations after every DDIM step (ssdnerf_chairs_recons1v.py:95-96) and the tiled (6, 128, 384) latent
+    layout (``code_permute=(1, 2, 0, 3)``; new_cfgs/ssdnerf_cars_recons1v_tiled.py:6-28, GroupNorm(16), widths that are not multiples of 64):
+    the GPU sampler (inference executor, device-resident loop where the step kind allows it) reproduces the CPU module run of the same model
+    with the same host-drawn noise."""
+    cfg = dict(img_size=(128, 128), num_timesteps=3, clip_range=[-2, 2], density_thresh=0.1, langevin_steps=2, langevin_delta=0.4)
+    tiled_unet = _unet(image_size=128, in_channels=6, base=48, cfg=(1, 1, 2), att=(32,), groups=16)
+    for kw in (dict(), dict(code_permute=(1, 2, 0, 3), code_reshape=(6, 128, 384), unet=tiled_unet)):
+        m = _sampling_model(None, "float32", cfg, **kw)
+        g = torch.Generator().manual_seed(9)
+        noise = torch.randn(1, 3, 6, 128, 128, generator=g)
+        plan = m.diffusion_ema.sampling_plan("ddim")
+        assert [s.kind for s in plan].count("langevin") == 2 * 2 and len(plan) == 3 + 4      # no correction after the last step (t_prev = -1)
+        torch.manual_seed(123)
+        with torch.no_grad():
+            lat_gpu = m.diffusion_ema(m.code_diff_pr(noise.cuda()), return_loss=False)
+        m.cpu()
+        torch.manual_seed(123)
+        with torch.no_grad():
+            lat_cpu = m.diffusion_ema(m.code_diff_pr(noise), return_loss=False)
+        assert lat_gpu.shape == lat_cpu.shape == ((1, 18, 128, 128) if not kw else (1, 6, 128, 384))
+        err = float((lat_gpu.cpu() - lat_cpu).abs().max())
+        assert err < 2e-3 * max(1.0, float(lat_cpu.abs().max())), err
+        back = m.code_diff_pr_inv(lat_cpu)
+        assert back.shape == (1, 3, 6, 128, 128) and torch.equal(m.code_diff_pr(back), lat_cpu)
+
+
+# ---------------------------------------------------------------------------------------------- (f)4: training steps on the GPU
+def test_training_steps_run_on_the_gpu(tmp_path):
+    """One ``DiffusionNeRF.train_step`` and one ``MultiSceneNeRF.train_step`` with the real renderer: prior loss through the UNet, seeded
+    code-only fitting iterations through the train-branch render (HIP march / decode forward+backward / composite), the joint step that also
+    moves the decoder, cache write-back.  Checks: every logged value finite, codes / denoiser / decoder all moved, the cached codes change from step to step."""
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.registry import MODELS
+    train_cfg = dict(dt_gamma_scale=0.5, density_thresh=0.1, extra_scene_step=2, n_inverse_rays=2 ** 12, n_decoder_rays=2 ** 12,
+                     loss_coef=0.1 / (64 * 64), optimizer=dict(type="Adam", lr=0.02), save_dir=str(tmp_path / "cache"))
+    m = MODELS.build(dict(type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2),
+                          grid_size=64, diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"),
+                                                       denoising=_unet(base=32, cfg=(1, 1), att=(), groups=8),
+                                                       timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+                                                       ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight",
+                                                                      data_info=dict(pred="v_t_pred", target="v_t"), weight_scale=4.0, scale_norm=True)),
+                          decoder=DEC, decoder_use_ema=True, freeze_decoder=False, bg_color=1, pixel_loss=dict(type="MSELoss", loss_weight=20.0),
+                          reg_loss=dict(type="RegLoss", power=2, loss_weight=3e-3), cache_size=4, init_scale=0.5, train_cfg=train_cfg))
+    _randomize(m.diffusion.denoising, 3)
+    m.decoder.load_state_dict(S.make_decoder_params(), strict=False)
+    m = m.cuda().train()
+    # targets: views of two synthetic scenes
+    dec = _decoder()
+    codes = torch.stack([S.make_triplane(51), S.make_triplane(52)]).cuda()
+    from ssdnerf_amd import nerf
+    from ssdnerf_amd.density import get_density
+    _, bits = get_density(dec, codes, 64, density_thresh=0.1, density_step=4)
+    poses = S.spiral_poses()[[30, 150]].cuda()[None].expand(2, -1, -1, -1).contiguous()
+    intr = S.cars_intrinsics(64, 64).cuda()[None, None].expand(2, 2, -1).contiguous()
+    target, _ = nerf.render(dec, codes, bits, 64, 64, intr, poses)
+    data = dict(scene_id=[0, 2], scene_name=["s0", "s2"], cond_imgs=target.clamp(0, 1), cond_poses=poses, cond_intrinsics=intr)
+    opt = dict(diffusion=torch.optim.Adam(m.diffusion.parameters(), lr=1e-4), decoder=torch.optim.Adam(m.decoder.parameters(), lr=1e-3))
+    unet_w = m.diffusion.denoising.out.conv.weight.detach().clone()
+    dec_w = m.decoder.base_net[0].weight.detach().clone()
+    np.random.seed(1); torch.manual_seed(1)
+    out1 = m.train_step(data, opt)
+    code_after_1 = m.cache[2]["param"]["code_"].clone()
+    out2 = m.train_step(data, opt)
+    for out in (out1, out2):
+        assert out["num_samples"] == 2
+        for k in ("loss_ddpm_mse", "pixel_loss", "loss_decoder", "train_psnr", "code_rms"):
+            assert bool(torch.isfinite(torch.as_tensor(out["log_vars"][k]).float()).all()), k
+    assert not torch.equal(m.cache[2]["param"]["code_"], code_after_1)                              # the cached codes keep moving (3 Adam steps per call)
+    assert not torch.equal(m.diffusion.denoising.out.conv.weight, unet_w) and not torch.equal(m.decoder.base_net[0].weight, dec_w)
+    assert sorted(os.listdir(tmp_path / "cache")) == ["s0.pth", "s2.pth"] and m.cache[0] is not None and m.cache[1] is None
+    assert float(m.cache[2]["param"]["code_"].abs().max()) > 0 and m.cache[2]["param"]["density_bitfield"].dtype == torch.uint8
+
+    ms = MODELS.build(dict(type="MultiSceneNeRF", code_size=(3, 6, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64, decoder=DEC,
+                           pixel_loss=dict(type="MSELoss", loss_weight=20.0), cache_size=4, init_scale=0.5,
+                           train_cfg=dict(train_cfg, save_dir=None, extra_scene_step=1)))
+    ms.decoder.load_state_dict(S.make_decoder_params(), strict=False)
+    ms = ms.cuda().train()
+    o1 = ms.train_step(data, dict(decoder=torch.optim.Adam(ms.decoder.parameters(), lr=1e-3)))
+    o2 = ms.train_step(data, dict(decoder=torch.optim.Adam(ms.decoder.parameters(), lr=1e-3)))
+    assert bool(torch.isfinite(o1["log_vars"]["loss"])) and bool(torch.isfinite(o2["log_vars"]["loss"])) and bool(torch.isfinite(o2["log_vars"]["train_psnr"]))
