@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip gpu_baseline / ddim / uniform_variant (profiling runs)")
     ap.add_argument("--cpu-views", type=int, default=64, help="views of scene 0 rendered by the CPU oracle")
-    ap.add_argument("--b1-views", type=int, default=32, help="views of scene 0 rendered by the reference-shaped eager GPU path")
+    ap.add_argument("--b1-views", type=int, default=251, help="views of scene 0 rendered by the reference-shaped eager GPU path (the reference batches all views of a scene)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     return ap.parse_args()
 

@@ -217,16 +217,27 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
             alive = t < far_;
             if (use_coarse && alive) {
                 const float step_t = ssd_coarse_step_t(r, c.m.two_rH * c.m.mip_bound);          // RQ_COARSE_STEP cells of world length, in t
+                // The test points run in COARSE-BLOCK coordinates, advanced by one add per axis: q(u) = ((o + u d) rb + 1) half_H / B.  The
+                // accumulated rounding of <= 128 adds on |q| <= H/B is < 1e-3 cell, far inside the 0.05-cell margin RQ_COARSE_STEP = B - 0.1
+                // leaves on either side (a test point only has to lie within that margin of the ray; it takes no part in the exact march).
+                const float hb = c.m.half_H * (1.0f / (float)(1 << RQ_COARSE_LOG2B));
+                float qx = ssd_fma(ssd_fma(t, r.dx, r.ox), c.m.rb, 1.0f) * hb, qy = ssd_fma(ssd_fma(t, r.dy, r.oy), c.m.rb, 1.0f) * hb,
+                      qz = ssd_fma(ssd_fma(t, r.dz, r.oz), c.m.rb, 1.0f) * hb;
+                const float sx = step_t * r.dx * c.m.rb * hb, sy = step_t * r.dy * c.m.rb * hb, sz = step_t * r.dz * c.m.rb * hb;
+                const uint32_t top = Hc - 1;
+                auto occupied = [&](float x, float y, float z) {
+                    const uint32_t bx = min((uint32_t)fmaxf(x, 0.0f), top), by = min((uint32_t)fmaxf(y, 0.0f), top), bz = min((uint32_t)fmaxf(z, 0.0f), top);
+                    const uint32_t ci = (((bz << log2Hc) + by) << log2Hc) + bx;
+                    return ((coarse_lds[ci >> 3] >> (ci & 7u)) & 1u) != 0;
+                };
                 int j_last = -1, j = 0;
-                for (float tc = t; ; tc += step_t, ++j) {                        // test points from near to (at least) far
-                    const float u = fminf(tc, far_);
-                    const int bx = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dx, r.ox), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;   // block of the point's exact cell
-                    const int by = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dy, r.oy), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
-                    const int bz = rq_cell(c.m, ssd_fma(ssd_fma(u, r.dz, r.oz), c.m.rb, 1.0f)) >> RQ_COARSE_LOG2B;
-                    const uint32_t ci = ((((uint32_t)bz << log2Hc) + (uint32_t)by) << log2Hc) + (uint32_t)bx;
-                    if ((coarse_lds[ci >> 3] >> (ci & 7u)) & 1u) j_last = j;
-                    if (!(tc < far_)) break;
+                for (float tc = t; tc < far_; tc += step_t, ++j) {                // test points near, near + step, ... below far
+                    if (occupied(qx, qy, qz)) j_last = j;
+                    qx += sx; qy += sy; qz += sz;
                 }
+                // ... and the segment's end point itself
+                if (occupied(ssd_fma(ssd_fma(far_, r.dx, r.ox), c.m.rb, 1.0f) * hb, ssd_fma(ssd_fma(far_, r.dy, r.oy), c.m.rb, 1.0f) * hb,
+                             ssd_fma(ssd_fma(far_, r.dz, r.oz), c.m.rb, 1.0f) * hb)) j_last = j;
                 alive = j_last >= 0;                                             // nothing within a cell of this ray: no march
                 // every test point after j_last is clear: past near + (j_last + 1) steps no cell the march could test is occupied, so the
                 // march (k_survivor_march and the shading kernel, via ssd_tail_far) may stop there; it still starts at `near`
