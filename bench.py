@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--ray-arrays", action="store_true", help="feed materialised (S,N,3) ray arrays instead of cameras")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip gpu_baseline / ddim / uniform_variant (profiling runs)")
-    ap.add_argument("--cpu-views", type=int, default=64, help="views of scene 0 rendered by the CPU oracle")
+    ap.add_argument("--cpu-views", type=int, default=251, help="views of scene 0 rendered by the CPU oracle (251 = the whole scene, ~10 s on 32 host threads)")
     ap.add_argument("--b1-views", type=int, default=251, help="views of scene 0 rendered by the reference-shaped eager GPU path (the reference batches all views of a scene)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     return ap.parse_args()
@@ -223,7 +223,8 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         w = tj["workload"]
-        if (w["scenes"], w["views"], w["size"], w["variant"], w["plane_dtype"]) == (ns, nv, hw, args.variant, args.plane_dtype) and tj["kernel"] == "k_shade_mfma":
+        if (w["scenes"], w["views"], w["size"], w["variant"], w["plane_dtype"]) == (ns, nv, hw, args.variant, args.plane_dtype) and tj["kernel"].startswith("k_shade_mfma") \
+                and w.get("ray_source", "arrays") == ("arrays" if args.ray_arrays else "cameras"):
             traffic = tj["hbm_bytes_per_launch"]
     except Exception:
         pass

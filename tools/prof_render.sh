@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd $R
-ARGS="${@:---scenes 2 --no-cpu-baseline}"
+ARGS="${@:---no-extras --no-cpu-baseline}"      # the default (8 scenes x 251 views) workload: traffic is per launch of THAT
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_kt -o kt -- python bench.py --steps 3 --warmup 1 $ARGS > $OUT/kt_bench.json 2> $OUT/kt_err.log
 find /tmp/rp_kt -name "*stats*.csv" -exec cp {} $OUT/ \;
 pmc() { # name, counters...
@@ -24,7 +24,7 @@ for f in glob.glob(f"/tmp/rp_{n}/**/*counter_collection*.csv", recursive=True):
 import os
 out = open(os.environ.get("OUT", ".") + f"/{n}_summary.txt", "w")
 for k, d in acc.items():
-    if not any(w in k for w in ("render", "density", "decode", "shade", "first_hit")): continue
+    if not any(w in k for w in ("k_shade", "k_ray_cull", "k_survivor", "k_density", "k_quantize", "k_bitfield")): continue
     for c, v in sorted(d.items()):
         line = f"{k:60s} {c:28s} total={v:.6g} dispatches={cnt[(k,c)]} per_dispatch={v/cnt[(k,c)]:.6g}"
         print(line); out.write(line + "\n")
