@@ -130,15 +130,20 @@ int ssdnerf_point_decode(const void* planes, int planes_dtype, uint32_t Hp, uint
                          const float* xyzs, const float* dirs, uint32_t P, float sigmoid_saturation, float* sigmas,
                          float* rgbs, void* stream);
 
-/* Gradient of ssdnerf_point_decode w.r.t. the planes with the decoder frozen -- what autograd does through grid_sample and the four
- * nn.Linear layers (triplane_decoder.py:136-179, TruncExp.backward lib/ops/activation.py:15-20) when the rendering loss is
- * differentiated w.r.t. the scene code (guidance: diffusion_nerf.py:282-294; fine-tuning: base_nerf.py:446-470).
- * grad_sigmas [P] (may be NULL), grad_rgbs [P,3] (NULL together with dirs: density head only) -> grad_planes (3,Hp,Wp,8) fp32,
- * ACCUMULATED with atomic adds: the caller zero-fills it and reads channels [0, Cch) back as d/d code.  Nothing is saved by the
- * forward; the hidden units are recomputed.  Points with an all-zero upstream gradient are skipped. */
-int ssdnerf_point_decode_backward(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
-                                  const float* xyzs, const float* dirs, uint32_t P, float sigmoid_saturation,
-                                  const float* grad_sigmas, const float* grad_rgbs, float* grad_planes, void* stream);
+/* Gradient of ssdnerf_point_decode w.r.t. the scene codes with the decoder frozen -- what autograd does through grid_sample and the
+ * four nn.Linear layers (triplane_decoder.py:136-179, TruncExp.backward lib/ops/activation.py:15-20) when the rendering loss is
+ * differentiated w.r.t. the scene code (guidance: diffusion_nerf.py:282-294; fine-tuning: base_nerf.py:446-470) -- for ALL scenes of a
+ * batch: planes (S,3,Hp,Wp,8); the samples of scene s are rows [offsets[s], offsets[s+1]) of xyzs / dirs / grad_sigmas / grad_rgbs
+ * (offsets: S+1 uint32 in DEVICE memory, offsets[S] == total).  grad_sigmas [total] (may be NULL), grad_rgbs [total,3] (NULL together
+ * with dirs: density head only) -> grad_code (S,3,6,Hp,Wp) fp32, the code's own NCHW layout, OVERWRITTEN (no zero-fill needed).
+ * Nothing is saved by the forward; the hidden units are recomputed.  Samples with an all-zero upstream gradient are skipped.  The
+ * scatter is a binned reduction in LDS (no global atomics); additions inside a 32x32-texel tile are unordered, so results are
+ * reproducible to fp32 rounding.  workspace: ssdnerf_point_decode_backward_workspace bytes (108 B per sample + the per-split tile images). */
+size_t ssdnerf_point_decode_backward_workspace(uint32_t S, uint32_t total, uint32_t Hp, uint32_t Wp);
+int ssdnerf_point_decode_backward(const void* planes, int planes_dtype, uint32_t S, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                  const float* xyzs, const float* dirs, const uint32_t* offsets, uint32_t total,
+                                  float sigmoid_saturation, const float* grad_sigmas, const float* grad_rgbs, float* grad_code,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused eval-branch render of VolumeRenderer.forward (base_volume_renderer.py:79-123) + the background blend
  * of BaseNeRF.render (base_nerf.py:522-523) for ONE scene: AABB -> bitfield-guided march -> gather -> MLP ->

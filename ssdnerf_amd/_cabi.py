@@ -23,7 +23,8 @@ EXPORTS = [
     "ssdnerf_last_error", "ssdnerf_abi_version", "ssdnerf_near_far_from_aabb", "ssdnerf_sph_from_ray", "ssdnerf_morton3D",
     "ssdnerf_morton3D_invert", "ssdnerf_packbits", "ssdnerf_march_rays_train_workspace", "ssdnerf_march_rays_train",
     "ssdnerf_composite_rays_train_forward", "ssdnerf_composite_rays_train_backward", "ssdnerf_march_rays", "ssdnerf_composite_rays",
-    "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode", "ssdnerf_point_decode_backward",
+    "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode", "ssdnerf_point_decode_backward_workspace",
+    "ssdnerf_point_decode_backward",
     "ssdnerf_render_rays_fused", "ssdnerf_render_rays_fused_batch", "ssdnerf_render_queue_workspace", "ssdnerf_render_first_hit",
     "ssdnerf_render_shade_queue", "ssdnerf_render_shade_queue_mfma", "ssdnerf_render_first_hit_cams", "ssdnerf_render_shade_queue_mfma_cams", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh", "ssdnerf_ddim_step_v",
     "ssdnerf_group_norm_workspace", "ssdnerf_group_norm_nhwc", "ssdnerf_group_norm_nhwc_backward", "ssdnerf_bias_residual_nhwc",
@@ -49,6 +50,8 @@ def lib() -> ctypes.CDLL:
         l.ssdnerf_march_rays_train_workspace.argtypes = [ctypes.c_uint32]
         l.ssdnerf_render_queue_workspace.restype = ctypes.c_size_t
         l.ssdnerf_render_queue_workspace.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        l.ssdnerf_point_decode_backward_workspace.restype = ctypes.c_size_t
+        l.ssdnerf_point_decode_backward_workspace.argtypes = [ctypes.c_uint32] * 4
         l.ssdnerf_group_norm_workspace.restype = ctypes.c_size_t
         l.ssdnerf_group_norm_workspace.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         if l.ssdnerf_abi_version() != ABI_VERSION:

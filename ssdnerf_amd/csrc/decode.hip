@@ -93,50 +93,320 @@ extern "C" int ssdnerf_point_decode(const void* planes, int planes_dtype, uint32
 }
 
 // ------------------------------------------------------------------------------------------------
-// Gradient of the point decode w.r.t. the planes (decoder frozen): one sample per lane, the arithmetic of decode_bwd_math.h --
-// re-gather the 18 features, run the 64 hidden units twice (outputs, then gradient), scatter d/df to the 3 x 4 bilinear corners
-// with fp32 hardware atomics into a (3, Hp, Wp, 8) gradient image (1.5 MiB per scene at 128^2: L2-resident, like the planes).
-// Points whose upstream gradient is exactly zero (the 128-alignment padding, samples behind the T_thresh cut) return at once.
-template <typename PT, bool COLOR>
-__global__ void __launch_bounds__(DEC_TPB) k_point_decode_bwd(const PT* __restrict__ planes, PlaneGeom g, const float* __restrict__ P,
-                                                               const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t n, float sat,
-                                                               const float* __restrict__ g_sigmas, const float* __restrict__ g_rgbs,
-                                                               float* __restrict__ gplanes) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float gs = g_sigmas ? g_sigmas[i] : 0.0f;
-    float gc[3] = {0.0f, 0.0f, 0.0f};
-    if (COLOR) { gc[0] = g_rgbs[3ull * i]; gc[1] = g_rgbs[3ull * i + 1]; gc[2] = g_rgbs[3ull * i + 2]; }
-    if (gs == 0.0f && gc[0] == 0.0f && gc[1] == 0.0f && gc[2] == 0.0f) return;
-    const float x = xyzs[3ull * i], y = xyzs[3ull * i + 1], z = xyzs[3ull * i + 2];
-    float f[18], gf[18], sh[16];
-    ssd_gather18<PT>(planes, g, x, y, z, f);
-    if (COLOR) shb::eval<4, false>(dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2], sh, nullptr, nullptr, nullptr);
-    ssdb_mlp_backward(P, f, COLOR ? sh : f, sat, gs, gc, COLOR ? 1 : 0, gf);
-    ssdb_scatter18(gplanes, g.Hp, g.Wp, x, y, z, gf);
+// Gradient of the point decode w.r.t. the scene codes (decoder frozen), all scenes of a batch in three launches.
+//
+// The r01 form -- one lane per sample scattering its 72 corner contributions with global fp32 atomics -- ran at the device's atomic
+// rate (~18 G/s, tools/ubench/atomic_scope.hip): 31 ms of a 65 ms guided DDIM step (5 M samples with a gradient out of ~20 M marched),
+// 40 x the forward decode of the same samples.  Now the scatter is a BINNED REDUCTION in LDS and the only global writes are plain stores:
+//
+//   k_decode_bwd_feat  sample -> dL/df[18] (the arithmetic of decode_bwd_math.h: re-gather, hidden units twice).  Samples WITH a gradient
+//                      (not the 128-alignment padding, not the samples behind the T_thresh cut) are compacted per scene -- one atomic
+//                      ticket per block on a per-scene counter -- and stored per plane as {key = y0 << 16 | x0, clipped texel coordinates
+//                      (ix, iy), gf[6]}.
+//   k_decode_bwd_bin   block = (scene, plane, 32 x 32-texel tile, split k of the scene's compacted samples).  Waves scan the 4-byte keys
+//                      (four coalesced loads in flight, the next step's issued before this step's are looked at), collect the samples
+//                      whose 2 x 2 footprint touches the tile in an LDS list (ballot + mbcnt), and 64 listed samples at a time add their
+//                      corner contributions -- same weights, same products as ssdb_scatter18 -- to a 24 KiB tile image with LDS atomics.
+//                      The tile is then STORED to partial[k] (every texel of every tile is written: nothing to zero-fill).
+//   k_decode_bwd_sum   grad_code[s][p][c][y][x] = sum_k partial[k][s][p][y][x][c]: the gradient in the code's own NCHW layout.
+//
+// The order of the additions inside a tile is not fixed, so the gradient is reproducible to rounding only, as before (and as with
+// ATen's grid_sampler_2d_backward, which this replaces).
+static constexpr uint32_t DB_TILE = 32;                       // texels per tile edge
+static constexpr uint32_t DB_TILE_FLOATS = DB_TILE * DB_TILE * 6;
+static constexpr uint32_t DB_LIST = 512;                      // per-wave ring of collected sample slots (a 256-key scan step adds at most 256 to < 64 waiting)
+static constexpr uint32_t DB_MAX_SPLIT = 32;                  // sample splits per (scene, plane, tile): many short blocks, so that the tiles most samples
+                                                              // fall in (the object's, or where a view's rays enter the box) do not end the launch with a few long ones
+static constexpr uint32_t DB_COUNTER_STRIDE = 32;             // one 128-byte line per scene counter (same-line device atomics serialise)
+
+struct DecodeBwdWs {
+    uint32_t* counters;  // [S][32]: samples with a gradient, per scene
+    uint32_t* keys;      // [3][total]      the three arrays below are indexed by compacted slot: offsets[s] + rank within the scene
+    float2* pos;         // [3][total]
+    float* gfeat;        // [3][total][6]
+    float* partial;      // [K][S][3][Hp][Wp][6]
+    uint32_t K;
+    size_t counter_bytes, bytes;
+};
+static DecodeBwdWs db_workspace(void* base, uint32_t S, uint32_t total, uint32_t Hp, uint32_t Wp) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    DecodeBwdWs w;
+    const uint32_t per_scene = S ? total / S : 0;
+    w.K = per_scene / 16384u;
+    w.K = w.K < 1 ? 1 : (w.K > DB_MAX_SPLIT ? DB_MAX_SPLIT : w.K);
+    char* p = (char*)base;
+    size_t off = 0;
+    w.counter_bytes = up((size_t)S * DB_COUNTER_STRIDE * sizeof(uint32_t));
+    w.counters = (uint32_t*)(p + off); off += w.counter_bytes;
+    w.keys = (uint32_t*)(p + off);     off += up((size_t)3 * total * sizeof(uint32_t));
+    w.pos = (float2*)(p + off);        off += up((size_t)3 * total * sizeof(float2));
+    w.gfeat = (float*)(p + off);       off += up((size_t)3 * total * 6 * sizeof(float));
+    w.partial = (float*)(p + off);     off += up((size_t)w.K * S * 3 * Hp * Wp * 6 * sizeof(float));
+    w.bytes = off;
+    return w;
 }
 
-extern "C" int ssdnerf_point_decode_backward(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params, const float* xyzs,
-                                             const float* dirs, uint32_t n, float sigmoid_saturation, const float* grad_sigmas, const float* grad_rgbs,
-                                             float* grad_planes, void* stream) {
-    if (n == 0) return SSDNERF_OK;
-    SSD_REQUIRE(planes && mlp_params && xyzs && grad_planes, "point_decode_backward: null pointer");
+extern "C" size_t ssdnerf_point_decode_backward_workspace(uint32_t S, uint32_t total, uint32_t Hp, uint32_t Wp) {
+    return db_workspace(nullptr, S, total, Hp, Wp).bytes;
+}
+
+SSD_DEV uint32_t db_scene_of(const uint32_t* __restrict__ offsets, uint32_t S, uint32_t i) {
+    uint32_t scene = 0;
+    while (scene + 1 < S && i >= offsets[scene + 1]) ++scene;
+    return scene;
+}
+
+template <typename PT, bool COLOR>
+__global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_feat(const PT* __restrict__ planes, PlaneGeom g, uint64_t plane_stride, const float* __restrict__ P,
+                                                              const float* __restrict__ xyzs, const float* __restrict__ dirs,
+                                                              const uint32_t* __restrict__ offsets, uint32_t S, uint32_t total, float sat,
+                                                              const float* __restrict__ g_sigmas, const float* __restrict__ g_rgbs,
+                                                              uint32_t* __restrict__ counters, uint32_t* __restrict__ keys, float2* __restrict__ pos,
+                                                              float* __restrict__ gfeat) {
+    __shared__ uint32_t wave_count[DEC_TPB / 64];
+    __shared__ uint32_t block_base;
+    const uint32_t first = blockIdx.x * blockDim.x, i = first + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gs = 0.0f, gc[3] = {0.0f, 0.0f, 0.0f};
+    if (i < total) {
+        gs = g_sigmas ? g_sigmas[i] : 0.0f;
+        if (COLOR) { gc[0] = g_rgbs[3ull * i]; gc[1] = g_rgbs[3ull * i + 1]; gc[2] = g_rgbs[3ull * i + 2]; }
+    }
+    const bool active = gs != 0.0f || gc[0] != 0.0f || gc[1] != 0.0f || gc[2] != 0.0f;
+    // ---- compacted slot of this sample within its scene
+    const uint32_t scene_first = db_scene_of(offsets, S, first), scene_last = db_scene_of(offsets, S, min(first + blockDim.x, total) - 1u);
+    uint32_t scene = scene_first, slot = 0;
+    const uint64_t am = __ballot(active);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+    if (scene_first == scene_last) {                 // the usual case: ONE ticket per block
+        if (lane == 0) wave_count[wave] = (uint32_t)__popcll(am);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t n = 0;
+            for (uint32_t w = 0; w < DEC_TPB / 64; ++w) n += wave_count[w];
+            block_base = n ? atomicAdd(counters + scene * DB_COUNTER_STRIDE, n) : 0u;
+        }
+        __syncthreads();
+        slot = block_base + rank;
+        for (int w = 0; w < wave; ++w) slot += wave_count[w];
+    } else {                                         // a block that straddles a scene boundary (at most S - 1 of them): one ticket per (wave, scene)
+        scene = i < total ? db_scene_of(offsets, S, i) : scene_last;
+        uint64_t todo = am;
+        while (todo != 0) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t s0 = __builtin_amdgcn_readlane(scene, leader);
+            const uint64_t m = __ballot(active && scene == s0);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(counters + s0 * DB_COUNTER_STRIDE, (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (active && scene == s0) slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            todo &= ~m;
+        }
+    }
+    if (!active) return;
+    const uint64_t j = (uint64_t)offsets[scene] + slot;
+    const float x = xyzs[3ull * i], y = xyzs[3ull * i + 1], z = xyzs[3ull * i + 2];
+    float f[18], gf[18], sh[16];
+    ssd_gather18<PT>(planes + scene * plane_stride, g, x, y, z, f);
+    if (COLOR) shb::eval<4, false>(dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2], sh, nullptr, nullptr, nullptr);
+    ssdb_mlp_backward(P, f, COLOR ? sh : f, sat, gs, gc, COLOR ? 1 : 0, gf);
+    const float us[3] = {x, x, y}, vs[3] = {y, z, z};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const float ix = ssdb_unnormalise(us[p], g.Wp), iy = ssdb_unnormalise(vs[p], g.Hp);
+        keys[(uint64_t)p * total + j] = ((uint32_t)floorf(iy) << 16) | (uint32_t)floorf(ix);
+        pos[(uint64_t)p * total + j] = make_float2(ix, iy);
+        float2* dst = reinterpret_cast<float2*>(gfeat + ((uint64_t)p * total + j) * 6);
+        dst[0] = make_float2(gf[0 + p], gf[3 + p]);
+        dst[1] = make_float2(gf[6 + p], gf[9 + p]);
+        dst[2] = make_float2(gf[12 + p], gf[15 + p]);
+    }
+}
+
+__global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_bin(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counters, uint32_t S,
+                                                             uint32_t total, uint32_t Hp, uint32_t Wp, uint32_t K, uint32_t tiles_x,
+                                                             const uint32_t* __restrict__ keys, const float2* __restrict__ pos,
+                                                             const float* __restrict__ gfeat, float* __restrict__ partial) {
+    __shared__ float acc[DB_TILE_FLOATS];
+    __shared__ uint32_t lists[DEC_TPB / 64][DB_LIST];
+    const uint32_t tile = blockIdx.x, p = blockIdx.y / K, k = blockIdx.y % K, scene = blockIdx.z;
+    const uint32_t tx0 = (tile % tiles_x) * DB_TILE, ty0 = (tile / tiles_x) * DB_TILE;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t e = threadIdx.x; e < DB_TILE_FLOATS; e += DEC_TPB) acc[e] = 0.0f;
+    __syncthreads();
+    const uint32_t o0 = offsets[scene], o1 = o0 + counters[scene * DB_COUNTER_STRIDE];      // the scene's compacted samples
+    const uint32_t chunk = (((o1 - o0) + K - 1) / K + DEC_TPB - 1) / DEC_TPB * DEC_TPB;
+    const uint32_t k0 = min(o1, o0 + k * chunk), k1 = min(o1, k0 + chunk);
+    const uint32_t* kp = keys + (uint64_t)p * total;
+    const float2* pp = pos + (uint64_t)p * total;
+    const float* gp = gfeat + (uint64_t)p * total * 6;
+    uint32_t* list = lists[wave];
+    uint32_t head = 0, cnt = 0;
+    // lanes [0, n): one listed sample each.  Listed samples are in march order, so runs of neighbouring lanes sit on the SAME texel -- whole
+    // waves of them on the plane a view looks down on -- and same-address LDS atomics serialise (~20 cycles per lane measured: 31 k cycles per
+    // 64-sample call on such a plane).  So equal-key runs are first summed inside each 16-lane row (segmented inclusive scan, 4 DPP row-shift
+    // steps: one v_fmac with a DPP operand per value and step) and only the last lane of a run adds to the tile.
+    auto add_listed = [&](uint32_t n) {
+        const bool on = (uint32_t)lane < n;
+        uint32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        float v[4][6];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[q][c] = 0.0f;
+        uint32_t key = 0xffffffffu;
+        if (on) {
+            const uint32_t j = list[(head + lane) % DB_LIST];
+            const float2 xy = pp[j];
+            float wx0, wx1, wy0, wy1;
+            ssdb_corners(xy.x, Wp, &x0, &x1, &wx0, &wx1);
+            ssdb_corners(xy.y, Hp, &y0, &y1, &wy0, &wy1);
+            key = (y0 << 16) | x0;
+            const float2* src = reinterpret_cast<const float2*>(gp + (uint64_t)j * 6);
+            const float2 g01 = src[0], g23 = src[1], g45 = src[2];
+            const float gv[6] = {g01.x, g01.y, g23.x, g23.y, g45.x, g45.y};
+            const float w[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[q][c] = gv[c] * w[q];
+        }
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true);          // row_shr:1
+        const uint64_t heads = __ballot((lane & 15) == 0 || key != prev);                                           // first lane of every run (per 16-lane row)
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int d = 1 << step;
+            // lane - d is in this lane's run iff no run starts in (lane - d, lane]
+            const bool same = (lane & 15) >= d && ((heads >> (lane - d + 1)) & ((1ull << d) - 1ull)) == 0;
+            const float take = same ? 1.0f : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float up = __int_as_float(step == 0 ? __builtin_amdgcn_update_dpp(0, __float_as_int(v[q][c]), 0x111, 0xf, 0xf, true)
+                                                    : step == 1 ? __builtin_amdgcn_update_dpp(0, __float_as_int(v[q][c]), 0x112, 0xf, 0xf, true)
+                                                    : step == 2 ? __builtin_amdgcn_update_dpp(0, __float_as_int(v[q][c]), 0x114, 0xf, 0xf, true)
+                                                                : __builtin_amdgcn_update_dpp(0, __float_as_int(v[q][c]), 0x118, 0xf, 0xf, true));
+                    v[q][c] = __builtin_fmaf(up, take, v[q][c]);
+                }
+        }
+        const bool tail = on && ((lane & 15) == 15 || (uint32_t)lane + 1 == n || ((heads >> (lane + 1)) & 1ull));
+        if (tail) {
+            const uint32_t cx[4] = {x0, x1, x0, x1}, cy[4] = {y0, y0, y1, y1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t lx = cx[q] - tx0, ly = cy[q] - ty0;
+                // (a clamped border corner, x1 == x0, carries weight 0 in every sample of the run: its sum is +-0 and adding it changes nothing)
+                if (lx < DB_TILE && ly < DB_TILE) {
+                    float* t = acc + (ly * DB_TILE + lx) * 6;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) atomicAdd(t + c, v[q][c]);
+                }
+            }
+        }
+    };
+    constexpr uint32_t STEP = 4 * 64;
+    auto load_keys = [&](uint32_t base, uint32_t (&kk)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = base + 64 * j + lane;
+            kk[j] = i < k1 ? kp[i] : 0xffffffffu;
+        }
+    };
+    uint32_t cur[4], nxt[4];
+    uint32_t base = k0 + wave * STEP;
+    load_keys(base, cur);
+    for (; base < k1; base += (DEC_TPB / 64) * STEP) {
+        load_keys(base + (DEC_TPB / 64) * STEP, nxt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // the 2 x 2 footprint {x0, x0+1} x {y0, y0+1} touches the tile iff x0 in [tx0 - 1, tx0 + 31] and the same for y
+            const bool hit = ((cur[j] & 0xffffu) + 1u - tx0) <= DB_TILE && ((cur[j] >> 16) + 1u - ty0) <= DB_TILE;
+            const uint64_t hm = __ballot(hit);
+            if (hm == 0) continue;
+            if (hit) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                list[(head + cnt + rank) % DB_LIST] = base + 64 * j + lane;
+            }
+            cnt += (uint32_t)__popcll(hm);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        while (cnt >= 64) {
+            add_listed(64);
+            head = (head + 64) % DB_LIST;
+            cnt -= 64;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+    add_listed(cnt);
+    __syncthreads();
+    float* out = partial + (((uint64_t)k * S + scene) * 3 + p) * Hp * Wp * 6;
+    for (uint32_t e = threadIdx.x; e < DB_TILE_FLOATS; e += DEC_TPB) {
+        const uint32_t ly = e / (DB_TILE * 6), r = e % (DB_TILE * 6);
+        const uint32_t y = ty0 + ly, xc = tx0 * 6 + r;
+        if (y < Hp && xc < Wp * 6) out[(uint64_t)y * Wp * 6 + xc] = acc[e];
+    }
+}
+
+__global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_sum(const float* __restrict__ partial, uint32_t K, uint64_t n_texels, uint32_t HW,
+                                                             float* __restrict__ grad_code) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;    // (scene, plane, y, x)
+    if (t >= n_texels) return;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint32_t k = 0; k < K; ++k) {
+        const float2* src = reinterpret_cast<const float2*>(partial + ((uint64_t)k * n_texels + t) * 6);
+        const float2 a = src[0], b = src[1], c = src[2];
+        s[0] += a.x; s[1] += a.y; s[2] += b.x; s[3] += b.y; s[4] += c.x; s[5] += c.y;
+    }
+    const uint64_t pl = t / HW, px = t - pl * HW;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) grad_code[(pl * 6 + c) * HW + px] = s[c];
+}
+
+extern "C" int ssdnerf_point_decode_backward(const void* planes, int planes_dtype, uint32_t S, uint32_t Hp, uint32_t Wp, const float* mlp_params,
+                                             const float* xyzs, const float* dirs, const uint32_t* offsets, uint32_t total, float sigmoid_saturation,
+                                             const float* grad_sigmas, const float* grad_rgbs, float* grad_code, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    if (S == 0) return SSDNERF_OK;
+    SSD_REQUIRE(grad_code, "point_decode_backward: null grad_code");
+    SSD_REQUIRE(Hp >= 1 && Wp >= 1 && Hp <= 32768 && Wp <= 32768, "point_decode_backward: plane size out of range");
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t n_texels = (uint64_t)S * 3 * Hp * Wp;
+    if (total == 0) {
+        if (hipMemsetAsync(grad_code, 0, n_texels * 6 * sizeof(float), s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "point_decode_backward: memset failed");
+        return SSDNERF_OK;
+    }
+    SSD_REQUIRE(planes && mlp_params && xyzs && offsets && workspace, "point_decode_backward: null pointer");
     SSD_REQUIRE((grad_rgbs == nullptr) == (dirs == nullptr), "point_decode_backward: grad_rgbs and dirs must both be given or both be NULL");
     SSD_REQUIRE(grad_sigmas || grad_rgbs, "point_decode_backward: no upstream gradient given");
     SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "point_decode_backward: unsupported plane dtype");
-    SSD_REQUIRE(Hp >= 1 && Wp >= 1, "point_decode_backward: empty plane");
+    const DecodeBwdWs w = db_workspace(workspace, S, total, Hp, Wp);
+    if (workspace_bytes < w.bytes) return ssdnerf_fail(SSDNERF_E_WORKSPACE, "point_decode_backward: workspace too small");
+    if (hipMemsetAsync(w.counters, 0, w.counter_bytes, s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "point_decode_backward: memset failed");
     const PlaneGeom g = ssd_plane_geom(Hp, Wp);
-    dim3 gr(ssd_blocks(n, DEC_TPB)), b(DEC_TPB);
-    hipStream_t s = (hipStream_t)stream;
+    const uint64_t plane_stride = (uint64_t)3 * Hp * Wp * 8;
+    dim3 gr(ssd_blocks(total, DEC_TPB)), b(DEC_TPB);
     const bool color = grad_rgbs != nullptr;
-    if (planes_dtype == 0) {
-        if (color) hipLaunchKernelGGL((k_point_decode_bwd<float, true>), gr, b, 0, s, (const float*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, grad_sigmas, grad_rgbs, grad_planes);
-        else hipLaunchKernelGGL((k_point_decode_bwd<float, false>), gr, b, 0, s, (const float*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, grad_sigmas, grad_rgbs, grad_planes);
-    } else {
-        if (color) hipLaunchKernelGGL((k_point_decode_bwd<__half, true>), gr, b, 0, s, (const __half*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, grad_sigmas, grad_rgbs, grad_planes);
-        else hipLaunchKernelGGL((k_point_decode_bwd<__half, false>), gr, b, 0, s, (const __half*)planes, g, mlp_params, xyzs, dirs, n, sigmoid_saturation, grad_sigmas, grad_rgbs, grad_planes);
-    }
-    SSD_CHECK_LAUNCH("point_decode_backward");
+#define SSD_LAUNCH_FEAT(PT, COL) hipLaunchKernelGGL((k_decode_bwd_feat<PT, COL>), gr, b, 0, s, (const PT*)planes, g, plane_stride, mlp_params, xyzs, dirs, offsets, S, \
+                                                    total, sigmoid_saturation, grad_sigmas, grad_rgbs, w.counters, w.keys, w.pos, w.gfeat)
+    if (planes_dtype == 0) { if (color) SSD_LAUNCH_FEAT(float, true); else SSD_LAUNCH_FEAT(float, false); }
+    else { if (color) SSD_LAUNCH_FEAT(__half, true); else SSD_LAUNCH_FEAT(__half, false); }
+#undef SSD_LAUNCH_FEAT
+    SSD_CHECK_LAUNCH("point_decode_backward (features)");
+    const uint32_t tiles_x = (Wp + DB_TILE - 1) / DB_TILE, tiles_y = (Hp + DB_TILE - 1) / DB_TILE;
+    hipLaunchKernelGGL(k_decode_bwd_bin, dim3(tiles_x * tiles_y, 3 * w.K, S), b, 0, s, offsets, w.counters, S, total, Hp, Wp, w.K, tiles_x, w.keys, w.pos,
+                       w.gfeat, w.partial);
+    SSD_CHECK_LAUNCH("point_decode_backward (binned reduction)");
+    hipLaunchKernelGGL(k_decode_bwd_sum, dim3(ssd_blocks(n_texels, DEC_TPB)), b, 0, s, w.partial, w.K, n_texels, Hp * Wp, grad_code);
+    SSD_CHECK_LAUNCH("point_decode_backward (sum)");
     return SSDNERF_OK;
 }
 

@@ -41,16 +41,22 @@
 
 SSDB_FN float ssdb_sigmoid(float u) { return SSDB_RCP(1.0f + SSDB_EXP2(u * -1.4426950408889634f)); }
 
-// unnormalise + clip one coordinate exactly as the forward gather does (decode_core.h ssd_grid_coord)
-SSDB_FN void ssdb_grid_coord(float u, uint32_t size, uint32_t* i0, uint32_t* i1, float* w0, float* w1) {
+// unnormalise + clip one coordinate exactly as the forward gather does (decode_core.h ssd_grid_coord), in two halves so that the binned
+// reduction of decode.hip can store the clipped coordinate between them
+SSDB_FN float ssdb_unnormalise(float u, uint32_t size) {
     const float size_f = (float)size;
-    float ix = ((u + 1.0f) * size_f - 1.0f) * 0.5f;
-    ix = fminf(size_f - 1.0f, fmaxf(ix, 0.0f));
+    const float ix = ((u + 1.0f) * size_f - 1.0f) * 0.5f;
+    return fminf(size_f - 1.0f, fmaxf(ix, 0.0f));
+}
+SSDB_FN void ssdb_corners(float ix, uint32_t size, uint32_t* i0, uint32_t* i1, float* w0, float* w1) {
     const float fl = floorf(ix);
     *i0 = (uint32_t)fl;
     *i1 = (*i0 + 1u < size) ? *i0 + 1u : size - 1u;
     *w1 = ix - fl;
     *w0 = (fl + 1.0f) - ix;
+}
+SSDB_FN void ssdb_grid_coord(float u, uint32_t size, uint32_t* i0, uint32_t* i1, float* w0, float* w1) {
+    ssdb_corners(ssdb_unnormalise(u, size), size, i0, i1, w0, w1);
 }
 
 // f[c*3 + p] from fp32 planes (3, Hp, Wp, 8); the host harness's forward (the device uses ssd_gather18)

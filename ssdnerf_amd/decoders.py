@@ -72,9 +72,10 @@ def pack_mlp_params(sd: Dict[str, torch.Tensor], device) -> torch.Tensor:
 
 class _PointDecodeFn(torch.autograd.Function):
     """Fused point decode, differentiable w.r.t. the scene code with the decoder frozen: forward = ``ssdnerf_point_decode`` per scene,
-    backward = ``ssdnerf_point_decode_backward`` (re-gather, recompute the hidden units, scatter to the bilinear corners with atomics)
-    instead of autograd through grid_sample + 4 nn.Linear (~20 eager kernels each way and ``grid_sampler_2d_backward``, which alone was
-    30 % of a guided DDIM step).  Sample positions and view directions are data: no gradient flows to them."""
+    backward = ONE ``ssdnerf_point_decode_backward`` for the whole batch (re-gather, recompute the hidden units, binned reduction of the
+    corner contributions in LDS, gradient written in the code's NCHW layout) instead of autograd through grid_sample + 4 nn.Linear
+    (~20 eager kernels each way and ``grid_sampler_2d_backward``, which alone was 30 % of a guided DDIM step).  Sample positions and
+    view directions are data: no gradient flows to them."""
 
     @staticmethod
     def forward(ctx, code, decoder, xyzs, dirs):
@@ -91,22 +92,25 @@ class _PointDecodeFn(torch.autograd.Function):
         decoder, planes = ctx.decoder, ctx.planes
         shape, dtype = ctx.code_meta
         s_, _, c, hp, wp = shape
+        assert c == 6, "the fused decode gradient is written for 6-channel planes (18 features)"
         total = sum(ctx.num_points)
         dev = planes.device
         g_sigmas = torch.zeros(total, dtype=torch.float32, device=dev) if g_sigmas is None else g_sigmas.float().contiguous()
         g_rgbs = torch.zeros(total, 3, dtype=torch.float32, device=dev) if g_rgbs is None else g_rgbs.float().contiguous()
-        grad_planes = torch.zeros(s_, 3, hp, wp, 8, dtype=torch.float32, device=dev)
-        params = decoder.packed_params()
-        off = 0
-        for s, n in enumerate(ctx.num_points):
-            if n == 0:
-                continue
-            C.check(C.lib().ssdnerf_point_decode_backward(
-                C.ptr(planes[s]), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.ptr(ctx.xyzs[s]), C.ptr(ctx.dirs[s]), C.u32(n),
-                C.f32(decoder.sigmoid_saturation), C.ptr(g_sigmas[off:off + n]), C.ptr(g_rgbs[off:off + n]), C.ptr(grad_planes[s]), C.stream()),
-                "point_decode_backward")
-            off += n
-        return grad_planes[..., :c].permute(0, 1, 4, 2, 3).to(dtype).contiguous(), None, None, None
+        xyzs = ctx.xyzs[0] if s_ == 1 else torch.cat(ctx.xyzs, dim=0)
+        dirs = ctx.dirs[0] if s_ == 1 else torch.cat(ctx.dirs, dim=0)
+        bounds = [0]
+        for n in ctx.num_points:
+            bounds.append(bounds[-1] + n)
+        offsets = torch.tensor(bounds, dtype=torch.int32).to(dev, non_blocking=True)
+        grad_code = torch.empty(s_, 3, 6, hp, wp, dtype=torch.float32, device=dev)
+        ws_bytes = int(C.lib().ssdnerf_point_decode_backward_workspace(C.u32(s_), C.u32(total), C.u32(hp), C.u32(wp)))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        C.check(C.lib().ssdnerf_point_decode_backward(
+            C.ptr(planes), C.dtype_code(planes), C.u32(s_), C.u32(hp), C.u32(wp), C.ptr(decoder.packed_params()), C.ptr(xyzs), C.ptr(dirs),
+            C.ptr(offsets), C.u32(total), C.f32(decoder.sigmoid_saturation), C.ptr(g_sigmas), C.ptr(g_rgbs), C.ptr(grad_code), C.ptr(ws),
+            C.ctypes.c_size_t(ws_bytes), C.stream()), "point_decode_backward")
+        return grad_code.to(dtype), None, None, None
 
 
 class VolumeRenderer(nn.Module):

@@ -32,11 +32,15 @@ def test_library_builds_and_exports_header_symbols():
     assert lib.ssdnerf_near_far_from_aabb(None, None, None, ctypes.c_uint32(0), ctypes.c_float(0.2), None, None, None) == 0   # empty input
     # the gradient entry points: empty inputs are no-ops, malformed ones are refused before any launch
     u32, f32 = ctypes.c_uint32, ctypes.c_float
-    assert lib.ssdnerf_point_decode_backward(None, 0, u32(128), u32(128), None, None, None, u32(0), f32(0.001), None, None, None, None) == 0
-    assert lib.ssdnerf_point_decode_backward(None, 0, u32(128), u32(128), None, None, None, u32(5), f32(0.001), None, None, None, None) == -1
+    lib.ssdnerf_point_decode_backward_workspace.restype = ctypes.c_size_t
+    assert lib.ssdnerf_point_decode_backward_workspace(u32(8), u32(1 << 20), u32(128), u32(128)) >= (1 << 20) * 96
+    size_t = ctypes.c_size_t
+    assert lib.ssdnerf_point_decode_backward(None, 0, u32(0), u32(128), u32(128), None, None, None, None, u32(0), f32(0.001), None, None, None, None, size_t(0), None) == 0
+    assert lib.ssdnerf_point_decode_backward(None, 0, u32(1), u32(128), u32(128), None, None, None, None, u32(5), f32(0.001), None, None, None, None, size_t(0), None) == -1
     assert b"point_decode_backward" in lib.ssdnerf_last_error()
     buf = (ctypes.c_float * 64)()
-    assert lib.ssdnerf_point_decode_backward(buf, 0, u32(2), u32(2), buf, buf, buf, u32(1), f32(0.001), buf, None, buf, None) == -1     # dirs without grad_rgbs
+    assert lib.ssdnerf_point_decode_backward(buf, 0, u32(1), u32(2), u32(2), buf, buf, buf, buf, u32(1), f32(0.001), buf, None, buf, buf, size_t(1 << 20),
+                                             None) == -1     # dirs without grad_rgbs
     assert b"both" in lib.ssdnerf_last_error()
     assert lib.ssdnerf_group_norm_nhwc_backward(None, None, 0, u32(0), u32(16), u32(32), u32(8), None, None, None, u32(0), f32(1e-5), 1, None, None, 0, None, None) == 0
     assert lib.ssdnerf_group_norm_nhwc_backward(buf, buf, 0, u32(1), u32(4), u32(6), u32(4), buf, buf, None, u32(0), f32(1e-5), 1, buf, buf, 1, buf, None) == -1

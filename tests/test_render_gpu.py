@@ -317,9 +317,13 @@ def test_coarse_pretest_other_grid_sizes(decoder, scene, grid, monkeypatch):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
-def test_fused_decode_backward_matches_autograd_through_the_eager_decode():
-    """d loss / d code of ``point_decode`` with the decoder frozen: fused kernels (ssdnerf_point_decode + _backward) vs PyTorch autograd through
-    grid_sample + nn.Linear on the same GPU.  Two scenes, ragged point lists, points outside the box (border clamp), zero upstream gradients."""
+@pytest.mark.parametrize("ns,plane_hw", [([70001, 40320], (128, 128)), ([200000, 0, 130001], (128, 128)), ([30011, 50000], (40, 72))],
+                         ids=["two-scenes", "split-sample-ranges-and-an-empty-scene", "ragged-tiles-non-square"])
+def test_fused_decode_backward_matches_autograd_through_the_eager_decode(ns, plane_hw):
+    """d loss / d code of ``point_decode`` with the decoder frozen: fused kernels (ssdnerf_point_decode + _backward: per-sample feature gradient,
+    binned LDS reduction over 32 x 32-texel tiles, NCHW sum) vs PyTorch autograd through grid_sample + nn.Linear on the same GPU.  Ragged
+    point lists, points outside the box (border clamp), zero upstream gradients; sample ranges split over several blocks per tile (> 64 k
+    samples per scene), a scene without samples, planes whose sides are not multiples of the tile."""
     import ssdnerf_amd  # noqa: F401
     from ssdnerf_amd.registry import MODULES
     from ssdnerf_amd import synthetic as S
@@ -329,8 +333,10 @@ def test_fused_decode_backward_matches_autograd_through_the_eager_decode():
     dec.load_state_dict(S.make_decoder_params(), strict=False)
     dec = dec.cuda().train(True).requires_grad_(False)
     g = torch.Generator().manual_seed(17)
-    code = torch.stack([S.make_triplane(3), S.make_triplane(4)]).cuda()
-    ns = [70001, 40320]
+    if plane_hw == (128, 128):
+        code = torch.stack([S.make_triplane(3 + i) for i in range(len(ns))]).cuda()
+    else:
+        code = (torch.randn(len(ns), 3, 6, *plane_hw, generator=g) * 0.5).cuda()
     xyzs = [(torch.rand(n, 3, generator=g) * 2.3 - 1.15).cuda() for n in ns]
     dirs = [torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda() for n in ns]
     gs = (torch.randn(sum(ns), generator=g) * 0.1).cuda()
