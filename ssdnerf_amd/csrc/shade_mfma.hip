@@ -129,15 +129,9 @@ SSD_DEV ProbeB sm_probe(const FastMarchB& m, const uint8_t* __restrict__ lin_bit
     p.y = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dy, r.oy), -m.bound, m.bound);
     p.z = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dz, r.oz), -m.bound, m.bound);
     p.dt = sm_dt<DTG0>(m, t);
-#ifdef SM_SAFE_CELL
-    p.nx = (int)ssd_clamp(ssd_fma(p.x, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
-    p.ny = (int)ssd_clamp(ssd_fma(p.y, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
-    p.nz = (int)ssd_clamp(ssd_fma(p.z, m.rb, 1.0f) * m.half_H, 0.0f, m.Hm1f);
-#else
     p.nx = (int)fminf(ssd_fma(p.x, m.rb, 1.0f) * m.half_H, m.Hm1f);
     p.ny = (int)fminf(ssd_fma(p.y, m.rb, 1.0f) * m.half_H, m.Hm1f);
     p.nz = (int)fminf(ssd_fma(p.z, m.rb, 1.0f) * m.half_H, m.Hm1f);
-#endif
     const uint32_t idx = ((((uint32_t)p.nz << m.log2H) + (uint32_t)p.ny) << m.log2H) + (uint32_t)p.nx;
     p.occ = (lin_bits[idx >> 3] >> (idx & 7u)) & 1u;
     return p;

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
-# tools/ab_shade.sh <variant names...> -- on the GPU box: bench each .variants/<name> build (and the in-tree library as "base") with both shading
-# schedules; prints ms/step, shade ms, first-hit ms, samples (a changed sample total flags a broken variant).
+# tools/ab_shade.sh <variant names...> -- on the GPU box: bench each .variants/<name> side build (tools/build_variant.sh) and the in-tree library
+# ("base"); prints ms/step, shade ms, first-hit ms, samples (a changed sample total flags a broken variant).
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/ab
 one() { # label, env...
   l=$1; shift
@@ -16,12 +16,9 @@ except Exception as e:
     print(l, "FAILED", e)
 PY
 }
-one base_v6 SSDNERF_SHADE_VARIANT=6
-one base_v4 SSDNERF_SHADE_VARIANT=4
+one base SSDNERF_DUMMY=0
 for v in "$@"; do
   [ -f .variants/$v/libssdnerf_hip.so ] || { echo "$v: not built"; continue; }
-  one ${v}_v4 SSDNERF_HIP_LIB=$R/.variants/$v/libssdnerf_hip.so SSDNERF_SHADE_VARIANT=4
-  one ${v}_v6 SSDNERF_HIP_LIB=$R/.variants/$v/libssdnerf_hip.so SSDNERF_SHADE_VARIANT=6
+  one $v SSDNERF_HIP_LIB=$R/.variants/$v/libssdnerf_hip.so
 done
-one base_v6_1wave SSDNERF_SHADE_VARIANT=6 SSDNERF_SHADE_BLOCKS_PER_CU=1
-one base_v4_1wave SSDNERF_SHADE_VARIANT=4 SSDNERF_SHADE_BLOCKS_PER_CU=1
+one base_1wave SSDNERF_SHADE_BLOCKS_PER_CU=1
