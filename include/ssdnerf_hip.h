@@ -130,6 +130,25 @@ int ssdnerf_point_decode(const void* planes, int planes_dtype, uint32_t Hp, uint
                          const float* xyzs, const float* dirs, uint32_t P, float sigmoid_saturation, float* sigmas,
                          float* rgbs, void* stream);
 
+/* The train-branch march of VolumeRenderer.forward for ALL S scenes of a batch (base_volume_renderer.py:59-77 calls march_rays_train once
+ * per scene, each call ending in a device->host read of the sample count, raymarching.py:268-274).  Two calls around ONE host read:
+ *   _count: rays_o/rays_d (S,N,3), grids (S, C*H^3/8) bitfields, nears/fars/noises (S,N); dt_gammas (S, device) or NULL (-> dt_gamma for all);
+ *           scene_offsets [S+1] int32 <- first sample of every scene in the packed arrays, scene_offsets[S] = total samples M.
+ *   _write: (same inputs, SAME workspace, after the caller has read M and allocated) xyzs/dirs [M,3], deltas [M,2] = (dt, t);
+ *           rays [S*N,3] int32 = (n, offset, count) with ray index n and offset GLOBAL over the batch -- the form the reference's
+ *           batch_composite_rays_train builds by rebasing (raymarching.py:349-395), so ssdnerf_composite_rays_train_* take them as they are.
+ * Per-ray arithmetic and deterministic slot order as ssdnerf_march_rays_train; samples are packed WITHOUT the per-scene 128-row padding
+ * (padding rows are never composited).  workspace: ssdnerf_march_rays_train_batch_workspace(S, N) bytes. */
+size_t ssdnerf_march_rays_train_batch_workspace(uint32_t S, uint32_t N);
+int ssdnerf_march_rays_train_batch_count(const float* rays_o, const float* rays_d, const uint8_t* grids, float bound, float dt_gamma,
+                                         const float* dt_gammas, uint32_t max_steps, uint32_t S, uint32_t N, uint32_t C, uint32_t H,
+                                         const float* nears, const float* fars, const float* noises, int32_t* scene_offsets,
+                                         void* workspace, size_t workspace_bytes, void* stream);
+int ssdnerf_march_rays_train_batch_write(const float* rays_o, const float* rays_d, const uint8_t* grids, float bound, float dt_gamma,
+                                         const float* dt_gammas, uint32_t max_steps, uint32_t S, uint32_t N, uint32_t C, uint32_t H,
+                                         uint32_t M, const float* nears, const float* fars, const float* noises, float* xyzs,
+                                         float* dirs, float* deltas, int32_t* rays, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Gradient of ssdnerf_point_decode w.r.t. the scene codes with the decoder frozen -- what autograd does through grid_sample and the
  * four nn.Linear layers (triplane_decoder.py:136-179, TruncExp.backward lib/ops/activation.py:15-20) when the rendering loss is
  * differentiated w.r.t. the scene code (guidance: diffusion_nerf.py:282-294; fine-tuning: base_nerf.py:446-470) -- for ALL scenes of a

@@ -22,6 +22,7 @@ F32, F16 = 0, 1
 EXPORTS = [
     "ssdnerf_last_error", "ssdnerf_abi_version", "ssdnerf_near_far_from_aabb", "ssdnerf_sph_from_ray", "ssdnerf_morton3D",
     "ssdnerf_morton3D_invert", "ssdnerf_packbits", "ssdnerf_march_rays_train_workspace", "ssdnerf_march_rays_train",
+    "ssdnerf_march_rays_train_batch_workspace", "ssdnerf_march_rays_train_batch_count", "ssdnerf_march_rays_train_batch_write",
     "ssdnerf_composite_rays_train_forward", "ssdnerf_composite_rays_train_backward", "ssdnerf_march_rays", "ssdnerf_composite_rays",
     "ssdnerf_sh_encode_forward", "ssdnerf_sh_encode_backward", "ssdnerf_triplane_pack", "ssdnerf_point_decode", "ssdnerf_point_decode_backward_workspace",
     "ssdnerf_point_decode_backward",
@@ -50,6 +51,8 @@ def lib() -> ctypes.CDLL:
         l.ssdnerf_march_rays_train_workspace.argtypes = [ctypes.c_uint32]
         l.ssdnerf_render_queue_workspace.restype = ctypes.c_size_t
         l.ssdnerf_render_queue_workspace.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        l.ssdnerf_march_rays_train_batch_workspace.restype = ctypes.c_size_t
+        l.ssdnerf_march_rays_train_batch_workspace.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         l.ssdnerf_point_decode_backward_workspace.restype = ctypes.c_size_t
         l.ssdnerf_point_decode_backward_workspace.argtypes = [ctypes.c_uint32] * 4
         l.ssdnerf_group_norm_workspace.restype = ctypes.c_size_t

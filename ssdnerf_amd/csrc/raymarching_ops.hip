@@ -142,11 +142,21 @@ SSD_DEV float ssd_jittered_start(const MarchCfg& c, float near_, float noise) {
     return ssd_fma(ssd_clamp(near_ * c.dt_gamma, c.dt_min, c.dt_max), noise, near_);
 }
 
-__global__ void k_march_train_count(MarchCfg c, const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t N,
+// Several scenes in one launch: ray n belongs to scene n / rays_per_scene, whose bitfield starts grid_stride bytes further and whose cone angle is
+// dt_gammas[scene] (rays_per_scene == N, stride 0, dt_gammas == NULL: the single-scene operator of the reference).
+struct SceneBatch { uint32_t rays_per_scene; uint64_t grid_stride; const float* dt_gammas; };
+SSD_DEV void ssd_select_scene(MarchCfg& c, const SceneBatch& sb, uint32_t n) {
+    const uint32_t scene = n / sb.rays_per_scene;
+    c.grid += scene * sb.grid_stride;
+    if (sb.dt_gammas) c.dt_gamma = sb.dt_gammas[scene];
+}
+
+__global__ void k_march_train_count(MarchCfg c, SceneBatch sb, const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t N,
                                     uint32_t max_steps, const float* __restrict__ nears, const float* __restrict__ fars,
                                     const float* __restrict__ noises, uint32_t* __restrict__ counts) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    ssd_select_scene(c, sb, n);
     const RayGeom r = ssd_load_ray(rays_o + 3ull * n, rays_d + 3ull * n);
     const float far_ = fars[n];
     float t = ssd_jittered_start(c, nears[n], noises[n]);
@@ -220,7 +230,7 @@ __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__ block_
     }
 }
 
-__global__ void __launch_bounds__(1024) k_march_train_write(MarchCfg c, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+__global__ void __launch_bounds__(1024) k_march_train_write(MarchCfg c, SceneBatch sb, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                             uint32_t N, uint32_t M, const float* __restrict__ nears,
                                                             const float* __restrict__ fars, const float* __restrict__ noises,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_offs,
@@ -241,6 +251,7 @@ __global__ void __launch_bounds__(1024) k_march_train_write(MarchCfg c, const fl
         rays[3ull * slot + 2] = (int32_t)cnt;
     }
     if (cnt == 0 || off + cnt > M) return;
+    ssd_select_scene(c, sb, n);
     const RayGeom r = ssd_load_ray(rays_o + 3ull * n, rays_d + 3ull * n);
     const float far_ = fars[n];
     float t = ssd_jittered_start(c, nears[n], noises[n]);
@@ -277,12 +288,89 @@ extern "C" int ssdnerf_march_rays_train(const float* rays_o, const float* rays_d
     uint32_t* counts = (uint32_t*)workspace;
     uint32_t* block_sums = counts + N;
     uint32_t* bases = block_sums + nb;
-    hipLaunchKernelGGL(k_march_train_count, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, s, c, rays_o, rays_d, N, max_steps, nears, fars, noises, counts);
+    const SceneBatch one = {N, 0, nullptr};
+    hipLaunchKernelGGL(k_march_train_count, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, s, c, one, rays_o, rays_d, N, max_steps, nears, fars, noises, counts);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, s, counts, N, block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, block_sums, nb, N, counter, bases);
-    hipLaunchKernelGGL(k_march_train_write, dim3(nb), dim3(1024), 0, s, c, rays_o, rays_d, N, M, nears, fars, noises, counts, block_sums, bases, rays, xyzs, dirs,
+    hipLaunchKernelGGL(k_march_train_write, dim3(nb), dim3(1024), 0, s, c, one, rays_o, rays_d, N, M, nears, fars, noises, counts, block_sums, bases, rays, xyzs, dirs,
                        deltas);
     SSD_CHECK_LAUNCH("march_rays_train");
+    return SSDNERF_OK;
+}
+
+// ---- the train-branch march of VolumeRenderer.forward for ALL scenes of a batch (base_volume_renderer.py:59-77 calls march_rays_train once per
+// scene, each call ending in a device->host read of the sample count, raymarching.py:268-274).  Two calls around ONE host read:
+//   _count : sample count per ray (S*N rays in one launch) -> block sums -> exclusive offsets; scene_offsets[s] = first sample of scene s,
+//            scene_offsets[S] = total.  The caller reads these S+1 integers, allocates EXACTLY total rows (the per-scene operator allocates N*max_steps)
+//   _write : the same march again, writing (xyz, dir, dt, t) at the scanned offsets; rays[n] = (n, offset, count) with n and offset GLOBAL over the
+//            batch, which is the form batch_composite_rays_train builds by rebasing.  Samples are packed without the per-scene 128-row padding of
+//            the reference (padding rows are never composited; their only effect there is extra decode work).
+__global__ void k_scene_offsets(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_offs, uint32_t S, uint32_t rays_per_scene,
+                                uint32_t total_rays, const uint32_t* __restrict__ bases, int32_t* __restrict__ scene_offsets) {
+    // block s: exclusive prefix of counts at ray s * rays_per_scene = offset of its 1024-block + the counts of the block's rays before it
+    const uint32_t s = blockIdx.x;
+    const uint32_t ray = s * rays_per_scene;                      // s == S: one past the end
+    const uint32_t blk = min(ray, total_rays - 1u) / 1024u;
+    const uint32_t n = blk * 1024u + threadIdx.x;
+    uint32_t v = (n < ray && n < total_rays) ? counts[n] : 0u;
+    uint32_t total;
+    (void)ssd_block_excl_scan_1024(v, &total);
+    if (threadIdx.x == 0) scene_offsets[s] = (int32_t)(bases[0] + block_offs[blk] + total);
+}
+
+extern "C" size_t ssdnerf_march_rays_train_batch_workspace(uint32_t S, uint32_t N) {
+    return ssdnerf_march_rays_train_workspace(S * N) + 2 * sizeof(int32_t);
+}
+
+static int ssd_train_batch_args(const char* what, uint32_t S, uint32_t N, uint32_t C, uint32_t H, uint32_t max_steps, const void* workspace, size_t workspace_bytes) {
+    SSD_REQUIRE((uint64_t)S * N <= 0x7fffffffull, "%s: too many rays", what);
+    SSD_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024 && max_steps >= 1, "%s: bad C=%u H=%u max_steps=%u", what, C, H, max_steps);
+    if (!workspace || workspace_bytes < ssdnerf_march_rays_train_batch_workspace(S, N))
+        return ssdnerf_fail(SSDNERF_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, ssdnerf_march_rays_train_batch_workspace(S, N));
+    return SSDNERF_OK;
+}
+
+extern "C" int ssdnerf_march_rays_train_batch_count(const float* rays_o, const float* rays_d, const uint8_t* grids, float bound, float dt_gamma,
+                                                    const float* dt_gammas, uint32_t max_steps, uint32_t S, uint32_t N, uint32_t C, uint32_t H,
+                                                    const float* nears, const float* fars, const float* noises, int32_t* scene_offsets,
+                                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (S == 0 || N == 0) return SSDNERF_OK;
+    SSD_REQUIRE(rays_o && rays_d && grids && nears && fars && noises && scene_offsets, "march_rays_train_batch_count: null pointer");
+    if (int rc = ssd_train_batch_args("march_rays_train_batch_count", S, N, C, H, max_steps, workspace, workspace_bytes)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t R = S * N, nb = ssd_blocks(R, 1024);
+    const MarchCfg c = ssd_make_march_cfg(bound, dt_gamma, max_steps, C, H, grids);
+    const SceneBatch sb = {N, (uint64_t)C * H * H * H / 8, dt_gammas};
+    uint32_t* counts = (uint32_t*)workspace;
+    uint32_t* block_sums = counts + R;
+    uint32_t* bases = block_sums + nb;
+    int32_t* counter = (int32_t*)(bases + 2);
+    if (hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "march_rays_train_batch_count: memset failed");
+    hipLaunchKernelGGL(k_march_train_count, dim3(ssd_blocks(R, TPB)), dim3(TPB), 0, s, c, sb, rays_o, rays_d, R, max_steps, nears, fars, noises, counts);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, s, counts, R, block_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, block_sums, nb, R, counter, bases);
+    hipLaunchKernelGGL(k_scene_offsets, dim3(S + 1), dim3(1024), 0, s, counts, block_sums, S, N, R, bases, scene_offsets);
+    SSD_CHECK_LAUNCH("march_rays_train_batch_count");
+    return SSDNERF_OK;
+}
+
+extern "C" int ssdnerf_march_rays_train_batch_write(const float* rays_o, const float* rays_d, const uint8_t* grids, float bound, float dt_gamma,
+                                                    const float* dt_gammas, uint32_t max_steps, uint32_t S, uint32_t N, uint32_t C, uint32_t H,
+                                                    uint32_t M, const float* nears, const float* fars, const float* noises, float* xyzs, float* dirs,
+                                                    float* deltas, int32_t* rays, void* workspace, size_t workspace_bytes, void* stream) {
+    if (S == 0 || N == 0) return SSDNERF_OK;
+    SSD_REQUIRE(rays_o && rays_d && grids && nears && fars && noises && rays && (M == 0 || (xyzs && dirs && deltas)), "march_rays_train_batch_write: null pointer");
+    if (int rc = ssd_train_batch_args("march_rays_train_batch_write", S, N, C, H, max_steps, workspace, workspace_bytes)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t R = S * N, nb = ssd_blocks(R, 1024);
+    const MarchCfg c = ssd_make_march_cfg(bound, dt_gamma, max_steps, C, H, grids);
+    const SceneBatch sb = {N, (uint64_t)C * H * H * H / 8, dt_gammas};
+    uint32_t* counts = (uint32_t*)workspace;                       // as left by _count on the same workspace
+    uint32_t* block_sums = counts + R;
+    uint32_t* bases = block_sums + nb;
+    hipLaunchKernelGGL(k_march_train_write, dim3(nb), dim3(1024), 0, s, c, sb, rays_o, rays_d, R, M, nears, fars, noises, counts, block_sums, bases, rays, xyzs, dirs,
+                       deltas);
+    SSD_CHECK_LAUNCH("march_rays_train_batch_write");
     return SSDNERF_OK;
 }
 

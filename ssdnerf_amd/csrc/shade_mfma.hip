@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                                                            float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
                                                            int32_t* __restrict__ sample_counts, int32_t* __restrict__ overflow_flag) {
     // LDS: [0,1 KiB) output-layer weights per accumulator slot; then per wave two pools of SM_POOL x 8 dwords.
-    // wout2: 64 entries x 8 floats; per (mt, pair p of adjacent accumulator registers, half): {ws_a, ws_b, wr_a, wr_b, wg_a, wg_b, wb_a, wb_b}
+    // wout2: 32 entries x 8 floats; per (mt, pair p of adjacent accumulator registers, half): {ws_a, ws_b, wr_a, wr_b, wg_a, wg_b, wb_a, wb_b}
     // sh   : per wave 64 rays x 16 SH' values as three bf16 terms in MFMA B-operand form, [term][sample][k 0-7 | k 8-15] (SH'_0 = 1, see the header)
     // stage: per wave 64 PREPARED rays x 16 dwords {ray, t, far, dt | o | d | 1/d | sample xyz}: queue entries and ray geometry are fetched
     //        64 at a time by the whole wave (coalesced, full lane utilisation) instead of one lane at a time inside the divergent refill
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     // ---- output weights: slot (mt, reg, half) <-> hidden row mt*32 + (reg&3) + 8*(reg>>2) + 4*half (32x32 MFMA C/D layout) ----
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 32) {                  // 2 row tiles x 8 pairs x 2 halves (r02 fix: 64 threads here read rows 64..127, 1.7 KB past the block)
         const int mt = threadIdx.x >> 4, pr_ = (threadIdx.x >> 1) & 7, hf = threadIdx.x & 1;       // slot = (mt*8 + pair)*2 + half
         float v[8];
 #pragma unroll

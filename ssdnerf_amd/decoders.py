@@ -27,12 +27,20 @@ import torch.nn.functional as F
 
 from . import _cabi as C
 from .activation import TruncExp
-from .raymarching import (batch_composite_rays_train, batch_near_far_from_aabb, composite_rays, march_rays,
+from .raymarching import (batch_composite_rays_train, batch_near_far_from_aabb, composite_rays, composite_rays_train, march_rays,
                           march_rays_train)
 from .registry import MODULES, build_module
 from .shencoder import SHEncoder
 
 MLP_PARAM_FLOATS = 64 * 24 + 64 * 16 + 64 + 4
+
+
+def _per_scene_floats(dt_gamma, num_scenes):
+    if isinstance(dt_gamma, (float, int)):
+        return [float(dt_gamma)] * num_scenes
+    if isinstance(dt_gamma, torch.Tensor):
+        return [float(v) for v in dt_gamma.detach().reshape(-1).tolist()]
+    return dt_gamma
 
 
 def _xavier_uniform_(m: nn.Linear):
@@ -159,23 +167,32 @@ class VolumeRenderer(nn.Module):
         assert num_scenes > 0
         if isinstance(grid_size, int):
             grid_size = [grid_size] * num_scenes
-        if isinstance(dt_gamma, (float, int)):
-            dt_gamma = [float(dt_gamma)] * num_scenes
-        elif isinstance(dt_gamma, torch.Tensor):
-            dt_gamma = [float(v) for v in dt_gamma.detach().reshape(-1).tolist()]
+        dt_gamma_in = dt_gamma
+        if not self.training:
+            dt_gamma = _per_scene_floats(dt_gamma, num_scenes)
 
         if self.training:
-            nears, fars = batch_near_far_from_aabb(rays_o, rays_d, self.aabb, self.min_near)
-            xyzs, dirs, deltas, rays = [], [], [], []
-            for s in range(num_scenes):
-                x, d, dl, r = march_rays_train(rays_o[s], rays_d[s], self.bound, density_bitfield[s], 1, grid_size[s], nears[s],
-                                               fars[s], perturb=perturb, align=128, force_all_rays=True, dt_gamma=dt_gamma[s],
-                                               max_steps=self.max_steps,
-                                               noises=None if self.injected_noises is None else self.injected_noises[s])
-                xyzs.append(x); dirs.append(d); deltas.append(dl); rays.append(r)
-            sigmas, rgbs, num_points = self.point_decode(xyzs, dirs, code)
-            weights_sum, depth, image = batch_composite_rays_train(sigmas, rgbs, deltas, rays, num_points, T_thresh)
-            results = dict(weights_sum=weights_sum, depth=depth, image=image)
+            dense = (isinstance(rays_o, torch.Tensor) and rays_o.dim() == 3 and rays_o.is_cuda and isinstance(density_bitfield, torch.Tensor)
+                     and all(g == grid_size[0] for g in grid_size))
+            if dense and self.batched_train_march:
+                xyzs, dirs, deltas, rays, num_points = self._march_train_batch(rays_o, rays_d, density_bitfield, grid_size[0], dt_gamma_in, perturb)
+                sigmas, rgbs, _ = self.point_decode(list(xyzs.split(num_points)), list(dirs.split(num_points)), code)
+                weights_sum, depth, image = composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+                n = rays_o.size(1)
+                results = dict(weights_sum=weights_sum.reshape(num_scenes, n), depth=depth.reshape(num_scenes, n), image=image.reshape(num_scenes, n, 3))
+            else:
+                dt_gamma = _per_scene_floats(dt_gamma_in, num_scenes)
+                nears, fars = batch_near_far_from_aabb(rays_o, rays_d, self.aabb, self.min_near)
+                xyzs, dirs, deltas, rays = [], [], [], []
+                for s in range(num_scenes):
+                    x, d, dl, r = march_rays_train(rays_o[s], rays_d[s], self.bound, density_bitfield[s], 1, grid_size[s], nears[s],
+                                                   fars[s], perturb=perturb, align=128, force_all_rays=True, dt_gamma=dt_gamma[s],
+                                                   max_steps=self.max_steps,
+                                                   noises=None if self.injected_noises is None else self.injected_noises[s])
+                    xyzs.append(x); dirs.append(d); deltas.append(dl); rays.append(r)
+                sigmas, rgbs, num_points = self.point_decode(xyzs, dirs, code)
+                weights_sum, depth, image = batch_composite_rays_train(sigmas, rgbs, deltas, rays, num_points, T_thresh)
+                results = dict(weights_sum=weights_sum, depth=depth, image=image)
         elif self.render_mode == "fused" and self.fused_supported(code):
             results = self._forward_eval_fused(rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color)
         else:
@@ -186,6 +203,50 @@ class VolumeRenderer(nn.Module):
 
     def fused_supported(self, code) -> bool:
         return False
+
+    #: False sends the train branch through one ``march_rays_train`` per scene (the reference's call pattern; parity / A-B runs)
+    batched_train_march = os.environ.get("SSDNERF_TRAIN_MARCH_BATCH", "1") != "0"
+
+    def _march_train_batch(self, rays_o, rays_d, bitfields, grid_size, dt_gamma, perturb):
+        """All scenes' train-branch march in two library calls around ONE host read (the per-scene sample totals, needed to size the packed
+        arrays); the reference -- and the per-scene path above -- reads one total per scene (raymarching.py:268-274) and allocates
+        N * max_steps rows per scene.  rays_o / rays_d (S,N,3), bitfields (S, H^3/8); dt_gamma: float, list of floats, or a DEVICE tensor (S,)."""
+        S, N, _ = rays_o.shape
+        dev = rays_o.device
+        ro, rd = rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous()
+        nears, fars = batch_near_far_from_aabb(ro, rd, self.aabb, self.min_near)
+        if self.injected_noises is not None:
+            nz = self.injected_noises
+            noises = (torch.stack(list(nz)) if not isinstance(nz, torch.Tensor) else nz).to(dev).float().reshape(S, N).contiguous()
+        elif perturb:
+            noises = torch.rand(S, N, dtype=torch.float32, device=dev)
+        else:
+            noises = torch.zeros(S, N, dtype=torch.float32, device=dev)
+        if isinstance(dt_gamma, torch.Tensor):
+            dtg_scalar, dtgs = 0.0, dt_gamma.detach().to(dev).float().reshape(-1).contiguous()
+            assert dtgs.numel() == S
+        elif isinstance(dt_gamma, (list, tuple)):
+            dtg_scalar, dtgs = 0.0, torch.tensor([float(v) for v in dt_gamma], dtype=torch.float32).to(dev, non_blocking=True)
+        else:
+            dtg_scalar, dtgs = float(dt_gamma), None
+        bits = bitfields.contiguous()
+        need = int(C.lib().ssdnerf_march_rays_train_batch_workspace(C.u32(S), C.u32(N)))
+        ws = self._workspace(need, dev)
+        offsets = torch.empty(S + 1, dtype=torch.int32, device=dev)
+        common = (C.ptr(ro), C.ptr(rd), C.ptr(bits), C.f32(self.bound), C.f32(dtg_scalar), C.ptr(dtgs), C.u32(self.max_steps), C.u32(S), C.u32(N),
+                  C.u32(1), C.u32(grid_size))
+        C.check(C.lib().ssdnerf_march_rays_train_batch_count(*common, C.ptr(nears), C.ptr(fars), C.ptr(noises), C.ptr(offsets), C.ptr(ws),
+                                                             C.ctypes.c_size_t(ws.numel()), C.stream()), "march_rays_train_batch_count")
+        offs = offsets.tolist()                                  # the one device->host read of the train branch
+        total = offs[-1]
+        xyzs = torch.empty(total, 3, dtype=torch.float32, device=dev)
+        dirs = torch.empty(total, 3, dtype=torch.float32, device=dev)
+        deltas = torch.empty(total, 2, dtype=torch.float32, device=dev)
+        rays = torch.empty(S * N, 3, dtype=torch.int32, device=dev)
+        C.check(C.lib().ssdnerf_march_rays_train_batch_write(*common, C.u32(total), C.ptr(nears), C.ptr(fars), C.ptr(noises), C.ptr(xyzs), C.ptr(dirs),
+                                                             C.ptr(deltas), C.ptr(rays), C.ptr(ws), C.ctypes.c_size_t(ws.numel()), C.stream()),
+                "march_rays_train_batch_write")
+        return xyzs, dirs, deltas, rays, [offs[s + 1] - offs[s] for s in range(S)]
 
     def _forward_eval_stepwise(self, rays_o, rays_d, code, density_bitfield, grid_size, dt_gamma, perturb, T_thresh):
         """The reference's alive-ray loop, verbatim in structure, over the unfused HIP operators."""

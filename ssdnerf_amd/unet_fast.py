@@ -35,7 +35,6 @@ _GN_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 #: GEMM for a 1x1 projection, scaled_dot_product_attention) appends its name to; ``FastUnet.library_fallbacks`` is its length (0 = every
 #: convolution / projection / attention of the forward ran on the hand-written kernels)
 _FALLBACK_LOG: Optional[list] = None
-_GRAVEYARD: list = []
 
 
 def _lib_call(what: str):
@@ -342,13 +341,7 @@ class FastUnet:
         self.fallback_log = None
 
     def _retire_graphs(self):
-        """Captured graphs are parked, not destroyed.  On this stack (ROCm 7.2, torch 2.10) destroying a captured hipGraph and releasing its
-        private pool is followed, a few allocations later, by "Memory access fault by GPU" in whatever kernel runs next -- reproduced with
-        tests/test_diffusion_gpu.py (fused DDIM test, ``.cpu()``, then a render: the SHADING kernel faulted), gone when the graphs stay alive
-        (r02, 8 bisecting runs).  Weights are re-packed rarely on the inference path (a checkpoint load), so the parked pools are a bounded
-        cost; a training loop that validates with a changing EMA model should call ``FastUnet.capture_by_default = False``."""
-        if self._graphs:
-            _GRAVEYARD.append(dict(self._graphs))
+        """Drop the captured graphs (their static buffers and private pools go back to the allocator)."""
         self._graphs.clear()
 
     def _pack(self):
