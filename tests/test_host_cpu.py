@@ -42,6 +42,18 @@ def test_library_builds_and_exports_header_symbols():
     assert lib.ssdnerf_point_decode_backward(buf, 0, u32(1), u32(2), u32(2), buf, buf, buf, buf, u32(1), f32(0.001), buf, None, buf, buf, size_t(1 << 20),
                                              None) == -1     # dirs without grad_rgbs
     assert b"both" in lib.ssdnerf_last_error()
+    # batched train-branch march: empty batch is a no-op, missing pointers / a short workspace are refused before any launch
+    lib.ssdnerf_march_rays_train_batch_workspace.restype = ctypes.c_size_t
+    need = lib.ssdnerf_march_rays_train_batch_workspace(u32(8), u32(16384))
+    assert need >= 8 * 16384 * 4
+    assert lib.ssdnerf_march_rays_train_batch_count(None, None, None, f32(1), f32(0), None, u32(256), u32(0), u32(16), u32(1), u32(64), None, None, None, None, None,
+                                                    size_t(0), None) == 0
+    assert lib.ssdnerf_march_rays_train_batch_count(None, None, None, f32(1), f32(0), None, u32(256), u32(2), u32(16), u32(1), u32(64), None, None, None, None, None,
+                                                    size_t(0), None) == -1
+    assert b"march_rays_train_batch_count" in lib.ssdnerf_last_error()
+    assert lib.ssdnerf_march_rays_train_batch_write(buf, buf, buf, f32(1), f32(0), None, u32(256), u32(2), u32(16), u32(1), u32(64), u32(0), buf, buf, buf, None, None,
+                                                    None, buf, buf, size_t(8), None) != 0      # workspace too small
+    assert b"workspace" in lib.ssdnerf_last_error()
     assert lib.ssdnerf_group_norm_nhwc_backward(None, None, 0, u32(0), u32(16), u32(32), u32(8), None, None, None, u32(0), f32(1e-5), 1, None, None, 0, None, None) == 0
     assert lib.ssdnerf_group_norm_nhwc_backward(buf, buf, 0, u32(1), u32(4), u32(6), u32(4), buf, buf, None, u32(0), f32(1e-5), 1, buf, buf, 1, buf, None) == -1
     assert b"divisible by groups" in lib.ssdnerf_last_error()
