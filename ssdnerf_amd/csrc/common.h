@@ -230,7 +230,7 @@ SSD_DEV float ssd_tail_far(const RayGeom& q, float cell_world, float near_, floa
 //   lin_bits [S][H^3/8]: the bitfield in linear z/y/x order         coarse [S][(H/2)^3/8] (room for the finest block size)
 //   queue [S][N] uint2 {ray | tail << 24, t_first}                    survivors [S][N] u32 {ray | tail << 24}
 #define SSD_COUNTER_STRIDE 32u     // u32 words per counter (128 B)
-enum { SSD_CNT_HITS = 0, SSD_CNT_TICKETS = 1, SSD_CNT_SURVIVORS = 2, SSD_CNT_BOUNDARY = 3, SSD_CNT_KINDS = 4 };
+enum { SSD_CNT_HITS = 0, SSD_CNT_TICKETS = 1, SSD_CNT_SURVIVORS = 2, SSD_CNT_BOUNDARY = 3, SSD_CNT_HITS_SHORT = 4, SSD_CNT_KINDS = 5 };
 __host__ __device__ static inline uint32_t ssd_counter(uint32_t kind, uint32_t S, uint32_t scene) { return (kind * S + scene) * SSD_COUNTER_STRIDE; }
 struct RenderWs { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; uint32_t* survivors; size_t counter_bytes, bytes; };
 static inline RenderWs ssd_render_ws(void* base, uint32_t S, uint32_t N, uint32_t grid_size) {

@@ -153,6 +153,9 @@ __global__ void __launch_bounds__(RQ_TPB) k_bitfield_coarsen(const uint8_t* __re
 //                     sequence.  r01 ran both phases in one kernel, where the march executed at ~22 live lanes of 64 (survivors are the
 //                     silhouette band of each view) and was 2/3 of the kernel's VALU issue; compacted through the list it runs full waves.
 struct CullGrid { uint32_t group; };   // rays per blockIdx.y group: hw (one view per y, cameras) or N (arrays, gridDim.y == 1)
+#ifndef RQ_LONG_STEPS
+#define RQ_LONG_STEPS 48                       // a hitting ray whose remaining segment (first hit .. tail bound) is longer than this many minimum steps goes to the FRONT of the queue
+#endif
 static constexpr unsigned RQ_CHUNKS = 8;       // 256-ray chunks per block: the block stages its list in LDS and reserves global slots ONCE
 
 // Appends `item` of every lane with `take` to the block's LDS list (one LDS atomic per wave).
@@ -263,9 +266,9 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
     const uint32_t scene = blockIdx.y;
     const uint32_t count = counters[ssd_counter(SSD_CNT_SURVIVORS, c.S, scene)];
     if (blockIdx.x * (RQ_CHUNKS * RQ_TPB) >= count) return;                  // the grid covers the worst case (every ray survives)
-    __shared__ uint2 list[RQ_CHUNKS * RQ_TPB];
-    __shared__ uint32_t list_count, slot;
-    if (threadIdx.x == 0) list_count = 0;
+    __shared__ uint2 list[RQ_CHUNKS * RQ_TPB];                                // long rays from the front, short rays from the back
+    __shared__ uint32_t list_count, short_count, slot, slot_short;
+    if (threadIdx.x == 0) { list_count = 0; short_count = 0; }
     __syncthreads();
     lin_bits += (uint64_t)scene * c.bitfield_stride;
     if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
         const uint32_t i = (blockIdx.x * RQ_CHUNKS + chunk) * RQ_TPB + threadIdx.x;
         bool hit = false;
         uint32_t e = 0;
-        float t = 0.f;
+        float t = 0.f, far_b = 0.f;
         if (i < count) {
             e = survivors[(uint64_t)scene * c.N + i];
             const uint32_t n = packing ? (e & SSD_RAY_ID_MASK) : e;
@@ -284,6 +287,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
             float near_, far_;
             ssd_near_far(c.aabb, r, c.min_near, near_, far_);
             far_ = ssd_tail_far(r, c.m.two_rH * c.m.mip_bound, near_, far_, e, packing);
+            far_b = far_;
             const float sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f), sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f), sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
             t = near_;
             while (t < far_) {
@@ -297,9 +301,50 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
                 if (sample_counts) sample_counts[gi] = 0;
             }
         }
-        rq_lds_append(hit, make_uint2(e, __float_as_uint(t)), list, &list_count);
+        const bool is_long = hit && (far_b - t) > (float)RQ_LONG_STEPS * c.m.dt_min;
+        rq_lds_append(is_long, make_uint2(e, __float_as_uint(t)), list, &list_count);
+        {   // short rays: the same append, growing down from the end of the list
+            const uint64_t m = __ballot(hit && !is_long);
+            if (m != 0) {
+                uint32_t base = 0;
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) base = atomicAdd(&short_count, (uint32_t)__popcll(m));
+                base = __shfl(base, __builtin_ctzll(m), 64);
+                if (hit && !is_long)
+                    list[RQ_CHUNKS * RQ_TPB - 1u - (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))] =
+                        make_uint2(e, __float_as_uint(t));
+            }
+        }
     }
-    rq_flush(list, &list_count, &slot, counters + ssd_counter(SSD_CNT_HITS, c.S, scene), queue + (uint64_t)scene * c.N);
+    // ---- the hit queue is filled from BOTH ends: rays that may still take many samples (upper bound: tail bound - first hit, in minimum steps)
+    // at the front, the others at the back.  The persistent shading kernel consumes the queue front to back, so the long rays are in flight
+    // early and the launch ends on short ones (its tail -- waves draining their last rays with no ticket left -- was 0.77 ms of 6.97 ms with the
+    // rays in arrival order).  k_queue_close then moves the back part up against the front part: one contiguous queue again.
+    __syncthreads();
+    const uint32_t n_long = list_count, n_short = short_count;
+    if (threadIdx.x == 0) {
+        slot = n_long ? atomicAdd(counters + ssd_counter(SSD_CNT_HITS, c.S, scene), n_long) : 0u;
+        slot_short = n_short ? atomicAdd(counters + ssd_counter(SSD_CNT_HITS_SHORT, c.S, scene), n_short) : 0u;
+    }
+    __syncthreads();
+    uint2* q = queue + (uint64_t)scene * c.N;
+    for (uint32_t i = threadIdx.x; i < n_long; i += blockDim.x) q[slot + i] = list[i];
+    for (uint32_t i = threadIdx.x; i < n_short; i += blockDim.x) q[c.N - 1u - (slot_short + i)] = list[RQ_CHUNKS * RQ_TPB - 1u - i];
+}
+
+// The short-ray entries sit at [N - n_short, N); the final queue is [0, n_long + n_short).  Entries beyond that range move into the holes
+// [n_long, N - n_short) (as many holes as such entries; source and destination ranges are disjoint); order inside a class is irrelevant.
+__global__ void __launch_bounds__(RQ_TPB) k_queue_close(uint32_t S, uint32_t N, uint2* __restrict__ queue, const uint32_t* __restrict__ counters) {
+    const uint32_t scene = blockIdx.y;
+    const uint32_t n_long = counters[ssd_counter(SSD_CNT_HITS, S, scene)], n_short = counters[ssd_counter(SSD_CNT_HITS_SHORT, S, scene)];
+    const uint32_t moves = min(n_short, N - n_long - n_short);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= moves) return;
+    uint2* q = queue + (uint64_t)scene * N;
+    q[n_long + k] = q[N - moves + k];
+}
+__global__ void k_queue_total(uint32_t S, uint32_t* __restrict__ counters) {
+    const uint32_t scene = blockIdx.x * blockDim.x + threadIdx.x;
+    if (scene < S) counters[ssd_counter(SSD_CNT_HITS, S, scene)] += counters[ssd_counter(SSD_CNT_HITS_SHORT, S, scene)];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -517,6 +562,8 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     else
         hipLaunchKernelGGL(k_survivor_march<false>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum,
                            sample_counts, w.queue, w.counters);
+    hipLaunchKernelGGL(k_queue_close, dim3(ssd_blocks(N / 2 + 1, RQ_TPB), S), dim3(RQ_TPB), 0, s, S, N, (uint2*)w.queue, w.counters);   // moves <= N/2 entries
+    hipLaunchKernelGGL(k_queue_total, dim3(ssd_blocks(S, 64)), dim3(64), 0, s, S, w.counters);
     SSD_CHECK_LAUNCH("render_first_hit");
     return SSDNERF_OK;
 }

@@ -52,7 +52,11 @@ SSD_DEV floatx2 sm_silu2(floatx2 h) {
 SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_elementwise_fma(w, v, acc); }
 
 static constexpr unsigned SM_TPB = 256;
-static constexpr unsigned SM_SLICE = 512;          // hit-queue entries per shading wave
+#ifndef SM_SLICE_RAYS
+#define SM_SLICE_RAYS 64                           // r02 A/B (bench scene, shade kernel): 512: 7.39, 256: 6.75, 128: 6.68, 64: 6.56 ms -- the kernel ENDS when the last
+                                                   // wave has consumed its last ticket and drained; a 512-ray ticket is ~2 ms of work for a wave
+#endif
+static constexpr unsigned SM_SLICE = SM_SLICE_RAYS;   // hit-queue entries per ticket
 #ifndef SM_PROBES
 #define SM_PROBES 2                                // r02 A/B (bench scene, shade kernel): 1: 7.58, 2: 7.29, 3: 7.51, 4: 7.58, 8: 8.31 ms
 #endif
@@ -242,6 +246,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
     const float b_sigma = P[MLP_OFF_TAIL + 0], bc0 = P[MLP_OFF_TAIL + 1], bc1 = P[MLP_OFF_TAIL + 2], bc2 = P[MLP_OFF_TAIL + 3];
     const float sat_k = ssd_fma(c.sat, 2.0f, 1.0f);
 
+#ifdef SM_DEBUG_ITERS
+  uint32_t dbg_iters = 0, dbg_live = 0;
+  const uint64_t dbg_t0 = wall_clock64();
+#endif
   for (uint32_t sk = 0; sk < c.S; ++sk) {
     const uint32_t scene = (start_scene + sk) % c.S;
     const uint32_t count = queue_count[ssd_counter(SSD_CNT_HITS, c.S, scene)];
@@ -413,6 +421,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             continue;
         }
 
+#ifdef SM_DEBUG_ITERS
+        ++dbg_iters; dbg_live += (uint32_t)__popcll(live);
+#endif
         // ================= shade: gather -> MFMA layers -> output layer -> composite =================
         float f[18];
         if (ray >= 0) ssd_gather18<PT, SM_GATHER_BY_PLANE != 0>(planes, c.g, sx, sy, sz, f);
@@ -590,6 +601,16 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         }
     }
   }   // scene loop
+#ifdef SM_DEBUG_ITERS
+  if (lane == 0) {   // words 1..3 of scene 0's boundary-counter line: sum of wave iterations, max over waves, sum of live lanes
+      uint32_t* d = queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 0);
+      atomicAdd(d + 1, dbg_iters); atomicMax(d + 2, dbg_iters); atomicAdd(d + 3, dbg_live >> 6);
+      const uint64_t t1 = wall_clock64();                       // 100 MHz: start (min), end (max), sum of ends over waves (relative to a coarse origin)
+      atomicMax(reinterpret_cast<unsigned long long*>(d + 4), ~(unsigned long long)dbg_t0);     // (counters start at zero: keep the complement)
+      atomicMax(reinterpret_cast<unsigned long long*>(d + 6), (unsigned long long)t1);
+      atomicAdd(reinterpret_cast<unsigned long long*>(d + 8), (unsigned long long)(t1 & 0xffffffffull));
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
