@@ -152,7 +152,63 @@ __global__ void __launch_bounds__(RQ_TPB) k_bitfield_coarsen(const uint8_t* __re
 //                     the tail bound (background).  The pre-test never advances a ray, so a marched ray keeps the reference's stepping
 //                     sequence.  r01 ran both phases in one kernel, where the march executed at ~22 live lanes of 64 (survivors are the
 //                     silhouette band of each view) and was 2/3 of the kernel's VALU issue; compacted through the list it runs full waves.
-struct CullGrid { uint32_t group; };   // rays per blockIdx.y group: hw (one view per y, cameras) or N (arrays, gridDim.y == 1)
+// ---- view-level cull (cameras only).  Every sample of a ray lies in an occupied cell, hence inside a SET coarse block; a pinhole ray through a
+// pixel meets such a block only if the pixel lies inside the bounding rectangle of the block's eight projected corners (all in front of the
+// camera).  One block of 256 threads per (view, scene) projects every set coarse block -- grown by one cell -- and marks the 16 x 16 image tiles its
+// rectangle (grown by 1.5 pixels) touches; k_ray_cull then writes the background for pixels in unmarked tiles without generating their rays.
+// The margins cover the fp32 differences between this test and the rays the kernels build; what it removes are rays the coarse pre-test would
+// have finished with the same outputs.  A view whose pose is not rigid, or with a set block that is not entirely in front of the camera,
+// gets a full mask (no cull).
+__global__ void __launch_bounds__(RQ_TPB) k_view_masks(FastMarch m, RaySrc src, uint32_t views_cap, const uint8_t* __restrict__ coarse_all,
+                                                        uint32_t* __restrict__ view_masks) {
+    __shared__ uint32_t mask[8];
+    __shared__ uint32_t give_up;
+    const uint32_t view = blockIdx.x, scene = blockIdx.y;
+    const uint32_t Hc = m.H >> RQ_COARSE_LOG2B, log2Hc = m.log2H - RQ_COARSE_LOG2B, n_blocks = Hc * Hc * Hc;
+    if (threadIdx.x < 8) mask[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) give_up = 0u;
+    __syncthreads();
+    const float* M = src.c2w + ((uint64_t)scene * src.V + view) * 16;
+    const float* K = src.intr + ((uint64_t)scene * src.V + view) * 4;
+    const float c00 = ssd_fma(M[0], M[0], ssd_fma(M[4], M[4], M[8] * M[8])), c11 = ssd_fma(M[1], M[1], ssd_fma(M[5], M[5], M[9] * M[9])),
+                c22 = ssd_fma(M[2], M[2], ssd_fma(M[6], M[6], M[10] * M[10])), c01 = ssd_fma(M[0], M[1], ssd_fma(M[4], M[5], M[8] * M[9])),
+                c02 = ssd_fma(M[0], M[2], ssd_fma(M[4], M[6], M[8] * M[10])), c12 = ssd_fma(M[1], M[2], ssd_fma(M[5], M[6], M[9] * M[10]));
+    const bool rigid = fabsf(c00 - 1.0f) < 1e-4f && fabsf(c11 - 1.0f) < 1e-4f && fabsf(c22 - 1.0f) < 1e-4f && fabsf(c01) < 1e-4f && fabsf(c02) < 1e-4f &&
+                       fabsf(c12) < 1e-4f && K[0] > 0.0f && K[1] > 0.0f;
+    const uint32_t h = src.hw / src.w, tw = (src.w + 15u) / 16u, th = (h + 15u) / 16u;          // tile size in pixels: always 16 x 16 tiles per view
+    const float cell = m.two_rH * m.mip_bound, blockw = cell * (float)RQ_COARSE_B;
+    const uint8_t* coarse = coarse_all + (uint64_t)scene * (n_blocks >> 3);
+    bool bad = !rigid;
+    for (uint32_t i = threadIdx.x; i < n_blocks && !bad; i += RQ_TPB) {
+        if (!((coarse[i >> 3] >> (i & 7u)) & 1u)) continue;
+        const uint32_t bx = i & (Hc - 1), by = (i >> log2Hc) & (Hc - 1), bz = i >> (2 * log2Hc);
+        const float lo[3] = {(float)bx * blockw - m.mip_bound - cell, (float)by * blockw - m.mip_bound - cell, (float)bz * blockw - m.mip_bound - cell};
+        const float span = blockw + 2.0f * cell;
+        float ulo = 3.0e38f, uhi = -3.0e38f, vlo = 3.0e38f, vhi = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float rx = lo[0] + ((k & 1) ? span : 0.0f) - M[3], ry = lo[1] + ((k & 2) ? span : 0.0f) - M[7], rz = lo[2] + ((k & 4) ? span : 0.0f) - M[11];
+            const float xc = ssd_fma(M[0], rx, ssd_fma(M[4], ry, M[8] * rz)), yc = ssd_fma(M[1], rx, ssd_fma(M[5], ry, M[9] * rz)),
+                        zc = ssd_fma(M[2], rx, ssd_fma(M[6], ry, M[10] * rz));           // camera coordinates: R^T (X - o)
+            if (!(zc > 1e-3f)) { bad = true; break; }
+            const float u = ssd_fma(K[0], xc / zc, K[2]), v = ssd_fma(K[1], yc / zc, K[3]);   // pixel-centre coordinates (pixel p has centre p + 0.5)
+            ulo = fminf(ulo, u); uhi = fmaxf(uhi, u); vlo = fminf(vlo, v); vhi = fmaxf(vhi, v);
+        }
+        if (bad) break;
+        // pixels whose centre lies in [ulo - 1.5, uhi + 1.5]: p + 0.5 >= ulo - 1.5  ->  p >= ulo - 2
+        const float p0 = floorf(ulo - 2.0f), p1 = ceilf(uhi + 1.0f), q0 = floorf(vlo - 2.0f), q1 = ceilf(vhi + 1.0f);
+        if (p1 < 0.0f || q1 < 0.0f || p0 > (float)(src.w - 1u) || q0 > (float)(h - 1u)) continue;
+        const uint32_t tx0 = (uint32_t)fmaxf(p0, 0.0f) / tw, tx1 = min((uint32_t)fminf(p1, (float)(src.w - 1u)) / tw, 15u);
+        const uint32_t ty0 = (uint32_t)fmaxf(q0, 0.0f) / th, ty1 = min((uint32_t)fminf(q1, (float)(h - 1u)) / th, 15u);
+        const uint32_t row = ((2u << tx1) - 1u) & ~((1u << tx0) - 1u);       // bits tx0 .. tx1 of a 16-bit tile row
+        for (uint32_t ty = ty0; ty <= ty1; ++ty) atomicOr(&mask[ty >> 1], row << ((ty & 1u) * 16u));
+    }
+    if (bad) give_up = 1u;
+    __syncthreads();
+    if (threadIdx.x < 8) view_masks[((uint64_t)scene * views_cap + view) * 8 + threadIdx.x] = give_up ? 0xffffffffu : mask[threadIdx.x];
+}
+
+struct CullGrid { uint32_t group; uint32_t views_cap; };   // rays per blockIdx.y group: hw (one view per y, cameras) or N (arrays, gridDim.y == 1)
 #ifndef RQ_LONG_STEPS
 #define RQ_LONG_STEPS 48                       // a hitting ray whose remaining segment (first hit .. tail bound) is longer than this many minimum steps goes to the FRONT of the queue
 #endif
@@ -182,8 +238,13 @@ SSD_DEV void rq_flush(const T* list, const uint32_t* list_count, uint32_t* slot 
 __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, CullGrid cg, const uint8_t* __restrict__ coarse_bits,
                                                       float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
                                                       int32_t* __restrict__ sample_counts, uint32_t* __restrict__ survivors,
-                                                      uint32_t* __restrict__ counters) {
+                                                      uint32_t* __restrict__ counters, const uint32_t* __restrict__ view_masks) {
     const uint32_t scene = blockIdx.z;
+    __shared__ uint32_t tile_mask[8];                                         // this block's view (cameras: one view per blockIdx.y), k_view_masks
+    const bool view_cull = view_masks != nullptr;
+    if (view_cull && threadIdx.x < 8) tile_mask[threadIdx.x] = view_masks[((uint64_t)scene * cg.views_cap + blockIdx.y) * 8 + threadIdx.x];
+    const uint32_t tile_w = view_cull ? (src.w + 15u) / 16u : 1u, tile_h = view_cull ? (src.hw / src.w + 15u) / 16u : 1u;
+    const bool tiled = view_cull && (src.w & 7u) == 0 && ((src.hw / src.w) & 7u) == 0;
     // this scene's coarse bitfield -> LDS ((H/4)^3 bits; 512 B for H = 64)
     __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
     __shared__ uint32_t list[RQ_CHUNKS * RQ_TPB];
@@ -199,25 +260,39 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
     const bool packing = c.N <= SSD_RAY_ID_MASK + 1u;
 #pragma unroll 1
     for (uint32_t chunk = 0; chunk < RQ_CHUNKS; ++chunk) {
-        const uint32_t in_group = (blockIdx.x * RQ_CHUNKS + chunk) * RQ_TPB + threadIdx.x;
+        uint32_t in_group = (blockIdx.x * RQ_CHUNKS + chunk) * RQ_TPB + threadIdx.x;
+        if (tiled && in_group < cg.group) {      // a wave takes an 8 x 8 pixel block of the view instead of 64 pixels of a row: whole waves fall in unmarked tiles
+            const uint32_t blk = in_group >> 6, l = in_group & 63u, bpr = src.w >> 3;
+            in_group = ((blk / bpr) * 8u + (l >> 3)) * src.w + (blk % bpr) * 8u + (l & 7u);
+        }
         const uint32_t n = blockIdx.y * cg.group + in_group;
         const uint64_t gi = (uint64_t)scene * c.N + n;
         bool alive = false;
         uint32_t tail = SSD_TAIL_NONE;
         if (in_group < cg.group && n < c.N) {
-            RayGeom r;
+            RayGeom r = {};
+            bool outside = false;
             if (src.c2w != nullptr) {       // the view is uniform over the block (blockIdx.y): pose and intrinsics are scalar loads
                 const uint64_t cam = (uint64_t)scene * src.V + blockIdx.y;
                 const uint32_t py = src.w_shift >= 0 ? in_group >> src.w_shift : in_group / src.w;
-                float o[3], d[3];
-                ssd_cam_ray(src.c2w + cam * 16, src.intr + cam * 4, in_group - py * src.w, py, o, d);
-                r = ssd_ray_geom(o[0], o[1], o[2], d[0], d[1], d[2]);
+                const uint32_t px = in_group - py * src.w;
+                if (view_cull) {
+                    const uint32_t tile = (py / tile_h) * 16u + px / tile_w;
+                    outside = !((tile_mask[tile >> 5] >> (tile & 31u)) & 1u);
+                }
+                if (!outside) {
+                    float o[3], d[3];
+                    ssd_cam_ray(src.c2w + cam * 16, src.intr + cam * 4, px, py, o, d);
+                    r = ssd_ray_geom(o[0], o[1], o[2], d[0], d[1], d[2]);
+                }
             } else {
                 r = ssd_load_ray(src.rays_o + 3 * gi, src.rays_d + 3 * gi);
             }
-            float t, far_;
-            ssd_near_far(c.aabb, r, c.min_near, t, far_);
-            alive = t < far_;
+            float t = 0.f, far_ = 0.f;
+            if (!outside) {
+                ssd_near_far(c.aabb, r, c.min_near, t, far_);
+                alive = t < far_;
+            }
             if (use_coarse && alive) {
                 const float step_t = ssd_coarse_step_t(r, c.m.two_rH * c.m.mip_bound);          // RQ_COARSE_STEP cells of world length, in t
                 // The test points run in COARSE-BLOCK coordinates, advanced by one add per axis: q(u) = ((o + u d) rb + 1) half_H / B.  The
@@ -551,11 +626,15 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     if (coarse_ok)
         hipLaunchKernelGGL(k_bitfield_coarsen, dim3(ssd_blocks(hc * hc * hc, RQ_TPB), S), dim3(RQ_TPB), 0, s, w.lin_bits, grid_size, c.m.log2H, c.bitfield_stride, w.coarse);
     CullGrid cg;
+    cg.views_cap = N / 64 + 1;
     dim3 grid;
     if (src.c2w != nullptr) { cg.group = src.hw; grid = dim3(ssd_blocks(src.hw, RQ_TPB * RQ_CHUNKS), src.V, S); }      // one view per blockIdx.y: camera loads are scalar
     else { cg.group = N; grid = dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), 1, S); }
+    const bool view_cull = coarse_ok && src.c2w != nullptr && src.hw >= 64 && src.w >= 16 && src.hw / src.w >= 16 && src.hw % src.w == 0;
+    if (view_cull)
+        hipLaunchKernelGGL(k_view_masks, dim3(src.V, S), dim3(RQ_TPB), 0, s, c.m, src, cg.views_cap, w.coarse, w.view_masks);
     hipLaunchKernelGGL(k_ray_cull, grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
-                       w.survivors, w.counters);
+                       w.survivors, w.counters, view_cull ? w.view_masks : (const uint32_t*)nullptr);
     if (dt_gammas == nullptr && dt_gamma == 0.0f)
         hipLaunchKernelGGL(k_survivor_march<true>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum,
                            sample_counts, w.queue, w.counters);
