@@ -458,3 +458,35 @@ def test_batched_train_march_equals_the_per_scene_path(scene, dt_gamma):
     scale = float(g0.abs().max())
     assert scale > 0 and float((g1 - g0).abs().max()) <= 1e-5 * scale, (float((g1 - g0).abs().max()), scale)
     assert float(g1[1].abs().max()) == 0.0
+
+
+def test_view_level_cull_edge_cases(decoder, scene):
+    """The view-level cull (k_view_masks + tile test in k_ray_cull) only ever removes rays that the exact path would finish with the background,
+    so a camera-fed render must equal the ray-array render (no view cull there) bit for bit for: a camera INSIDE the box and one so close that set
+    blocks lie behind its image plane (mask gives up), a zoomed-in view (object larger than the image), an off-centre principal point, a pose
+    with a scaled rotation (not rigid: gives up), view sizes that are not multiples of 8 or of 16, and views smaller than 16 pixels (cull off)."""
+    from ssdnerf_amd import nerf, synthetic as S
+    from ssdnerf_amd.decoders import pack_triplanes
+    code = scene["code"].cuda()[None]
+    bits = torch.from_numpy(scene["bits"]).cuda()[None]
+    planes = pack_triplanes(code, decoder.plane_dtype)
+    base = S.spiral_poses()[[5, 77, 140, 222]].clone()
+    inside = base[0].clone(); inside[:3, 3] = torch.tensor([0.15, -0.1, 0.2])
+    close = base[1].clone(); close[:3, 3] = close[:3, 3] * (1.02 / close[:3, 3].norm())
+    scaled = base[2].clone(); scaled[:3, :3] = scaled[:3, :3] * 1.3
+    poses = torch.stack([base[0], inside, close, scaled, base[3]]).cuda()[None].contiguous()
+    hit_any = 0
+    for (h, w, fscale, shift) in ((128, 128, 1.0, 0.0), (64, 64, 3.0, 0.0), (36, 50, 1.0, 7.5), (40, 72, 0.6, -11.0), (12, 12, 1.0, 0.0)):
+        intr = S.cars_intrinsics(w, h).clone()
+        intr[:2] *= fscale; intr[2] += shift
+        intr = intr.cuda()[None, None].expand(1, poses.size(1), -1).contiguous()
+        ro, rd = nerf.get_cam_rays(poses, intr, h, w)
+        a = decoder.render_packed(planes, ro.reshape(1, -1, 3), rd.reshape(1, -1, 3), bits, 64, [0.0], 1e-4, bg_color=1.0, want_counts=True, check_overflow=False)
+        ca = decoder.last_render_stats["sample_counts"].clone()
+        b = decoder.render_packed(planes, None, None, bits, 64, [0.0], 1e-4, bg_color=1.0, want_counts=True, check_overflow=False, cams=(poses, intr, h, w))
+        cb = decoder.last_render_stats["sample_counts"]
+        hit_any += int((ca > 0).sum())
+        assert torch.equal(ca, cb), (h, w)
+        for k in ("image", "depth", "weights_sum"):
+            assert torch.equal(a[k], b[k]), (h, w, k)
+    assert hit_any > 5000
