@@ -3,7 +3,7 @@
 ssdnerf_cars_uncond, 128x128 novel-view render of cached triplanes, 251 views/scene, 8 scenes/GPU/batch).
 
 One "step" = BaseNeRF.render of one batch: S scenes x V views x 128x128 rays through
-camera -> ray -> AABB -> bitfield-guided march -> triplane gather -> tiny MLP -> composite -> background blend -> uint8 quantise
+camera -> ray -> AABB -> bitfield-guided march -> triplane gather -> tiny MLP -> composite -> background blend -> uint8 quantise (in the same kernels)
 (and, for N > 1 GPUs, the RCCL all-gather of the rendered uint8 views).  Inputs (packed triplanes, bitfields, MLP
 weights, camera poses + intrinsics) are resident in HBM before the timed region; rays are generated inside the kernels
 (`--ray-arrays` feeds pre-materialised (S,N,3) arrays instead, the reference API's form).  Scenes shard over ranks (weak
@@ -135,7 +135,8 @@ def main():
     def render(planes_, bits_, **kw):
         if rays is not None:
             return dec.render_packed(planes_, rays[0], rays[1], bits_, 64, [0.0] * ns, 1e-4, bg_color=1.0, check_overflow=False, **kw)
-        return dec.render_packed(planes_, None, None, bits_, 64, [0.0] * ns, 1e-4, bg_color=1.0, check_overflow=False, cams=(poses, intr, hw, hw), **kw)
+        return dec.render_packed(planes_, None, None, bits_, 64, [0.0] * ns, 1e-4, bg_color=1.0, check_overflow=False, cams=(poses, intr, hw, hw), want_u8=True,
+                                 **kw)
 
     # N > 1: every rank ends up with every rank's quantised views (RCCL all-gather over xGMI).  The collective of step i runs on RCCL's
     # stream while step i+1 renders (two landing buffers); the compute stream only waits for it before issuing the next collective.
@@ -148,7 +149,8 @@ def main():
         if events is not None:
             events.append(dec.stage_events)
             dec.stage_events = None
-        img_u8 = nerf.quantize_u8(out["image"]).reshape(ns, nv, hw, hw, 3)
+        # the uint8 views that are gathered / written: stored by the render kernels next to the float image (camera-fed path), else one more pass
+        img_u8 = (out["image_u8"] if "image_u8" in out else nerf.quantize_u8(out["image"])).reshape(ns, nv, hw, hw, 3)
         if world > 1:
             if pending["work"] is not None:
                 pending["work"].wait()

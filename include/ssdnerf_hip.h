@@ -222,17 +222,20 @@ int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dtype, uint32
  * ray n = pixel (n % (h*w)) of view n / (h*w), N = V*h*w rays per scene, generated in the kernels by the arithmetic of
  * ssdnerf_cam_rays (get_cam_rays, lib/core/utils/nerf_utils.py:17-61; a generated ray is bit-identical to the stored one), so
  * BaseNeRF.render (base_nerf.py:494-533) never materialises its (S,V,h,w,3) ray arrays: 80 B per view instead of 24 B per ray.
- * Workspace: ssdnerf_render_queue_workspace(S, V*h*w, grid_size).  Outputs as above, (S, V*h*w, ...). */
+ * Workspace: ssdnerf_render_queue_workspace(S, V*h*w, grid_size).  Outputs as above, (S, V*h*w, ...).  image_u8 (S, V*h*w, 3) uint8, may be
+ * NULL: the image ALSO quantised the way eval_and_viz does before views are gathered and written (base_nerf.py:551-553: clamp to [0,1], x 255,
+ * round half to even -- ssdnerf_quantize_u8's arithmetic), stored by the same kernels that store the float image (both calls must get it). */
 int ssdnerf_render_first_hit_cams(const uint8_t* bitfield, uint32_t grid_size, const float* c2w, const float* intrinsics, uint32_t S,
                                   uint32_t V, uint32_t h, uint32_t w, float bound, float min_near, float dt_gamma,
                                   const float* dt_gammas, uint32_t max_steps, float bg_color, float* image, float* depth,
-                                  float* weights_sum, int32_t* sample_counts, void* workspace, size_t workspace_bytes, void* stream);
+                                  float* weights_sum, int32_t* sample_counts, uint8_t* image_u8, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 int ssdnerf_render_shade_queue_mfma_cams(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
                                          uint32_t grid_size, const float* c2w, const float* intrinsics, uint32_t S, uint32_t V,
                                          uint32_t h, uint32_t w, float bound, float min_near, float dt_gamma, const float* dt_gammas,
                                          uint32_t max_steps, float T_thresh, float bg_color, float sigmoid_saturation, float* image,
                                          float* depth, float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag,
-                                         void* workspace, size_t workspace_bytes, void* stream);
+                                         uint8_t* image_u8, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused full-refresh branch of BaseNeRF.update_extra_state (base_nerf.py:328-351,377-387) for S scenes:
  * for every cell of the H^3 grid (x-major order like custom_meshgrid) decode sigma at the jittered cell centre

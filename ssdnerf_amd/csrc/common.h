@@ -49,6 +49,8 @@ static inline unsigned ssd_blocks(uint64_t work, unsigned threads) { return (uns
 #define SSD_SQRT3 1.7320508075688772f
 
 SSD_DEV float ssd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// the output quantisation of eval_and_viz (base_nerf.py:551-553; k_quantize_u8): clamp to [0, 1], x 255, round half to even
+SSD_DEV uint8_t ssd_quant_u8(float v) { return (uint8_t)rintf(fminf(fmaxf(v, 0.f), 1.f) * 255.f); }
 SSD_DEV float ssd_clamp(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
 SSD_DEV float ssd_sign1(float v) { return copysignf(1.0f, v); }
 

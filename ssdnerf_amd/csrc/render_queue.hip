@@ -49,6 +49,7 @@ struct QueueCfg {
     uint64_t plane_stride;      // elements per scene
     uint32_t bitfield_stride;   // bytes per scene
     const float* dt_gammas;     // [S] on device or null
+    uint8_t* image_u8;          // [S][N][3] or null: the quantised image, written next to the float one (saves the separate quantisation pass)
 };
 
 // cell index of v = p * rb + 1: only the upper clamp can bind (v > -1 always, and (int) truncates (-1, 0) to 0 exactly like a clamp at 0)
@@ -330,6 +331,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
             }
             if (!alive) {  // misses the box, or nothing within a cell of the ray: background only
                 image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
+                if (c.image_u8) { const uint8_t q8 = ssd_quant_u8(c.bg); c.image_u8[3 * gi + 0] = q8; c.image_u8[3 * gi + 1] = q8; c.image_u8[3 * gi + 2] = q8; }
                 depth[gi] = 0.f; weights_sum[gi] = 0.f;
                 if (sample_counts) sample_counts[gi] = 0;
             }
@@ -379,6 +381,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
             }
             if (!hit) {  // the ray left the object's neighbourhood without a sample: background only
                 image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
+                if (c.image_u8) { const uint8_t q8 = ssd_quant_u8(c.bg); c.image_u8[3 * gi + 0] = q8; c.image_u8[3 * gi + 1] = q8; c.image_u8[3 * gi + 2] = q8; }
                 depth[gi] = 0.f; weights_sum[gi] = 0.f;
                 if (sample_counts) sample_counts[gi] = 0;
             }
@@ -595,6 +598,7 @@ static int rq_make_cfg(QueueCfg& c, uint32_t Hp, uint32_t Wp, uint32_t grid_size
     c.plane_stride = (uint64_t)3 * Hp * Wp * 8;
     c.bitfield_stride = (grid_size * grid_size * grid_size) / 8;
     c.dt_gammas = dt_gammas;
+    c.image_u8 = nullptr;
     return SSDNERF_OK;
 }
 
@@ -616,7 +620,7 @@ static int rq_ray_src(RaySrc& src, const char* who, const float* rays_o, const f
 
 static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySrc& src, uint32_t S, uint32_t N, float bound, float min_near,
                         float dt_gamma, const float* dt_gammas, uint32_t max_steps, float bg_color, float* image, float* depth, float* weights_sum,
-                        int32_t* sample_counts, void* workspace, size_t workspace_bytes, void* stream) {
+                        int32_t* sample_counts, uint8_t* image_u8, void* workspace, size_t workspace_bytes, void* stream) {
     SSD_REQUIRE(bitfield && image && depth && weights_sum && workspace, "render_first_hit: null pointer");
     if (workspace_bytes < ssdnerf_render_queue_workspace(S, N, grid_size))
         return ssdnerf_fail(SSDNERF_E_WORKSPACE, "render_first_hit: workspace %zu < %zu bytes", workspace_bytes, ssdnerf_render_queue_workspace(S, N, grid_size));
@@ -624,6 +628,7 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     QueueCfg c;
     int rc = rq_make_cfg(c, 1, 1, grid_size, S, N, bound, min_near, dt_gamma, dt_gammas, max_steps, 0.f, bg_color, 0.f);
     if (rc) return rc;
+    c.image_u8 = image_u8;
     hipStream_t s = (hipStream_t)stream;
     const RenderWs w = ssd_render_ws(workspace, S, N, grid_size);
     if (hipMemsetAsync(w.counters, 0, w.counter_bytes, s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "render_first_hit: memset failed");   // hit counts, slice tickets, survivor counts, boundary tests
@@ -662,20 +667,20 @@ extern "C" int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_s
     RaySrc src;
     if (int rc = rq_ray_src(src, "render_first_hit", rays_o, rays_d, nullptr, nullptr, 0, 0, 0, N)) return rc;
     return rq_first_hit(bitfield, grid_size, src, S, N, bound, min_near, dt_gamma, dt_gammas, max_steps, bg_color, image, depth, weights_sum, sample_counts,
-                        workspace, workspace_bytes, stream);
+                        nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ssdnerf_render_first_hit_cams(const uint8_t* bitfield, uint32_t grid_size, const float* c2w, const float* intrinsics, uint32_t S, uint32_t V,
                                              uint32_t h, uint32_t w, float bound, float min_near, float dt_gamma, const float* dt_gammas,
                                              uint32_t max_steps, float bg_color, float* image, float* depth, float* weights_sum,
-                                             int32_t* sample_counts, void* workspace, size_t workspace_bytes, void* stream) {
+                                             int32_t* sample_counts, uint8_t* image_u8, void* workspace, size_t workspace_bytes, void* stream) {
     const uint64_t N64 = (uint64_t)V * h * w;
     if (N64 == 0 || S == 0) return SSDNERF_OK;
     SSD_REQUIRE(N64 <= 0xffffffffull, "render_first_hit_cams: more than 2^32 rays per scene");
     RaySrc src;
     if (int rc = rq_ray_src(src, "render_first_hit_cams", nullptr, nullptr, c2w, intrinsics, V, h, w, (uint32_t)N64)) return rc;
     return rq_first_hit(bitfield, grid_size, src, S, (uint32_t)N64, bound, min_near, dt_gamma, dt_gammas, max_steps, bg_color, image, depth, weights_sum,
-                        sample_counts, workspace, workspace_bytes, stream);
+                        sample_counts, image_u8, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ssdnerf_render_shade_queue(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params, uint32_t grid_size,

@@ -115,6 +115,7 @@ struct ShadeCfg {
     uint64_t plane_stride;
     uint32_t bitfield_stride;
     const float* dt_gammas;
+    uint8_t* image_u8;          // [S][N][3] or null: quantised copy of the image (k_quantize_u8's rounding), written with it
 };
 
 struct ProbeB { float x, y, z, dt; int nx, ny, nz; bool occ; };
@@ -278,9 +279,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
     auto write_out = [&](uint32_t rid, float ws_, float dep_, float cr_, float cg_, float cb_, uint32_t cnt_) {
         const uint64_t gi = ray0 + (rid & id_mask);
         const float bgk = c.bg * (1.0f - ws_);
-        image[3 * gi + 0] = cr_ + bgk;
-        image[3 * gi + 1] = cg_ + bgk;
-        image[3 * gi + 2] = cb_ + bgk;
+        const float o0 = cr_ + bgk, o1 = cg_ + bgk, o2 = cb_ + bgk;
+        image[3 * gi + 0] = o0;
+        image[3 * gi + 1] = o1;
+        image[3 * gi + 2] = o2;
+        if (c.image_u8) { c.image_u8[3 * gi + 0] = ssd_quant_u8(o0); c.image_u8[3 * gi + 1] = ssd_quant_u8(o1); c.image_u8[3 * gi + 2] = ssd_quant_u8(o2); }
         depth[gi] = dep_;
         weights_sum[gi] = ws_;
         if (sample_counts) sample_counts[gi] = (int32_t)cnt_;
@@ -619,7 +622,7 @@ extern "C" size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_
 static int sm_shade(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params, uint32_t grid_size, const RaySrc& src,
                     uint32_t S, uint32_t N, float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps, float T_thresh,
                     float bg_color, float sigmoid_saturation, float* image, float* depth, float* weights_sum, int32_t* sample_counts,
-                    int32_t* overflow_flag, void* workspace, size_t workspace_bytes, void* stream) {
+                    int32_t* overflow_flag, uint8_t* image_u8, void* workspace, size_t workspace_bytes, void* stream) {
     SSD_REQUIRE(planes && mlp_params && image && depth && weights_sum && workspace, "render_shade_queue_mfma: null pointer");
     SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "render_shade_queue_mfma: unsupported plane dtype");
     SSD_REQUIRE(grid_size >= 8 && grid_size <= 512 && (grid_size & (grid_size - 1)) == 0, "render_shade_queue_mfma: grid_size must be a power of two in [8, 512]");
@@ -638,6 +641,7 @@ static int sm_shade(const void* planes, int planes_dtype, uint32_t Hp, uint32_t 
     c.plane_stride = (uint64_t)3 * Hp * Wp * 8;
     c.bitfield_stride = (grid_size * grid_size * grid_size) / 8;
     c.dt_gammas = dt_gammas;
+    c.image_u8 = image_u8;
     const RenderWs w = ssd_render_ws(workspace, S, N, grid_size);
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -676,7 +680,8 @@ extern "C" int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dt
     if (N == 0 || S == 0) return SSDNERF_OK;
     SSD_REQUIRE(rays_o && rays_d, "render_shade_queue_mfma: null ray arrays");
     return sm_shade(planes, planes_dtype, Hp, Wp, mlp_params, grid_size, ssd_ray_src_arrays(rays_o, rays_d), S, N, bound, min_near, dt_gamma, dt_gammas,
-                    max_steps, T_thresh, bg_color, sigmoid_saturation, image, depth, weights_sum, sample_counts, overflow_flag, workspace, workspace_bytes, stream);
+                    max_steps, T_thresh, bg_color, sigmoid_saturation, image, depth, weights_sum, sample_counts, overflow_flag, nullptr, workspace, workspace_bytes,
+                    stream);
 }
 
 extern "C" int ssdnerf_render_shade_queue_mfma_cams(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
@@ -684,11 +689,11 @@ extern "C" int ssdnerf_render_shade_queue_mfma_cams(const void* planes, int plan
                                                     uint32_t w, float bound, float min_near, float dt_gamma, const float* dt_gammas,
                                                     uint32_t max_steps, float T_thresh, float bg_color, float sigmoid_saturation, float* image,
                                                     float* depth, float* weights_sum, int32_t* sample_counts, int32_t* overflow_flag,
-                                                    void* workspace, size_t workspace_bytes, void* stream) {
+                                                    uint8_t* image_u8, void* workspace, size_t workspace_bytes, void* stream) {
     const uint64_t N64 = (uint64_t)V * h * w;
     if (N64 == 0 || S == 0) return SSDNERF_OK;
     SSD_REQUIRE(c2w && intrinsics && N64 <= 0xffffffffull && V <= 65535, "render_shade_queue_mfma_cams: bad camera arguments");
     return sm_shade(planes, planes_dtype, Hp, Wp, mlp_params, grid_size, ssd_ray_src_cams(c2w, intrinsics, V, h, w), S, (uint32_t)N64, bound, min_near,
-                    dt_gamma, dt_gammas, max_steps, T_thresh, bg_color, sigmoid_saturation, image, depth, weights_sum, sample_counts, overflow_flag, workspace,
-                    workspace_bytes, stream);
+                    dt_gamma, dt_gammas, max_steps, T_thresh, bg_color, sigmoid_saturation, image, depth, weights_sum, sample_counts, overflow_flag, image_u8,
+                    workspace, workspace_bytes, stream);
 }

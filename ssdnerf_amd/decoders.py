@@ -504,8 +504,9 @@ class TriPlaneDecoder(VolumeRenderer):
         return out
 
     def render_packed(self, planes, rays_o, rays_d, density_bitfield, grid_size, dt_gamma, T_thresh=1e-4, bg_color=None,
-                      want_counts=False, check_overflow=True, cams=None):
-        """Fused render of S scenes from already-packed planes (S,3,h,w,8).
+                      want_counts=False, check_overflow=True, cams=None, want_u8=False):
+        """Fused render of S scenes from already-packed planes (S,3,h,w,8).  ``want_u8`` (camera-fed renders with a background colour): the result
+        also carries ``image_u8`` (S,N,3) uint8 -- the image quantised as ``eval_and_viz`` does, written by the render kernels themselves.
 
         rays_o/rays_d: a dense (S,N,3) tensor -> ONE launch for the whole batch (outputs are (S,N,3)/(S,N) tensors, indexable
         per scene like the reference's lists); or per-scene lists of (N_s,3) -> one launch per scene.
@@ -515,7 +516,7 @@ class TriPlaneDecoder(VolumeRenderer):
         params = self.packed_params()
         if cams is not None:
             assert rays_o is None and rays_d is None, "render_packed: give ray arrays or cameras, not both"
-            return self._render_packed_cams(planes, cams, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color, want_counts, check_overflow)
+            return self._render_packed_cams(planes, cams, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color, want_counts, check_overflow, want_u8)
         num_scenes = len(rays_o)
         dev = planes.device
         _, _, hp, wp, _ = planes.shape
@@ -601,7 +602,7 @@ class TriPlaneDecoder(VolumeRenderer):
         """per-scene count of termination tests that landed within 2e-6 of T_thresh (diagnostic counters at the head of the workspace)"""
         return wsp[:4 * num_scenes * 128].view(torch.int32).view(4, num_scenes, 32)[3, :, 0].clone()        # csrc/common.h: ssd_counter(SSD_CNT_BOUNDARY, ...)
 
-    def _render_packed_cams(self, planes, cams, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color, want_counts, check_overflow):
+    def _render_packed_cams(self, planes, cams, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color, want_counts, check_overflow, want_u8=False):
         c2w, intr, h, w = cams
         dev = planes.device
         num_scenes, nv = int(c2w.shape[0]), int(c2w.shape[1])
@@ -609,8 +610,12 @@ class TriPlaneDecoder(VolumeRenderer):
         if self.fused_pipeline != "queue_mfma" or gs < 8 or (gs & (gs - 1)) != 0:
             from .nerf import get_cam_rays                                   # forms without in-kernel ray generation: materialise the arrays
             o, d = get_cam_rays(c2w, intr, h, w)
-            return self.render_packed(planes, o.reshape(num_scenes, -1, 3), d.reshape(num_scenes, -1, 3), density_bitfield, grid_size, dt_gamma,
-                                      T_thresh, bg_color, want_counts, check_overflow)
+            out = self.render_packed(planes, o.reshape(num_scenes, -1, 3), d.reshape(num_scenes, -1, 3), density_bitfield, grid_size, dt_gamma,
+                                     T_thresh, bg_color, want_counts, check_overflow)
+            if want_u8:
+                from .nerf import quantize_u8
+                out["image_u8"] = quantize_u8(out["image"])
+            return out
         params = self.packed_params()
         _, _, hp, wp, _ = planes.shape
         pose = c2w.detach().to(torch.float32).reshape(num_scenes, nv, 16).contiguous()
@@ -630,25 +635,29 @@ class TriPlaneDecoder(VolumeRenderer):
         dp = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
         ws = torch.empty(num_scenes, n, dtype=torch.float32, device=dev)
         cn = torch.empty(num_scenes, n, dtype=torch.int32, device=dev) if want_counts else None
+        im8 = torch.empty(num_scenes, n, 3, dtype=torch.uint8, device=dev) if want_u8 else None      # the quantised image, written by the same kernels
         wsp = self._workspace(C.lib().ssdnerf_render_queue_workspace(num_scenes, n, gs), dev)
         ev = self.stage_events
         if ev is not None:
             ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
         C.check(C.lib().ssdnerf_render_first_hit_cams(
             C.ptr(bits), C.u32(gs), C.ptr(pose), C.ptr(k), C.u32(num_scenes), C.u32(nv), C.u32(h), C.u32(w), C.f32(self.bound), C.f32(self.min_near),
-            C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(blend), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(wsp),
+            C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(blend), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(im8), C.ptr(wsp),
             C.ctypes.c_size_t(wsp.numel()), C.stream()), "render_first_hit_cams")
         if ev is not None:
             ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
         C.check(C.lib().ssdnerf_render_shade_queue_mfma_cams(
             C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.u32(gs), C.ptr(pose), C.ptr(k), C.u32(num_scenes), C.u32(nv),
             C.u32(h), C.u32(w), C.f32(self.bound), C.f32(self.min_near), C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(T_thresh), C.f32(blend),
-            C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.ptr(wsp), C.ctypes.c_size_t(wsp.numel()),
-            C.stream()), "render_shade_queue_mfma_cams")
+            C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.ptr(im8), C.ptr(wsp),
+            C.ctypes.c_size_t(wsp.numel()), C.stream()), "render_shade_queue_mfma_cams")
         if ev is not None:
             ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
         self.last_render_stats = dict(mode="fused", overflow=overflow, sample_counts=cn if want_counts else None,
                                       boundary_tests=self._boundary_tests(wsp, num_scenes) if want_counts else None)
         if check_overflow and int(overflow.item()) != 0:
             raise RuntimeError("render_rays_fused: a ray hit the max_steps cap; use render_mode='stepwise' for this batch")
-        return dict(weights_sum=ws, depth=dp, image=im, blended=bg_color is not None)
+        out = dict(weights_sum=ws, depth=dp, image=im, blended=bg_color is not None)
+        if im8 is not None:
+            out["image_u8"] = im8
+        return out

@@ -490,3 +490,19 @@ def test_view_level_cull_edge_cases(decoder, scene):
         for k in ("image", "depth", "weights_sum"):
             assert torch.equal(a[k], b[k]), (h, w, k)
     assert hit_any > 5000
+
+
+def test_render_kernels_write_the_quantised_image_too(decoder, scene):
+    """``want_u8``: the camera-fed render kernels store the uint8 image next to the float one; it must equal ssdnerf_quantize_u8 of the float image
+    (clamp, x 255, round half to even) for every pixel -- background pixels of the cull / march kernels and shaded pixels alike."""
+    from ssdnerf_amd import nerf, synthetic as S
+    from ssdnerf_amd.decoders import pack_triplanes
+    planes = pack_triplanes(scene["code"].cuda()[None], decoder.plane_dtype)
+    bits = torch.from_numpy(scene["bits"]).cuda()[None]
+    poses = S.spiral_poses()[[7, 99, 201]].cuda()[None].contiguous()
+    intr = S.cars_intrinsics(128, 128).cuda()[None, None].expand(1, 3, -1).contiguous()
+    for bg in (1.0, 0.3):
+        out = decoder.render_packed(planes, None, None, bits, 64, [0.0], 1e-4, bg_color=bg, check_overflow=False, cams=(poses, intr, 128, 128), want_u8=True)
+        assert out["image_u8"].dtype == torch.uint8 and out["image_u8"].shape == out["image"].shape
+        assert torch.equal(out["image_u8"], nerf.quantize_u8(out["image"]))
+        assert int((out["weights_sum"] > 0.5).sum()) > 1000
