@@ -64,8 +64,8 @@ static constexpr unsigned SM_SEARCH_PROBES = SM_PROBES;   // in-lane search budg
 // Kernel forms (template parameter MODE):
 //   0: any power-of-two grid, any plane size, per-scene cone angle.
 //   1: the hot-path geometry as compile-time constants -- 64^3 grid, 128 x 128 planes, bound 1, 256 steps (configs/paper_cfgs/ssdnerf_*.py) --
-//      so that march / plane constants are immediates instead of ~25 SGPRs (the generic form spills 76 of them to VGPR lanes and pays
-//      a v_readlane per use, ~130 in the composite / search section alone).
+//      so that march / plane constants are immediates instead of ~25 SGPRs (the generic form spills 81 SGPRs to VGPR lanes and pays a
+//      v_readlane per use, ~130 in the composite / search section alone; this form still spills 44: pointers, camera source, loop state).
 //   2: MODE 1 with dt_gamma == 0 (the uncond render of cached triplanes): the march step is a constant.
 // The MLP schedule is the tile-interleaved one (r01 "variant 6"): both 32-sample tiles hold their accumulators and every MFMA group is followed, in
 // program order, by SiLU pairs of the other tile, so a wave overlaps its own matrix-pipe time (7.72 vs 7.88 ms for tile-after-tile, r02 A/B).
