@@ -216,6 +216,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                     pb[1][s] = *reinterpret_cast<const bf16x8*>(&ul);
                 }
             }
+            // P (and the rescaled accumulators) were just written by VALU instructions and are read by the matrix pipe next: pad the hazard the
+            // compiler leaves open on gfx950 (shade_mfma.hip, sm_operand_guard, has the measurement)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 4");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll

@@ -102,6 +102,19 @@ SSD_DEV void sm_swap_u(uint32_t& a, uint32_t& b) {
 #define SM_GATHER_BY_PLANE 1                       // gather one plane at a time (24 texel registers in flight instead of 72)
 #endif
 
+// VALU-written registers read by the matrix pipe (or swapped across lane halves) a few cycles later.  r02: with two waves per SIMD, a render
+// repeated on the same inputs differed on groups of EXACTLY 16 neighbouring rays -- one quarter-wave, one sample each, errors up to 6e-3 in
+// rgb / depth -- about 30 rays of 4 M per launch; never with one wave per SIMD, with another instruction order, or with larger tickets.  The B
+// operands of this kernel are produced by VALU instructions (v_perm_b32 packs, v_mov of the bias pair, v_permlane32_swap) immediately before
+// the MFMAs that read them, and the hazard recogniser of this toolchain leaves too few wait states for that on gfx950: a quarter of the lanes
+// is read one issue slot early.  Five idle states in front of every MFMA group, pinned by scheduling barriers, remove it (18 of 18 repeated
+// renders bit-identical; before: 0 of 18); the cost is ~0.6 % of the loop.  csrc/attention.hip pads its VALU-built P operands the same way.
+SSD_DEV void sm_operand_guard() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 4");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 struct FastMarchB {
     float bound, dt_gamma, dt_min, dt_max, mip_bound, rb, half_H, two_rH, Hm1f;
     uint32_t H, log2H;
@@ -468,6 +481,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             const int i = TI[pr_i], j = TJ[pr_i];
             const sm_bf16x8 b0 = sm_op(T[j][4 * nt], T[j][4 * nt + 1], T[j][4 * nt + 2], T[j][4 * nt + 3]);
             const sm_bf16x8 b1 = sm_op(nt == 0 ? T[j][8] : Z[j], j == 0 ? bias_pair : 0u, 0u, 0u);
+            sm_operand_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0, acc[nt][mt], 0, 0, 0);
@@ -481,6 +495,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         };
         auto dir_term = [&](int nt, int pr_i) {                          // 2 MFMA: h += Wd' SH'(d)
             const int i = TI[pr_i], j = TJ[pr_i];
+            sm_operand_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][i], sb[j], acc[nt][mt], 0, 0, 0);
         };
@@ -539,6 +554,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
         sm_swap(ps0, ps1); sm_swap(pr0, pr1); sm_swap(pg0, pg1); sm_swap(pb0, pb1);
+        sm_operand_guard();                                              // (both results of every swap are read next)
         const float sigma = ssd_exp(ps0 + ps1 + b_sigma);
         const float sr = ssd_fma(ssd_sigmoid(pr0 + pr1 + bc0), sat_k, -c.sat);
         const float sg = ssd_fma(ssd_sigmoid(pg0 + pg1 + bc1), sat_k, -c.sat);

@@ -256,3 +256,34 @@ def test_training_steps_run_on_the_gpu(tmp_path):
     o1 = ms.train_step(data, dict(decoder=torch.optim.Adam(ms.decoder.parameters(), lr=1e-3)))
     o2 = ms.train_step(data, dict(decoder=torch.optim.Adam(ms.decoder.parameters(), lr=1e-3)))
     assert bool(torch.isfinite(o1["log_vars"]["loss"])) and bool(torch.isfinite(o2["log_vars"]["loss"])) and bool(torch.isfinite(o2["log_vars"]["train_psnr"]))
+
+
+# ---------------------------------------------------------------------------------------------- run-to-run reproducibility at bench scale
+def test_fused_render_is_reproducible_bit_for_bit():
+    """The same 251-view render issued five times must give the same bits every time (counts, image, depth).  Nothing in the fused path is
+    order-dependent per ray -- queue order and ticket assignment vary from run to run, the arithmetic of a ray does not -- so any difference is a
+    hardware hazard or a race.  r02 found one this way: VALU-written MFMA operands read a quarter-wave too early with two waves per SIMD (16
+    neighbouring rays off by up to 6e-3, ~30 rays of 4 M per launch; csrc/shade_mfma.hip, sm_operand_guard)."""
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.decoders import pack_triplanes
+    from ssdnerf_amd.density import get_density
+    dec = _decoder()
+    g = torch.Generator().manual_seed(7)
+    jit = [torch.rand(64 ** 3, 3, generator=g).cuda() for _ in range(8)]
+    code = S.make_triplane(2022, "object").cuda()[None]
+    _, bits = get_density(dec, code, 64, density_thresh=0.1, density_step=8, jitters=jit)
+    planes = pack_triplanes(code)
+    poses = S.spiral_poses(251).cuda()[None].contiguous()
+    intr = S.cars_intrinsics(128, 128).cuda()[None, None].expand(1, 251, -1).contiguous()
+
+    def render():
+        out = dec.render_packed(planes, None, None, bits, 64, [0.0], 1e-4, bg_color=1.0, want_counts=True, check_overflow=False,
+                                cams=(poses, intr, 128, 128), want_u8=True)
+        return dec.last_render_stats["sample_counts"][0].clone(), out["image"].clone(), out["depth"].clone(), out["image_u8"].clone()
+
+    ref = render()
+    assert int((ref[0] > 0).sum()) > 100000
+    for _ in range(5):
+        again = render()
+        for a, b, name in zip(ref, again, ("sample_counts", "image", "depth", "image_u8")):
+            assert torch.equal(a, b), (name, int((a != b).sum()))
