@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                 if constexpr (F32) {
                     bf16x8 khi, klo;
                     load8(kb * 32 + l31, 1, 2 * s + hf, khi, klo);
+                    __builtin_amdgcn_sched_barrier(0);                       // khi / klo are VALU results (the bf16 split): same operand hazard as P below
+                    asm volatile("s_nop 4");
+                    __builtin_amdgcn_sched_barrier(0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qf[0][s], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[1][s], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[0][s], sacc, 0, 0, 0);
