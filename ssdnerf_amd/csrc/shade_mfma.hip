@@ -108,7 +108,10 @@ SSD_DEV void sm_swap_u(uint32_t& a, uint32_t& b) {
 // operands of this kernel are produced by VALU instructions (v_perm_b32 packs, v_mov of the bias pair, v_permlane32_swap) immediately before
 // the MFMAs that read them, and the hazard recogniser of this toolchain leaves too few wait states for that on gfx950: a quarter of the lanes
 // is read one issue slot early.  Five idle states in front of every MFMA group, pinned by scheduling barriers, remove it (18 of 18 repeated
-// renders bit-identical; before: 0 of 18); the cost is ~0.6 % of the loop.  csrc/attention.hip pads its VALU-built P operands the same way.
+// renders bit-identical; before: 0 of 18); the cost is 1-2 % of the loop.  csrc/attention.hip pads its VALU-built P operands the same way.
+// The guard is needed in front of the direction-term groups as well, whose B operands come from LDS loads (without it the render is
+// irreproducible again and the sample total changes): so the exposed dependency is not only "VALU result -> MFMA source"; what is
+// established is the symptom, the granularity (a quarter-wave, one sample) and the configuration that is reproducible.
 SSD_DEV void sm_operand_guard() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 4");
