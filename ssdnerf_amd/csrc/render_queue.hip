@@ -6,13 +6,12 @@
 // wave spending most of its instructions marching empty rays at ~5 % lane utilisation while the lanes that own
 // shading work wait.  So:
 //
-//   stage A  k_first_hit   one lane per ray, ~40 VGPRs -> 8 waves/SIMD hide the dependent bitfield loads; every lane
-//                          is busy.  A ray that never meets an occupied voxel is finished here (background colour
-//                          written, 44 B of HBM traffic, nothing else).  A ray that does is appended - with ONE
-//                          atomic per wave (ballot + mbcnt rank) - to its scene's hit queue as (ray id | tail bound << 24, t_first).
-//                          Before marching, a conservative coarse-occupancy scan (k_bitfield_coarsen's table, in LDS) finishes
-//                          the rays that cannot meet an occupied cell at all and bounds the march of the others (see k_first_hit).
-//   stage B  k_shade_queue persistent waves; each wave owns a slice of one scene's hit queue and keeps 64 LIVE hitting
+//   stage A  k_view_masks -> k_ray_cull -> k_survivor_march -> k_queue_close (described in front of each kernel below): every ray that
+//                          cannot meet an occupied voxel is finished with the background colour (a view-level tile mask, then the conservative
+//                          coarse-occupancy scan, then the exact march of the survivors), every ray that does is filed in its scene's hit
+//                          queue as (ray id | tail bound << 24, t_first), rays that may still take many samples FIRST.
+//   stage B  k_shade_mfma (shade_mfma.hip, the default) or k_shade_queue (below, its VALU-only predecessor): persistent waves; each wave
+//                          owns a slice of one scene's hit queue and keeps 64 LIVE hitting
 //                          rays, refilling finished lanes from the slice (ballot + mbcnt compaction, no atomics):
 //                          gather -> tiny MLP -> composite -> advance to the next occupied sample, all in registers.
 //                          blockIdx is mapped so that all workgroups of scene s run on XCD (s mod 8): that XCD's 4 MiB

@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
     uint4* sh_lds = reinterpret_cast<uint4*>(lds + 512 + (SM_TPB / 64) * 2 * SM_POOL * 8 + wave * SM_SHF);   // [term][sample][2 x 16 B]
     float4* stage = reinterpret_cast<float4*>(lds + 512 + (SM_TPB / 64) * (2 * SM_POOL * 8 + SM_SHF) + wave * SM_STAGE * 16);   // [slot][4]
 
-    // ---- persistent grid: every wave pulls 512-ray slices of a scene's hit queue with one atomic ticket per slice.  Waves of
+    // ---- persistent grid: every wave pulls SM_SLICE-ray slices (64) of a scene's hit queue with one atomic ticket per slice; the queue holds
+    // the rays that may still take many samples first (render_queue.hip, k_survivor_march), so the launch ends on short rays.  Waves of
     // XCD x (workgroups are dispatched round-robin over the 8 XCDs, b % 8) start on scene x so that the scene's 1.5 MiB of
     // planes stay in that XCD's L2, and move on to the next scene when theirs has no slices left (work stealing: a wrong
     // placement guess only costs L2 misses).  Counters (hits per scene, slice tickets): common.h, ssd_counter. ----
