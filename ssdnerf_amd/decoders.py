@@ -110,7 +110,7 @@ class _PointDecodeFn(torch.autograd.Function):
         bounds = [0]
         for n in ctx.num_points:
             bounds.append(bounds[-1] + n)
-        offsets = torch.tensor(bounds, dtype=torch.int32).to(dev, non_blocking=True)
+        offsets = torch.tensor(bounds, dtype=torch.int32, device=dev)          # (a blocking copy: the host list dies with this frame)
         grad_code = torch.empty(s_, 3, 6, hp, wp, dtype=torch.float32, device=dev)
         ws_bytes = int(C.lib().ssdnerf_point_decode_backward_workspace(C.u32(s_), C.u32(total), C.u32(hp), C.u32(wp)))
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
@@ -226,7 +226,7 @@ class VolumeRenderer(nn.Module):
             dtg_scalar, dtgs = 0.0, dt_gamma.detach().to(dev).float().reshape(-1).contiguous()
             assert dtgs.numel() == S
         elif isinstance(dt_gamma, (list, tuple)):
-            dtg_scalar, dtgs = 0.0, torch.tensor([float(v) for v in dt_gamma], dtype=torch.float32).to(dev, non_blocking=True)
+            dtg_scalar, dtgs = 0.0, torch.tensor([float(v) for v in dt_gamma], dtype=torch.float32, device=dev)
         else:
             dtg_scalar, dtgs = float(dt_gamma), None
         bits = bitfields.contiguous()
