@@ -31,7 +31,7 @@ static inline int ssdnerf_fail(int code, const char* fmt, ...) {
 static inline unsigned ssd_blocks(uint64_t work, unsigned threads) { return (unsigned)((work + threads - 1) / threads); }
 
 // ------------------------------------------------------------------------------------------------
-// conservative coarse occupancy shared by k_first_hit (pre-test, render_queue.hip) and the shading kernels (tail bound):
+// conservative coarse occupancy shared by k_ray_cull (pre-test, render_queue.hip) and the shading kernels (tail bound):
 // one bit per block of B^3 cells, B = 2^SSD_COARSE_LOG2B, dilated by B/2 cells; rays are sampled every SSD_COARSE_STEP cells.
 #ifndef RQ_COARSE_LOG2B
 #define RQ_COARSE_LOG2B 2

@@ -108,10 +108,10 @@ __global__ void k_bitfield_linearize(const uint8_t* __restrict__ morton_bits, ui
 
 // ------------------------------------------------------------------------------------------------
 // Conservative coarse occupancy: one bit per block of B^3 cells (B = 2^RQ_COARSE_LOG2B), set if ANY cell of the block dilated by B/2 cells
-// is occupied.  k_first_hit walks it with points RQ_COARSE_STEP = B - 0.1 cells apart: every point q of the segment is then within
+// is occupied.  k_ray_cull walks it with points RQ_COARSE_STEP = B - 0.1 cells apart: every point q of the segment is then within
 // (B - 0.1)/2 cells, per axis, of a test point p, so the cell of q -- and the neighbour the reference's fp32 rounding may pick instead --
 // has an index within B/2 of p's (the test point's block is taken from ITS exact cell index, >> LOG2B).  If every point lands in a clear
-// cell of the ray is occupied, so the exact march would test nothing but empty cells and need not run at all (see k_first_hit).
+// cell of the ray is occupied, so the exact march would test nothing but empty cells and need not run at all (see k_ray_cull).
 static constexpr int RQ_COARSE_B = 1 << RQ_COARSE_LOG2B;                 // (common.h)
 static constexpr int RQ_COARSE_DILATE = RQ_COARSE_B / 2;
 static constexpr float RQ_COARSE_STEP = SSD_COARSE_STEP;                 // in cells

@@ -1,4 +1,4 @@
-"""The decode gradient (triplane gather + tiny MLP, d loss / d planes) that the device kernel k_point_decode_bwd computes, checked on the
+"""The decode gradient (triplane gather + tiny MLP, d loss / d planes) that the device kernels k_decode_bwd_feat / _bin / _sum compute, checked on the
 CPU: ssdnerf_amd/csrc/decode_bwd_math.h is plain C, a gcc build of it (tests/host/decode_bwd_host.c) is compared with PyTorch autograd
 through the oracle's decode (grid_sample + Linear + SiLU + TruncExp + Sigmoid).  The device kernel compiles the same header."""
 import ctypes

@@ -252,7 +252,7 @@ def test_density_grid_update_matches_oracle(scene, decoder):
 
 @pytest.mark.parametrize("view,dt_gamma", [(64, 0.0), (17, 0.0038095), (230, 0.0)])
 def test_coarse_empty_space_pretest_changes_nothing(scene, decoder, view, dt_gamma, monkeypatch):
-    """k_first_hit's conservative coarse-occupancy pre-test only removes marches that cannot find a sample: every output, including the
+    """k_ray_cull's conservative coarse-occupancy pre-test (and the view-level tile masks) only removes marches that cannot find a sample: every output, including the
     per-ray sample counts, is bit-identical with the pre-test switched off (SSDNERF_NO_COARSE=1)."""
     ro, rd = _view(view)
     with_pretest = _render_gpu(decoder, scene, ro, rd, "fused", dt_gamma)
