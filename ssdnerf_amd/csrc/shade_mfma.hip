@@ -107,14 +107,13 @@ SSD_DEV void sm_swap_u(uint32_t& a, uint32_t& b) {
 // rgb / depth -- about 30 rays of 4 M per launch; never with one wave per SIMD, with another instruction order, or with larger tickets.  The B
 // operands of this kernel are produced by VALU instructions (v_perm_b32 packs, v_mov of the bias pair, v_permlane32_swap) immediately before
 // the MFMAs that read them, and the hazard recogniser of this toolchain leaves too few wait states for that on gfx950: a quarter of the lanes
-// is read one issue slot early.  Five idle states in front of every MFMA group, pinned by scheduling barriers, remove it (18 of 18 repeated
-// renders bit-identical; before: 0 of 18); the cost is 1-2 % of the loop.  csrc/attention.hip pads its VALU-built P operands the same way.
-// The guard is needed in front of the direction-term groups as well, whose B operands come from LDS loads (without it the render is
-// irreproducible again and the sample total changes): so the exposed dependency is not only "VALU result -> MFMA source"; what is
-// established is the symptom, the granularity (a quarter-wave, one sample) and the configuration that is reproducible.
+// is read one issue slot early.  What removes it is a SCHEDULING BARRIER in front of every MFMA group, i.e. forbidding the compiler to move
+// the group's MFMAs up into the preceding VALU code (0 differing renders in 135 repeats with the barrier alone, in 450 with barrier + five idle
+// states; 135 of 135 differ with the idle states alone) -- idle states are not needed, so the guard is the barrier (cost: within noise).
+// It is needed in front of the direction-term groups too, whose B operands come from LDS loads (without it the sample total itself changes),
+// so the exposed dependency is not only "VALU result -> MFMA source"; what is established is the symptom, its granularity (a quarter-wave,
+// one sample) and the schedule that is reproducible.  csrc/attention.hip guards its VALU-built operands the same way (plus idle states).
 SSD_DEV void sm_operand_guard() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 4");
     __builtin_amdgcn_sched_barrier(0);
 }
 
