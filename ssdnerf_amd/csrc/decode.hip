@@ -117,6 +117,7 @@ static constexpr uint32_t DB_TILE_FLOATS = DB_TILE * DB_TILE * 6;
 static constexpr uint32_t DB_LIST = 512;                      // per-wave ring of collected sample slots (a 256-key scan step adds at most 256 to < 64 waiting)
 static constexpr uint32_t DB_MAX_SPLIT = 32;                  // sample splits per (scene, plane, tile): many short blocks, so that the tiles most samples
                                                               // fall in (the object's, or where a view's rays enter the box) do not end the launch with a few long ones
+static constexpr size_t DB_PARTIAL_BUDGET = (size_t)256 << 20;  // bytes of per-split tile images (r02 advisor: K was chosen from the sample count alone)
 static constexpr uint32_t DB_COUNTER_STRIDE = 32;             // one 128-byte line per scene counter (same-line device atomics serialise)
 
 struct DecodeBwdWs {
@@ -134,6 +135,11 @@ static DecodeBwdWs db_workspace(void* base, uint32_t S, uint32_t total, uint32_t
     const uint32_t per_scene = S ? total / S : 0;
     w.K = per_scene / 16384u;
     w.K = w.K < 1 ? 1 : (w.K > DB_MAX_SPLIT ? DB_MAX_SPLIT : w.K);
+    // the per-split tile images are written and re-read once per backward: keep them under DB_PARTIAL_BUDGET whatever the plane size
+    // (8 scenes of 128 x 128 planes: 9.4 MB per split -> 27 splits; 256 x 256 planes: 37.7 MB per split -> 6)
+    const size_t per_split = (size_t)(S ? S : 1) * 3 * Hp * Wp * 6 * sizeof(float);
+    const size_t fit = per_split ? DB_PARTIAL_BUDGET / per_split : DB_MAX_SPLIT;
+    if (w.K > fit) w.K = fit < 1 ? 1u : (uint32_t)fit;
     char* p = (char*)base;
     size_t off = 0;
     w.counter_bytes = up((size_t)S * DB_COUNTER_STRIDE * sizeof(uint32_t));

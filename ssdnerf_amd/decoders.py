@@ -113,7 +113,7 @@ class _PointDecodeFn(torch.autograd.Function):
         offsets = torch.tensor(bounds, dtype=torch.int32, device=dev)          # (a blocking copy: the host list dies with this frame)
         grad_code = torch.empty(s_, 3, 6, hp, wp, dtype=torch.float32, device=dev)
         ws_bytes = int(C.lib().ssdnerf_point_decode_backward_workspace(C.u32(s_), C.u32(total), C.u32(hp), C.u32(wp)))
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        ws = decoder._workspace(max(ws_bytes, 1), dev, "decode_bwd")                       # the decoder's cached scratch (grown on demand), not a fresh tensor per backward
         C.check(C.lib().ssdnerf_point_decode_backward(
             C.ptr(planes), C.dtype_code(planes), C.u32(s_), C.u32(hp), C.u32(wp), C.ptr(decoder.packed_params()), C.ptr(xyzs), C.ptr(dirs),
             C.ptr(offsets), C.u32(total), C.f32(decoder.sigmoid_saturation), C.ptr(g_sigmas), C.ptr(g_rgbs), C.ptr(grad_code), C.ptr(ws),
@@ -139,8 +139,8 @@ class VolumeRenderer(nn.Module):
         self.register_buffer("aabb", torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32))
         self.last_render_stats: Dict[str, object] = {}
 
-    def _workspace(self, nbytes: int, device) -> torch.Tensor:
-        key = (device.index, torch.cuda.current_stream().cuda_stream)
+    def _workspace(self, nbytes: int, device, tag: str = "render") -> torch.Tensor:
+        key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
         buf = self._ws_cache.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -384,8 +384,13 @@ class GaussianDiffusion(nn.Module):
             session = self.denoising.inference_session(x_t, t_rows[0])
             if session is not None:
                 session.x.copy_(x_t)                                         # the latent lives in the UNet's static input buffer from here on
+        pending_x0 = None                                                    # x0 of the last emitting (DDIM) step; its trajectory point is the latent AFTER
+                                                                             # the Langevin corrections that follow it (gaussian_diffusion.py:313-326)
         for i, s in enumerate(plan):
             cond = concat_cond[:, i % concat_cond.size(1)] if concat_cond is not None else None
+            if kept is not None and s.emit and pending_x0 is not None:
+                kept += [pending_x0, session.x.clone() if session is not None else x_t]
+                pending_x0 = None
             if session is not None and s.kind == "ddim" and s.n == 0:
                 # ---- device-resident unguided DDIM step: t -> static buffer, graph replay, one fused update written back in place
                 session.t.copy_(t_rows[i])
@@ -394,16 +399,18 @@ class GaussianDiffusion(nn.Module):
                 C.check(C.lib().ssdnerf_ddim_step_v(C.ptr(session.x), C.ptr(v), C.ctypes.c_uint64(v.numel()), C.f32(s.a), C.f32(s.b), C.f32(s.c),
                                                     C.f32(s.d), C.f32(clip[0]), C.f32(clip[1]), C.ptr(x0), C.ptr(session.x), C.stream()), "ddim_step_v")
                 if kept is not None:
-                    kept += [x0, session.x.clone()]
+                    pending_x0 = x0
                 continue
             if session is not None:                                          # a step kind the fused form does not cover: leave the session
                 x_t, session = session.x.clone(), None
             x0, _ = self.pred_x_0(x_t, t_rows[i], grad_guide_fn=grad_guide_fn, concat_cond=cond, cfg=cfg, **kwargs)
             x_t = self._advance(s, x_t.detach() if grad_guide_fn is not None else x_t, x0)
             if kept is not None and s.emit:
-                kept += [x0, x_t]
+                pending_x0 = x0
         if session is not None:
             x_t = session.x.clone()
+        if pending_x0 is not None:
+            kept += [pending_x0, x_t]
         return kept if save_intermediates else x_t
 
     def ddim_sample(self, noise, show_pbar=False, concat_cond=None, save_intermediates=False, **kwargs):

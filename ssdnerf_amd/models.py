@@ -467,14 +467,37 @@ class DiffusionNeRF(MultiSceneNeRF):
     @torch.no_grad()
     def val_uncond(self, data, show_pbar=False, density_jitters=None, **kwargs):
         """noise -> DDIM over the triplane latents -> scene codes -> their occupancy state (``density_step`` grid refreshes)"""
-        if self.test_cfg.get("n_inverse_steps", 0) > 0:
-            raise NotImplementedError("post-sampling code optimisation (n_inverse_steps > 0) is not used by the hot-path configs")
+        prior_timesteps, prior_noises = kwargs.pop("prior_timesteps", None), kwargs.pop("prior_noises", None)
         noise = self._start_noise(data, len(data["scene_id"]), get_module_device(self))
+        diffusion = self._eval_diffusion()
         with self._autocast():
-            latent = self._eval_diffusion()(self.code_diff_pr(noise), return_loss=False, show_pbar=show_pbar, **kwargs)
+            latent = diffusion(self.code_diff_pr(noise), return_loss=False, show_pbar=show_pbar, **kwargs)
         code = self.code_diff_pr_inv(latent.float())
+        n_refine = self.test_cfg.get("n_inverse_steps", 0)
+        if n_refine > 0:
+            code = self._refine_under_prior(diffusion, code, n_refine, prior_timesteps, prior_noises)
         grid, bits = self.get_density(self._modules_for_eval(), code, cfg=self.test_cfg, jitters=density_jitters)
         return code, grid, bits
+
+    def _refine_under_prior(self, diffusion, code, n_steps, timesteps=None, noises=None):
+        """``test_cfg['n_inverse_steps']`` on a batch WITHOUT conditioning views (every recons config sets it, and the reference's val_uncond then
+        polishes the sampled codes under the prior alone, lib/models/autodecoders/diffusion_nerf.py:212-229): n optimizer steps on the
+        pre-activation code against the diffusion loss, denoiser frozen.  ``timesteps`` / ``noises``: injected draws per step (parity runs)."""
+        cfg = self.test_cfg
+        with frozen(diffusion), torch.enable_grad():
+            leaf = self.code_activation.inverse(code).detach().requires_grad_(True)
+            opt = self.build_optimizer(leaf, cfg)
+            sch = self.build_scheduler(opt, cfg)
+            for k in range(n_steps):
+                opt.zero_grad()
+                with self._autocast():
+                    prior, _ = diffusion(self.code_diff_pr(self.code_activation(leaf)), return_loss=True, cfg=cfg,
+                                         timesteps=None if timesteps is None else timesteps[k], noise=None if noises is None else noises[k])
+                prior.backward()
+                opt.step()
+                if sch is not None:
+                    sch.step()
+        return self.code_activation(leaf).detach()
 
     # ---- rendering-guided sampling ------------------------------------------------------------------------------------------------------------------
     def val_guide(self, data, guide_noises=None, density_jitters=None, **kwargs):

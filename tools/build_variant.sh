@@ -5,7 +5,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; SRC=$2; shift 2
-python -m ssdnerf_amd.build > /dev/null
+[ -n "$SSDNERF_SKIP_BUILD" ] || python -m ssdnerf_amd.build > /dev/null 2>&1
 mkdir -p $R/.variants/$NAME
 OBJ=$R/.variants/$NAME/${SRC%.hip}.o
 /opt/rocm/bin/hipcc "$@" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -Wno-shift-op-parentheses -c $R/ssdnerf_amd/csrc/$SRC -o $OBJ
