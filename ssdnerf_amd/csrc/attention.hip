@@ -169,9 +169,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                 if constexpr (F32) {
                     bf16x8 khi, klo;
                     load8(kb * 32 + l31, 1, 2 * s + hf, khi, klo);
-                    __builtin_amdgcn_sched_barrier(0);                       // khi / klo are VALU results (the bf16 split): same operand hazard as P below
+#ifdef SSD_LEGACY_MFMA_GUARD                                                 // r02 padding in front of MFMAs with VALU-built operands: not the cause (shade_mfma.hip, sm_operand_guard)
+                    __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_nop 4");
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qf[0][s], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[1][s], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[0][s], sacc, 0, 0, 0);
@@ -219,11 +221,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                     pb[1][s] = *reinterpret_cast<const bf16x8*>(&ul);
                 }
             }
-            // P (and the rescaled accumulators) were just written by VALU instructions and are read by the matrix pipe next: pad the hazard the
-            // compiler leaves open on gfx950 (shade_mfma.hip, sm_operand_guard, has the measurement)
+#ifdef SSD_LEGACY_MFMA_GUARD                                                 // (r02 padding between the VALU-built P and the MFMAs that read it; see above)
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop 4");
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll

@@ -959,6 +959,268 @@ __global__ __launch_bounds__(256) void k_conv_splitk_finish(float* __restrict__ 
     }
 }
 
+// ================================================================================================================================
+// Round 3: the large layers (M >= 16 384 output pixels, 63 % of the UNet's convolution time) on a TWO-GROUP ("ping-pong") schedule.
+// What bounded the 128 x 128 kernels above (r01 / r02 profiles, and the programming guide's "128^2 tile + two barriers per K-step ~900 TFLOP/s
+// ceiling"): every wave runs load -> wait -> barrier -> 16 MFMA in lockstep, so the matrix pipe idles while the waves issue their LDS-DMA
+// instructions and wait for them.  Here a block has 8 waves in two groups of four (one wave of each group per SIMD) that run the SAME phase
+// sequence ONE BARRIER APART: while group 0 multiplies, group 1 reads its fragments and issues DMA, and vice versa, so each SIMD's matrix
+// pipe always has one wave in an MFMA segment; `s_setprio` lets that wave win the issue port.
+//   * tile 256 x 128, 8 waves as 4 (M) x 2 (N), 64 x 64 per wave; K-tile 64 in TWO phases of two 16-deep k-steps (8 MFMA 32x32x16 = 256
+//     matrix-pipe cycles per phase and wave);
+//   * per phase and wave: 8 ds_read_b128 (fragments of the phase), its share of the DMA of the K-tile TWO ahead, `s_waitcnt vmcnt(N)
+//     lgkmcnt(0)` + s_barrier, then the MFMAs, s_barrier;
+//   * three LDS stages (generic form: 3 x 48 KiB): a stage is re-filled in the K-tile after its last read; the reads are retired (lgkmcnt(0))
+//     BEFORE the barrier the other group's first DMA into that stage waits behind, and a stage is read only after every wave has waited for
+//     its own DMA pieces of it (counted vmcnt: only the pieces of the youngest K-tile stay in flight) and passed a barrier (the argument is
+//     written out at pp_phase below);
+//   * ROWS form (3 x 3, stride 1, tile = whole image rows): the A tile is loaded once per (kh, channel tile) and the three kw taps read it
+//     shifted by a row (zero rows between image rows, as k_conv3x3_bf16_rows): 3.3 instead of 6 DMA instructions per wave and K-tile;
+//   * epilogue = cv_epilogue_bf16 (bias, residual, bf16 rounding, GroupNorm sums).
+// One block per CU (144.5 / 114.8 KiB of LDS).
+SSD_DEV void pp_wait_vm_lgkm_barrier(uint32_t n) {          // n = DMA instructions of this wave that may stay in flight (younger than what must have landed)
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+}
+SSD_DEV void pp_wait_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+SSD_DEV void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <bool ROWS>
+__global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
+    constexpr int BM = 256, BN = 128, TM = 2, TN = 2;
+    constexpr int A_ROWS = ROWS ? BM + 8 + 1 : BM;                            // ROWS: up to eight image rows per tile (W = 32) + their zero rows
+    constexpr int A_BUF = A_ROWS * CV_ROWB, B_BUF = BN * CV_ROWB;
+    constexpr int NA = ROWS ? 2 : 3, NB = 3;                                 // stages per operand
+    constexpr int EPI = 128 * BN * 4;                                        // cv_epilogue_bf16 goes through LDS in passes of 128 rows
+    constexpr int RING = NA * A_BUF + NB * B_BUF;
+    constexpr int LDS_BYTES = (RING > EPI ? RING : EPI) + 512;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    unsigned char* const abuf = lds;
+    unsigned char* const bbuf = lds + NA * A_BUF;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const uint32_t group = __builtin_amdgcn_readfirstlane(wave >> 2);        // waves 0-3 / 4-7: one wave of each group per SIMD
+
+    const uint32_t n_blocks = a.m_tiles * a.n_tiles;
+    uint32_t tile;
+    {
+        const uint32_t xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n_blocks >> 3, r = n_blocks & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const uint32_t m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
+    const uint32_t taps = a.ksize * a.ksize, kc = a.Cin / CV_BK, KT = taps * kc, Cin2 = a.Cin - a.Cin1;
+    const uint32_t W = a.W;
+    const uint32_t seg_w = ROWS ? (W >= (uint32_t)BM ? (uint32_t)BM : W) : 1u, n_seg = ROWS ? (uint32_t)BM / seg_w : 0u;
+    if (ROWS) {
+        for (uint32_t i = tid; i < NA * (n_seg + 1) * (CV_ROWB / 16); i += 512) {      // zero rows of the A stages (never overwritten)
+            const uint32_t chunk = i % (CV_ROWB / 16), row = (i / (CV_ROWB / 16)) % (n_seg + 1), buf = i / ((CV_ROWB / 16) * (n_seg + 1));
+            *reinterpret_cast<uint4*>(abuf + buf * A_BUF + row * (seg_w + 1) * CV_ROWB + chunk * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    // ---- loader geometry: this wave's DMA pieces.  A piece i (0..3) = tile rows (wave * 4 + i) * 8 + (lane >> 3); B piece i (0..1) = rows (wave * 2 + i) * 8 + (lane >> 3)
+    const uint32_t Hv = a.upsample ? a.H * 2 : a.H, Wv = a.upsample ? a.W * 2 : a.W;
+    int32_t a_y0[4], a_x0[4];
+    uint32_t a_img[4], a_chunk[4], a_lds[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t r8 = (wave * 4 + i) * 8, r = r8 + (lane >> 3), m = m0 + r;
+        a_ok[i] = m < a.M;
+        const uint32_t mm = a_ok[i] ? m : 0;
+        if (ROWS) {
+            const uint32_t b = mm / (a.H * W), rem = mm % (a.H * W);
+            a_y0[i] = (int32_t)(rem / W) - 1;
+            a_x0[i] = 0;
+            a_img[i] = b * a.H * W + (rem % W);                                  // + y * W
+            const uint32_t rho = r + r / seg_w + 1;
+            a_chunk[i] = ((lane & 7) ^ ((rho >> 1) & 7)) * 16;                   // source-side swizzle keyed by the LDS row
+            a_lds[i] = (r8 + r8 / seg_w + 1) * CV_ROWB;
+        } else {
+            const uint32_t b = mm / (a.Ho * a.Wo), rem = mm % (a.Ho * a.Wo);
+            a_y0[i] = (int32_t)((rem / a.Wo) * a.stride) - (int32_t)a.pad;
+            a_x0[i] = (int32_t)((rem % a.Wo) * a.stride) - (int32_t)a.pad;
+            a_img[i] = b * a.H * a.W;
+            a_chunk[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+            a_lds[i] = r8 * CV_ROWB;
+        }
+    }
+    uint32_t b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t r = (wave * 2 + i) * 8 + (lane >> 3);
+        b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+    }
+    uint64_t a_src[4], a_src2[4];
+    bool a_zero[4];
+    auto set_tap = [&](uint32_t tap) {                                          // generic: tap = kh * ksize + kw;  ROWS: tap = kh (the kw shift happens at read time)
+        const int32_t kh = ROWS ? (int32_t)tap : (int32_t)(tap / a.ksize), kw = ROWS ? 0 : (int32_t)(tap % a.ksize);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int32_t yv = a_y0[i] + kh, xv = a_x0[i] + kw;
+            const bool ok = a_ok[i] && yv >= 0 && xv >= 0 && yv < (int32_t)Hv && (ROWS || xv < (int32_t)Wv);
+            uint64_t pix;
+            if (ROWS) pix = (uint64_t)a_img[i] + (uint64_t)(ok ? yv : 0) * W;
+            else {
+                const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
+                pix = (uint64_t)(a_img[i] + yi * a.W + xi);
+            }
+            a_zero[i] = !ok;
+            a_src[i] = ok ? (uint64_t)a.x + pix * a.Cin1 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
+            a_src2[i] = (ok && a.x2) ? (uint64_t)a.x2 + pix * Cin2 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
+        }
+    };
+    auto issue_a = [&](int i, uint32_t ci0, uint32_t buf) {                      // one A piece of the tap set by set_tap
+        const bool second = ci0 >= a.Cin1;
+        const uint64_t coff = (uint64_t)(second ? ci0 - a.Cin1 : ci0) * 2;
+        cv_glds16((const void*)((second ? a_src2[i] : a_src[i]) + (a_zero[i] ? 0 : coff)), abuf + buf * A_BUF + __builtin_amdgcn_readfirstlane(a_lds[i]));
+    };
+    auto issue_b = [&](int i, uint32_t tap, uint32_t ci0, uint32_t buf) {
+        cv_glds16(a.w + b_off[i] + (uint64_t)(tap * a.Cin + ci0) * 2, bbuf + buf * B_BUF + (wave * 2 + i) * 1024);
+    };
+
+    // ---- reader geometry ---------------------------------------------------------------------------------------------------------------
+    uint32_t a_rd[TM][ROWS ? 3 : 1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const uint32_t t0 = wm * 64 + i * 32;
+        if (ROWS) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const uint32_t rho = t0 + (lane & 31) + t0 / seg_w + kw;          // = 1 + seg (seg_w + 1) + x + (kw - 1)
+                a_rd[i][kw % (ROWS ? 3 : 1)] = rho * CV_ROWB + (((lane >> 5) ^ ((rho >> 1) & 7)) * 16);
+            }
+        } else {
+            a_rd[i][0] = (t0 + (lane & 31)) * CV_ROWB + (((lane >> 5) ^ ((lane >> 1) & 7)) * 16);
+        }
+    }
+    const uint32_t b_rd = (wn * 64 + (lane & 31)) * CV_ROWB + (((lane >> 5) ^ ((lane >> 1) & 7)) * 16);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- the K loop ------------------------------------------------------------------------------------------------------------------------
+    // K-tile t: generic (tap, ci) = (t / kc, t % kc); ROWS: group g = t / 3 = kh * kc + ci, kw = t % 3, B tap = kh * 3 + kw.
+    // DMA schedule of one wave: phase q = 2 t + p issues B piece p of K-tile t + 2 and
+    //   generic: A pieces 2 p, 2 p + 1 of K-tile t + 2;        ROWS: A piece (q % 6) of group g + 1 when q % 6 < 4.
+    // pp_phase safety (P = number of DMA instructions this wave issued in phases 2 t and 2 t + 1):
+    //   RAW  the wait of phase 2 t + 1, `vmcnt(P)`, retires every piece issued BEFORE phase 2 t: all of K-tile t + 1 (and, ROWS, of the A group read
+    //        next).  It sits before that phase's first barrier; a wave reads K-tile t + 1 only after the phase's second barrier, which the other
+    //        group reaches only after ITS wait (the groups are one barrier apart), so every wave's pieces have landed.
+    //   WAR  the stage K-tile t + 2 goes to was last read in phase 2 t - 1, and those reads are retired (`lgkmcnt(0)`) before that phase's first
+    //        barrier; the first DMA into it is issued in phase 2 t, i.e. after the second barrier of phase 2 t - 1, which the other group cannot
+    //        pass before its own first barrier of phase 2 t - 1.
+    uint32_t l_tap = 0, l_ci = 0, l_kt = 0;                                      // loader iterator (generic: the K-tile being issued; ROWS: its B side)
+    uint32_t g_kh = 0, g_ci = 0, g_next = 0;                                     // ROWS: the A group being issued
+    auto advance_l = [&]() { ++l_kt; if (ROWS) { if (l_kt % 3 == 0) { if (++l_ci == kc) { l_ci = 0; ++l_tap; } } } else { if (++l_ci == kc) { l_ci = 0; ++l_tap; } } };
+    // prologue: K-tiles 0 and 1 (ROWS: A group 0, B of K-tiles 0 and 1)
+    uint32_t in_flight_young = 0;
+    if (ROWS) {
+        set_tap(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_a(i, 0, 0);
+        g_next = 1; g_ci = 1 % kc; g_kh = 1 / kc;                                // next group to issue
+        issue_b(0, 0, 0, 0); issue_b(1, 0, 0, 0);
+        if (KT > 1) { issue_b(0, 1, 0, 1); issue_b(1, 1, 0, 1); in_flight_young = 2; }
+        l_kt = 2; l_tap = 0; l_ci = 0;                                           // B iterator: K-tile 2 = (kh 0, ci 0, kw 2); l_tap counts kh * kc + ci groups here
+    } else {
+        set_tap(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_a(i, 0, 0);
+        issue_b(0, 0, 0, 0); issue_b(1, 0, 0, 0);
+        advance_l();
+        if (KT > 1) {
+            if (l_ci == 0) set_tap(l_tap);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_a(i, l_ci * CV_BK, 1);
+            issue_b(0, l_tap, l_ci * CV_BK, 1); issue_b(1, l_tap, l_ci * CV_BK, 1);
+            advance_l();
+            in_flight_young = 6;
+        }
+        if (l_kt < KT && l_ci == 0) set_tap(l_tap);
+    }
+    pp_wait_vm_lgkm_barrier(in_flight_young);                                    // K-tile 0 (and the zero rows) in place for every wave
+    if (group == 1) pp_barrier();                                                // the stagger: group 1 runs one barrier behind
+
+    uint32_t issued_prev = 0;
+    for (uint32_t t = 0; t < KT; ++t) {
+        const unsigned char* sb = bbuf + (t % NB) * B_BUF;
+        const unsigned char* sa;
+        uint32_t kw = 0;
+        if (ROWS) { kw = t % 3; sa = abuf + ((t / 3) & 1) * A_BUF; } else sa = abuf + (t % NA) * A_BUF;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            // ---- load segment: this phase's fragments ...
+            bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const uint32_t off = ROWS ? (kw == 0 ? a_rd[i][0] : kw == 1 ? a_rd[i][1 % (ROWS ? 3 : 1)] : a_rd[i][2 % (ROWS ? 3 : 1)]) : a_rd[i][0];
+                    fa[s][i] = *reinterpret_cast<const bf16x8*>(sa + (off ^ ((2 * p + s) * 32)));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(sb + ((b_rd + j * 32 * CV_ROWB) ^ ((2 * p + s) * 32)));
+            }
+            // ---- ... and this wave's share of the DMA two K-tiles ahead
+            uint32_t issued = 0;
+            if (ROWS) {
+                if (l_kt < KT) {                                                 // B piece p of K-tile l_kt = t + 2: tap = kh * 3 + kw with (kh, ci) of group l_kt / 3
+                    const uint32_t g = l_kt / 3, bkh = g / kc, bci = g % kc;
+                    issue_b(p, bkh * 3 + l_kt % 3, bci * CV_BK, l_kt % NB);
+                    ++issued;
+                }
+                const uint32_t q6 = (2 * t + p) % 6;
+                if (q6 < 4 && g_next < 3 * kc && g_next == t / 3 + 1) {          // A piece q6 of the next group
+                    if (q6 == 0) set_tap(g_kh);
+                    issue_a((int)q6 == 0 ? 0 : (int)q6 == 1 ? 1 : (int)q6 == 2 ? 2 : 3, g_ci * CV_BK, g_next & 1);
+                    ++issued;
+                    if (q6 == 3) { ++g_next; if (++g_ci == kc) { g_ci = 0; ++g_kh; } }
+                }
+                if (p == 1) ++l_kt;
+            } else {
+                if (l_kt < KT) {
+                    issue_a(2 * p, l_ci * CV_BK, l_kt % NA); issue_a(2 * p + 1, l_ci * CV_BK, l_kt % NA);
+                    issue_b(p, l_tap, l_ci * CV_BK, l_kt % NB);
+                    issued = 3;
+                    if (p == 1) { advance_l(); if (l_kt < KT && l_ci == 0) set_tap(l_tap); }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (p == 0) pp_wait_lgkm_barrier();
+            else pp_wait_vm_lgkm_barrier(issued_prev + issued);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- compute segment
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issued_prev = issued;
+        }
+    }
+    if (group == 0) pp_barrier();                                                // even out the stagger
+    __syncthreads();                                                             // every wave is done with the stages (the epilogue reuses them)
+    cv_epilogue_bf16<TM, TN, 4, 2>(a, acc, lds, m0, n0);
+}
+
 template <int TM, int TN, int WM, int WN, int NS>
 int cv_launch(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;

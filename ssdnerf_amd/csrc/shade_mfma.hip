@@ -32,6 +32,8 @@
 // Results are bit-identical in the integer outputs and within fp32 rounding of k_shade_queue for the floats (the MFMA
 // accumulates the same products in a different, fixed order); tests/test_render_gpu.py checks both against the oracle.
 #include "decode_core.h"
+#include <type_traits>
+#include <utility>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
@@ -95,26 +97,26 @@ SSD_DEV void sm_swap_u(uint32_t& a, uint32_t& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0]; b = r[1];
 }
+template <class F, int... I> SSD_DEV void sm_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 #ifndef SM_HEAD_GROUP
-#define SM_HEAD_GROUP 1                            // SiLU pairs per scheduling group minus one (r02 A/B: 1 -> 7.29, 3 -> 7.44, 7 -> 7.64 ms)
+#define SM_HEAD_GROUP 4                            // SiLU pairs per stage-ordered group of the colour head that runs without MFMAs beside it (16 % SM_HEAD_GROUP == 0)
 #endif
 #ifndef SM_GATHER_BY_PLANE
 #define SM_GATHER_BY_PLANE 1                       // gather one plane at a time (24 texel registers in flight instead of 72)
 #endif
 
-// VALU-written registers read by the matrix pipe (or swapped across lane halves) a few cycles later.  r02: with two waves per SIMD, a render
-// repeated on the same inputs differed on groups of EXACTLY 16 neighbouring rays -- one quarter-wave, one sample each, errors up to 6e-3 in
-// rgb / depth -- about 30 rays of 4 M per launch; never with one wave per SIMD, with another instruction order, or with larger tickets.  The B
-// operands of this kernel are produced by VALU instructions (v_perm_b32 packs, v_mov of the bias pair, v_permlane32_swap) immediately before
-// the MFMAs that read them, and the hazard recogniser of this toolchain leaves too few wait states for that on gfx950: a quarter of the lanes
-// is read one issue slot early.  What removes it is a SCHEDULING BARRIER in front of every MFMA group, i.e. forbidding the compiler to move
-// the group's MFMAs up into the preceding VALU code (0 differing renders in 135 repeats with the barrier alone, in 450 with barrier + five idle
-// states; 135 of 135 differ with the idle states alone) -- idle states are not needed, so the guard is the barrier (cost: within noise).
-// It is needed in front of the direction-term groups too, whose B operands come from LDS loads (without it the sample total itself changes),
-// so the exposed dependency is not only "VALU result -> MFMA source"; what is established is the symptom, its granularity (a quarter-wave,
-// one sample) and the schedule that is reproducible.  csrc/attention.hip guards its VALU-built operands the same way (plus idle states).
+// Run-to-run reproducibility (r02 symptom, r03 cause).  r02: with two waves per SIMD a render repeated on the same inputs differed on groups of
+// EXACTLY 16 neighbouring rays -- one quarter-wave, one sample each, up to 6e-3 in rgb / depth, ~30 rays of 4 M per launch -- and a scheduling
+// barrier in front of every MFMA group made it go away; it was taken for a VALU -> MFMA operand hazard.  r03 (profiles/r03/hazard.txt): the
+// barriers only MOVED code.  The pair is  v_exp_f32 / v_rcp_f32 (quarter rate: 16 lanes per pass) -> the packed op that reads the result  in the
+// SiLUs below: the toolchain pads that hazard (VALUTransUseHazard) to one wait state, and with two waves on a SIMD the consumer occasionally
+// reads the register before the last 16-lane pass is written.  Evidence: any 4-byte shift of the instruction stream in front of those pairs hid
+// the failure, a 64-byte shift did not; lengthening only the compiler's own `s_nop 0` behind transcendentals to `s_nop 1` IN PLACE (identical code
+// layout) gave 0 differing renders of 200 at every placement, 40 of 40 without.  The fix is therefore not here but in the build: asm_postpass.py
+// gives every transcendental -> use pair of the library two wait states.  -DSSD_LEGACY_MFMA_GUARD restores the r02 barriers (A/B runs only).
 SSD_DEV void sm_operand_guard() {
-#ifndef SM_NO_GUARD                                 // -DSM_NO_GUARD: experiment builds only (tools/asm_patch_build.sh, profiles/r03/hazard.txt)
+#ifdef SSD_LEGACY_MFMA_GUARD
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
@@ -506,55 +508,80 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         };
         floatx2 ps_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
         floatx2 pr_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pg_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}}, pb_[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
-        auto density_pair = [&](int nt, int q) {
-            const int mt = q >> 3, p2 = q & 7;
-            const float4 w = wout2[((mt * 8 + p2) * 2 + half) * 2];
-            ps_[nt] = sm_fma2(floatx2{w.x, w.y}, sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]}), ps_[nt]);
-        };
-        auto colour_pair = [&](int nt, int q) {
-            const int mt = q >> 3, p2 = q & 7;
-            const float4 w0 = wout2[((mt * 8 + p2) * 2 + half) * 2], w1 = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
-            const floatx2 cc = sm_silu2(floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]});
-            pr_[nt] = sm_fma2(floatx2{w0.z, w0.w}, cc, pr_[nt]);
-            pg_[nt] = sm_fma2(floatx2{w1.x, w1.y}, cc, pg_[nt]);
-            pb_[nt] = sm_fma2(floatx2{w1.z, w1.w}, cc, pb_[nt]);
+        // SiLU + output layer of pairs [Q0, Q0 + N) of tile NT, STAGE BY STAGE (r03): all scalings, all v_exp, the LDS weight reads, all adds, all
+        // v_rcp, all products.  A pair-by-pair chain (exp, exp -> add -> rcp, rcp -> mul) puts every transcendental directly in front of its
+        // consumer, where the toolchain must pad (one `s_nop` per pair and stage: 108 of the 777 instructions of this block in r02) and where
+        // gfx950 needs MORE than that pad with two waves per SIMD (asm_postpass.py); staged, the consumers sit N instructions behind their
+        // producers, the quarter-rate unit runs N * 2 ops back to back under the ordinary ones, and the post-pass has next to nothing to add.
+        auto heads = [&](auto ntc, auto colour_c, auto q0c, auto nc) {
+            constexpr int nt = decltype(ntc)::value, Q0 = decltype(q0c)::value, N = decltype(nc)::value;
+            constexpr bool COLOUR = decltype(colour_c)::value;
+            floatx2 h[N], u[N], v[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int q = Q0 + i, mt = q >> 3, p2 = q & 7;
+                h[i] = floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]};
+                u[i] = h[i] * floatx2{-1.4426950408889634f, -1.4426950408889634f};
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) { v[i].x = __builtin_amdgcn_exp2f(u[i].x); v[i].y = __builtin_amdgcn_exp2f(u[i].y); }
+            float4 w0[N], w1[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int q = Q0 + i, mt = q >> 3, p2 = q & 7;
+                w0[i] = wout2[((mt * 8 + p2) * 2 + half) * 2];
+                if (COLOUR) w1[i] = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) u[i] = v[i] + floatx2{1.0f, 1.0f};
+#pragma unroll
+            for (int i = 0; i < N; ++i) { v[i].x = __builtin_amdgcn_rcpf(u[i].x); v[i].y = __builtin_amdgcn_rcpf(u[i].y); }
+#pragma unroll
+            for (int i = 0; i < N; ++i) h[i] = h[i] * v[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                if (COLOUR) {
+                    pr_[nt] = sm_fma2(floatx2{w0[i].z, w0[i].w}, h[i], pr_[nt]);
+                    pg_[nt] = sm_fma2(floatx2{w1[i].x, w1[i].y}, h[i], pg_[nt]);
+                    pb_[nt] = sm_fma2(floatx2{w1[i].z, w1[i].w}, h[i], pb_[nt]);
+                } else {
+                    ps_[nt] = sm_fma2(floatx2{w0[i].x, w0[i].y}, h[i], ps_[nt]);
+                }
+            }
         };
         constexpr int QB[7] = {0, 3, 6, 9, 12, 14, 16};                 // 16 SiLU pairs spread over the 6 MFMA groups of a phase
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
         // ---- A
 #pragma unroll
         for (int g = 0; g < 6; ++g) layer1(0, g);
-        // ---- B
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
+        // ---- B: layer 1 of tile 1 || density head of tile 0;  C: direction term of tile 0 || density head of tile 1;  D: direction term of tile 1 || colour head of tile 0
+        sm_static_for<6>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
             layer1(1, g);
-#pragma unroll
-            for (int q = QB[g]; q < QB[g + 1]; ++q) density_pair(0, q);
+            heads(I0{}, std::false_type{}, std::integral_constant<int, QB[g]>{}, std::integral_constant<int, QB[g + 1] - QB[g]>{});
             __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- C
+        });
         load_sh(0);
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
+        sm_static_for<6>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
             dir_term(0, g);
-#pragma unroll
-            for (int q = QB[g]; q < QB[g + 1]; ++q) density_pair(1, q);
+            heads(I1{}, std::false_type{}, std::integral_constant<int, QB[g]>{}, std::integral_constant<int, QB[g + 1] - QB[g]>{});
             __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- D
+        });
         load_sh(1);
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
+        sm_static_for<6>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
             dir_term(1, g);
-#pragma unroll
-            for (int q = QB[g]; q < QB[g + 1]; ++q) colour_pair(0, q);
+            heads(I0{}, std::true_type{}, std::integral_constant<int, QB[g]>{}, std::integral_constant<int, QB[g + 1] - QB[g]>{});
             __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- E
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            colour_pair(1, q);
-            if ((q & SM_HEAD_GROUP) == SM_HEAD_GROUP) __builtin_amdgcn_sched_barrier(0);
-        }
+        });
+        // ---- E: colour head of tile 1, SM_HEAD_GROUP pairs at a time
+        sm_static_for<16 / SM_HEAD_GROUP>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            heads(I1{}, std::true_type{}, std::integral_constant<int, g * SM_HEAD_GROUP>{}, std::integral_constant<int, SM_HEAD_GROUP>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
         ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y; pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y;
         pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
