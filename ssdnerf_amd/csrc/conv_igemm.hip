@@ -28,6 +28,7 @@
 //
 // Bound: MFMA (dense bf16 peak ~2.5 PFLOP/s).  Arithmetic: bf16 products, fp32 accumulation in MFMA order.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -976,7 +977,7 @@ __global__ __launch_bounds__(256) void k_conv_splitk_finish(float* __restrict__ 
 //     written out at pp_phase below);
 //   * ROWS form (3 x 3, stride 1, tile = whole image rows): the A tile is loaded once per (kh, channel tile) and the three kw taps read it
 //     shifted by a row (zero rows between image rows, as k_conv3x3_bf16_rows): 3.3 instead of 6 DMA instructions per wave and K-tile;
-//   * epilogue = cv_epilogue_bf16 (bias, residual, bf16 rounding, GroupNorm sums).
+//   * epilogue straight from the accumulators (cv_epilogue_direct: transposed product, permlane32_swap, 16-byte stores).
 // One block per CU (144.5 / 114.8 KiB of LDS).
 SSD_DEV void pp_wait_vm_lgkm_barrier(uint32_t n) {          // n = DMA instructions of this wave that may stay in flight (younger than what must have landed)
     switch (n) {
@@ -992,6 +993,106 @@ SSD_DEV void pp_wait_vm_lgkm_barrier(uint32_t n) {          // n = DMA instructi
 SSD_DEV void pp_wait_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 SSD_DEV void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+// LDS-DMA through a BUFFER descriptor (r03): `buffer_load_dwordx4 voffset, rsrc, soffset offen lds`.  Against the flat form used above
+// (global_load_lds with a 64-bit address per lane) it takes ONE 32-bit offset register per lane and a scalar offset -- the channel tile / tap of a
+// K-tile is a scalar add -- and a lane whose offset lies outside the buffer (>= num_records) reads zeros: padding taps are an offset of 2^31, no zero
+// page, no 64-bit selects.  The r02 loop spent ~190 VALU + SALU instructions per K-tile and wave on addresses beside 16 MFMAs (PMC: active-issue
+// 1000 cycles per K-tile against 512 MFMA cycles); this form needs ~40.
+// Epilogue of the two-group kernel, straight from the accumulators (r03).  The K loop multiplies TRANSPOSED -- weights as the MFMA's A operand, pixels
+// as B -- so that in the 32 x 32 C layout a lane holds ONE output pixel (lane & 31) and four runs of four consecutive output channels
+// (e = 4 q + r  ->  channel 8 q + 4 (lane >> 5) + r): bias (+ residual) are added in fp32, the 16 values are rounded once to bf16 and packed, one
+// v_permlane32_swap per packed dword pairs the two lane halves so that every lane holds 8 consecutive channels, and the tile leaves as 16-byte stores
+// (programming guide T21).  No LDS round trip, no block barrier: the LDS-staged epilogue above cost 17 - 25 us of a 56 us layer once the K loop no
+// longer hid it (profiles/r03/d_pp_epilogue_split.txt).  GroupNorm sums of the rounded values: per lane over its pixels, DPP-reduced over the 32
+// lanes of each half, one LDS atomic per 4-channel run and wave, then the same per-group fp64 atomics as cv_epilogue_bf16.
+SSD_DEV float cv_half_wave_sum(float v) {                                       // sum over the 32 lanes of each wave half, valid in lanes 16-31 / 48-63
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+template <int TM, int TN>
+SSD_DEV void cv_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TN][TM], unsigned char* lds, uint32_t m0, uint32_t n0, uint32_t wm, uint32_t wn) {
+    constexpr int BN = 128;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    float* red = reinterpret_cast<float*>(lds);                              // [BN / 4 runs][sum, sumsq]: the caller hands in 512 bytes BEHIND the stage ring (the
+                                                                             // persistent kernel's zero rows at the head of A stage 0 must survive this epilogue)
+    if (a.gn_sums) {
+        if (tid < BN / 4 * 2) red[tid] = 0.f;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const uint32_t cb = n0 + wn * 32 * TN + j * 32;                      // first channel of this 32-channel tile
+        float4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t m = m0 + wm * 32 * TM + i * 32 + (lane & 31);
+            const bool ok = m < a.M;
+            const size_t row = (size_t)(ok ? m : 0) * a.Cout;
+            uint2 pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float f[4] = {acc[j][i][4 * q] + bv[q].x, acc[j][i][4 * q + 1] + bv[q].y, acc[j][i][4 * q + 2] + bv[q].z, acc[j][i][4 * q + 3] + bv[q].w};
+                if (a.res) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.res + (row + cb + 8 * q + 4 * half) * 2);
+                    f[0] += __uint_as_float(rv.x << 16); f[1] += __uint_as_float(rv.x & 0xffff0000u);
+                    f[2] += __uint_as_float(rv.y << 16); f[3] += __uint_as_float(rv.y & 0xffff0000u);
+                }
+                pk[q] = make_uint2(cv_bf16_rne(f[0]) | (cv_bf16_rne(f[1]) << 16), cv_bf16_rne(f[2]) | (cv_bf16_rne(f[3]) << 16));
+                if (a.gn_sums && ok) {
+                    const float r0 = __uint_as_float(pk[q].x << 16), r1 = __uint_as_float(pk[q].x & 0xffff0000u);
+                    const float r2 = __uint_as_float(pk[q].y << 16), r3 = __uint_as_float(pk[q].y & 0xffff0000u);
+                    gs[q] += (r0 + r1) + (r2 + r3);
+                    gq[q] = __builtin_fmaf(r0, r0, gq[q]); gq[q] = __builtin_fmaf(r1, r1, gq[q]);
+                    gq[q] = __builtin_fmaf(r2, r2, gq[q]); gq[q] = __builtin_fmaf(r3, r3, gq[q]);
+                }
+            }
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {                                 // lower half ends up with channels 16 qp .. + 7, upper half with 16 qp + 8 .. + 15 of ITS pixel
+                auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * qp].x, pk[2 * qp + 1].x, false, false);
+                auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * qp].y, pk[2 * qp + 1].y, false, false);
+                if (ok) *reinterpret_cast<uint4*>(a.y + (row + cb + 16 * qp + 8 * half) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+        }
+        if (a.gn_sums) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s1 = cv_half_wave_sum(gs[q]), s2 = cv_half_wave_sum(gq[q]);
+                if ((lane & 31) == 31) {                                     // lanes 31 and 63 hold their half's totals: run index = (channel - n0) / 4
+                    const uint32_t run = (cb - n0 + 8 * q + 4 * half) / 4;
+                    atomicAdd(&red[run * 2], s1);
+                    atomicAdd(&red[run * 2 + 1], s2);
+                }
+            }
+        }
+    }
+    if (a.gn_sums) {                                                         // host guarantees: the tile lies in ONE sample, groups are multiples of 4 channels
+        __syncthreads();
+        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;
+        if (tid < ng && m0 < a.M) {
+            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
+            float ss = 0.f, qq = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
+            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
+            atomicAdd(dst, (double)ss);
+            atomicAdd(dst + 1, (double)qq);
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) void* cv_lds_ptr;
+SSD_DEV __amdgpu_buffer_rsrc_t cv_rsrc(const void* base, uint64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (uint32_t)bytes, 0x00020000);
+}
+static constexpr uint32_t CV_OOB = 0x80000000u;                              // voffset of a padding / out-of-range row (tensors are < 2^31 bytes: host check)
+
 template <bool ROWS>
 __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     constexpr int BM = 256, BN = 128, TM = 2, TN = 2;
@@ -1004,16 +1105,11 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
     unsigned char* const abuf = lds;
     unsigned char* const bbuf = lds + NA * A_BUF;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const uint32_t group = __builtin_amdgcn_readfirstlane(wave >> 2);        // waves 0-3 / 4-7: one wave of each group per SIMD
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;     // (scalar: LDS-DMA destinations are wave-uniform)
+    const uint32_t group = wave >> 2;                                        // waves 0-3 / 4-7: one wave of each group per SIMD
 
     const uint32_t n_blocks = a.m_tiles * a.n_tiles;
-    uint32_t tile;
-    {
-        const uint32_t xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n_blocks >> 3, r = n_blocks & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const uint32_t m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
     const uint32_t taps = a.ksize * a.ksize, kc = a.Cin / CV_BK, KT = taps * kc, Cin2 = a.Cin - a.Cin1;
     const uint32_t W = a.W;
     const uint32_t seg_w = ROWS ? (W >= (uint32_t)BM ? (uint32_t)BM : W) : 1u, n_seg = ROWS ? (uint32_t)BM / seg_w : 0u;
@@ -1023,9 +1119,26 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
             *reinterpret_cast<uint4*>(abuf + buf * A_BUF + row * (seg_w + 1) * CV_ROWB + chunk * 16) = make_uint4(0, 0, 0, 0);
         }
     }
+    const __amdgpu_buffer_rsrc_t rs_x = cv_rsrc(a.x, (uint64_t)a.B * a.H * a.W * a.Cin1 * 2);
+    const __amdgpu_buffer_rsrc_t rs_x2 = cv_rsrc(a.x2 ? a.x2 : a.x, a.x2 ? (uint64_t)a.B * a.H * a.W * Cin2 * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rs_w = cv_rsrc(a.w, (uint64_t)a.Cout * taps * a.Cin * 2);
 
-    // ---- loader geometry: this wave's DMA pieces.  A piece i (0..3) = tile rows (wave * 4 + i) * 8 + (lane >> 3); B piece i (0..1) = rows (wave * 2 + i) * 8 + (lane >> 3)
+    // ---- PERSISTENT over tiles: block b takes tiles b, b + gridDim, ... (gridDim = min(tiles, CUs), a multiple of 8).  The stores of a tile's
+    // epilogue are posted writes: they drain while the next tile's K loop runs, instead of ending every round of blocks with a chip-wide burst of
+    // 64 KiB per CU that nothing overlaps (measured: 12 us per round on the 128 x 128 layers).
     const uint32_t Hv = a.upsample ? a.H * 2 : a.H, Wv = a.upsample ? a.W * 2 : a.W;
+  for (uint32_t vb = blockIdx.x; vb < n_blocks; vb += gridDim.x) {
+    uint32_t tile;
+    {
+        const uint32_t xcd = vb & 7, idx = vb >> 3, q = n_blocks >> 3, r = n_blocks & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const uint32_t m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
+#ifdef CV_PP_TIMING                                                              // (instrumented build: shader-clock stamps per tile into the split-K workspace pointer)
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.splitk_ws) + (size_t)vb * 4;
+    if (tid == 0) stamps[0] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- loader geometry: this wave's DMA pieces.  A piece i (0..3) = tile rows (wave * 4 + i) * 8 + (lane >> 3); B piece i (0..1) = rows (wave * 2 + i) * 8 + (lane >> 3)
     int32_t a_y0[4], a_x0[4];
     uint32_t a_img[4], a_chunk[4], a_lds[4];
     bool a_ok[4];
@@ -1041,7 +1154,7 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
             a_img[i] = b * a.H * W + (rem % W);                                  // + y * W
             const uint32_t rho = r + r / seg_w + 1;
             a_chunk[i] = ((lane & 7) ^ ((rho >> 1) & 7)) * 16;                   // source-side swizzle keyed by the LDS row
-            a_lds[i] = (r8 + r8 / seg_w + 1) * CV_ROWB;
+            a_lds[i] = (r8 + r8 / seg_w + 1) * CV_ROWB;                          // (scalar)
         } else {
             const uint32_t b = mm / (a.Ho * a.Wo), rem = mm % (a.Ho * a.Wo);
             a_y0[i] = (int32_t)((rem / a.Wo) * a.stride) - (int32_t)a.pad;
@@ -1051,38 +1164,36 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
             a_lds[i] = r8 * CV_ROWB;
         }
     }
-    uint32_t b_off[2];
+    uint32_t b_voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const uint32_t r = (wave * 2 + i) * 8 + (lane >> 3);
-        b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        b_voff[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
     }
-    uint64_t a_src[4], a_src2[4];
-    bool a_zero[4];
+    uint32_t a_voff[4], a_voff2[4];                                          // per tap: byte offset of this lane's 16 bytes in x / x2 at channel 0, or CV_OOB
     auto set_tap = [&](uint32_t tap) {                                          // generic: tap = kh * ksize + kw;  ROWS: tap = kh (the kw shift happens at read time)
         const int32_t kh = ROWS ? (int32_t)tap : (int32_t)(tap / a.ksize), kw = ROWS ? 0 : (int32_t)(tap % a.ksize);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int32_t yv = a_y0[i] + kh, xv = a_x0[i] + kw;
             const bool ok = a_ok[i] && yv >= 0 && xv >= 0 && yv < (int32_t)Hv && (ROWS || xv < (int32_t)Wv);
-            uint64_t pix;
-            if (ROWS) pix = (uint64_t)a_img[i] + (uint64_t)(ok ? yv : 0) * W;
+            uint32_t pix;
+            if (ROWS) pix = a_img[i] + (uint32_t)yv * W;
             else {
                 const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
-                pix = (uint64_t)(a_img[i] + yi * a.W + xi);
+                pix = a_img[i] + yi * a.W + xi;
             }
-            a_zero[i] = !ok;
-            a_src[i] = ok ? (uint64_t)a.x + pix * a.Cin1 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
-            a_src2[i] = (ok && a.x2) ? (uint64_t)a.x2 + pix * Cin2 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
+            a_voff[i] = ok ? pix * a.Cin1 * 2 + a_chunk[i] : CV_OOB;
+            a_voff2[i] = ok ? pix * Cin2 * 2 + a_chunk[i] : CV_OOB;
         }
     };
-    auto issue_a = [&](int i, uint32_t ci0, uint32_t buf) {                      // one A piece of the tap set by set_tap
-        const bool second = ci0 >= a.Cin1;
-        const uint64_t coff = (uint64_t)(second ? ci0 - a.Cin1 : ci0) * 2;
-        cv_glds16((const void*)((second ? a_src2[i] : a_src[i]) + (a_zero[i] ? 0 : coff)), abuf + buf * A_BUF + __builtin_amdgcn_readfirstlane(a_lds[i]));
+    auto issue_a = [&](int i, uint32_t ci0, uint32_t buf) {                      // one A piece of the tap set by set_tap; ci0 is scalar
+        const cv_lds_ptr dst = (cv_lds_ptr)(abuf + buf * A_BUF + a_lds[i]);
+        if (ci0 >= a.Cin1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, dst, 16, a_voff2[i], (ci0 - a.Cin1) * 2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, dst, 16, a_voff[i], ci0 * 2, 0, 0);
     };
     auto issue_b = [&](int i, uint32_t tap, uint32_t ci0, uint32_t buf) {
-        cv_glds16(a.w + b_off[i] + (uint64_t)(tap * a.Cin + ci0) * 2, bbuf + buf * B_BUF + (wave * 2 + i) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (cv_lds_ptr)(bbuf + buf * B_BUF + (wave * 2 + i) * 1024), 16, b_voff[i], (tap * a.Cin + ci0) * 2, 0, 0);
     };
 
     // ---- reader geometry ---------------------------------------------------------------------------------------------------------------
@@ -1094,7 +1205,7 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const uint32_t rho = t0 + (lane & 31) + t0 / seg_w + kw;          // = 1 + seg (seg_w + 1) + x + (kw - 1)
-                a_rd[i][kw % (ROWS ? 3 : 1)] = rho * CV_ROWB + (((lane >> 5) ^ ((rho >> 1) & 7)) * 16);
+                a_rd[i][ROWS ? kw : 0] = rho * CV_ROWB + (((lane >> 5) ^ ((rho >> 1) & 7)) * 16);
             }
         } else {
             a_rd[i][0] = (t0 + (lane & 31)) * CV_ROWB + (((lane >> 5) ^ ((lane >> 1) & 7)) * 16);
@@ -1102,13 +1213,13 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     }
     const uint32_t b_rd = (wn * 64 + (lane & 31)) * CV_ROWB + (((lane >> 5) ^ ((lane >> 1) & 7)) * 16);
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TN][TM];                                                          // TRANSPOSED: [channel tile][pixel tile], rows of a tile = output channels (cv_epilogue_direct)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
     // ---- the K loop ------------------------------------------------------------------------------------------------------------------------
     // K-tile t: generic (tap, ci) = (t / kc, t % kc); ROWS: group g = t / 3 = kh * kc + ci, kw = t % 3, B tap = kh * 3 + kw.
@@ -1151,74 +1262,106 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
         if (l_kt < KT && l_ci == 0) set_tap(l_tap);
     }
     pp_wait_vm_lgkm_barrier(in_flight_young);                                    // K-tile 0 (and the zero rows) in place for every wave
+#ifdef CV_PP_TIMING
+    if (tid == 0) stamps[1] = __builtin_amdgcn_s_memtime();
+#endif
     if (group == 1) pp_barrier();                                                // the stagger: group 1 runs one barrier behind
 
     uint32_t issued_prev = 0;
-    for (uint32_t t = 0; t < KT; ++t) {
-        const unsigned char* sb = bbuf + (t % NB) * B_BUF;
-        const unsigned char* sa;
-        uint32_t kw = 0;
-        if (ROWS) { kw = t % 3; sa = abuf + ((t / 3) & 1) * A_BUF; } else sa = abuf + (t % NA) * A_BUF;
+    // one phase: P = k-half of the K-tile (compile time), KW = tap column (ROWS; compile time: the K-tiles of a group are unrolled), t = K-tile
+    auto phase = [&](auto pc, auto kwc, uint32_t t, const unsigned char* sa, const unsigned char* sb) {
+        constexpr int P = decltype(pc)::value, KW = decltype(kwc)::value;
+        // ---- load segment: this phase's fragments ...
+        bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            // ---- load segment: this phase's fragments ...
-            bf16x8 fa[2][TM], fb[2][TN];
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(sa + (a_rd[i][ROWS ? KW : 0] ^ ((2 * P + s) * 32)));
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const uint32_t off = ROWS ? (kw == 0 ? a_rd[i][0] : kw == 1 ? a_rd[i][1 % (ROWS ? 3 : 1)] : a_rd[i][2 % (ROWS ? 3 : 1)]) : a_rd[i][0];
-                    fa[s][i] = *reinterpret_cast<const bf16x8*>(sa + (off ^ ((2 * p + s) * 32)));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(sb + ((b_rd + j * 32 * CV_ROWB) ^ ((2 * p + s) * 32)));
+            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(sb + ((b_rd + j * 32 * CV_ROWB) ^ ((2 * P + s) * 32)));
+        }
+        // ---- ... and this wave's share of the DMA two K-tiles ahead
+        uint32_t issued = 0;
+        if (ROWS) {
+            if (l_kt < KT) {                                                     // B piece P of K-tile l_kt = t + 2: tap = kh * 3 + kw of group l_kt / 3
+                const uint32_t g = l_kt / 3, bkh = g / kc, bci = g % kc;
+                issue_b(P, bkh * 3 + l_kt % 3, bci * CV_BK, l_kt % NB);
+                ++issued;
             }
-            // ---- ... and this wave's share of the DMA two K-tiles ahead
-            uint32_t issued = 0;
-            if (ROWS) {
-                if (l_kt < KT) {                                                 // B piece p of K-tile l_kt = t + 2: tap = kh * 3 + kw with (kh, ci) of group l_kt / 3
-                    const uint32_t g = l_kt / 3, bkh = g / kc, bci = g % kc;
-                    issue_b(p, bkh * 3 + l_kt % 3, bci * CV_BK, l_kt % NB);
-                    ++issued;
-                }
-                const uint32_t q6 = (2 * t + p) % 6;
-                if (q6 < 4 && g_next < 3 * kc && g_next == t / 3 + 1) {          // A piece q6 of the next group
-                    if (q6 == 0) set_tap(g_kh);
-                    issue_a((int)q6 == 0 ? 0 : (int)q6 == 1 ? 1 : (int)q6 == 2 ? 2 : 3, g_ci * CV_BK, g_next & 1);
-                    ++issued;
-                    if (q6 == 3) { ++g_next; if (++g_ci == kc) { g_ci = 0; ++g_kh; } }
-                }
-                if (p == 1) ++l_kt;
-            } else {
-                if (l_kt < KT) {
-                    issue_a(2 * p, l_ci * CV_BK, l_kt % NA); issue_a(2 * p + 1, l_ci * CV_BK, l_kt % NA);
-                    issue_b(p, l_tap, l_ci * CV_BK, l_kt % NB);
-                    issued = 3;
-                    if (p == 1) { advance_l(); if (l_kt < KT && l_ci == 0) set_tap(l_tap); }
-                }
+            constexpr int Q6 = 2 * KW + P;                                       // phase within the group: A piece Q6 of the NEXT group in its first four phases
+            if (Q6 < 4 && g_next < 3 * kc) {
+                if (Q6 == 0) set_tap(g_kh);
+                issue_a(Q6 < 4 ? Q6 : 0, g_ci * CV_BK, g_next & 1);
+                ++issued;
+                if (Q6 == 3) { ++g_next; if (++g_ci == kc) { g_ci = 0; ++g_kh; } }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (p == 0) pp_wait_lgkm_barrier();
-            else pp_wait_vm_lgkm_barrier(issued_prev + issued);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- compute segment
-            __builtin_amdgcn_s_setprio(1);
+            if (P == 1) ++l_kt;
+        } else {
+            if (l_kt < KT) {
+                issue_a(2 * P, l_ci * CV_BK, l_kt % NA); issue_a(2 * P + 1, l_ci * CV_BK, l_kt % NA);
+                issue_b(P, l_tap, l_ci * CV_BK, l_kt % NB);
+                issued = 3;
+                if (P == 1) { advance_l(); if (l_kt < KT && l_ci == 0) set_tap(l_tap); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (P == 0) pp_wait_lgkm_barrier();
+        else pp_wait_vm_lgkm_barrier(issued_prev + issued);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute segment
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            pp_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            issued_prev = issued;
+                for (int j = 0; j < TN; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s][j], fa[s][i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issued_prev = issued;
+        (void)t;
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+#ifdef CV_PP_SKIP_KLOOP
+    if (false)
+#endif
+    if (ROWS) {
+        for (uint32_t g = 0, t = 0; g < 3 * kc; ++g, t += 3) {                    // group (kh, ci): three K-tiles (kw) from one A stage
+            const unsigned char* sa = abuf + (g & 1) * A_BUF;
+            phase(P0{}, std::integral_constant<int, 0>{}, t, sa, bbuf + (t % NB) * B_BUF);
+            phase(P1{}, std::integral_constant<int, 0>{}, t, sa, bbuf + (t % NB) * B_BUF);
+            phase(P0{}, std::integral_constant<int, 1>{}, t + 1, sa, bbuf + ((t + 1) % NB) * B_BUF);
+            phase(P1{}, std::integral_constant<int, 1>{}, t + 1, sa, bbuf + ((t + 1) % NB) * B_BUF);
+            phase(P0{}, std::integral_constant<int, 2>{}, t + 2, sa, bbuf + ((t + 2) % NB) * B_BUF);
+            phase(P1{}, std::integral_constant<int, 2>{}, t + 2, sa, bbuf + ((t + 2) % NB) * B_BUF);
+        }
+    } else {
+        for (uint32_t t = 0; t < KT; ++t) {
+            const unsigned char* sa = abuf + (t % NA) * A_BUF;
+            const unsigned char* sb = bbuf + (t % NB) * B_BUF;
+            phase(P0{}, P0{}, t, sa, sb);
+            phase(P1{}, P0{}, t, sa, sb);
         }
     }
     if (group == 0) pp_barrier();                                                // even out the stagger
     __syncthreads();                                                             // every wave is done with the stages (the epilogue reuses them)
-    cv_epilogue_bf16<TM, TN, 4, 2>(a, acc, lds, m0, n0);
+#ifdef CV_PP_SKIP_EPILOGUE                                                       // (timing experiment: keep the accumulators alive, store nothing)
+    if (acc[0][0][0] == 12345.678f) a.y[0] = 1;
+    continue;
+#endif
+#ifdef CV_PP_TIMING
+    if (tid == 0) stamps[2] = __builtin_amdgcn_s_memtime();
+#endif
+    cv_epilogue_direct<TM, TN>(a, acc, lds + RING, m0, n0, wm, wn);
+#ifdef CV_PP_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // (stamp 3 = this wave's stores acknowledged)
+    if (tid == 0) stamps[3] = __builtin_amdgcn_s_memtime();
+#endif
+    if (a.gn_sums) __syncthreads();                                              // (the next tile's epilogue zeroes the statistics scratch again)
+  }
 }
 
 template <int TM, int TN, int WM, int WN, int NS>
@@ -1239,11 +1382,12 @@ int cv_launch(ConvArgs& a, hipStream_t st) {
 static void cv_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, bool may_split, int splits_hint, int* choice_out, uint32_t* splits_out) {
     int choice = tile_hint;
     if (choice < 1 || choice > 4) {
-        const uint64_t t256 = (uint64_t)((M + 255) / 256) * (Cout / 128);
+        // r03 sweep of every low-resolution layer over (tile, splits) (profiles/r03/e_small_layer_sweep.jsonl): 128 x 128 tiles once they fill the chip
+        // 1.5 times over, 64 x 128 only for very wide outputs, else 64 x 64 -- more, shorter blocks beat fewer, longer ones below 32 x 32.
+        // (256 x 128 on 8 lock-step waves, hint 4, measures no faster than 128 x 128 at 2 blocks / CU; the two-group 256 x 128 kernel is hints 5 / 6.)
         const uint64_t t128 = (uint64_t)((M + 127) / 128) * (Cout / 128);
         const uint64_t t64 = (uint64_t)((M + 63) / 64) * (Cout / 128);
-        (void)t256;   // 256x128 (8 waves, hint 4) measures no faster than 128x128 at 2 blocks/CU: the loop is bound by DMA issue slots per MFMA, not by L2 bytes
-        choice = (Cout % 128 != 0) ? 3 : (t128 >= 384) ? 1 : (t64 >= 256) ? 2 : 3;
+        choice = (Cout % 128 != 0) ? 3 : (t128 >= 384) ? 1 : (t64 >= 512) ? 2 : 3;
     }
     const uint32_t bm = choice == 4 ? 256 : choice == 1 ? 128 : 64;
     const uint32_t tiles = ((M + bm - 1) / bm) * (Cout / (choice == 3 ? 64 : 128));
@@ -1251,7 +1395,14 @@ static void cv_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int
     uint32_t splits = 1;
     if (may_split) {
         if (splits_hint > 0) splits = (uint32_t)splits_hint;
-        else if (tiles < 512 && (uint64_t)M * Cout <= (1u << 20)) splits = (1024 + tiles - 1) / tiles;   // larger outputs: the fp32 atomics cost more than they buy
+        else if (tiles < 384 && (uint64_t)M * Cout <= (1u << 20)) {
+            // enough blocks for ~1.5 per CU, at least 12 K-tiles each; a 2-way split of a short K (< 64 K-tiles) costs more in fp32 atomics and
+            // the finishing pass than the half-empty chip it avoids (same sweep: 1 x 1 layers and 256 -> 512 @ 16 x 16 are fastest unsplit)
+            splits = (384 + tiles / 2) / tiles;
+            if (splits > KT / 12) splits = KT / 12;
+            if (splits == 2 && KT < 64) splits = 1;
+            if (splits < 1) splits = 1;
+        }
         if (splits > 16) splits = 16;
         if (splits > KT / 2) splits = KT / 2 ? KT / 2 : 1;                   // at least two K-tiles per block
     }
@@ -1356,6 +1507,38 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     a.Wo = (Wv + 2 * a.pad - ksize) / stride + 1;
     SSD_REQUIRE((uint64_t)B * a.Ho * a.Wo < (1ull << 31) && (uint64_t)B * H * W * Cin * 2 < (1ull << 40), "conv2d_nhwc_bf16: tensor too large");
     a.M = B * a.Ho * a.Wo;
+    hipStream_t st = (hipStream_t)stream;
+    // tile_hint 0: the two-group kernel takes the layers it measures faster on (r03, profiles/r03/e_bench_conv_two_group.jsonl): 3 x 3 / stride 1 layers
+    // whose 256-pixel tiles are whole image rows, from 64 x 64 upwards (row-reuse form), and the upsampling convolution of the 128 x 128 level
+    static const bool pp_auto = getenv("SSDNERF_CONV_NO_TWO_GROUP") == nullptr;
+    if (tile_hint == 0 && pp_auto && Cout % 128 == 0 && ksize == 3 && stride == 1 && a.M >= 32768 && (!gn_sums || (a.Ho * a.Wo) % 256 == 0)
+        && ((!upsample && (W == 128 || W == 64) && (H * W) % 256 == 0) || (upsample && a.M >= 131072)))
+        tile_hint = 6;
+    if (tile_hint == 5 || tile_hint == 6) {                                  // two-group ("ping-pong") 256 x 128 kernel; 6: the row-reuse form where it applies
+        SSD_REQUIRE(Cout % 128 == 0, "conv2d_nhwc_bf16: the 256 x 128 kernel needs Cout %% 128 == 0");
+        SSD_REQUIRE(!gn_sums || (a.Ho * a.Wo) % 256 == 0, "conv2d_nhwc_bf16: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
+        a.splits = 1;
+#ifdef CV_PP_TIMING
+        a.splitk_ws = (float*)splitk_ws;                                     // instrumented build: the caller's scratch receives the time stamps
+#else
+        a.splitk_ws = nullptr;
+#endif
+        a.m_tiles = (a.M + 255) / 256; a.n_tiles = Cout / 128;
+        const bool pp_rows = tile_hint == 6 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 256 == 0;
+        static int n_cu = 0;                                                 // one block per CU (LDS), persistent over the tiles
+        if (n_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu < 8) n_cu = 256;
+            n_cu &= ~7;
+        }
+        const uint32_t tiles = a.m_tiles * a.n_tiles, grid = tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu;
+        if (pp_rows) hipLaunchKernelGGL((k_conv_pp_bf16<true>), dim3(grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_pp_bf16<false>), dim3(grid), dim3(512), 0, st, a);
+        SSD_CHECK_LAUNCH("conv2d_nhwc_bf16");
+        return SSDNERF_OK;
+    }
     int choice; uint32_t splits;
     cv_plan(a.M, Cin, Cout, ksize, tile_hint, splitk_ws && splitk_ws_bytes >= (size_t)a.M * Cout * 4 && Cout <= 1024, splits_hint, &choice, &splits);
     if (choice != 3) SSD_REQUIRE(Cout % 128 == 0, "conv2d_nhwc_bf16: 128-wide tiles need Cout %% 128 == 0");
@@ -1363,7 +1546,6 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     a.splits = splits; a.splitk_ws = (float*)splitk_ws;
     double* stats = a.gn_sums;
     if (splits > 1) a.gn_sums = nullptr;                                     // a split layer's statistics are taken by the finishing pass
-    hipStream_t st = (hipStream_t)stream;
     static const bool rows_ok = getenv("SSDNERF_CONV_NO_ROW_REUSE") == nullptr;
     const bool rows = rows_ok && choice == 1 && splits == 1 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 128 == 0;
     if (rows) {

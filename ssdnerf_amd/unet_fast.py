@@ -435,7 +435,7 @@ class FastUnet:
         plan = C.lib().ssdnerf_conv2d_nhwc_bf16_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, int(_Conv.splitk_ws is not None), 0)
         if plan >> 8 != 1:
             return True                                                     # a split-K layer: its finishing pass takes the statistics
-        return hw % 128 == 0                                                # unsplit: the M tile must lie inside one sample
+        return hw % (256 if (plan & 0xff) == 4 else 128 if (plan & 0xff) == 1 else 64) == 0   # unsplit: the M tile must lie inside one sample
 
     def _res(self, x, stats, op, ss_all, x2=None):
         """One residual block.  ``x2``: the block's input is the concatenation [x | x2] (decoder half) and is never built."""

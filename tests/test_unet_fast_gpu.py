@@ -186,6 +186,26 @@ CONV_CASES = [
     (8, 64, 64, 512, 256, 3, 1, False, 0),
     (8, 8, 8, 512, 512, 3, 1, False, 0),       # split-K at 8 x 8
     (8, 4, 4, 512, 512, 3, 1, False, 0),       # ... and at 4 x 4
+    # r03: the two-group ("ping-pong") 256 x 128 kernel, generic (hint 5) and row-reuse (hint 6) forms
+    (2, 16, 16, 128, 128, 3, 1, False, 5),
+    (2, 16, 16, 128, 128, 3, 1, False, 6),     # W = 16: not eligible for row reuse -> generic form
+    (3, 10, 10, 64, 256, 3, 1, False, 5),      # ragged last tile (M = 300), every border case, one channel tile per tap
+    (2, 8, 8, 64, 128, 1, 1, False, 5),        # ONE K-tile in all
+    (3, 9, 6, 128, 256, 1, 1, False, 5),       # two K-tiles
+    (2, 16, 16, 128, 128, 3, 2, False, 5),     # stride 2
+    (1, 16, 16, 128, 256, 3, 1, True, 5),      # upsample fused into the gather
+    (1, 32, 32, 128, 256, 3, 1, False, 6),     # row reuse: eight image rows per tile
+    (1, 64, 64, 128, 128, 3, 1, False, 6),     # ... four
+    (2, 128, 128, 128, 128, 3, 1, False, 6),   # ... two, tiles of two samples
+    (1, 64, 64, 384, 256, 3, 1, False, 6),     # six channel tiles per tap row
+    (8, 128, 128, 128, 128, 3, 1, False, 6),   # bench shapes
+    (8, 128, 128, 256, 128, 3, 1, False, 6),
+    (8, 64, 64, 256, 256, 3, 1, False, 6),
+    (8, 64, 64, 256, 256, 3, 1, True, 5),
+    (8, 128, 128, 256, 128, 1, 1, False, 5),
+    (8, 128, 128, 128, 128, 3, 2, False, 5),
+    (8, 128, 128, 64, 128, 3, 1, False, 6),    # the stem after channel padding: ONE channel tile per tap row
+    (8, 64, 64, 64, 128, 3, 1, False, 6),
 ]
 
 
@@ -207,15 +227,17 @@ def test_conv_igemm_matches_fp32_reference(B, H, W, Cin, Cout, k, stride, upsamp
     assert ((got.float() - want).norm() / want.norm()).item() < 4e-3
 
 
-@pytest.mark.parametrize("C,hint,H", [(128, 1, 16), (256, 2, 8), (384 * 2, 3, 8), (512, 0, 32), (128, 4, 16), (256, 4, 32)])
-def test_conv_igemm_fused_groupnorm_statistics(C, hint, H):
+@pytest.mark.parametrize("C,hint,H", [(128, 1, 16), (256, 2, 8), (384 * 2, 3, 8), (512, 0, 32), (128, 4, 16), (256, 4, 32), (128, 5, 16), (256, 6, 32), (128, 6, 64)])
+def test_conv_igemm_fused_groupnorm_statistics(C, hint, H, B=2):
     g = torch.Generator().manual_seed(C)
-    B, G = 2, 32
+    G = 32
     x = torch.randn(B, 64, H, H, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(C, 64, 3, 3, generator=g) / 24).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
     bias = torch.randn(C, generator=g).cuda()
     sums = torch.zeros(B, G, 2, dtype=torch.float64, device="cuda")
     y = unet_fast.conv2d_nhwc_bf16(x, w, bias, None, gn_sums=sums, gn_groups=G, tile_hint=hint)
+    want_y = _conv_ref(x, w, bias, None, 1, False)
+    assert ((y.float() - want_y).norm() / want_y.norm()).item() < 4e-3        # (the statistics epilogue must not disturb the product itself)
     yf = y.double().reshape(B, G, C // G, H * H)
     assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-5, atol=1e-3)
     assert torch.allclose(sums[..., 1], yf.square().sum((2, 3)), rtol=1e-5, atol=1e-3)
@@ -224,6 +246,13 @@ def test_conv_igemm_fused_groupnorm_statistics(C, hint, H):
     out = unet_fast.group_norm_nhwc(y, G, gamma, beta, None, 1e-5, True, sums, stats_ready=True)
     want = F.silu(F.group_norm(y.float(), G, gamma, beta, 1e-5))
     assert (out.float() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+
+
+def test_two_group_kernel_statistics_with_several_tiles_per_block():
+    """512 tiles on 256 persistent blocks (the bench shape): every block runs its epilogue -- and its GroupNorm scratch -- twice (r03: the scratch
+    once overlapped the zero rows the row-reuse form keeps at the head of its first stage, which the second tile then multiplied as padding)"""
+    test_conv_igemm_fused_groupnorm_statistics(128, 6, 128, B=8)
+    test_conv_igemm_fused_groupnorm_statistics(128, 5, 128, B=8)
 
 
 @pytest.mark.parametrize("B,H,Cin,Cout,k,splits", [(8, 8, 512, 512, 3, 0), (2, 16, 1024, 512, 3, 5), (4, 8, 256, 512, 1, 2), (1, 5, 128, 64, 3, 3)])
@@ -317,6 +346,9 @@ def test_concat_is_fused_into_norm_and_shortcut(C1, C2, H):
     assert torch.equal(unet_fast.conv2d_nhwc_bf16(a, w, x2=b), unet_fast.conv2d_nhwc_bf16(cat, w))
     w3 = (torch.randn(128, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
     assert torch.equal(unet_fast.conv2d_nhwc_bf16(a, w3, x2=b), unet_fast.conv2d_nhwc_bf16(cat, w3))
+    for hint in (5, 6):                                                      # the two-group kernel reads the two tensors the same way
+        assert torch.equal(unet_fast.conv2d_nhwc_bf16(a, w3, x2=b, tile_hint=hint), unet_fast.conv2d_nhwc_bf16(cat, w3, tile_hint=hint))
+        assert torch.equal(unet_fast.conv2d_nhwc_bf16(a, w, x2=b, tile_hint=hint), unet_fast.conv2d_nhwc_bf16(cat, w, tile_hint=hint))
 
 
 def test_statistics_from_split_k_and_residual_add():

@@ -2,7 +2,7 @@
 # tools/prof_conv.sh [hint] -- rocprofv3 kernel trace + PMC counters of the implicit-GEMM convolution kernel (run on the GPU box).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_conv
+OUT=$R/gpurun_out/prof_conv_h${1:-0}
 rm -rf $OUT && mkdir -p $OUT
 cd $R
 HINT=${1:-0}
@@ -11,7 +11,7 @@ find /tmp/rc_kt -name "*kernel_trace.csv" -exec cp {} $OUT/ \;
 python - <<'PY' > $OUT/kernel_durations.txt
 import csv, glob, collections
 for f in glob.glob("/tmp/rc_kt/**/*kernel_trace.csv", recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "conv_igemm" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "k_conv" in r["Kernel_Name"]]
     for i, r in enumerate(rows):
         print(i, r["Kernel_Name"][:70], "grid", r.get("Grid_Size_X", r.get("Grid_Size", "?")), "us", (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 PY
@@ -23,7 +23,7 @@ n = sys.argv[1]
 rows = collections.OrderedDict()
 for f in glob.glob(f"/tmp/rc_{n}/**/*counter_collection*.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv_igemm" not in r["Kernel_Name"]: continue
+        if "k_conv" not in r["Kernel_Name"]: continue
         rows.setdefault((r["Dispatch_Id"], r["Grid_Size"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 for (d, g), c in rows.items():
     print(n, "dispatch", d, "grid", g, " ".join(f"{k}={v:.6g}" for k, v in sorted(c.items())))
