@@ -67,6 +67,112 @@ SSD_DEV uint32_t cv_bf16_rne(float x) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// LDS-DMA through a BUFFER descriptor (r03): `buffer_load_dwordx4 voffset, rsrc, soffset offen lds`.  Against the flat form used above
+// (global_load_lds with a 64-bit address per lane) it takes ONE 32-bit offset register per lane and a scalar offset -- the channel tile / tap of a
+// K-tile is a scalar add -- and a lane whose offset lies outside the buffer (>= num_records) reads zeros: padding taps are an offset of 2^31, no zero
+// page, no 64-bit selects.  The r02 loop spent ~190 VALU + SALU instructions per K-tile and wave on addresses beside 16 MFMAs (PMC: active-issue
+// 1000 cycles per K-tile against 512 MFMA cycles); this form needs ~40.
+// Epilogue of the two-group kernel, straight from the accumulators (r03).  The K loop multiplies TRANSPOSED -- weights as the MFMA's A operand, pixels
+// as B -- so that in the 32 x 32 C layout a lane holds ONE output pixel (lane & 31) and four runs of four consecutive output channels
+// (e = 4 q + r  ->  channel 8 q + 4 (lane >> 5) + r): bias (+ residual) are added in fp32, the 16 values are rounded once to bf16 and packed, one
+// v_permlane32_swap per packed dword pairs the two lane halves so that every lane holds 8 consecutive channels, and the tile leaves as 16-byte stores
+// (programming guide T21).  No LDS round trip, no block barrier: the LDS-staged epilogue above cost 17 - 25 us of a 56 us layer once the K loop no
+// longer hid it (profiles/r03/d_pp_epilogue_split.txt).  GroupNorm sums of the rounded values: per lane over its pixels, DPP-reduced over the 32
+// lanes of each half, one LDS atomic per 4-channel run and wave, then the same per-group fp64 atomics as cv_epilogue_bf16.
+SSD_DEV float cv_half_wave_sum(float v) {                                       // sum over the 32 lanes of each wave half, valid in lanes 16-31 / 48-63
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+template <int TM, int TN>
+SSD_DEV void cv_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TN][TM], unsigned char* lds, uint32_t m0, uint32_t n0, uint32_t wm, uint32_t wn) {
+    constexpr int BN = 128;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    float* red = reinterpret_cast<float*>(lds);                              // [BN / 4 runs][sum, sumsq]: the caller hands in 512 bytes BEHIND the stage ring (the
+                                                                             // persistent kernel's zero rows at the head of A stage 0 must survive this epilogue)
+    if (a.gn_sums) {
+        if (tid < BN / 4 * 2) red[tid] = 0.f;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const uint32_t cb = n0 + wn * 32 * TN + j * 32;                      // first channel of this 32-channel tile
+        float4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t m = m0 + wm * 32 * TM + i * 32 + (lane & 31);
+            const bool ok = m < a.M;
+            const size_t row = (size_t)(ok ? m : 0) * a.Cout;
+            uint2 pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float f[4] = {acc[j][i][4 * q] + bv[q].x, acc[j][i][4 * q + 1] + bv[q].y, acc[j][i][4 * q + 2] + bv[q].z, acc[j][i][4 * q + 3] + bv[q].w};
+                if (a.res) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.res + (row + cb + 8 * q + 4 * half) * 2);
+                    f[0] += __uint_as_float(rv.x << 16); f[1] += __uint_as_float(rv.x & 0xffff0000u);
+                    f[2] += __uint_as_float(rv.y << 16); f[3] += __uint_as_float(rv.y & 0xffff0000u);
+                }
+                pk[q] = make_uint2(cv_bf16_rne(f[0]) | (cv_bf16_rne(f[1]) << 16), cv_bf16_rne(f[2]) | (cv_bf16_rne(f[3]) << 16));
+                if (a.gn_sums && ok) {
+                    const float r0 = __uint_as_float(pk[q].x << 16), r1 = __uint_as_float(pk[q].x & 0xffff0000u);
+                    const float r2 = __uint_as_float(pk[q].y << 16), r3 = __uint_as_float(pk[q].y & 0xffff0000u);
+                    gs[q] += (r0 + r1) + (r2 + r3);
+                    gq[q] = __builtin_fmaf(r0, r0, gq[q]); gq[q] = __builtin_fmaf(r1, r1, gq[q]);
+                    gq[q] = __builtin_fmaf(r2, r2, gq[q]); gq[q] = __builtin_fmaf(r3, r3, gq[q]);
+                }
+            }
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {                                 // lower half ends up with channels 16 qp .. + 7, upper half with 16 qp + 8 .. + 15 of ITS pixel
+                auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * qp].x, pk[2 * qp + 1].x, false, false);
+                auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * qp].y, pk[2 * qp + 1].y, false, false);
+                if (ok) *reinterpret_cast<uint4*>(a.y + (row + cb + 16 * qp + 8 * half) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+        }
+        if (a.gn_sums) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s1 = cv_half_wave_sum(gs[q]), s2 = cv_half_wave_sum(gq[q]);
+                if ((lane & 31) == 31) {                                     // lanes 31 and 63 hold their half's totals: run index = (channel - n0) / 4
+                    const uint32_t run = (cb - n0 + 8 * q + 4 * half) / 4;
+                    atomicAdd(&red[run * 2], s1);
+                    atomicAdd(&red[run * 2 + 1], s2);
+                }
+            }
+        }
+    }
+    if (a.gn_sums) {                                                         // host guarantees: the tile lies in ONE sample, groups are multiples of 4 channels
+        __syncthreads();
+        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;
+        if (tid < ng && m0 < a.M) {
+            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
+            float ss = 0.f, qq = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
+            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
+            atomicAdd(dst, (double)ss);
+            atomicAdd(dst + 1, (double)qq);
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) void* cv_lds_ptr;
+SSD_DEV __amdgpu_buffer_rsrc_t cv_rsrc(const void* base, uint64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (uint32_t)bytes, 0x00020000);
+}
+// (a plain function on purpose: with the builtin written directly inside the five-parameter kernel template, this toolchain's HOST pass marks the
+// instantiation invalid without a diagnostic and emits no launch stub -- an undefined `__device_stub__` at load time)
+SSD_DEV void cv_dma16(__amdgpu_buffer_rsrc_t r, unsigned char* dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (cv_lds_ptr)dst, 16, voff, soff, 0, 0);
+}
+static constexpr uint32_t CV_OOB = 0x80000000u;                              // voffset of a padding / out-of-range row (tensors are < 2^31 bytes: host check)
+
+
 template <int N> SSD_DEV void cv_wait_tiles_and_barrier() {
     // this wave's DMA of the tile about to be read has landed (N younger loads may stay in flight), its own LDS reads of the previous
     // tile have returned; after the barrier that holds for every wave, so the buffer of the previous tile may be refilled
@@ -166,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && EP_ROWS % (32 * TM) == 0, "tile / wave grid mismatch");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: LDS-DMA destinations are wave-uniform)
     const uint32_t wm = wave / WN, wn = wave % WN;
 
     // ---- XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous range of tiles (M-major) ----------------
@@ -204,8 +310,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
         b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
     }
 
-    uint64_t a_src[A_INST], a_src2[A_INST];                                  // per-tap source of each A row in x / x2 (or the zero page)
-    bool a_zero[A_INST];
+    // r03: LDS-DMA through buffer descriptors (see cv_rsrc): one 32-bit offset per piece and tap, the channel tile as the scalar offset, padding taps
+    // as an out-of-range offset that reads zeros -- the 64-bit source selects of r02 were most of the ~190 address instructions per K-tile
+    const __amdgpu_buffer_rsrc_t rs_x = cv_rsrc(a.x, (uint64_t)a.B * a.H * a.W * a.Cin1 * 2);
+    const __amdgpu_buffer_rsrc_t rs_x2 = cv_rsrc(a.x2 ? a.x2 : a.x, a.x2 ? (uint64_t)a.B * a.H * a.W * (a.Cin - a.Cin1) * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rs_w = cv_rsrc(a.w, (uint64_t)a.Cout * taps * a.Cin * 2);
+    uint32_t a_voff[A_INST], a_voff2[A_INST];
     const uint32_t Cin2 = a.Cin - a.Cin1;
     auto set_tap = [&](uint32_t tap) {
         const int32_t kh = (int32_t)(tap / a.ksize), kw = (int32_t)(tap % a.ksize);
@@ -214,10 +324,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
             const int32_t yv = a_y0[i] + kh, xv = a_x0[i] + kw;
             const bool ok = a_ok[i] && yv >= 0 && xv >= 0 && yv < (int32_t)Hv && xv < (int32_t)Wv;
             const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
-            const uint64_t pix = (uint64_t)(a_img[i] + yi * a.W + xi);
-            a_zero[i] = !ok;
-            a_src[i] = ok ? (uint64_t)a.x + pix * a.Cin1 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
-            a_src2[i] = (ok && a.x2) ? (uint64_t)a.x2 + pix * Cin2 * 2 + a_chunk[i] : (uint64_t)g_conv_zero_page;
+            const uint32_t pix = a_img[i] + yi * a.W + xi;
+            a_voff[i] = ok ? pix * a.Cin1 * 2 + a_chunk[i] : CV_OOB;
+            a_voff2[i] = ok ? pix * Cin2 * 2 + a_chunk[i] : CV_OOB;
         }
     };
 
@@ -225,13 +334,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
         unsigned char* sa = lds + buf * STAGE;
         unsigned char* sb = sa + BM * CV_ROWB;
         const bool second = ci0 >= a.Cin1;                                   // K-tiles never straddle the two tensors (Cin1 % 64 == 0)
-        const uint64_t coff = (uint64_t)(second ? ci0 - a.Cin1 : ci0) * 2;
+        const uint32_t coff = (second ? ci0 - a.Cin1 : ci0) * 2;
 #pragma unroll
-        for (int i = 0; i < A_INST; ++i)
-            cv_glds16((const void*)((second ? a_src2[i] : a_src[i]) + (a_zero[i] ? 0 : coff)), sa + (wave * A_INST + i) * 1024);
+        for (int i = 0; i < A_INST; ++i) {
+            unsigned char* dst = sa + (wave * A_INST + i) * 1024;
+            if (second) cv_dma16(rs_x2, dst, a_voff2[i], coff);
+            else cv_dma16(rs_x, dst, a_voff[i], coff);
+        }
 #pragma unroll
         for (int i = 0; i < B_INST; ++i)
-            cv_glds16(a.w + b_off[i] + (uint64_t)(tap * a.Cin + ci0) * 2, sb + (wave * B_INST + i) * 1024);
+            cv_dma16(rs_w, sb + (wave * B_INST + i) * 1024, b_off[i], (tap * a.Cin + ci0) * 2);
     };
 
     // ---- reader geometry ---------------------------------------------------------------------------------------------------
@@ -993,106 +1105,6 @@ SSD_DEV void pp_wait_vm_lgkm_barrier(uint32_t n) {          // n = DMA instructi
 SSD_DEV void pp_wait_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 SSD_DEV void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// LDS-DMA through a BUFFER descriptor (r03): `buffer_load_dwordx4 voffset, rsrc, soffset offen lds`.  Against the flat form used above
-// (global_load_lds with a 64-bit address per lane) it takes ONE 32-bit offset register per lane and a scalar offset -- the channel tile / tap of a
-// K-tile is a scalar add -- and a lane whose offset lies outside the buffer (>= num_records) reads zeros: padding taps are an offset of 2^31, no zero
-// page, no 64-bit selects.  The r02 loop spent ~190 VALU + SALU instructions per K-tile and wave on addresses beside 16 MFMAs (PMC: active-issue
-// 1000 cycles per K-tile against 512 MFMA cycles); this form needs ~40.
-// Epilogue of the two-group kernel, straight from the accumulators (r03).  The K loop multiplies TRANSPOSED -- weights as the MFMA's A operand, pixels
-// as B -- so that in the 32 x 32 C layout a lane holds ONE output pixel (lane & 31) and four runs of four consecutive output channels
-// (e = 4 q + r  ->  channel 8 q + 4 (lane >> 5) + r): bias (+ residual) are added in fp32, the 16 values are rounded once to bf16 and packed, one
-// v_permlane32_swap per packed dword pairs the two lane halves so that every lane holds 8 consecutive channels, and the tile leaves as 16-byte stores
-// (programming guide T21).  No LDS round trip, no block barrier: the LDS-staged epilogue above cost 17 - 25 us of a 56 us layer once the K loop no
-// longer hid it (profiles/r03/d_pp_epilogue_split.txt).  GroupNorm sums of the rounded values: per lane over its pixels, DPP-reduced over the 32
-// lanes of each half, one LDS atomic per 4-channel run and wave, then the same per-group fp64 atomics as cv_epilogue_bf16.
-SSD_DEV float cv_half_wave_sum(float v) {                                       // sum over the 32 lanes of each wave half, valid in lanes 16-31 / 48-63
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
-    return v;
-}
-
-template <int TM, int TN>
-SSD_DEV void cv_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TN][TM], unsigned char* lds, uint32_t m0, uint32_t n0, uint32_t wm, uint32_t wn) {
-    constexpr int BN = 128;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    float* red = reinterpret_cast<float*>(lds);                              // [BN / 4 runs][sum, sumsq]: the caller hands in 512 bytes BEHIND the stage ring (the
-                                                                             // persistent kernel's zero rows at the head of A stage 0 must survive this epilogue)
-    if (a.gn_sums) {
-        if (tid < BN / 4 * 2) red[tid] = 0.f;
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const uint32_t cb = n0 + wn * 32 * TN + j * 32;                      // first channel of this 32-channel tile
-        float4 bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const uint32_t m = m0 + wm * 32 * TM + i * 32 + (lane & 31);
-            const bool ok = m < a.M;
-            const size_t row = (size_t)(ok ? m : 0) * a.Cout;
-            uint2 pk[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float f[4] = {acc[j][i][4 * q] + bv[q].x, acc[j][i][4 * q + 1] + bv[q].y, acc[j][i][4 * q + 2] + bv[q].z, acc[j][i][4 * q + 3] + bv[q].w};
-                if (a.res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(a.res + (row + cb + 8 * q + 4 * half) * 2);
-                    f[0] += __uint_as_float(rv.x << 16); f[1] += __uint_as_float(rv.x & 0xffff0000u);
-                    f[2] += __uint_as_float(rv.y << 16); f[3] += __uint_as_float(rv.y & 0xffff0000u);
-                }
-                pk[q] = make_uint2(cv_bf16_rne(f[0]) | (cv_bf16_rne(f[1]) << 16), cv_bf16_rne(f[2]) | (cv_bf16_rne(f[3]) << 16));
-                if (a.gn_sums && ok) {
-                    const float r0 = __uint_as_float(pk[q].x << 16), r1 = __uint_as_float(pk[q].x & 0xffff0000u);
-                    const float r2 = __uint_as_float(pk[q].y << 16), r3 = __uint_as_float(pk[q].y & 0xffff0000u);
-                    gs[q] += (r0 + r1) + (r2 + r3);
-                    gq[q] = __builtin_fmaf(r0, r0, gq[q]); gq[q] = __builtin_fmaf(r1, r1, gq[q]);
-                    gq[q] = __builtin_fmaf(r2, r2, gq[q]); gq[q] = __builtin_fmaf(r3, r3, gq[q]);
-                }
-            }
-#pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {                                 // lower half ends up with channels 16 qp .. + 7, upper half with 16 qp + 8 .. + 15 of ITS pixel
-                auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * qp].x, pk[2 * qp + 1].x, false, false);
-                auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * qp].y, pk[2 * qp + 1].y, false, false);
-                if (ok) *reinterpret_cast<uint4*>(a.y + (row + cb + 16 * qp + 8 * half) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-            }
-        }
-        if (a.gn_sums) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float s1 = cv_half_wave_sum(gs[q]), s2 = cv_half_wave_sum(gq[q]);
-                if ((lane & 31) == 31) {                                     // lanes 31 and 63 hold their half's totals: run index = (channel - n0) / 4
-                    const uint32_t run = (cb - n0 + 8 * q + 4 * half) / 4;
-                    atomicAdd(&red[run * 2], s1);
-                    atomicAdd(&red[run * 2 + 1], s2);
-                }
-            }
-        }
-    }
-    if (a.gn_sums) {                                                         // host guarantees: the tile lies in ONE sample, groups are multiples of 4 channels
-        __syncthreads();
-        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;
-        if (tid < ng && m0 < a.M) {
-            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
-            float ss = 0.f, qq = 0.f;
-            for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
-            double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
-            atomicAdd(dst, (double)ss);
-            atomicAdd(dst + 1, (double)qq);
-        }
-    }
-}
-
-typedef __attribute__((address_space(3))) void* cv_lds_ptr;
-SSD_DEV __amdgpu_buffer_rsrc_t cv_rsrc(const void* base, uint64_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (uint32_t)bytes, 0x00020000);
-}
-static constexpr uint32_t CV_OOB = 0x80000000u;                              // voffset of a padding / out-of-range row (tensors are < 2^31 bytes: host check)
-
 template <bool ROWS>
 __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     constexpr int BM = 256, BN = 128, TM = 2, TN = 2;
@@ -1188,12 +1200,12 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
         }
     };
     auto issue_a = [&](int i, uint32_t ci0, uint32_t buf) {                      // one A piece of the tap set by set_tap; ci0 is scalar
-        const cv_lds_ptr dst = (cv_lds_ptr)(abuf + buf * A_BUF + a_lds[i]);
-        if (ci0 >= a.Cin1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, dst, 16, a_voff2[i], (ci0 - a.Cin1) * 2, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, dst, 16, a_voff[i], ci0 * 2, 0, 0);
+        unsigned char* dst = abuf + buf * A_BUF + a_lds[i];
+        if (ci0 >= a.Cin1) cv_dma16(rs_x2, dst, a_voff2[i], (ci0 - a.Cin1) * 2);
+        else cv_dma16(rs_x, dst, a_voff[i], ci0 * 2);
     };
     auto issue_b = [&](int i, uint32_t tap, uint32_t ci0, uint32_t buf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (cv_lds_ptr)(bbuf + buf * B_BUF + (wave * 2 + i) * 1024), 16, b_voff[i], (tap * a.Cin + ci0) * 2, 0, 0);
+        cv_dma16(rs_w, bbuf + buf * B_BUF + (wave * 2 + i) * 1024, b_voff[i], (tap * a.Cin + ci0) * 2);
     };
 
     // ---- reader geometry ---------------------------------------------------------------------------------------------------------------

@@ -33,12 +33,18 @@ REF = os.environ.get("REF", "/root/reference")
 sys.path.insert(0, ROOT)
 
 
-def _install_stubs():
-    import oracle
-    ops = oracle.ref_ops("fma") or oracle.ops()
-    backend_name = "oracle/_ref (reference kernels on CPU)" if oracle.ref_ops("fma") else "C oracle"
-
-    torch.Tensor.cuda = lambda self, *a, **k: self            # the wrappers call .cuda() unconditionally
+def _install_stubs(native="oracle"):
+    """native="oracle": `_raymarching` / `_shencoder` backed by the CPU oracle (fixture generation, no GPU).
+    native="dropin": the product's drop-in modules (ssdnerf_amd/dropin) are left to resolve those two names -- the reference's own wrappers
+    and renderer then run on the MI355X library (tools/option_a_on_gpu.py); only the mmcv / mmgen helpers are stubbed."""
+    if native == "dropin":
+        ops, backend_name = None, "ssdnerf_amd/dropin over libssdnerf_hip.so"
+        sys.path.insert(0, os.path.join(ROOT, "ssdnerf_amd", "dropin"))
+    else:
+        import oracle
+        ops = oracle.ref_ops("fma") or oracle.ops()
+        backend_name = "oracle/_ref (reference kernels on CPU)" if oracle.ref_ops("fma") else "C oracle"
+        torch.Tensor.cuda = lambda self, *a, **k: self        # the wrappers call .cuda() unconditionally
     if not hasattr(np, "cumproduct"):
         np.cumproduct = np.cumprod                            # numpy >= 2 dropped the alias the reference uses (gaussian_diffusion.py:134)
 
@@ -99,7 +105,8 @@ def _install_stubs():
               composite_rays_train_backward, march_rays, composite_rays):
         setattr(rm, f.__name__, f)
     rm.LOG = LOG
-    sys.modules["_raymarching"] = rm
+    if native != "dropin":
+        sys.modules["_raymarching"] = rm
 
     sh = types.ModuleType("_shencoder")
 
@@ -114,7 +121,8 @@ def _install_stubs():
         grad_inputs.add_(torch.from_numpy(ops.sh_encode_backward(npv(grad), npv(inputs), C, npv(dy_dx))))
 
     sh.sh_encode_forward, sh.sh_encode_backward = sh_encode_forward, sh_encode_backward
-    sys.modules["_shencoder"] = sh
+    if native != "dropin":
+        sys.modules["_shencoder"] = sh
 
     # ---- mmcv / mmgen: only what the imported files touch ----
     class Registry:

@@ -286,3 +286,124 @@ def test_guide_optim_end_to_end(recons_model):
     assert float(out["code"].abs().max()) <= 2.0 and out["pred_imgs"].shape == (2, 1, 3, 128, 128)
     assert m.diffusion_ema.ddpm_loss.weight_scale == 1.0 and not m.decoder_ema.training
     assert all(p.requires_grad for p in m.diffusion_ema.denoising.parameters())
+
+
+# ---------------------------------------------------------------------------------------------- the training step
+def test_diffusion_nerf_train_step_matches_oracle(tmp_path):
+    """``DiffusionNeRF.train_step`` (lib/models/autodecoders/diffusion_nerf.py:66-189) through the REAL renderer on the GPU against the same step
+    written out on the CPU with the oracle's renderer (C march / composite, PyTorch-CPU decode with autograd): prior loss at drawn (t, noise) ->
+    its gradient on the pre-activation code seeds ``extra_scene_step`` code-only rendering iterations (grid refresh with decay, jittered march)
+    -> the joint iteration that steps the decoder as well.  Every random draw is injected on both sides (initial code, timestep and noise through
+    the host generators, march jitter and grid jitter through the model's public hooks); SGD everywhere, so updates are linear in the
+    gradients.  Compared: the cached pre-activation code, the stepped decoder weights, the logged losses, the density grid."""
+    import ssdnerf_amd  # noqa: F401
+    from oracle import diffusion as OD, guidance as OG, render as R
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.registry import MODELS
+    E, lr_c, lr_d = 1, 200.0, 0.05
+    hw = 64
+    m = MODELS.build(dict(
+        type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64,
+        diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(type="linear"),
+                       denoising=dict(type="DenoisingUnetMod", image_size=128, in_channels=18, base_channels=32, channels_cfg=[1, 1, 2],
+                                      resblocks_per_downsample=1, dropout=0.0, use_scale_shift_norm=True, num_heads=4, attention_res=[32],
+                                      norm_cfg=dict(type="GN", num_groups=8)),
+                       timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+                       ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight", data_info=dict(pred="v_t_pred", target="v_t"),
+                                      weight_scale=4.0, scale_norm=True)),
+        decoder=dict(type="TriPlaneDecoder", interp_mode="bilinear", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3],
+                     use_dir_enc=True, dir_layers=[16, 64], activation="silu", sigma_activation="trunc_exp", sigmoid_saturation=0.001, max_steps=256),
+        decoder_use_ema=True, freeze_decoder=False, bg_color=1, pixel_loss=dict(type="MSELoss", loss_weight=20.0),
+        reg_loss=dict(type="RegLoss", power=2, loss_weight=3e-3), cache_size=4,
+        train_cfg=dict(dt_gamma_scale=0.5, density_thresh=0.1, extra_scene_step=E, n_inverse_rays=hw * hw, n_decoder_rays=hw * hw,
+                       loss_coef=0.1 / (hw * hw), optimizer=dict(type="SGD", lr=lr_c))))
+    _randomize(m.diffusion.denoising, 9)
+    params0 = S.make_decoder_params()
+    m.decoder.load_state_dict(params0, strict=False)
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(41)
+    code0_ = m.code_activation.inverse(S.make_triplane(37)).contiguous()                 # the "fresh" pre-activation code of the scene
+    target = torch.rand(hw * hw, 3, generator=g)
+    marches = [torch.rand(hw * hw, generator=g) for _ in range(E + 1)]
+    jits = [torch.rand(64 ** 3, 3, generator=g) for _ in range(E + 1)]                  # one refresh in the code-only iterations (k = 0), one in the joint step
+    pose, intr = S.spiral_poses()[[64]], S.cars_intrinsics(hw, hw)
+
+    # ---- the product, with the draws routed in through its public hooks
+    m.get_init_code_ = lambda num_scenes, device=None: code0_.clone().to(device).requires_grad_(True)
+    orig_loss, orig_update = m.loss, m.update_extra_state
+    it_m, it_j, losses = iter(marches), iter(jits), []
+
+    def loss_with_injected_jitter(decoder, *a, **k):
+        decoder.injected_noises = next(it_m).cuda()[None]
+        try:
+            out = orig_loss(decoder, *a, **k)
+        finally:
+            decoder.injected_noises = None
+        losses.append(out[1].detach())
+        return out
+
+    m.loss = loss_with_injected_jitter
+    m.update_extra_state = lambda decoder, code, grid, bits, it, **k: orig_update(decoder, code, grid, bits, it, **dict(k, jitter=next(it_j).cuda()))
+    data = dict(scene_id=[1], scene_name=["a"], cond_imgs=target.reshape(1, 1, hw, hw, 3).cuda(), cond_poses=pose.cuda()[None],
+                cond_intrinsics=intr.cuda()[None, None])
+    opt = dict(diffusion=torch.optim.SGD(m.diffusion.parameters(), lr=1e-3), decoder=torch.optim.SGD(m.decoder.parameters(), lr=lr_d))
+    sd = {k: v.detach().cpu().clone() for k, v in m.diffusion.denoising.state_dict().items()}
+    norm0 = float(m.diffusion.ddpm_loss.norm_factor)
+    unet_before = m.diffusion.denoising.out.conv.weight.detach().clone()
+    np.random.seed(13); torch.manual_seed(13)
+    state = torch.random.get_rng_state()
+    t_exp = m.diffusion.sampler(1)                                                       # the draws train_step is about to make, in its order
+    n_exp = torch.randn(1, 18, 128, 128)
+    np.random.seed(13); torch.random.set_rng_state(state)
+    out = m.train_step(data, opt)
+    assert len(losses) == E + 1 and not torch.equal(m.diffusion.denoising.out.conv.weight, unet_before)
+    got_code_ = m.cache[1]["param"]["code_"].float().cpu()
+    got_grid = m.cache[1]["param"]["density_grid"].float().cpu().numpy()
+
+    # ---- the same step on the CPU
+    den = lambda x, t: OD.unet_forward(sd, x, t, image_size=128, base_channels=32, channels_cfg=(1, 1, 2), resblocks_per_downsample=1,
+                                       num_heads=4, attention_res=(32,), norm_groups=8)
+    tables = OD.schedule_tables(1000, "linear")
+    w, _ = OD.snr_timestep_weights(tables, 0.5, "V")
+    ro, rd = R.get_cam_rays(pose, intr[None], hw, hw)
+    ro, rd = ro.reshape(-1, 3).numpy(), rd.reshape(-1, 3).numpy()
+    dt_gamma = 0.5 / float(intr[:2].mean())
+    c_ = code0_.clone().requires_grad_(True)
+    x0 = (c_.tanh() * 2).reshape(1, 18, 128, 128)
+    norm1 = 0.999 * norm0 + 0.001 * float(x0.detach().square().mean())                   # training mode: the running norm moves before it divides
+    prior = OD.prior_loss_v(den, x0, t_exp, n_exp, tables, w, weight_scale=4.0, norm_factor=norm1)
+    (pg,) = torch.autograd.grad(prior, c_)
+    params = {k: v.clone() for k, v in params0.items()}
+    grid = np.zeros(64 ** 3, dtype=np.float16)                                           # a fresh scene's grid is fp16 zeros (get_init_density_grid)
+    kw = dict(loss_weight=20.0, loss_coef=0.1 / (hw * hw), reg_weight=3e-3, reg_power=2, scale_num_ray=hw * hw)
+    want_losses = []
+    for i in range(E):                                                                   # code-only iterations, decoder frozen
+        code = c_.tanh() * 2
+        bits, _ = R.update_extra_state(params, code.detach(), grid, jits[i].numpy(), density_thresh=0.1, decay=0.9)
+        loss, _ = OG.guidance_loss(params, code, bits, ro, rd, target, marches[i].numpy(), dt_gamma, **kw)
+        (rg,) = torch.autograd.grad(loss, c_)
+        with torch.no_grad():
+            c_ -= lr_c * (pg + rg)
+        want_losses.append(float(loss.detach()))
+    leaf_params = {k: v.clone().requires_grad_(True) for k, v in params.items()}         # the joint iteration: decoder and code
+    code = c_.tanh() * 2
+    bits, _ = R.update_extra_state(params, code.detach(), grid, jits[E].numpy(), density_thresh=0.1, decay=0.9)
+    loss, _ = OG.guidance_loss(leaf_params, code, bits, ro, rd, target, marches[E].numpy(), dt_gamma, **kw)
+    grads = torch.autograd.grad(loss, [c_] + list(leaf_params.values()))
+    want_losses.append(float(loss.detach()))
+    with torch.no_grad():
+        c_ -= lr_c * (pg + grads[0])
+    want_dec = {k: v.detach() - lr_d * gk for (k, v), gk in zip(leaf_params.items(), grads[1:])}
+
+    moved = float((c_.detach() - code0_).abs().max())
+    err = float((got_code_ - c_.detach()).abs().max())
+    lo = [float(v) for v in losses]
+    print(f"train_step parity: max|code_ - oracle| = {err:.3e}, max|update| = {moved:.3e}, losses {lo} vs {want_losses}")
+    assert moved > 1e-3 and err <= 2e-3 * moved
+    assert all(abs(a - b) <= 3e-4 * abs(b) for a, b in zip(lo, want_losses))
+    sd_dec = m.decoder.state_dict()
+    for k, v in want_dec.items():
+        step = float((v - params0[k]).abs().max())
+        assert float((sd_dec[k].cpu() - v).abs().max()) <= 2e-3 * step + 1e-7, k        # every decoder tensor moved by the oracle's gradient
+    assert float(out["log_vars"]["loss_decoder"]) == pytest.approx(want_losses[-1], rel=3e-4)
+    np.testing.assert_allclose(got_grid, grid.astype(np.float32), rtol=2e-3, atol=1e-4)
