@@ -180,7 +180,7 @@ template <int N> SSD_DEV void cv_wait_tiles_and_barrier() {
 }
 
 // bf16 epilogue shared by the bf16 kernels: accumulators -> fp32 tile in LDS (EP_ROWS rows per pass) -> (+bias, +residual) -> bf16 rows (+ GroupNorm sums)
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, bool PT = false>
 SSD_DEV void cv_epilogue_bf16(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* lds, uint32_t m0, uint32_t n0) {
     constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int EP_ROWS = BM < 128 ? BM : 128, EPI = EP_ROWS * BN * 4;
@@ -190,9 +190,10 @@ SSD_DEV void cv_epilogue_bf16(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned
     float* red = reinterpret_cast<float*>(lds + EPI);                        // [CPR][2 halves][sum, sumsq] block partials for the GroupNorm statistics
     if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
     const uint32_t cc = tid % CPR, co = n0 + cc * 8;
+    const bool c_ok = !PT || co < a.Cout;                                    // (PT: Cout is a multiple of 8 and need not fill the last N tile)
     float bias_v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
+    for (int k = 0; k < 8; ++k) bias_v[k] = (a.bias && c_ok) ? a.bias[co + k] : 0.f;
     float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
@@ -213,7 +214,7 @@ SSD_DEV void cv_epilogue_bf16(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned
 #pragma unroll 2
         for (uint32_t row = tid / CPR; row < (uint32_t)EP_ROWS; row += NT / CPR) {
             const uint32_t m = m0 + pass * EP_ROWS + row;
-            if (m >= a.M) break;
+            if (m >= a.M || !c_ok) break;
             const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8);
             const float4 v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
             float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -245,10 +246,11 @@ SSD_DEV void cv_epilogue_bf16(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned
 #pragma unroll
         for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
         __syncthreads();
-        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;   // groups this tile touches (BN and cpg are multiples of 4)
+        const uint32_t n1 = PT ? min(n0 + BN, a.Cout) : n0 + BN;              // end of the tile's channels
+        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n1 - 1) / cpg - g0 + 1;   // groups this tile touches (BN and cpg are multiples of 4)
         if (tid < ng && m0 < a.M) {
             // half chunks of group g0 + tid inside this tile: global half-chunk index range [g*hpg, (g+1)*hpg) minus the tile's first, n0/4
-            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
+            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, n1 / 4) - n0 / 4;
             float ss = 0.f, qq = 0.f;
             for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
             double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
@@ -258,8 +260,11 @@ SSD_DEV void cv_epilogue_bf16(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned
     }
 }
 
-// TM x TN MFMA tiles (32 x 32) per wave, WM x WN waves per block, NS staging buffers.
-template <int TM, int TN, int WM, int WN, int NS>
+// TM x TN MFMA tiles (32 x 32) per wave, WM x WN waves per block, NS staging buffers.  PT ("partial tiles", r03): channel counts are multiples of
+// 8 instead of 64 / the N tile -- the last K-tile of a tensor and the last N tile may be partly empty (the tiled UNet's 80 / 160 / 240 / 480-channel
+// layers, the 18 -> 24-channel stem and head).  A separate instantiation: the masks cost the small layers of the cars UNet (4 MFMAs per K-tile and
+// wave on the 64 x 64 tile) up to 30 % when they were unconditional (profiles/r03/f_partial_tiles_ab.txt).
+template <int TM, int TN, int WM, int WN, int NS, bool PT>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
     const uint32_t taps = a.ksize * a.ksize;
     const uint32_t Hv = a.upsample ? a.H * 2 : a.H, Wv = a.upsample ? a.W * 2 : a.W;   // the (virtual) image the taps move over
     int32_t a_y0[A_INST], a_x0[A_INST];
-    uint32_t a_img[A_INST], a_chunk[A_INST];
+    uint32_t a_img[A_INST], a_sc[A_INST];
     bool a_ok[A_INST];
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
@@ -301,13 +306,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
         a_y0[i] = (int32_t)((rem / a.Wo) * a.stride) - (int32_t)a.pad;
         a_x0[i] = (int32_t)((rem % a.Wo) * a.stride) - (int32_t)a.pad;
         a_img[i] = b * a.H * a.W;
-        a_chunk[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;                     // source-side swizzle
+        a_sc[i] = (lane & 7) ^ ((r >> 1) & 7);                               // source-side swizzle: the 8-channel chunk of the K-tile this lane fetches
     }
-    uint32_t b_off[B_INST];
+    uint32_t b_off[B_INST], b_sc[B_INST];
 #pragma unroll
     for (int i = 0; i < B_INST; ++i) {
         const uint32_t r = (wave * B_INST + i) * 8 + (lane >> 3);
-        b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        b_sc[i] = (lane & 7) ^ ((r >> 1) & 7);
+        b_off[i] = (!PT || n0 + r < a.Cout) ? ((n0 + r) * taps * a.Cin) * 2 + b_sc[i] * 16 : CV_OOB;   // (PT: rows past Cout read zeros)
     }
 
     // r03: LDS-DMA through buffer descriptors (see cv_rsrc): one 32-bit offset per piece and tap, the channel tile as the scalar offset, padding taps
@@ -325,25 +331,34 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
             const bool ok = a_ok[i] && yv >= 0 && xv >= 0 && yv < (int32_t)Hv && xv < (int32_t)Wv;
             const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
             const uint32_t pix = a_img[i] + yi * a.W + xi;
-            a_voff[i] = ok ? pix * a.Cin1 * 2 + a_chunk[i] : CV_OOB;
-            a_voff2[i] = ok ? pix * Cin2 * 2 + a_chunk[i] : CV_OOB;
+            a_voff[i] = ok ? pix * a.Cin1 * 2 + a_sc[i] * 16 : CV_OOB;
+            a_voff2[i] = ok ? pix * Cin2 * 2 + a_sc[i] * 16 : CV_OOB;
         }
     };
 
-    auto issue = [&](uint32_t tap, uint32_t ci0, uint32_t buf) {
+    // K-tiles of a tap: kc1 over the first tensor's channels, then kc2 over the second's; a tensor's LAST tile may hold fewer than 64 channels
+    // (channel counts are multiples of 8, e.g. the 80 / 160 / 240 / 480-channel layers of the tiled UNet): its missing 16-byte chunks read zeros on
+    // both operands, and the multiply loop runs only the 16-deep k-steps that hold channels
+    const uint32_t kc1 = (a.Cin1 + CV_BK - 1) / CV_BK, kc = kc1 + (Cin2 + CV_BK - 1) / CV_BK;
+    auto tile_channels = [&](uint32_t ci) {                                  // channels in K-tile ci of a tap
+        if (!PT) return (uint32_t)CV_BK;
+        const uint32_t left = ci >= kc1 ? Cin2 - (ci - kc1) * CV_BK : a.Cin1 - ci * CV_BK;
+        return left < (uint32_t)CV_BK ? left : (uint32_t)CV_BK;
+    };
+    auto issue = [&](uint32_t tap, uint32_t ci, uint32_t buf) {
         unsigned char* sa = lds + buf * STAGE;
         unsigned char* sb = sa + BM * CV_ROWB;
-        const bool second = ci0 >= a.Cin1;                                   // K-tiles never straddle the two tensors (Cin1 % 64 == 0)
-        const uint32_t coff = (second ? ci0 - a.Cin1 : ci0) * 2;
+        const bool second = ci >= kc1;                                       // K-tiles never straddle the two tensors
+        const uint32_t cb = (second ? ci - kc1 : ci) * CV_BK, coff = cb * 2, nchunk = tile_channels(ci) >> 3;
 #pragma unroll
         for (int i = 0; i < A_INST; ++i) {
             unsigned char* dst = sa + (wave * A_INST + i) * 1024;
-            if (second) cv_dma16(rs_x2, dst, a_voff2[i], coff);
-            else cv_dma16(rs_x, dst, a_voff[i], coff);
+            if (second) cv_dma16(rs_x2, dst, (!PT || a_sc[i] < nchunk) ? a_voff2[i] : CV_OOB, coff);
+            else cv_dma16(rs_x, dst, (!PT || a_sc[i] < nchunk) ? a_voff[i] : CV_OOB, coff);
         }
 #pragma unroll
         for (int i = 0; i < B_INST; ++i)
-            cv_dma16(rs_w, sb + (wave * B_INST + i) * 1024, b_off[i], (tap * a.Cin + ci0) * 2);
+            cv_dma16(rs_w, sb + (wave * B_INST + i) * 1024, (!PT || b_sc[i] < nchunk) ? b_off[i] : CV_OOB, (tap * a.Cin + (second ? a.Cin1 : 0u) + cb) * 2);
     };
 
     // ---- reader geometry ---------------------------------------------------------------------------------------------------
@@ -360,14 +375,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const uint32_t kc = a.Cin / CV_BK, KT_all = taps * kc;
+    const uint32_t KT_all = taps * kc;
     const uint32_t kt_begin = (uint32_t)((uint64_t)split * KT_all / a.splits), KT = (uint32_t)((uint64_t)(split + 1) * KT_all / a.splits) - kt_begin;
     // NS-stage pipeline, one barrier per K-tile: tiles kt+1 .. kt+NS-2 stay in flight while tile kt is multiplied
     uint32_t tap = kt_begin / kc, ci = kt_begin % kc, issued = 0;
+    uint32_t ci_mul = ci;                                                    // the multiply loop's own position inside the tap
     set_tap(tap);
     auto issue_next = [&]() {
         if (issued) { if (++ci == kc) { ci = 0; ++tap; set_tap(tap); } }
-        issue(tap, ci * CV_BK, issued % NS);
+        issue(tap, ci, issued % NS);
         ++issued;
     };
 #pragma unroll
@@ -380,22 +396,38 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
         else cv_wait_tiles_and_barrier<0>();
         if (issued < KT) issue_next();                                       // refills the buffer tile kt-1 was read from
         const unsigned char* st = lds + (kt % NS) * STAGE;
-        // all of the K-tile's fragments are requested before the first MFMA: the LDS latency is paid once per tile, not per k-step
-        bf16x8 fa[4][TM], fb[4][TN];
+        const uint32_t ksteps = (tile_channels(ci_mul) + 15) >> 4;           // 16-deep k-steps that hold channels (4 except in a tensor's last tile)
+        if (PT && ++ci_mul == kc) ci_mul = 0;
+        if (!PT || ksteps == 4) {
+            // all of the K-tile's fragments are requested before the first MFMA: the LDS latency is paid once per tile, not per k-step
+            bf16x8 fa[4][TM], fb[4][TN];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(st + ((a_rd + i * 32 * CV_ROWB) ^ (s * 32)));
+                for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(st + ((a_rd + i * 32 * CV_ROWB) ^ (s * 32)));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(st + ((b_rd + j * 32 * CV_ROWB) ^ (s * 32)));
+                for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(st + ((b_rd + j * 32 * CV_ROWB) ^ (s * 32)));
+            }
+            __builtin_amdgcn_sched_barrier(0);                               // keep the reads clustered ahead of the MFMAs (the scheduler would re-serialise them)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+        } else {
+            for (uint32_t s = 0; s < ksteps; ++s) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(st + ((a_rd + i * 32 * CV_ROWB) ^ (s * 32)));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(st + ((b_rd + j * 32 * CV_ROWB) ^ (s * 32)));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);                                   // keep the reads clustered ahead of the MFMAs (the scheduler would re-serialise them)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();                                                         // every wave is done with the staging buffers (the epilogue reuses them)
 
@@ -409,16 +441,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
                 for (int e = 0; e < 16; ++e) {
                     const uint32_t m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                     const uint32_t col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
-                    if (m < a.M) unsafeAtomicAdd(a.splitk_ws + (size_t)m * a.Cout + col, acc[i][j][e]);
+                    if (m < a.M && (!PT || col < a.Cout)) unsafeAtomicAdd(a.splitk_ws + (size_t)m * a.Cout + col, acc[i][j][e]);
                 }
         return;
     }
 
-    cv_epilogue_bf16<TM, TN, WM, WN>(a, acc, lds, m0, n0);
+    cv_epilogue_bf16<TM, TN, WM, WN, PT>(a, acc, lds, m0, n0);
 }
 
 // fp32 epilogue shared by the fp32-class kernels: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> fp32 rows (+ GroupNorm sums)
-template <int TM, int TN>
+template <int TM, int TN, bool PT = false>
 SSD_DEV void cv_epilogue_f32(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* lds, uint32_t m0, uint32_t n0) {
     constexpr int BM = 64 * TM, BN = 64 * TN, EPI = BM * BN * 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -435,16 +467,17 @@ SSD_DEV void cv_epilogue_f32(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned 
     if (a.gn_sums && tid < CPR * 4) red[tid] = 0.f;
     __syncthreads();
     const uint32_t cc = tid % CPR, co = n0 + cc * 8;
+    const bool c_ok = !PT || co < a.Cout;
     float bias_v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bias_v[k] = a.bias ? a.bias[co + k] : 0.f;
+    for (int k = 0; k < 8; ++k) bias_v[k] = (a.bias && c_ok) ? a.bias[co + k] : 0.f;
     float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
     float* yo = reinterpret_cast<float*>(a.y);
     const float* ro = reinterpret_cast<const float*>(a.res);
 #pragma unroll 2
     for (uint32_t row = tid / CPR; row < (uint32_t)BM; row += 256 / CPR) {
         const uint32_t m = m0 + row;
-        if (m >= a.M) break;
+        if (m >= a.M || !c_ok) break;
         const float4 v0 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8), v1 = *reinterpret_cast<const float4*>(tile_f + row * BN + cc * 8 + 4);
         float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
@@ -465,9 +498,10 @@ SSD_DEV void cv_epilogue_f32(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned 
 #pragma unroll
         for (int h = 0; h < 2; ++h) { atomicAdd(&red[(cc * 2 + h) * 2], gs[h]); atomicAdd(&red[(cc * 2 + h) * 2 + 1], gq[h]); }
         __syncthreads();
-        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n0 + BN - 1) / cpg - g0 + 1;
+        const uint32_t n1 = PT ? min(n0 + BN, a.Cout) : n0 + BN;
+        const uint32_t cpg = a.Cout / a.G, hpg = cpg / 4, g0 = n0 / cpg, ng = (n1 - 1) / cpg - g0 + 1;
         if (tid < ng && m0 < a.M) {
-            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, (n0 + BN) / 4) - n0 / 4;
+            const uint32_t lo = max((g0 + tid) * hpg, n0 / 4) - n0 / 4, hi = min((g0 + tid + 1) * hpg, n1 / 4) - n0 / 4;
             float ss = 0.f, qq = 0.f;
             for (uint32_t i = lo; i < hi; ++i) { ss += red[i * 2]; qq += red[i * 2 + 1]; }
             double* dst = a.gn_sums + ((size_t)(m0 / (a.Ho * a.Wo)) * a.G + g0 + tid) * 2;
@@ -627,7 +661,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_rows(const ConvArgs a) {
 //   * K-tile 32 (64-byte rows, chunks XOR-swizzled by (row >> 2) & 3: conflict-free ds_read_b128), 24 MFMAs per K-tile and wave for the
 //     128 x 128 tile -- three times the bf16 kernel's MFMA work per byte of L2 traffic, which is what that DMA-issue-bound kernel had spare;
 //   * epilogue as in the bf16 kernel, fp32 out (+ bias, + fp32 residual, + GroupNorm sums).
-template <int TM, int TN>
+template <int TM, int TN, bool PT>
 __global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, const unsigned char* __restrict__ w_lo) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, ROWB = BK * 2;          // 64-byte bf16 rows
     constexpr int A_PIECES = BM * (BK / 4) / 256;                              // 16-byte fp32 pieces (4 channels) per thread per K-tile
@@ -680,14 +714,23 @@ __global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, cons
             a_src2[i] = (ok && a.x2) ? reinterpret_cast<const float*>(a.x2) + pix * Cin2 + c4 * 4 : nullptr;
         }
     };
+    // K-tiles of a tap: kc1 over the first tensor's channels, then the second's; a tensor's last tile may hold fewer than 32 channels (channel counts
+    // are multiples of 8): its missing pieces are zeros on both operands and the multiply loop runs only the k-steps that hold channels
+    const uint32_t kc1 = (a.Cin1 + BK - 1) / BK, kc = kc1 + (Cin2 + BK - 1) / BK;
+    auto tile_channels = [&](uint32_t ci) {
+        if (!PT) return (uint32_t)BK;
+        const uint32_t left = ci >= kc1 ? Cin2 - (ci - kc1) * BK : a.Cin1 - ci * BK;
+        return left < (uint32_t)BK ? left : (uint32_t)BK;
+    };
     float4 a_reg[A_PIECES];
-    auto a_load = [&](uint32_t ci0) {
-        const bool second = ci0 >= a.Cin1;
-        const uint32_t coff = second ? ci0 - a.Cin1 : ci0;
+    auto a_load = [&](uint32_t ci) {
+        const bool second = ci >= kc1;
+        const uint32_t coff = (second ? ci - kc1 : ci) * BK;
+        const bool c_ok = !PT || c4 * 4 < tile_channels(ci);
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             const float* p = second ? a_src2[i] : a_src[i];
-            a_reg[i] = p ? *reinterpret_cast<const float4*>(p + coff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a_reg[i] = (p && c_ok) ? *reinterpret_cast<const float4*>(p + coff) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto a_store = [&](uint32_t buf) {                                          // split and park: hi = truncation to bf16, lo = truncation of the exact remainder
@@ -706,19 +749,24 @@ __global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, cons
         }
     };
     // ---- B loader: DMA instruction i of this wave covers rows (wave*B_INST + i)*16 + (lane >> 2), 16-byte chunk lane & 3 ----------------
-    uint32_t b_off[B_INST];
+    uint32_t b_off[B_INST], b_sc[B_INST];
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);               // (LDS-DMA destinations are wave-uniform)
 #pragma unroll
     for (int i = 0; i < B_INST; ++i) {
-        const uint32_t r = (wave * B_INST + i) * 16 + (lane >> 2);
-        b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 3) ^ ((r >> 2) & 3)) * 16;
+        const uint32_t r = (wave_u * B_INST + i) * 16 + (lane >> 2);
+        b_sc[i] = (lane & 3) ^ ((r >> 2) & 3);
+        b_off[i] = (!PT || n0 + r < a.Cout) ? ((n0 + r) * taps * a.Cin) * 2 + b_sc[i] * 16 : CV_OOB;   // PT: rows past Cout (last N tile) read zeros
     }
-    auto b_issue = [&](uint32_t tap, uint32_t ci0, uint32_t buf) {
+    const __amdgpu_buffer_rsrc_t rs_wh = cv_rsrc(a.w, (uint64_t)a.Cout * taps * a.Cin * 2), rs_wl = cv_rsrc(w_lo, (uint64_t)a.Cout * taps * a.Cin * 2);
+    auto b_issue = [&](uint32_t tap, uint32_t ci, uint32_t buf) {
         unsigned char* sb = lds + buf * STAGE + 2 * BM * ROWB;
-        const uint64_t koff = (uint64_t)(tap * a.Cin + ci0) * 2;
+        const bool second = ci >= kc1;
+        const uint32_t koff = (tap * a.Cin + (second ? a.Cin1 + (ci - kc1) * BK : ci * BK)) * 2, nchunk = tile_channels(ci) >> 3;
 #pragma unroll
         for (int i = 0; i < B_INST; ++i) {
-            cv_glds16(a.w + b_off[i] + koff, sb + (wave * B_INST + i) * 1024);
-            cv_glds16(w_lo + b_off[i] + koff, sb + BN * ROWB + (wave * B_INST + i) * 1024);
+            const uint32_t v = (!PT || b_sc[i] < nchunk) ? b_off[i] : CV_OOB;
+            cv_dma16(rs_wh, sb + (wave_u * B_INST + i) * 1024, v, koff);
+            cv_dma16(rs_wl, sb + BN * ROWB + (wave_u * B_INST + i) * 1024, v, koff);
         }
     };
     // ---- reader geometry ---------------------------------------------------------------------------------------------------------------
@@ -735,25 +783,27 @@ __global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, cons
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const uint32_t kc = a.Cin / BK, KT_all = taps * kc;
+    const uint32_t KT_all = taps * kc;
     const uint32_t kt_begin = (uint32_t)((uint64_t)split * KT_all / a.splits), KT = (uint32_t)((uint64_t)(split + 1) * KT_all / a.splits) - kt_begin;
     uint32_t tap = kt_begin / kc, ci = kt_begin % kc;
     set_tap(tap);
-    a_load(ci * BK);
-    b_issue(tap, ci * BK, 0);
+    a_load(ci);
+    b_issue(tap, ci, 0);
     a_store(0);
     __syncthreads();
     for (uint32_t kt = 0; kt < KT; ++kt) {
         const uint32_t buf = kt & 1;
         const bool more = kt + 1 < KT;
+        const uint32_t ksteps = (tile_channels(ci) + 15) >> 4;               // of the tile multiplied now (ci still names it)
         if (more) {
             if (++ci == kc) { ci = 0; ++tap; set_tap(tap); }
-            a_load(ci * BK);                                                 // tile kt+1: fp32 -> registers (in flight under the MFMAs below)
-            b_issue(tap, ci * BK, buf ^ 1);
+            a_load(ci);                                                      // tile kt+1: fp32 -> registers (in flight under the MFMAs below)
+            b_issue(tap, ci, buf ^ 1);
         }
         const unsigned char* st = lds + buf * STAGE;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+            if (PT && s2 >= (int)ksteps) break;
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -788,12 +838,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, cons
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const uint32_t m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (m < a.M) unsafeAtomicAdd(yo + (size_t)m * a.Cout + n0 + wn * 32 * TN + j * 32 + (lane & 31), acc[i][j][e]);
+                    const uint32_t col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
+                    if (m < a.M && (!PT || col < a.Cout)) unsafeAtomicAdd(yo + (size_t)m * a.Cout + col, acc[i][j][e]);
                 }
         return;
     }
 
-    cv_epilogue_f32<TM, TN>(a, acc, lds, m0, n0);
+    cv_epilogue_f32<TM, TN, PT>(a, acc, lds, m0, n0);
 }
 
 // 3x3 / stride 1 variant of k_conv_igemm_f32x2 that loads the A tile ONCE per (kh, channel tile) and serves the three kw taps from it:
@@ -1380,8 +1431,10 @@ template <int TM, int TN, int WM, int WN, int NS>
 int cv_launch(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     a.m_tiles = (a.M + BM - 1) / BM;
-    a.n_tiles = a.Cout / BN;
-    hipLaunchKernelGGL((k_conv_igemm_bf16<TM, TN, WM, WN, NS>), dim3(a.m_tiles * a.n_tiles * a.splits), dim3(64 * WM * WN), 0, st, a);
+    a.n_tiles = (a.Cout + BN - 1) / BN;
+    const bool partial = a.Cin1 % CV_BK != 0 || (a.Cin - a.Cin1) % CV_BK != 0 || a.Cout % BN != 0;
+    if (partial) hipLaunchKernelGGL((k_conv_igemm_bf16<TM, TN, WM, WN, NS, true>), dim3(a.m_tiles * a.n_tiles * a.splits), dim3(64 * WM * WN), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_igemm_bf16<TM, TN, WM, WN, NS, false>), dim3(a.m_tiles * a.n_tiles * a.splits), dim3(64 * WM * WN), 0, st, a);
     return 0;
 }
 
@@ -1401,9 +1454,9 @@ static void cv_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int
         const uint64_t t64 = (uint64_t)((M + 63) / 64) * (Cout / 128);
         choice = (Cout % 128 != 0) ? 3 : (t128 >= 384) ? 1 : (t64 >= 512) ? 2 : 3;
     }
-    const uint32_t bm = choice == 4 ? 256 : choice == 1 ? 128 : 64;
-    const uint32_t tiles = ((M + bm - 1) / bm) * (Cout / (choice == 3 ? 64 : 128));
-    const uint32_t KT = ksize * ksize * (Cin / 64);
+    const uint32_t bm = choice == 4 ? 256 : choice == 1 ? 128 : 64, bn = choice == 3 ? 64 : 128;
+    const uint32_t tiles = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+    const uint32_t KT = ksize * ksize * ((Cin + 63) / 64);
     uint32_t splits = 1;
     if (may_split) {
         if (splits_hint > 0) splits = (uint32_t)splits_hint;
@@ -1433,7 +1486,7 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16_plan(uint32_t M, uint32_t Cin, uint32_t 
 extern "C" int ssdnerf_conv2d_nhwc_f32x2_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int splits_hint) {
     int choice = tile_hint;
     if (choice != 1 && choice != 3) choice = (Cout % 128 == 0 && (uint64_t)((M + 127) / 128) * (Cout / 128) >= 384) ? 1 : 3;
-    const uint32_t bm = choice == 1 ? 128 : 64, tiles = ((M + bm - 1) / bm) * (Cout / bm), KT = ksize * ksize * (Cin / 32);
+    const uint32_t bm = choice == 1 ? 128 : 64, tiles = ((M + bm - 1) / bm) * ((Cout + bm - 1) / bm), KT = ksize * ksize * ((Cin + 31) / 32);
     uint32_t splits = 1;
     if (splits_hint > 0) splits = (uint32_t)splits_hint;
     else if (tiles < 512 && (uint64_t)M * Cout <= (1u << 21) && Cout <= 1024) splits = (1024 + tiles - 1) / tiles;
@@ -1447,10 +1500,11 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
                                          void* gn_sums, uint32_t gn_groups, int tile_hint, int splits_hint, int y_is_zero, void* stream) {
     if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
     SSD_REQUIRE(x && w_hi && w_lo && y, "conv2d_nhwc_f32x2: null pointer");
-    SSD_REQUIRE((Cin % 64 == 0) && (Cout % 64 == 0) && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && !(upsample && stride != 1),
-                "conv2d_nhwc_f32x2: needs Cin %% 64 == 0, Cout %% 64 == 0, ksize 1|3, stride 1|2 (no stride with upsample)");
+    SSD_REQUIRE(ssdnerf_conv2d_nhwc_bf16_supported(Cin, Cout, ksize, stride, upsample),
+                "conv2d_nhwc_f32x2: needs Cin %% 8 == 0, Cout %% 8 == 0, ksize 1|3, stride 1|2 (no stride with upsample)");
     if (!x2) Cin1 = Cin;
-    SSD_REQUIRE(Cin1 <= Cin && Cin1 % 64 == 0 && (x2 || Cin1 == Cin), "conv2d_nhwc_f32x2: the first input's channel count must be a multiple of 64 and <= Cin");
+    SSD_REQUIRE(Cin1 <= Cin && Cin1 % 8 == 0 && (x2 || Cin1 == Cin), "conv2d_nhwc_f32x2: the first input's channel count must be a multiple of 8 and <= Cin");
+    SSD_REQUIRE((uint64_t)Cout * ksize * ksize * Cin * 2 < (1ull << 31), "conv2d_nhwc_f32x2: weight tensor too large");
     SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0), "conv2d_nhwc_f32x2: fused GroupNorm statistics need groups of a multiple of 4 channels");
     ConvArgs a;
     a.x2 = (const unsigned char*)x2; a.Cin1 = Cin1;
@@ -1476,13 +1530,19 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
         a.gn_sums = nullptr;
         if (!y_is_zero && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2: memset failed");
     }
-    a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = Cout / bm;
+    a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = (Cout + bm - 1) / bm;
     // 3x3 / stride 1 layers whose 128-pixel tiles are whole image rows take the row-reuse kernel (A loaded once per kh, shared by the three kw taps)
     static const bool rows_ok = getenv("SSDNERF_CONV_NO_ROW_REUSE") == nullptr;
-    const bool rows = rows_ok && choice == 1 && splits == 1 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 128 == 0;
+    const bool rows = rows_ok && Cin % 64 == 0 && Cin1 % 64 == 0 && choice == 1 && splits == 1 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 128 == 0;
     if (rows) hipLaunchKernelGGL(k_conv3x3_f32x2_rows, dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a, (const unsigned char*)w_lo);
-    else if (choice == 1) hipLaunchKernelGGL((k_conv_igemm_f32x2<2, 2>), dim3(a.m_tiles * a.n_tiles * splits), dim3(256), 0, st, a, (const unsigned char*)w_lo);
-    else hipLaunchKernelGGL((k_conv_igemm_f32x2<1, 1>), dim3(a.m_tiles * a.n_tiles * splits), dim3(256), 0, st, a, (const unsigned char*)w_lo);
+    else {
+        const bool partial = Cin1 % 32 != 0 || (Cin - Cin1) % 32 != 0 || Cout % bm != 0;
+        const dim3 grid(a.m_tiles * a.n_tiles * splits);
+        if (choice == 1 && partial) hipLaunchKernelGGL((k_conv_igemm_f32x2<2, 2, true>), grid, dim3(256), 0, st, a, (const unsigned char*)w_lo);
+        else if (choice == 1) hipLaunchKernelGGL((k_conv_igemm_f32x2<2, 2, false>), grid, dim3(256), 0, st, a, (const unsigned char*)w_lo);
+        else if (partial) hipLaunchKernelGGL((k_conv_igemm_f32x2<1, 1, true>), grid, dim3(256), 0, st, a, (const unsigned char*)w_lo);
+        else hipLaunchKernelGGL((k_conv_igemm_f32x2<1, 1, false>), grid, dim3(256), 0, st, a, (const unsigned char*)w_lo);
+    }
     if (splits > 1) {
         const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
         uint32_t rows = HWo;
@@ -1493,8 +1553,9 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
     return SSDNERF_OK;
 }
 
+// (r03: channel counts are multiples of 8 -- one 16-byte bf16 chunk --, no longer of 64: a tensor's last K-tile and the last N tile may be partial)
 extern "C" int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample) {
-    return (Cin % 64 == 0) && (Cout % 64 == 0) && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && !(upsample && stride != 1);
+    return Cin > 0 && Cout > 0 && (Cin % 8 == 0) && (Cout % 8 == 0) && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && !(upsample && stride != 1);
 }
 
 extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t Cin1, const void* w, const float* bias, const void* residual, void* y, uint32_t B,
@@ -1503,11 +1564,13 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
     SSD_REQUIRE(x && w && y, "conv2d_nhwc_bf16: null pointer");
     SSD_REQUIRE(ssdnerf_conv2d_nhwc_bf16_supported(Cin, Cout, ksize, stride, upsample),
-                "conv2d_nhwc_bf16: needs Cin %% 64 == 0, Cout %% 64 == 0, ksize 1|3, stride 1|2 (no stride with upsample)");
+                "conv2d_nhwc_bf16: needs Cin %% 8 == 0, Cout %% 8 == 0, ksize 1|3, stride 1|2 (no stride with upsample)");
     SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0),
                 "conv2d_nhwc_bf16: fused GroupNorm statistics need groups of a multiple of 4 channels");
     if (!x2) Cin1 = Cin;
-    SSD_REQUIRE(Cin1 <= Cin && Cin1 % 64 == 0 && (x2 || Cin1 == Cin), "conv2d_nhwc_bf16: the first input's channel count must be a multiple of 64 and <= Cin");
+    SSD_REQUIRE(Cin1 <= Cin && Cin1 % 8 == 0 && (x2 || Cin1 == Cin), "conv2d_nhwc_bf16: the first input's channel count must be a multiple of 8 and <= Cin");
+    SSD_REQUIRE((uint64_t)Cout * ksize * ksize * Cin * 2 < (1ull << 31), "conv2d_nhwc_bf16: weight tensor too large");
+    const bool c64 = Cin % 64 == 0 && Cin1 % 64 == 0;                         // what the row-reuse and two-group kernels take
     ConvArgs a;
     a.x2 = (const unsigned char*)x2; a.Cin1 = Cin1;
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
@@ -1517,17 +1580,17 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     const uint32_t Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     a.Ho = (Hv + 2 * a.pad - ksize) / stride + 1;
     a.Wo = (Wv + 2 * a.pad - ksize) / stride + 1;
-    SSD_REQUIRE((uint64_t)B * a.Ho * a.Wo < (1ull << 31) && (uint64_t)B * H * W * Cin * 2 < (1ull << 40), "conv2d_nhwc_bf16: tensor too large");
+    SSD_REQUIRE((uint64_t)B * a.Ho * a.Wo < (1ull << 31) && (uint64_t)B * H * W * Cin * 2 < (1ull << 31), "conv2d_nhwc_bf16: tensor too large (32-bit buffer offsets)");
     a.M = B * a.Ho * a.Wo;
     hipStream_t st = (hipStream_t)stream;
     // tile_hint 0: the two-group kernel takes the layers it measures faster on (r03, profiles/r03/e_bench_conv_two_group.jsonl): 3 x 3 / stride 1 layers
     // whose 256-pixel tiles are whole image rows, from 64 x 64 upwards (row-reuse form), and the upsampling convolution of the 128 x 128 level
     static const bool pp_auto = getenv("SSDNERF_CONV_NO_TWO_GROUP") == nullptr;
-    if (tile_hint == 0 && pp_auto && Cout % 128 == 0 && ksize == 3 && stride == 1 && a.M >= 32768 && (!gn_sums || (a.Ho * a.Wo) % 256 == 0)
+    if (tile_hint == 0 && pp_auto && c64 && Cout % 128 == 0 && ksize == 3 && stride == 1 && a.M >= 32768 && (!gn_sums || (a.Ho * a.Wo) % 256 == 0)
         && ((!upsample && (W == 128 || W == 64) && (H * W) % 256 == 0) || (upsample && a.M >= 131072)))
         tile_hint = 6;
     if (tile_hint == 5 || tile_hint == 6) {                                  // two-group ("ping-pong") 256 x 128 kernel; 6: the row-reuse form where it applies
-        SSD_REQUIRE(Cout % 128 == 0, "conv2d_nhwc_bf16: the 256 x 128 kernel needs Cout %% 128 == 0");
+        SSD_REQUIRE(c64 && Cout % 128 == 0, "conv2d_nhwc_bf16: the 256 x 128 kernel needs Cin %% 64 == 0 and Cout %% 128 == 0");
         SSD_REQUIRE(!gn_sums || (a.Ho * a.Wo) % 256 == 0, "conv2d_nhwc_bf16: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
         a.splits = 1;
 #ifdef CV_PP_TIMING
@@ -1559,7 +1622,7 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     double* stats = a.gn_sums;
     if (splits > 1) a.gn_sums = nullptr;                                     // a split layer's statistics are taken by the finishing pass
     static const bool rows_ok = getenv("SSDNERF_CONV_NO_ROW_REUSE") == nullptr;
-    const bool rows = rows_ok && choice == 1 && splits == 1 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 128 == 0;
+    const bool rows = rows_ok && c64 && choice == 1 && splits == 1 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 128 == 0;
     if (rows) {
         a.m_tiles = (a.M + 127) / 128; a.n_tiles = Cout / 128;
         hipLaunchKernelGGL(k_conv3x3_bf16_rows, dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);

@@ -61,7 +61,7 @@ class _Conv2d(nn.Conv2d):
         return (self.grad_conv and torch.is_grad_enabled() and x.requires_grad and not self.weight.requires_grad and _device_ok(x)
                 and x.dtype == torch.float32 and not torch.is_autocast_enabled(x.device.type) and x.dim() == 4 and self.groups == 1
                 and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.dilation == (1, 1) and self.padding == (k // 2, k // 2)
-                and self.padding_mode == "zeros" and self.in_channels % 64 == 0 and self.out_channels % 64 == 0
+                and self.padding_mode == "zeros" and self.in_channels % 8 == 0 and self.out_channels % 8 == 0
                 and (self.bias is None or not self.bias.requires_grad))
 
     def _split_pair(self, transposed):

@@ -231,9 +231,10 @@ class _Conv:
     """A convolution split into its bias-less GEMM part (``mm``) and an fp32 bias that the *consumer* folds in: the following
     GroupNorm (``pre_bias``) or the residual epilogue -- the library convolution would spend a pass of its own on it.
 
-    ``pad_in`` / ``pad_out``: zero-pad the input / output channels of the weights up to a multiple of 64 so that the two edge layers of the UNet
-    (18 -> 128 stem, 128 -> 18 head; denoising.py:116-118,178-187) run on the hand-written implicit GEMM as well: the executor hands the stem
-    a zero-padded input and slices the head's output (the extra products are exact zeros)."""
+    ``pad_in`` / ``pad_out``: zero-pad the input / output channels of the weights up to a multiple of 8 (one 16-byte bf16 chunk: the granularity of
+    the hand-written implicit GEMM since r03; r02 needed 64) so that the two edge layers of the UNet (18 -> 128 stem, 128 -> 18 head;
+    denoising.py:116-118,178-187) run on it as well: the executor hands the stem a zero-padded input and slices the head's output (the extra
+    products are exact zeros)."""
     __slots__ = ("w", "w_lo", "bias", "stride", "padding", "fold", "own", "cin", "cout")
     SPLITK_BYTES = 16 << 20
 
@@ -247,8 +248,8 @@ class _Conv:
         assert groups == 1
         self.cout, self.cin = int(weight.shape[0]), int(weight.shape[1])
         bias = conv.bias.detach().float() if conv.bias is not None else None
-        pin = (-self.cin) % 64 if pad_in else 0
-        pout = (-self.cout) % 64 if pad_out else 0
+        pin = (-self.cin) % 8 if pad_in else 0
+        pout = (-self.cout) % 8 if pad_out else 0
         if pin or pout:
             weight = F.pad(weight, (0, 0, 0, 0, 0, pin, 0, pout))
             if bias is not None and pout:
@@ -257,7 +258,7 @@ class _Conv:
         self.bias = bias.contiguous() if bias is not None else None
         self.stride, self.padding = tuple(stride), tuple(padding)
         self.fold = weight.shape[0] % 8 == 0                          # the 16-byte vector kernels need C % 8 == 0
-        # the hand-written MFMA implicit GEMM (csrc/conv_igemm.hip) takes every layer whose (padded) channel counts are multiples of 64: bf16 as
+        # the hand-written MFMA implicit GEMM (csrc/conv_igemm.hip) takes every layer whose (padded) channel counts are multiples of 8: bf16 as
         # is, fp32 with fp32-class products (weights pre-split into a bf16 pair; the library's fp32 convolution is kept for everything else)
         self.own = bool(dtype in (torch.bfloat16, torch.float32) and self.w.is_cuda and k[0] == k[1] and stride[0] == stride[1]
                         and tuple(padding) == (k[0] // 2, k[0] // 2) and tuple(dilation) == (1, 1)
@@ -393,7 +394,7 @@ class FastUnet:
 
         self.in_ops = [seq(b) for b in net.in_blocks]
         stem = net.in_blocks[0][0]
-        if len(net.in_blocks[0]) == 1 and isinstance(stem, torch.nn.Conv2d):     # 18 -> 128: input channels zero-padded to 64 (see _Conv)
+        if len(net.in_blocks[0]) == 1 and isinstance(stem, torch.nn.Conv2d):     # 18 -> 128: input channels zero-padded to 24 (see _Conv)
             self.in_ops[0] = [("conv", _Conv(stem, dt, pad_in=True))]
         self.stem_cin = self.in_ops[0][0][1].w.shape[1] if self.in_ops[0][0][0] == "conv" and self.in_ops[0][0][1].own else None
         self.mid_ops = seq(net.mid_blocks)
@@ -442,7 +443,7 @@ class FastUnet:
         _, gn1, conv1, gn2, (off, n), conv2, shortcut, out_bias = op
         ss = ss_all[:, off:off + n]
         own = conv1.own and conv2.own and (shortcut is None or shortcut.own)
-        if x2 is not None and not (own and shortcut is not None and x.size(1) % 64 == 0):
+        if x2 is not None and not (own and shortcut is not None and x.size(1) % 8 == 0 and x2.size(1) % 8 == 0):
             x, x2, stats = torch.cat([x, x2], dim=1).contiguous(memory_format=torch.channels_last), None, None
         g1 = self._gn(x, gn1, None, True, stats=stats, x2=x2)
         if own:

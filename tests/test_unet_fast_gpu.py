@@ -206,6 +206,19 @@ CONV_CASES = [
     (8, 128, 128, 128, 128, 3, 2, False, 5),
     (8, 128, 128, 64, 128, 3, 1, False, 6),    # the stem after channel padding: ONE channel tile per tap row
     (8, 64, 64, 64, 128, 3, 1, False, 6),
+    # r03: channel counts that are multiples of 8, not of 64 (the tiled UNet's base 80: configs/new_cfgs/ssdnerf_cars_recons1v_tiled.py:15-28) --
+    # a partial last K-tile per tap and a partial last N tile
+    (2, 16, 48, 80, 80, 3, 1, False, 0),
+    (2, 16, 48, 80, 160, 3, 1, False, 0),
+    (1, 5, 7, 24, 40, 3, 1, False, 0),         # one partial K-tile per tap, one partial N tile, ragged M
+    (2, 8, 24, 320, 160, 3, 1, False, 0),
+    (2, 8, 24, 480, 320, 1, 1, False, 0),
+    (2, 16, 16, 160, 160, 3, 2, False, 0),
+    (2, 8, 8, 80, 80, 3, 1, True, 0),
+    (1, 16, 16, 8, 128, 3, 1, False, 1),       # a stem with 8 input channels on the 128 x 128 tile
+    (1, 16, 16, 136, 128, 3, 1, False, 2),     # 64 + 64 + 8
+    (2, 32, 96, 80, 80, 3, 1, False, 3),
+    (8, 128, 384, 8, 80, 3, 1, False, 0),      # the tiled config's stem at its real size (6 -> 8 input channels)
 ]
 
 
@@ -268,6 +281,64 @@ def test_conv_igemm_split_k(B, H, Cin, Cout, k, splits):
         got = unet_fast.conv2d_nhwc_bf16(x, w, bias, res, splitk_ws=ws, splits_hint=splits)
         assert ((got.float() - want).norm() / want.norm()).item() < 4e-3
         assert ws.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("C1,C2,Cout,k", [(80, 80, 80, 3), (320, 160, 320, 3), (160, 80, 160, 1), (72, 24, 40, 3)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_conv_concat_with_partial_channel_tiles(C1, C2, Cout, k, dtype):
+    """[x | x2] where neither tensor's channel count is a multiple of the K-tile: each tensor ends on a partial tile of its own"""
+    g = torch.Generator().manual_seed(C1 + C2 + Cout)
+    B, H, W, G = 2, 8, 24, 8
+    a = torch.randn(B, C1, H, W, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(B, C2, H, W, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, C1 + C2, k, k, generator=g) / ((C1 + C2) * k * k) ** 0.5).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    cat = torch.cat([a, b], 1).contiguous(memory_format=torch.channels_last)
+    want = F.conv2d(cat.double(), w.to(dtype).double() if dtype == torch.bfloat16 else w.double(), bias.double(), 1, k // 2)
+    fuse = (Cout // G) % 4 == 0
+    sums = torch.zeros(B, G, 2, dtype=torch.float64, device="cuda") if fuse else None
+    if dtype == torch.bfloat16:
+        wb = w.bfloat16().contiguous(memory_format=torch.channels_last)
+        got = unet_fast.conv2d_nhwc_bf16(a, wb, bias, x2=b, gn_sums=sums, gn_groups=G if fuse else 0)
+        got_cat = unet_fast.conv2d_nhwc_bf16(cat, wb, bias)
+        tol = 4e-3
+    else:
+        hi, lo = [t.contiguous(memory_format=torch.channels_last) for t in unet_fast.split_bf16x2(w)]
+        got = unet_fast.conv2d_nhwc_f32x2(a, hi, lo, bias, x2=b, gn_sums=sums, gn_groups=G if fuse else 0, splits_hint=1)
+        got_cat = unet_fast.conv2d_nhwc_f32x2(cat, hi, lo, bias, splits_hint=1)
+        tol = 3e-5
+    assert ((got.double() - want).norm() / want.norm()).item() < tol
+    assert ((got_cat.double() - want).norm() / want.norm()).item() < tol
+    if fuse:
+        yf = got.double().reshape(B, G, Cout // G, H * W)
+        assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-5, atol=1e-3) and torch.allclose(sums[..., 1], yf.square().sum((2, 3)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,splits", [(2, 8, 320, 320, 3, 4), (2, 4, 640, 320, 3, 0), (2, 8, 80, 320, 1, 2)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_conv_split_k_with_partial_channel_tiles(B, H, Cin, Cout, k, splits, dtype):
+    g = torch.Generator().manual_seed(Cin + Cout + k + 5)
+    x = torch.randn(B, Cin, H, H, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, Cout, H, H, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    G = 16
+    sums = torch.zeros(B, G, 2, dtype=torch.float64, device="cuda")
+    if dtype == torch.bfloat16:
+        wb = w.bfloat16().contiguous(memory_format=torch.channels_last)
+        ws = torch.zeros(B * H * H * Cout, dtype=torch.float32, device="cuda")
+        got = unet_fast.conv2d_nhwc_bf16(x, wb, bias, res, splitk_ws=ws, splits_hint=splits, gn_sums=sums, gn_groups=G)
+        want = F.conv2d(x.double(), wb.double(), bias.double(), 1, k // 2) + res.double()
+        assert ws.abs().max().item() == 0.0
+        tol = 4e-3
+    else:
+        hi, lo = [t.contiguous(memory_format=torch.channels_last) for t in unet_fast.split_bf16x2(w)]
+        got = unet_fast.conv2d_nhwc_f32x2(x, hi, lo, bias, res, gn_sums=sums, gn_groups=G, splits_hint=splits)
+        want = F.conv2d(x.double(), w.double(), bias.double(), 1, k // 2) + res.double()
+        tol = 3e-5
+    assert ((got.double() - want).norm() / want.norm()).item() < tol
+    yf = got.double().reshape(B, G, Cout // G, H * H)
+    assert torch.allclose(sums[..., 0], yf.sum((2, 3)), rtol=1e-5, atol=1e-3)
 
 
 def test_conv_igemm_rejects_unsupported():
@@ -393,6 +464,16 @@ F32X2_CASES = [
     (8, 64, 64, 256, 256, 3, 1, True, 0),
     (8, 8, 8, 512, 512, 3, 1, False, 0),
     (8, 4, 4, 512, 512, 3, 1, False, 0),
+    # r03: channel counts that are multiples of 8, not of 64 / 32 (see CONV_CASES)
+    (2, 16, 48, 80, 80, 3, 1, False, 0),
+    (2, 16, 48, 80, 160, 3, 1, False, 0),
+    (1, 5, 7, 24, 40, 3, 1, False, 0),
+    (2, 8, 24, 320, 160, 3, 1, False, 0),
+    (2, 8, 24, 480, 320, 1, 1, False, 0),
+    (2, 16, 16, 160, 160, 3, 2, False, 0),
+    (2, 8, 8, 80, 80, 3, 1, True, 0),
+    (1, 16, 16, 8, 128, 3, 1, False, 1),
+    (2, 32, 96, 80, 80, 3, 1, False, 3),
 ]
 
 

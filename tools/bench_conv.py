@@ -10,6 +10,7 @@ from ssdnerf_amd import unet_fast
 ap = argparse.ArgumentParser(); ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--hints", default="0"); ap.add_argument("--no-lib", action="store_true")
 ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="bf16: k_conv_igemm_bf16; fp32: the fp32-class bf16x2 kernels vs the library's fp32 convolution")
+ap.add_argument("--extra", default="", help="more layers, 'H,Cin,Cout,k;...' (stride 1): e.g. the stem / head after channel padding, 128,24,128,3;128,128,24,3")
 a = ap.parse_args()
 B = a.scenes
 WS = torch.zeros(4 << 20, dtype=torch.float32, device="cuda")     # split-K scratch (all zero between calls)
@@ -25,6 +26,11 @@ LAYERS = [
     (16, 768, 512, 3, 1, 0, 1), (16, 768, 512, 1, 1, 0, 1), (16, 512, 512, 3, 2, 0, 1), (8, 512, 512, 3, 1, 1, 1),
     (8, 512, 512, 3, 1, 0, 11), (8, 1024, 512, 3, 1, 0, 3), (8, 1024, 512, 1, 1, 0, 3),
 ]
+
+
+for spec in [v for v in a.extra.split(";") if v]:
+    h_, ci_, co_, k_ = (int(v) for v in spec.split(","))
+    LAYERS.append((h_, ci_, co_, k_, 1, 0, 1))
 
 
 def timeit(fn):

@@ -1,0 +1,9 @@
+#!/usr/bin/env bash
+# call 20: per-layer A/B again (partial tiles as a separate instantiation) + tests
+mkdir -p gpurun_out/r03
+for dt in bf16 fp32; do
+SSDNERF_HIP_LIB=.variants/prev/libssdnerf_hip.so timeout 600 python tools/bench_conv.py --no-lib --dtype $dt --extra "128,64,128,3;128,128,64,3" > gpurun_out/r03/ab_prev_$dt.jsonl 2>&1
+timeout 600 python tools/bench_conv.py --no-lib --dtype $dt --extra "128,64,128,3;128,128,64,3;128,24,128,3;128,128,24,3" > gpurun_out/r03/ab_new_$dt.jsonl 2>&1
+tail -1 gpurun_out/r03/ab_prev_$dt.jsonl; tail -1 gpurun_out/r03/ab_new_$dt.jsonl
+done
+timeout 1200 python -m pytest tests/test_unet_fast_gpu.py tests/test_unet_golden.py -x -q -m gpu 2>&1 | tail -4
