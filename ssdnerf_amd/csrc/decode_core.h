@@ -22,10 +22,11 @@
 #include "common.h"
 #include "sh_basis.h"
 
-// SSD_GATHER_PAIRS=1: packed form of the bilinear interpolation (see ssd_gather18).  Experimental: identical arithmetic by construction,
-// off until it has been parity-run and timed on hardware.
+// SSD_GATHER_PAIRS=1: packed form of the bilinear interpolation (see ssd_gather18): identical arithmetic by construction (bit-identical results).
+// r02 measured it at 0 %; since r03 (shading kernel bound by VALU issue, not latency) it is worth 2 % there -- the scalar form is auto-vectorised
+// ACROSS texels, which costs 56 register moves per sample to assemble the operand pairs (profiles/r03/h_shade_valu_diet.txt: 0.537 -> 0.550).
 #ifndef SSD_GATHER_PAIRS
-#define SSD_GATHER_PAIRS 0
+#define SSD_GATHER_PAIRS 1
 #endif
 
 #define MLP_OFF_WD (64 * 24)

@@ -51,7 +51,24 @@ SSD_DEV floatx2 sm_silu2(floatx2 h) {
     rcp.y = __builtin_amdgcn_rcpf(d.y);
     return h * rcp;
 }
+// SM_ASM_PK (r03 experiment, OFF): the packed fp32 ops of the heads as inline assembly.  Written as vector arithmetic, ROCm 7.2's backend UNPACKS the
+// packed ops it finds in the shadow of an MFMA into two plain ones (plain VALU ops execute beside the matrix pipe, packed ones do not: 62 of the
+// 467 VALU instructions of the MFMA block are such halves).  Forcing them to stay packed -- fewer issue slots -- measured 7 % SLOWER
+// (profiles/r03/h_shade_valu_diet.txt: roofline fraction 0.550 -> 0.513): the matrix pipe's shadow is worth more than the issue slots.
+#ifndef SM_ASM_PK
+#define SM_ASM_PK 0
+#endif
+#if SM_ASM_PK
+SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { floatx2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "v"(v), "v"(acc)); return r; }
+SSD_DEV floatx2 sm_mul2(floatx2 a, floatx2 b) { floatx2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+SSD_DEV floatx2 sm_add_one2(floatx2 a) { floatx2 r; asm("v_pk_add_f32 %0, %1, 1.0 op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }
+SSD_DEV floatx2 sm_sub2(floatx2 a, floatx2 b) { floatx2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
 SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_elementwise_fma(w, v, acc); }
+SSD_DEV floatx2 sm_mul2(floatx2 a, floatx2 b) { return a * b; }
+SSD_DEV floatx2 sm_add_one2(floatx2 a) { return a + floatx2{1.0f, 1.0f}; }
+SSD_DEV floatx2 sm_sub2(floatx2 a, floatx2 b) { return a - b; }
+#endif
 
 static constexpr unsigned SM_TPB = 256;
 #ifndef SM_SLICE_RAYS
@@ -89,6 +106,21 @@ SSD_DEV void sm_split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     lo = __float_as_uint(r1 - __uint_as_float(mid));           // exact, at most 8 significant bits
 }
 SSD_DEV uint32_t sm_pack2(uint32_t even, uint32_t odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }   // {bf16(even), bf16(odd)}
+// the same split for a feature PAIR with the two exact subtractions as packed ops (r03 experiment, OFF: 0.513 -> 0.509, same file): packed terms
+// {bf16(x0), bf16(x1)} per term
+#ifndef SM_PK_SPLIT
+#define SM_PK_SPLIT 0
+#endif
+SSD_DEV void sm_split3_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const floatx2 x = {x0, x1};
+    const floatx2 h = {__uint_as_float(__float_as_uint(x0) & 0xffff0000u), __uint_as_float(__float_as_uint(x1) & 0xffff0000u)};
+    const floatx2 r1 = sm_sub2(x, h);
+    const floatx2 m = {__uint_as_float(__float_as_uint(r1.x) & 0xffff0000u), __uint_as_float(__float_as_uint(r1.y) & 0xffff0000u)};
+    const floatx2 r2 = sm_sub2(r1, m);
+    hi = sm_pack2(__float_as_uint(x0), __float_as_uint(x1));      // (the pack takes the upper halves: no mask needed)
+    mid = sm_pack2(__float_as_uint(r1.x), __float_as_uint(r1.y));
+    lo = sm_pack2(__float_as_uint(r2.x), __float_as_uint(r2.y));
+}
 SSD_DEV sm_bf16x8 sm_op(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const uint4 u = make_uint4(a, b, c, d);
     return *reinterpret_cast<const sm_bf16x8*>(&u);
@@ -177,6 +209,13 @@ SSD_DEV void sm_swap(float& a, float& b) {
     b = __uint_as_float(r[1]);
 }
 
+// SM_PRESCALE (r03): silu(h) = h / (1 + 2^(-log2(e) h)).  The hidden layers' weights and biases are multiplied by -log2(e) when they are split into
+// matrix-core operands (in fp64, one rounding to fp32 -- the same rounding class as the split itself), so that the accumulators hold
+// h' = -log2(e) h and feed v_exp directly; the output layer's weights carry the inverse factor, w' = -ln(2) w, because w silu(h) = w' h' / (1 + 2^h').
+// Saves the 64 packed multiplies per 64 samples that scaled the 128 pre-activations (the kernel is VALU-issue bound: DESIGN.md section 5).
+SSD_DEV float sm_prescale(double w) { return (float)(w * -1.4426950408889634074); }
+SSD_DEV float sm_outscale(float w) { return (float)((double)w * -0.69314718055994530942); }
+
 template <typename PT, int MODE>
 __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, RaySrc src, const PT* __restrict__ planes,
                                                            const float* __restrict__ P, const uint8_t* __restrict__ lin_bits,
@@ -214,7 +253,8 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             const int reg = 2 * pr_ + e;
             const int row = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
             const float* rec = P + row * 24;                         // rec[19] = w_sigma, rec[20..22] = Wc[0..2][row]
-            v[0 + e] = rec[19]; v[2 + e] = rec[20]; v[4 + e] = rec[21]; v[6 + e] = rec[22];
+            // (x -ln 2: the hidden layers arrive scaled by -log2(e), see SM_PRESCALE below)
+            v[0 + e] = sm_outscale(rec[19]); v[2 + e] = sm_outscale(rec[20]); v[4 + e] = sm_outscale(rec[21]); v[6 + e] = sm_outscale(rec[22]);
         }
         reinterpret_cast<float4*>(lds)[threadIdx.x * 2 + 0] = make_float4(v[0], v[1], v[2], v[3]);
         reinterpret_cast<float4*>(lds)[threadIdx.x * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -239,21 +279,42 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
     const float cell_world = c.m.two_rH * c.m.mip_bound;
     // ---- pre-split A operands.  wa1[mt][ks][term]: lane l holds the 8 bf16 terms of [W1 | b1 | 0][mt*32 + (l&31)][16 ks + 8 (l>>5) + e];
     // wa2[mt][term]: the same for Wd' (16 columns, one k-step; column 0 = fl32(Wd[:,0] * SH_0 + bd), the folded bias) ----
-    sm_bf16x8 wa1[2][2][3], wa2[2][3];
+    // SM_K1_PACK (r03): layer 1 has 19 rows (18 features + the bias row), three more than a 16-deep k-step.  r01 / r02 ran a second k-step per
+    // product -- 24 of the 72 MFMAs and three operand registers of zeros per product for rows 16 .. 18.  Now those rows of ALL six products share
+    // ONE k-step: lane half 0 (k 0-7) carries [x_hi | x_mid | x_lo | x_hi](features 16, 17) against [W_hi | W_hi | W_hi | W_mid], lane half 1
+    // (k 8-15) [x_hi | x_mid | (1, 1) | (1, 0)] against [W_lo | W_mid | (b_hi, b_mid) | (b_lo, 0)]: the same six products and the bias, 4 MFMAs
+    // per 64 samples instead of 24, and the operand is four registers of data (no zero fill).  wa1x[mt] is that A operand.
+#ifndef SM_K1_PACK
+#define SM_K1_PACK 1
+#endif
+    sm_bf16x8 wa1[2][SM_K1_PACK ? 1 : 2][3], wa2[2][3];
+#if SM_K1_PACK
+    sm_bf16x8 wa1x[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 32 + (lane & 31);
+        uint32_t wt[3][3];                                                   // [feature 16, feature 17, bias][term]
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sm_split3(sm_prescale((double)P[row * 24 + 16 + q]), wt[q][0], wt[q][1], wt[q][2]);
+        const uint32_t w_hi = sm_pack2(wt[0][0], wt[1][0]), w_mid = sm_pack2(wt[0][1], wt[1][1]), w_lo = sm_pack2(wt[0][2], wt[1][2]);
+        wa1x[mt] = half == 0 ? sm_op(w_hi, w_hi, w_hi, w_mid) : sm_op(w_lo, w_mid, sm_pack2(wt[2][0], wt[2][1]), sm_pack2(wt[2][2], 0u));
+    }
+#endif
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int row = mt * 32 + (lane & 31);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < (SM_K1_PACK ? 1 : 2); ++ks) {
             uint32_t t1[3][8], t2[3][8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = 16 * ks + 8 * half + e;
-                const float w1 = k < 19 ? P[row * 24 + k] : 0.0f;                                                        // W1 | b1 | 0
+                const float w1 = k < 19 ? sm_prescale((double)P[row * 24 + k]) : 0.0f;                                   // W1 | b1 | 0
                 sm_split3(w1, t1[0][e], t1[1][e], t1[2][e]);
                 if (ks == 0) {
-                    float w2 = P[MLP_OFF_WD + row * 16 + k];
-                    if (k == 0) w2 = (float)((double)w2 * (double)shb::C0 + (double)P[MLP_OFF_BD + row]);
+                    double w2d = (double)P[MLP_OFF_WD + row * 16 + k];
+                    if (k == 0) w2d = w2d * (double)shb::C0 + (double)P[MLP_OFF_BD + row];
+                    const float w2 = sm_prescale(w2d);
                     sm_split3(w2, t2[0][e], t2[1][e], t2[2][e]);
                 }
             }
@@ -457,20 +518,39 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         // Split every feature into three bf16 terms, pack feature pairs, and trade halves so that T[t][0..3] is tile 0's k-step-0 operand
         // (features 0-15 of the samples of lanes 0-31) and T[t][4..7] tile 1's; T[t][8] / Z[t] carry features 16, 17 for k-step 1 (their other
         // k slots are the bias row and zeros).
-        uint32_t T[3][9], Z[3] = {0u, 0u, 0u};
+        uint32_t T[3][9];
+#if SM_K1_PACK
+        uint32_t K1[2][4];                                                   // k-step 1 operands of tile 0 / tile 1 (see SM_K1_PACK)
+#else
+        uint32_t Z[3] = {0u, 0u, 0u};
+#endif
 #pragma unroll
         for (int p2 = 0; p2 < 9; ++p2) {
+#if SM_PK_SPLIT
+            sm_split3_pair(f[2 * p2], f[2 * p2 + 1], T[0][p2], T[1][p2], T[2][p2]);
+#else
             uint32_t h0, m0, l0, h1, m1, l1;
             sm_split3(f[2 * p2], h0, m0, l0);
             sm_split3(f[2 * p2 + 1], h1, m1, l1);
             T[0][p2] = sm_pack2(h0, h1); T[1][p2] = sm_pack2(m0, m1); T[2][p2] = sm_pack2(l0, l1);
+#endif
         }
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) sm_swap_u(T[tt][k], T[tt][4 + k]);
+#if !SM_K1_PACK
             sm_swap_u(T[tt][8], Z[tt]);
+#endif
         }
+#if SM_K1_PACK
+        // v_permlane32_swap(a, b): a = [a.lo ; b.lo], b = [a.hi ; b.hi] (lane halves).  With a = b = X: a = X of samples 0-31 in both halves (tile 0),
+        // b = X of samples 32-63 (tile 1); with b = a constant: the constant lands in the upper half (k 8-15) of both tiles' operands
+        K1[0][0] = T[0][8]; K1[1][0] = T[0][8]; sm_swap_u(K1[0][0], K1[1][0]);
+        K1[0][1] = T[1][8]; K1[1][1] = T[1][8]; sm_swap_u(K1[0][1], K1[1][1]);
+        K1[0][2] = T[2][8]; K1[1][2] = 0x3F803F80u; sm_swap_u(K1[0][2], K1[1][2]);     // (1.0, 1.0) x (b_hi, b_mid)
+        K1[0][3] = T[0][8]; K1[1][3] = 0x00003F80u; sm_swap_u(K1[0][3], K1[1][3]);     // (1.0, 0)   x (b_lo, 0)
+#endif
         const uint32_t bias_pair = half == 0 ? 0x00003F80u : 0u;          // {bf16(1.0), 0}: the bias row of layer 1's k-step 1 (k = 18), lane half 0 only
         constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};   // products (weight term i) x (input term j), i + j <= 2, smallest first
         float ps0, ps1, pr0, pr1, pg0, pg1, pb0, pb1;            // per tile: this lane half's share of (sigma, r, g, b) pre-activations
@@ -487,6 +567,16 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         auto layer1 = [&](int nt, int pr_i) {                            // 4 MFMA: products (weight term i) x (feature term j) of both row tiles
             const int i = TI[pr_i], j = TJ[pr_i];
             const sm_bf16x8 b0 = sm_op(T[j][4 * nt], T[j][4 * nt + 1], T[j][4 * nt + 2], T[j][4 * nt + 3]);
+#if SM_K1_PACK
+            sm_operand_guard();
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0, acc[nt][mt], 0, 0, 0);
+            if (pr_i == 5) {                                             // rows 16 .. 18 of all six products, after the last (largest) product of rows 0 .. 15
+                const sm_bf16x8 b1 = sm_op(K1[nt][0], K1[nt][1], K1[nt][2], K1[nt][3]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1x[mt], b1, acc[nt][mt], 0, 0, 0);
+            }
+#else
             const sm_bf16x8 b1 = sm_op(nt == 0 ? T[j][8] : Z[j], j == 0 ? bias_pair : 0u, 0u, 0u);
             sm_operand_guard();
 #pragma unroll
@@ -494,6 +584,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0, acc[nt][mt], 0, 0, 0);
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][1][i], b1, acc[nt][mt], 0, 0, 0);
             }
+#endif
         };
         sm_bf16x8 sb[3];
         auto load_sh = [&](int nt) {
@@ -520,11 +611,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const int q = Q0 + i, mt = q >> 3, p2 = q & 7;
-                h[i] = floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]};
-                u[i] = h[i] * floatx2{-1.4426950408889634f, -1.4426950408889634f};
+                h[i] = floatx2{acc[nt][mt][2 * p2], acc[nt][mt][2 * p2 + 1]};              // = -log2(e) x the pre-activation (SM_PRESCALE)
             }
 #pragma unroll
-            for (int i = 0; i < N; ++i) { v[i].x = __builtin_amdgcn_exp2f(u[i].x); v[i].y = __builtin_amdgcn_exp2f(u[i].y); }
+            for (int i = 0; i < N; ++i) { v[i].x = __builtin_amdgcn_exp2f(h[i].x); v[i].y = __builtin_amdgcn_exp2f(h[i].y); }
             float4 w0[N], w1[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -533,11 +623,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                 if (COLOUR) w1[i] = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
             }
 #pragma unroll
-            for (int i = 0; i < N; ++i) u[i] = v[i] + floatx2{1.0f, 1.0f};
+            for (int i = 0; i < N; ++i) u[i] = sm_add_one2(v[i]);
 #pragma unroll
             for (int i = 0; i < N; ++i) { v[i].x = __builtin_amdgcn_rcpf(u[i].x); v[i].y = __builtin_amdgcn_rcpf(u[i].y); }
 #pragma unroll
-            for (int i = 0; i < N; ++i) h[i] = h[i] * v[i];
+            for (int i = 0; i < N; ++i) h[i] = sm_mul2(h[i], v[i]);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 if (COLOUR) {
