@@ -32,23 +32,30 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int AT_ROW = 80;                 // bytes per LDS row of V^T (32 keys * 2 B + 16 B pad: conflict-free ds_read_b128)
 
-SSD_DEV uint32_t at_bf16_rne(float x) {
-    const uint32_t u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+// {bf16(lo), bf16(hi)}, round to nearest even: gfx950's v_cvt_pk_bf16_f32, one instruction per pair (r03; the integer form was five per element --
+// the operand splits of the fp32-class kernel were ~90 VALU instructions per 8 values, now 24)
+SSD_DEV uint32_t at_pack_bf16(float lo, float hi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 r = __builtin_convertvector(f2{lo, hi}, b2);
+    return *reinterpret_cast<const uint32_t*>(&r);
 }
-SSD_DEV float at_bf16_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+// the pair's lo terms: bf16 of what the hi terms left over
+SSD_DEV uint32_t at_pack_bf16_rest(float lo, float hi, uint32_t packed_hi) {
+    return at_pack_bf16(lo - __uint_as_float(packed_hi << 16), hi - __uint_as_float(packed_hi & 0xffff0000u));
+}
 
 // 8 fp32 values -> bf16 hi and lo operand vectors (x ~= hi + lo to >= 16 significand bits)
 SSD_DEV void at_split8(const float4& a, const float4& b, bf16x8& hi, bf16x8& lo) {
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    uint32_t h[8], l[8];
+    uint32_t h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h[e] = at_bf16_rne(v[e]);
-        l[e] = at_bf16_rne(v[e] - at_bf16_to_f32(h[e]));
+    for (int e = 0; e < 4; ++e) {
+        h[e] = at_pack_bf16(v[2 * e], v[2 * e + 1]);
+        l[e] = at_pack_bf16_rest(v[2 * e], v[2 * e + 1], h[e]);
     }
-    const uint4 uh = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    const uint4 ul = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    const uint4 uh = make_uint4(h[0], h[1], h[2], h[3]);
+    const uint4 ul = make_uint4(l[0], l[1], l[2], l[3]);
     hi = *reinterpret_cast<const bf16x8*>(&uh);
     lo = *reinterpret_cast<const bf16x8*>(&ul);
 }
@@ -209,10 +216,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                 uint32_t wh[4], wl[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t h0 = at_bf16_rne(p[8 * s + 2 * k]), h1 = at_bf16_rne(p[8 * s + 2 * k + 1]);
-                    wh[k] = h0 | (h1 << 16);
-                    if constexpr (F32)
-                        wl[k] = at_bf16_rne(p[8 * s + 2 * k] - at_bf16_to_f32(h0)) | (at_bf16_rne(p[8 * s + 2 * k + 1] - at_bf16_to_f32(h1)) << 16);
+                    wh[k] = at_pack_bf16(p[8 * s + 2 * k], p[8 * s + 2 * k + 1]);
+                    if constexpr (F32) wl[k] = at_pack_bf16_rest(p[8 * s + 2 * k], p[8 * s + 2 * k + 1], wh[k]);
                 }
                 const uint4 u = make_uint4(wh[0], wh[1], wh[2], wh[3]);
                 pb[0][s] = *reinterpret_cast<const bf16x8*>(&u);
@@ -255,8 +260,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
             if constexpr (F32) {
                 *reinterpret_cast<float4*>(op + c0 * 4) = make_float4(o[c][4 * g] * inv_l, o[c][4 * g + 1] * inv_l, o[c][4 * g + 2] * inv_l, o[c][4 * g + 3] * inv_l);
             } else {
-                const uint32_t w0 = at_bf16_rne(o[c][4 * g] * inv_l) | (at_bf16_rne(o[c][4 * g + 1] * inv_l) << 16);
-                const uint32_t w1 = at_bf16_rne(o[c][4 * g + 2] * inv_l) | (at_bf16_rne(o[c][4 * g + 3] * inv_l) << 16);
+                const uint32_t w0 = at_pack_bf16(o[c][4 * g] * inv_l, o[c][4 * g + 1] * inv_l);
+                const uint32_t w1 = at_pack_bf16(o[c][4 * g + 2] * inv_l, o[c][4 * g + 3] * inv_l);
                 *reinterpret_cast<uint2*>(op + c0 * 2) = make_uint2(w0, w1);
             }
         }

@@ -230,12 +230,12 @@ SSD_DEV float ssd_tail_far(const RayGeom& q, float cell_world, float near_, floa
 //              side; r02 measured 2.7 ms for ~250 k wave-level appends that all landed in ONE cache line (profiles/r02/a_kernel_stats_*.csv),
 //              so every counter has its own line and the producers reserve per BLOCK, not per wave.
 //   lin_bits [S][H^3/8]: the bitfield in linear z/y/x order         coarse [S][(H/2)^3/8] (room for the finest block size)
-//   queue [S][N] uint2 {ray | tail << 24, t_first}                    survivors [S][N] u32 {ray | tail << 24}
+//   queue [S][N] uint2 {ray | tail << 24, t_first}                    survivors [S][N] uint2 {ray | tail << 24, t_start (r03: head skip)}
 #define SSD_COUNTER_STRIDE 32u     // u32 words per counter (128 B)
 enum { SSD_CNT_HITS = 0, SSD_CNT_TICKETS = 1, SSD_CNT_SURVIVORS = 2, SSD_CNT_BOUNDARY = 3, SSD_CNT_HITS_SHORT = 4, SSD_CNT_KINDS = 5 };
 __host__ __device__ static inline uint32_t ssd_counter(uint32_t kind, uint32_t S, uint32_t scene) { return (kind * S + scene) * SSD_COUNTER_STRIDE; }
 //   view_masks [S][<= N/64 views][8] u32: per view, a 16 x 16-tile mask of the image tiles that a set coarse block projects into (k_view_masks)
-struct RenderWs { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; uint32_t* survivors; uint32_t* view_masks; size_t counter_bytes, bytes; };
+struct RenderWs { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; uint2* survivors; uint32_t* view_masks; size_t counter_bytes, bytes; };
 static inline RenderWs ssd_render_ws(void* base, uint32_t S, uint32_t N, uint32_t grid_size) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t counters = up((size_t)SSD_CNT_KINDS * S * SSD_COUNTER_STRIDE * 4), bits = up((size_t)S * grid_size * grid_size * grid_size / 8);
@@ -246,8 +246,8 @@ static inline RenderWs ssd_render_ws(void* base, uint32_t S, uint32_t N, uint32_
     w.lin_bits = b + counters;
     w.coarse = b + counters + bits;
     w.queue = (uint2*)(b + counters + bits + coarse);
-    w.survivors = (uint32_t*)(b + counters + bits + coarse + queue);
-    const size_t surv = up((size_t)S * N * sizeof(uint32_t));
+    w.survivors = (uint2*)(b + counters + bits + coarse + queue);
+    const size_t surv = up((size_t)S * N * sizeof(uint2));
     w.view_masks = (uint32_t*)(b + counters + bits + coarse + queue + surv);
     w.counter_bytes = counters;
     w.bytes = counters + bits + coarse + queue + surv + up((size_t)S * (N / 64 + 1) * 32);

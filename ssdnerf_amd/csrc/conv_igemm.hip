@@ -62,9 +62,12 @@ SSD_DEV void cv_glds16(const void* gptr, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-SSD_DEV uint32_t cv_bf16_rne(float x) {
-    const uint32_t u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+// {bf16(lo), bf16(hi)}, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (r03; the integer form cost five instructions per element)
+SSD_DEV uint32_t cv_pack_bf16(float lo, float hi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 r = __builtin_convertvector(f2{lo, hi}, b2);
+    return *reinterpret_cast<const uint32_t*>(&r);
 }
 
 // LDS-DMA through a BUFFER descriptor (r03): `buffer_load_dwordx4 voffset, rsrc, soffset offen lds`.  Against the flat form used above
@@ -119,7 +122,7 @@ SSD_DEV void cv_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TN][TM], unsign
                     f[0] += __uint_as_float(rv.x << 16); f[1] += __uint_as_float(rv.x & 0xffff0000u);
                     f[2] += __uint_as_float(rv.y << 16); f[3] += __uint_as_float(rv.y & 0xffff0000u);
                 }
-                pk[q] = make_uint2(cv_bf16_rne(f[0]) | (cv_bf16_rne(f[1]) << 16), cv_bf16_rne(f[2]) | (cv_bf16_rne(f[3]) << 16));
+                pk[q] = make_uint2(cv_pack_bf16(f[0], f[1]), cv_pack_bf16(f[2], f[3]));
                 if (a.gn_sums && ok) {
                     const float r0 = __uint_as_float(pk[q].x << 16), r1 = __uint_as_float(pk[q].x & 0xffff0000u);
                     const float r2 = __uint_as_float(pk[q].y << 16), r3 = __uint_as_float(pk[q].y & 0xffff0000u);
@@ -229,7 +232,7 @@ SSD_DEV void cv_epilogue_bf16(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned
             }
             uint32_t pk[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
+            for (int k = 0; k < 4; ++k) pk[k] = cv_pack_bf16(f[2 * k], f[2 * k + 1]);
             *reinterpret_cast<uint4*>(a.y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             if (a.gn_sums) {                                                 // statistics of what the next norm will read (the rounded values)
 #pragma unroll
@@ -1096,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_conv_splitk_finish(float* __restrict__ 
         }
         uint32_t pk[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pk[k] = cv_bf16_rne(f[2 * k]) | (cv_bf16_rne(f[2 * k + 1]) << 16);
+        for (int k = 0; k < 4; ++k) pk[k] = cv_pack_bf16(f[2 * k], f[2 * k + 1]);
         *reinterpret_cast<uint4*>(y + q * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         if (gn_sums) {
 #pragma unroll

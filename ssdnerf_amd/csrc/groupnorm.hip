@@ -43,17 +43,18 @@ template <> struct GnVec<GN_BF16> {
             f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
-    __device__ static uint32_t rne(float x) {          // fp32 -> bf16 bits, round to nearest even (finite inputs)
-        const uint32_t u = __float_as_uint(x);
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    // fp32 -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32, one instruction per PAIR (r03; the integer form -- add, shift, and, add,
+    // shift per element plus the pack -- was a third of k_gn_apply's VALU work, which at bf16 is what bounds that kernel, not HBM)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    __device__ static uint32_t pack2(float lo, float hi) {
+        const b2 r = __builtin_convertvector(f2{lo, hi}, b2);
+        return *reinterpret_cast<const uint32_t*>(&r);
     }
     __device__ static void store(void* p, size_t idx, const float* f) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = rne(f[2 * i]) | (rne(f[2 * i + 1]) << 16);
-        reinterpret_cast<uint4*>(p)[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+        reinterpret_cast<uint4*>(p)[idx] = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
     }
-    __device__ static float round(float x) { return __uint_as_float(rne(x) << 16); }
+    __device__ static float round(float x) { return __uint_as_float(pack2(x, 0.f) << 16); }
 };
 template <> struct GnVec<GN_F16> {
     static constexpr int V = 8;
@@ -164,11 +165,16 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x,
     for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
         float f[V];
         GnVec<DT>::load(src, sbase + (size_t)r * stpr, f);
+        typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float v = __builtin_fmaf(f[i], a[i], o[i]);
-            if (act) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));        // SiLU
-            f[i] = v;
+        for (int i = 0; i < V; i += 2) {                                      // pairs: packed fp32 math around the two transcendentals (SiLU = v / (1 + 2^(-log2(e) v)))
+            f2 v = __builtin_elementwise_fma(f2{f[i], f[i + 1]}, f2{a[i], a[i + 1]}, f2{o[i], o[i + 1]});
+            if (act) {
+                const f2 u = v * f2{-1.4426950408889634f, -1.4426950408889634f};
+                const f2 d = f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + f2{1.0f, 1.0f};
+                v = v * f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            }
+            f[i] = v.x; f[i + 1] = v.y;
         }
         GnVec<DT>::store(y, base + (size_t)r * tpr, f);
     }
