@@ -285,6 +285,13 @@ size_t ssdnerf_group_norm_workspace(uint32_t B, uint32_t G);
 int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C1, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* pre_bias,
                             const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride,
                             float eps, int act, void* workspace, int workspace_state, void* y, void* stream);
+/* The normalisation pass alone, from statistics kept per RUN of 4 consecutive channels: runs1 fp64 [B][C1/4][sum, sum of squares] for x, runs2
+ * [B][(C-C1)/4][2] for x2 (NULL without x2) -- what ssdnerf_conv2d_nhwc_* write with gn_groups = Cout / 4.  A producer then does not need to
+ * know how its consumer groups the channels, and the decoder's concatenated inputs (groups of 12 / 24 channels straddling the two tensors,
+ * denoising.py:209-213) need no statistics pass of their own.  (C / G) % 4 == 0. */
+int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint32_t C1, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* gamma,
+                                 const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act, const void* runs1,
+                                 const void* runs2, void* y, void* stream);
 
 /* d/dx of ssdnerf_group_norm_nhwc (single source x, no pre_bias) for frozen gamma / beta and a scale/shift that does not depend on x --
  * the gradient rendering guidance and the fine-tuning prior push through every norm of the UNet (what autograd assembles from
@@ -332,13 +339,14 @@ int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t Cin1, const
  * channel-last; the weights are passed pre-split, w_hi = bf16(w), w_lo = bf16(w - w_hi), each [Cout][ksize][ksize][Cin]; activations are
  * split in the kernel; hi*hi + hi*lo + lo*hi accumulate in fp32 (>= 16 significand bits per product; TF32, the reference's cuDNN default on
  * Ampere, keeps 11).  tile_hint 0 = choose, 1 = 128x128, 3 = 64x64; layers with too few tiles are cut along K (splits_hint 0 = choose) and
- * reduced straight into the output, which the call zeroes first unless y_is_zero != 0 (ssdnerf_conv2d_nhwc_f32x2_plan tells a caller in
- * advance: tile | splits << 8).  Residual must not alias y.  Other arguments as ssdnerf_conv2d_nhwc_bf16. */
+ * reduced through splitk_ws (as for the bf16 form: all zero on entry, left all zero) or, without it, straight into the output, which the call
+ * zeroes first unless y_is_zero != 0 (ssdnerf_conv2d_nhwc_f32x2_plan tells a caller in advance: tile | splits << 8).  Residual must not alias
+ * y.  Other arguments as ssdnerf_conv2d_nhwc_bf16. */
 int ssdnerf_conv2d_nhwc_f32x2_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int splits_hint);
 int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, const void* w_hi, const void* w_lo, const float* bias,
                               const void* residual, void* y, uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout,
                               uint32_t ksize, uint32_t stride, uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint,
-                              int splits_hint, int y_is_zero, void* stream);
+                              int splits_hint, int y_is_zero, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
 /* Self-attention of MultiHeadAttentionMod (modules.py:12-48; mmgen QKVAttention) over the qkv projection of a channel-last
  * activation: qkv bf16 [B][T][3*heads*ch] with the reference's channel order [head][q | k | v][ch], out bf16 [B][T][heads*ch]

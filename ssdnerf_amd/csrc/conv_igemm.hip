@@ -831,9 +831,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, cons
         __syncthreads();
     }
 
-    // ---- split-K: partial sums are added straight into the (pre-zeroed) fp32 output; k_conv_f32_finish adds bias / residual / statistics ------
+    // ---- split-K: partial sums are added into the caller's all-zero fp32 scratch (or, without one, straight into the pre-zeroed output);
+    // k_conv_f32_finish adds bias / residual / statistics ------
     if (a.splits > 1) {
-        float* yo = reinterpret_cast<float*>(a.y);
+        float* yo = a.splitk_ws ? a.splitk_ws : reinterpret_cast<float*>(a.y);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1025,9 +1026,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_f32x2_rows(const ConvArgs a, co
     cv_epilogue_f32<TM, TN>(a, acc, lds, m0, n0);
 }
 
-// fp32 split-K finish, in place: y += bias + residual, plus the GroupNorm sums of the result.  Same thread layout as k_conv_splitk_finish.
-__global__ __launch_bounds__(256) void k_conv_f32_finish(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ res, uint32_t HW, uint32_t cpr,
-                                                         uint32_t rows_per_block, double* __restrict__ gn_sums, uint32_t G) {
+// fp32 split-K finish: y = (ws or y) + bias + residual, plus the GroupNorm sums of the result; ws (the shared scratch the partial sums went to, r03: saves
+// the zero fill of y in front of every split layer -- 46 fill kernels per forward) goes back to zero.  Same thread layout as k_conv_splitk_finish.
+__global__ __launch_bounds__(256) void k_conv_f32_finish(float* __restrict__ y, float* __restrict__ ws, const float* __restrict__ bias, const float* __restrict__ res, uint32_t HW,
+                                                         uint32_t cpr, uint32_t rows_per_block, double* __restrict__ gn_sums, uint32_t G) {
     __shared__ float red[512];
     const uint32_t tid = threadIdx.x, cc = tid % cpr, rstep = 256 / cpr, b = blockIdx.y;
     const uint32_t Cout = cpr * 8, co = cc * 8;
@@ -1039,7 +1041,9 @@ __global__ __launch_bounds__(256) void k_conv_f32_finish(float* __restrict__ y, 
     const uint32_t row_end = (tid / cpr < rstep) ? min((blockIdx.x + 1) * rows_per_block, HW) : 0u;
     for (uint32_t row = blockIdx.x * rows_per_block + tid / cpr; row < row_end; row += rstep) {
         const size_t o = (((size_t)b * HW + row) * cpr + cc) * 8;
-        float4 v0 = *reinterpret_cast<const float4*>(y + o), v1 = *reinterpret_cast<const float4*>(y + o + 4);
+        float* src = ws ? ws : y;
+        float4 v0 = *reinterpret_cast<const float4*>(src + o), v1 = *reinterpret_cast<const float4*>(src + o + 4);
+        if (ws) { *reinterpret_cast<float4*>(ws + o) = make_float4(0.f, 0.f, 0.f, 0.f); *reinterpret_cast<float4*>(ws + o + 4) = make_float4(0.f, 0.f, 0.f, 0.f); }
         float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int k = 0; k < 8; ++k) f[k] += bv[k];
@@ -1500,7 +1504,8 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2_plan(uint32_t M, uint32_t Cin, uint32_t
 
 extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, const void* w_hi, const void* w_lo, const float* bias, const void* residual,
                                          void* y, uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample,
-                                         void* gn_sums, uint32_t gn_groups, int tile_hint, int splits_hint, int y_is_zero, void* stream) {
+                                         void* gn_sums, uint32_t gn_groups, int tile_hint, int splits_hint, int y_is_zero, void* splitk_ws, size_t splitk_ws_bytes,
+                                         void* stream) {
     if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
     SSD_REQUIRE(x && w_hi && w_lo && y, "conv2d_nhwc_f32x2: null pointer");
     SSD_REQUIRE(ssdnerf_conv2d_nhwc_bf16_supported(Cin, Cout, ksize, stride, upsample),
@@ -1520,7 +1525,7 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
     a.Wo = (Wv + 2 * a.pad - ksize) / stride + 1;
     SSD_REQUIRE((uint64_t)B * a.Ho * a.Wo < (1ull << 31), "conv2d_nhwc_f32x2: tensor too large");
     a.M = B * a.Ho * a.Wo;
-    a.splitk_ws = nullptr;
+    a.splitk_ws = (splitk_ws && splitk_ws_bytes >= (size_t)a.M * Cout * 4) ? (float*)splitk_ws : nullptr;
     const int plan = ssdnerf_conv2d_nhwc_f32x2_plan(a.M, Cin, Cout, ksize, tile_hint, splits_hint);
     const int choice = plan & 0xff;
     const uint32_t splits = (uint32_t)plan >> 8, bm = choice == 1 ? 128 : 64;
@@ -1531,7 +1536,9 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
     double* stats = a.gn_sums;
     if (splits > 1) {
         a.gn_sums = nullptr;
-        if (!y_is_zero && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2: memset failed");
+        if (!a.splitk_ws && !y_is_zero && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2: memset failed");
+    } else {
+        a.splitk_ws = nullptr;
     }
     a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = (Cout + bm - 1) / bm;
     // 3x3 / stride 1 layers whose 128-pixel tiles are whole image rows take the row-reuse kernel (A loaded once per kh, shared by the three kw taps)
@@ -1550,7 +1557,7 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
         const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
         uint32_t rows = HWo;
         while (rows > rstep && rows % 2 == 0 && (uint64_t)B * (HWo / rows) < 1024) rows /= 2;
-        hipLaunchKernelGGL(k_conv_f32_finish, dim3((HWo + rows - 1) / rows, B), dim3(256), 0, st, (float*)y, bias, (const float*)residual, HWo, cpr, rows, stats, a.G);
+        hipLaunchKernelGGL(k_conv_f32_finish, dim3((HWo + rows - 1) / rows, B), dim3(256), 0, st, (float*)y, a.splitk_ws, bias, (const float*)residual, HWo, cpr, rows, stats, a.G);
     }
     SSD_CHECK_LAUNCH("conv2d_nhwc_f32x2");
     return SSDNERF_OK;

@@ -124,11 +124,15 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_stats(const void* __restrict__ x,
     }
 }
 
-template <int DT>
+// RUNS (r03): the statistics arrive per (sample, RUN of 4 consecutive channels) instead of per group -- `sums` [B][C1 / 4][2] for x, `sums2`
+// [B][(C - C1) / 4][2] for x2 -- and a group's sums are the sums of its runs.  Every producer (convolution epilogue, split-K finishing pass) writes
+// them without knowing how its consumer groups the channels, so the concatenated skip connections of the decoder half -- groups of 12 or 24
+// channels that straddle the two tensors -- no longer need a statistics pass of their own (k_gn_stats: 20 launches, 0.28 / 0.45 ms per forward).
+template <int DT, bool RUNS = false>
 __global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x, const void* __restrict__ x2, uint32_t C1, const float* __restrict__ pre_bias,
                                                       uint32_t HW, uint32_t C, uint32_t G, uint32_t rows_per_block, const double* __restrict__ sums, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ scale_shift, uint32_t ss_stride, float eps,
-                                                      int act, void* __restrict__ y) {
+                                                      int act, void* __restrict__ y, const double* __restrict__ sums2 = nullptr) {
     constexpr int V = GnVec<DT>::V;
     __shared__ float fa[GN_MAX_C], fb[GN_MAX_C];
     const uint32_t tpr = C / V, rif = GN_TPB / tpr;
@@ -136,10 +140,31 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x,
     const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
     const uint32_t cpg = C / G;
     const double inv_n = 1.0 / ((double)HW * (double)cpg);
+    __shared__ double grp[RUNS ? 2 * GN_TPB : 2];                           // RUNS: one thread per group adds up the group's runs (all loads in flight at once)
+    if (RUNS) {
+        const uint32_t R1 = C1 / 4, R2 = C / 4 - R1, rpg = cpg / 4;
+        for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
+            double gs = 0.0, gq = 0.0;
+            for (uint32_t r0 = g * rpg; r0 < (g + 1) * rpg; r0 += 8) {
+                double2 v[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t r = r0 + k;
+                    const double* p = r < R1 ? sums + ((size_t)b * R1 + r) * 2 : sums2 + ((size_t)b * R2 + (r - R1)) * 2;
+                    v[k] = r < (g + 1) * rpg ? *reinterpret_cast<const double2*>(p) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) { gs += v[k].x; gq += v[k].y; }
+            }
+            grp[2 * g] = gs; grp[2 * g + 1] = gq;
+        }
+        __syncthreads();
+    }
     for (uint32_t c = threadIdx.x; c < C; c += GN_TPB) {
         const uint32_t g = c / cpg;
-        const double mean = sums[((size_t)b * G + g) * 2 + 0] * inv_n;
-        double var = sums[((size_t)b * G + g) * 2 + 1] * inv_n - mean * mean;
+        const double gs = RUNS ? grp[2 * g] : sums[((size_t)b * G + g) * 2 + 0], gq = RUNS ? grp[2 * g + 1] : sums[((size_t)b * G + g) * 2 + 1];
+        const double mean = gs * inv_n;
+        double var = gq * inv_n - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         float a = rstd * gamma[c];
@@ -379,6 +404,31 @@ extern "C" int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C
     if (dtype == GN_F32) { SSD_GN_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_GN_LAUNCH(GN_F16) } else { SSD_GN_LAUNCH(GN_BF16) }
 #undef SSD_GN_LAUNCH
     SSD_CHECK_LAUNCH("group_norm_nhwc");
+    return SSDNERF_OK;
+}
+
+// The normalisation pass alone, from RUN-level statistics (k_gn_apply<RUNS>): runs1 fp64 [B][C1 / 4][2] for x, runs2 [B][(C - C1) / 4][2] for x2.
+extern "C" int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint32_t C1, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* gamma,
+                                            const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act, const void* runs1,
+                                            const void* runs2, void* y, void* stream) {
+    if (B == 0 || HW == 0 || C == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x && y && gamma && beta && runs1 && (!x2 || runs2), "group_norm_nhwc_runs: null pointer");
+    SSD_REQUIRE(dtype == GN_F32 || dtype == GN_F16 || dtype == GN_BF16, "group_norm_nhwc_runs: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    const uint32_t V = dtype == GN_F32 ? 4 : 8;
+    SSD_REQUIRE(G > 0 && G <= GN_TPB && C % G == 0 && (C / G) % 4 == 0, "group_norm_nhwc_runs: groups must be multiples of 4 channels (and at most 256 groups)");
+    SSD_REQUIRE(!scale_shift || scale_shift_stride >= 2 * C, "group_norm_nhwc_runs: scale_shift_stride must be >= 2*C");
+    SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc_runs: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
+    if (!x2) C1 = C;
+    SSD_REQUIRE(C1 <= C && C1 % V == 0 && (x2 || C1 == C), "group_norm_nhwc_runs: the first tensor's channel count must be a multiple of the 16-byte vector and <= C");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t rows_a = gn_rows_per_block(B, HW, 2048, 16);
+    const dim3 grid_a(HW / rows_a, B), block(GN_TPB);
+#define SSD_GN_LAUNCH(DT)                                                                                                                    \
+    hipLaunchKernelGGL((k_gn_apply<DT, true>), grid_a, block, 0, st, x, x2, C1, (const float*)nullptr, HW, C, G, rows_a, (const double*)runs1, gamma, beta, scale_shift,    \
+                       scale_shift_stride, eps, act, y, (const double*)runs2);
+    if (dtype == GN_F32) { SSD_GN_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_GN_LAUNCH(GN_F16) } else { SSD_GN_LAUNCH(GN_BF16) }
+#undef SSD_GN_LAUNCH
+    SSD_CHECK_LAUNCH("group_norm_nhwc_runs");
     return SSDNERF_OK;
 }
 

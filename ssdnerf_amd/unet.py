@@ -41,13 +41,13 @@ class _ConvF32x2Fn(torch.autograd.Function):
         from . import unet_fast as UF
         hi, lo = conv._split_pair(False)
         ctx.conv = conv
-        return UF.conv2d_nhwc_f32x2(x.contiguous(memory_format=torch.channels_last), hi, lo, bias=conv.bias)
+        return UF.conv2d_nhwc_f32x2(x.contiguous(memory_format=torch.channels_last), hi, lo, bias=conv.bias, splitk_ws=UF.shared_splitk_ws(x.device))
 
     @staticmethod
     def backward(ctx, gy):
         from . import unet_fast as UF
         hi, lo = ctx.conv._split_pair(True)
-        return UF.conv2d_nhwc_f32x2(gy.contiguous(memory_format=torch.channels_last), hi, lo), None
+        return UF.conv2d_nhwc_f32x2(gy.contiguous(memory_format=torch.channels_last), hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)), None
 
 
 class _Conv2d(nn.Conv2d):

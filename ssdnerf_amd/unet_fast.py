@@ -44,11 +44,14 @@ def _lib_call(what: str):
 
 def group_norm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, scale_shift: Optional[torch.Tensor], eps: float,
                     act: bool, workspace: torch.Tensor, out: Optional[torch.Tensor] = None, pre_bias: Optional[torch.Tensor] = None,
-                    workspace_is_zero: bool = False, stats_ready: bool = False, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    workspace_is_zero: bool = False, stats_ready: bool = False, x2: Optional[torch.Tensor] = None,
+                    runs: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> torch.Tensor:
     """``x``: (B, C, H, W) tensor in channels_last memory format, or (B, T, C) contiguous.  ``scale_shift``: fp32 view (B, 2C) whose
     rows may be strided.  ``pre_bias``: fp32 (C,) added to x before the norm.  ``stats_ready``: ``workspace`` already holds the sums
     (written by the producing convolution's epilogue).  ``x2``: normalise the channel concatenation [x | x2] without building it
-    (4-D only).  Returns a tensor of the input's shape/strides (of the concatenation's shape with ``x2``)."""
+    (4-D only).  ``runs`` = (runs of x, runs of x2 or None): statistics per run of 4 channels (fp64 (B, C/4, 2) each, what the convolutions
+    write with ``gn_groups = Cout // 4``) instead of ``workspace``; only the normalisation pass runs.
+    Returns a tensor of the input's shape/strides (of the concatenation's shape with ``x2``)."""
     if x.dim() == 4:
         B, C1, H, W = x.shape
         HW = H * W
@@ -74,6 +77,12 @@ def group_norm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: tor
     if scale_shift is not None:
         assert scale_shift.dtype == torch.float32 and scale_shift.shape == (B, 2 * Cc) and scale_shift.stride(1) == 1
         ss_stride = scale_shift.stride(0)
+    if runs is not None:
+        assert pre_bias is None and (x2 is None) == (runs[1] is None)
+        C.check(C.lib().ssdnerf_group_norm_nhwc_runs(C.ptr(x), C.ptr(x2), C.u32(C1), _GN_DTYPE[x.dtype], C.u32(B), C.u32(HW), C.u32(Cc), C.u32(groups), C.ptr(gamma),
+                                                      C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)), C.ptr(runs[0]), C.ptr(runs[1]),
+                                                      C.ptr(y), C.stream()), "group_norm_nhwc_runs")
+        return y
     C.check(C.lib().ssdnerf_group_norm_nhwc(C.ptr(x), C.ptr(x2), C.u32(C1), _GN_DTYPE[x.dtype], C.u32(B), C.u32(HW), C.u32(Cc), C.u32(groups), C.ptr(pre_bias), C.ptr(gamma),
                                              C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)), C.ptr(workspace),
                                              2 if stats_ready else int(bool(workspace_is_zero)), C.ptr(y), C.stream()),
@@ -162,7 +171,7 @@ def split_bf16x2(w: torch.Tensor):
 
 def conv2d_nhwc_f32x2(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                       stride: int = 1, upsample: bool = False, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0, tile_hint: int = 0,
-                      x2: Optional[torch.Tensor] = None, splits_hint: int = 0) -> torch.Tensor:
+                      x2: Optional[torch.Tensor] = None, splits_hint: int = 0, splitk_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 convolution with fp32-class (bf16 x 2) products on the matrix cores (csrc/conv_igemm.hip, k_conv_igemm_f32x2).  ``x`` (B, Cin, H, W)
     fp32 channels_last, ``w_hi`` / ``w_lo`` = ``split_bf16x2(weight)`` in channels_last, ``residual`` / result fp32 channels_last."""
     if x.dtype != torch.float32 or w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16:
@@ -182,7 +191,9 @@ def conv2d_nhwc_f32x2(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, b
     pad = k // 2
     Ho, Wo = (Hv + 2 * pad - k) // stride + 1, (Wv + 2 * pad - k) // stride + 1
     plan = C.lib().ssdnerf_conv2d_nhwc_f32x2_plan(C.u32(B * Ho * Wo), C.u32(Cin), C.u32(Cout), C.u32(k), int(tile_hint), int(splits_hint))
-    split = (plan >> 8) > 1                             # split-K accumulates into the output: hand it over zeroed (a fill kernel, graph-capturable like any other)
+    ws_bytes = 0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size()
+    # split-K accumulates into ``splitk_ws`` (all zero, left all zero) or, without a large enough one, into the output: hand that over zeroed
+    split = (plan >> 8) > 1 and ws_bytes < B * Ho * Wo * Cout * 4
     y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if split:
         y.zero_()
@@ -190,7 +201,7 @@ def conv2d_nhwc_f32x2(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, b
         raise RuntimeError("conv2d_nhwc_f32x2: residual must match the output's shape, dtype and layout")
     C.check(C.lib().ssdnerf_conv2d_nhwc_f32x2(C.ptr(x), C.ptr(x2), C.u32(Cin1), C.ptr(w_hi), C.ptr(w_lo), C.ptr(bias), C.ptr(residual), C.ptr(y), C.u32(B), C.u32(H),
                                                C.u32(W), C.u32(Cin), C.u32(Cout), C.u32(k), C.u32(stride), C.u32(int(upsample)), C.ptr(gn_sums), C.u32(gn_groups),
-                                               int(tile_hint), int(splits_hint), int(split), C.stream()), "conv2d_nhwc_f32x2")
+                                               int(tile_hint), int(splits_hint), int(split), C.ptr(splitk_ws), ctypes.c_size_t(ws_bytes), C.stream()), "conv2d_nhwc_f32x2")
     return y
 
 
@@ -278,7 +289,7 @@ class _Conv:
 
     def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0, x2=None):
         if self.w_lo is not None:
-            return conv2d_nhwc_f32x2(x, self.w_lo[0], self.w_lo[1], bias, residual, self.stride[0], upsample, gn_sums, gn_groups, x2=x2)
+            return conv2d_nhwc_f32x2(x, self.w_lo[0], self.w_lo[1], bias, residual, self.stride[0], upsample, gn_sums, gn_groups, x2=x2, splitk_ws=_Conv.splitk_ws)
         return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups, splitk_ws=_Conv.splitk_ws, x2=x2)
 
     def _w_lib(self):                                               # weight for the library path of a block whose other convolutions do not fit the own kernel
@@ -297,6 +308,13 @@ class _Conv:
             _lib_call(f"conv2d {tuple(self.w.shape)}")
             return F.conv2d(x, self.w, self.bias.to(self.w.dtype), self.stride, self.padding)
         return bias_residual_nhwc(self.mm(x), self.bias, None)
+
+
+def shared_splitk_ws(device) -> torch.Tensor:
+    """The all-zero fp32 scratch the split-K convolutions reduce through (every call leaves it all zero again; one per process, one stream)."""
+    if _Conv.splitk_ws is None or _Conv.splitk_ws.device != torch.device(device):
+        _Conv.splitk_ws = torch.zeros(_Conv.SPLITK_BYTES // 4, dtype=torch.float32, device=device)
+    return _Conv.splitk_ws
 
 
 class _GN:
@@ -401,33 +419,40 @@ class FastUnet:
         self.out_ops = [seq(b) for b in net.out_blocks]
         self.head = (_GN(net.out.gn), _Conv(net.out.conv, dt, pad_out=True))
         self.emb_w, self.emb_b = torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous()
-        if dt == torch.bfloat16 and self.device.type == "cuda" and _Conv.splitk_ws is None:
-            _Conv.splitk_ws = torch.zeros(_Conv.SPLITK_BYTES // 4, dtype=torch.float32, device=self.device)
+        if self.device.type == "cuda":
+            shared_splitk_ws(self.device)
         self._ws, self._ws_by_batch = None, {}
+        self._max_c = max(int(p.shape[0]) for p in net.parameters() if p.dim() == 4)
 
     # ------------------------------------------------------------------------------------------------ blocks
-    # Every block function takes and returns (activation, stats): ``stats`` is a slice of the statistics arena that already holds
-    # the GroupNorm sums of the activation (written by the epilogue of the convolution that produced it), or None.
-    def _stats_slice(self, batch):
-        n = batch * 64 * 2                                                  # one slice of the pre-zeroed statistics arena per norm
+    # Every block function takes and returns (activation, stats): ``stats`` is a slice of the statistics arena that already holds the sums of
+    # the activation PER RUN OF 4 CHANNELS (fp64 (B, C/4, 2), written by the epilogue of the convolution that produced it: r03 -- the producer
+    # then need not know how its consumer groups the channels, and a skip tensor's sums serve the encoder's next norm AND the decoder's
+    # concatenated one), or None (the consuming norm then runs its own statistics pass).
+    def _stats_slice(self, batch, channels=256):
+        n = batch * (channels // 4) * 2                                     # a slice of the pre-zeroed statistics arena
         ws = self._ws[self._ws_next:self._ws_next + n]
         self._ws_next += n
         assert ws.numel() == n, "GroupNorm statistics arena exhausted"
         return ws
 
-    def _gn(self, x, gn: _GN, ss, act, pre_bias=None, stats=None, x2=None):
-        if stats is not None:
-            return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, stats, stats_ready=True, x2=x2)
+    def _gn(self, x, gn: _GN, ss, act, pre_bias=None, stats=None, x2=None, stats2=None):
+        Cc = (x.size(1) if x.dim() == 4 else x.size(2)) + (x2.size(1) if x2 is not None else 0)
+        if stats is not None and (x2 is None or stats2 is not None) and (Cc // gn.groups) % 4 == 0:
+            return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, stats, x2=x2, runs=(stats, stats2))
         return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, self._stats_slice(x.size(0)), pre_bias=pre_bias, workspace_is_zero=True,
                                x2=x2)
 
-    def _can_fuse_stats(self, conv: _Conv, x, gn: _GN, upsample=False):
+    def _can_fuse_stats(self, conv: _Conv, x, upsample=False):
         if not conv.own:
             return False
         hw = x.size(2) * x.size(3) * (4 if upsample else 1) // (conv.stride[0] * conv.stride[1])
         cout, cin, k = conv.w.size(0), conv.w.size(1), conv.w.size(2)
-        if (cout // gn.groups) % 4 != 0:
+        if cout % 4 != 0:
             return False                                                    # csrc/conv_igemm.hip: statistics per 4-channel half chunk
+        if hw > 128 * 256:
+            return False                                                    # every output tile of a sample adds to the same few dozen fp64 addresses: beyond ~500
+                                                                            # tiles per sample (the tiled layout's 128 x 384 levels) a separate pass is faster
         if conv.w_lo is not None:                                           # fp32 kernel (mirrors ssdnerf_conv2d_nhwc_f32x2's choice of tile and split)
             plan = C.lib().ssdnerf_conv2d_nhwc_f32x2_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, 0)
             if plan >> 8 != 1:
@@ -438,21 +463,24 @@ class FastUnet:
             return True                                                     # a split-K layer: its finishing pass takes the statistics
         return hw % (256 if (plan & 0xff) == 4 else 128 if (plan & 0xff) == 1 else 64) == 0   # unsplit: the M tile must lie inside one sample
 
-    def _res(self, x, stats, op, ss_all, x2=None):
+    def _conv_stats(self, conv: _Conv, x, bias=None, residual=None, upsample=False, x2=None):
+        """An own convolution with the run-level statistics of its output where the kernel can take them (else None)."""
+        st = self._stats_slice(x.size(0), conv.w.size(0)) if self._can_fuse_stats(conv, x, upsample) else None
+        return conv.igemm(x, bias, residual, upsample=upsample, gn_sums=st, gn_groups=conv.w.size(0) // 4 if st is not None else 0, x2=x2), st
+
+    def _res(self, x, stats, op, ss_all, x2=None, stats2=None):
         """One residual block.  ``x2``: the block's input is the concatenation [x | x2] (decoder half) and is never built."""
         _, gn1, conv1, gn2, (off, n), conv2, shortcut, out_bias = op
         ss = ss_all[:, off:off + n]
         own = conv1.own and conv2.own and (shortcut is None or shortcut.own)
         if x2 is not None and not (own and shortcut is not None and x.size(1) % 8 == 0 and x2.size(1) % 8 == 0):
-            x, x2, stats = torch.cat([x, x2], dim=1).contiguous(memory_format=torch.channels_last), None, None
-        g1 = self._gn(x, gn1, None, True, stats=stats, x2=x2)
+            x, x2, stats, stats2 = torch.cat([x, x2], dim=1).contiguous(memory_format=torch.channels_last), None, None, None
+        g1 = self._gn(x, gn1, None, True, stats=stats, x2=x2, stats2=stats2)
         if own:
-            st1 = self._stats_slice(x.size(0)) if self._can_fuse_stats(conv1, g1, gn2) else None
-            h = conv1.igemm(g1, conv1.bias, gn_sums=st1, gn_groups=gn2.groups)             # conv + bias (+ statistics for gn2)
+            h, st1 = self._conv_stats(conv1, g1, conv1.bias)                                # conv + bias (+ statistics for gn2)
             g2 = self._gn(h, gn2, ss, True, stats=st1)
             skip = shortcut.igemm(x, x2=x2) if shortcut is not None else x                  # the shortcut's bias rides in out_bias
-            st2 = self._stats_slice(x.size(0)) if self._can_fuse_stats(conv2, g2, gn1) else None
-            return conv2.igemm(g2, out_bias, skip, gn_sums=st2, gn_groups=gn1.groups), st2  # conv + bias + skip (+ statistics for the next norm)
+            return self._conv_stats(conv2, g2, out_bias, skip)                              # conv + bias + skip (+ statistics for whatever reads it next)
         h = conv1.mm(g1)
         h = conv2.mm(self._gn(h, gn2, ss, True, pre_bias=conv1.bias))
         return bias_residual_nhwc(h, out_bias, shortcut.mm(x) if shortcut is not None else x), None   # + b_conv2 (+ b_shortcut) + skip
@@ -469,9 +497,7 @@ class FastUnet:
             # its epilogue), softmax(QK^T)V on the MFMA flash-attention kernel
             qkv = qkv_conv.igemm(xn.view(B, H, W, Cc).permute(0, 3, 1, 2), qkv_conv.bias)           # (B, 3C, H, W) channels_last
             a = attention_qkv(qkv.permute(0, 2, 3, 1).reshape(B, T, 3 * Cc), heads)                  # (B, T, C)
-            st = self._stats_slice(B) if self._can_fuse_stats(proj_conv, x, gn) else None
-            h = proj_conv.igemm(a.view(B, H, W, Cc).permute(0, 3, 1, 2), proj_conv.bias, x, gn_sums=st, gn_groups=gn.groups)
-            return h, st
+            return self._conv_stats(proj_conv, a.view(B, H, W, Cc).permute(0, 3, 1, 2), proj_conv.bias, x)
         _lib_call(f"attention block C={Cc} T={T} (linear, sdpa, linear)")
         wqkv, wproj = qkv_conv._w_lib()[:, :, 0, 0], proj_conv._w_lib()[:, :, 0, 0]
         qkv = F.linear(xn, wqkv.to(xn.dtype), qkv_conv.bias.to(xn.dtype))   # (B, T, 3C), channel = head*3ch + {q,k,v}*ch + i
@@ -480,29 +506,28 @@ class FastUnet:
         else:
             q, k, v = qkv.view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)   # each (B, heads, T, ch)
             a = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(B, T, Cc)
-        st = self._stats_slice(B)                                            # h + x, and the sums the next block's norm needs, in one pass
-        h = bias_residual_nhwc(F.linear(a, wproj.to(a.dtype), proj_conv.bias.to(a.dtype)), None, xt, gn_sums=st, gn_groups=gn.groups)
-        return h.view(B, H, W, Cc).permute(0, 3, 1, 2), st                  # back to a channels_last (B, C, H, W) view
+        h = bias_residual_nhwc(F.linear(a, wproj.to(a.dtype), proj_conv.bias.to(a.dtype)), None, xt)      # h + x
+        return h.view(B, H, W, Cc).permute(0, 3, 1, 2), None                # back to a channels_last (B, C, H, W) view
 
-    def _run(self, ops, h, ss_all, stats=None, x2=None):
+    def _run(self, ops, h, ss_all, stats=None, x2=None, stats2=None):
         for op in ops:
             kind = op[0]
             if kind == "res":
-                h, stats = self._res(h, stats, op, ss_all, x2=x2)
-                x2 = None
+                h, stats = self._res(h, stats, op, ss_all, x2=x2, stats2=stats2)
+                x2 = stats2 = None
             elif kind == "att":
                 h, stats = self._att(h, stats, op)
             elif kind == "conv":
-                h, stats = op[1](h), None
+                h, stats = self._conv_stats(op[1], h, op[1].bias) if op[1].own else (op[1](h), None)
             elif kind == "up":
                 if op[1] is not None and op[1].own:
-                    h = op[1].igemm(h, op[1].bias, upsample=True)           # the upsampled tensor is never built
+                    h, stats = self._conv_stats(op[1], h, op[1].bias, upsample=True)       # the upsampled tensor is never built
                 else:
                     _lib_call("interpolate (+ library convolution)")
                     h = F.interpolate(h, scale_factor=2, mode="nearest")
                     if op[1] is not None:
                         h = op[1](h)
-                stats = None
+                    stats = None
         return h, stats
 
     def _time_embedding(self, t):
@@ -531,11 +556,12 @@ class FastUnet:
         hs, stats = [], None
         for ops in self.in_ops:
             h, stats = self._run(ops, h, ss_all, stats)
-            hs.append(h)
+            hs.append((h, stats))
         h, stats = self._run(self.mid_ops, h, ss_all, stats)
         for ops in self.out_ops:
             assert ops[0][0] == "res"
-            h, stats = self._run(ops, h, ss_all, x2=hs.pop())                # torch.cat([h, skip]) happens inside the block's kernels
+            skip, skip_stats = hs.pop()
+            h, stats = self._run(ops, h, ss_all, stats, x2=skip, stats2=skip_stats)   # torch.cat([h, skip]) happens inside the block's kernels
         gn, conv = self.head
         out = conv(self._gn(h, gn, None, True, stats=stats))
         return out[:, :net.out_channels].float().contiguous()               # NCHW fp32, what the DDIM update consumes (drops the head's padding)
@@ -543,7 +569,7 @@ class FastUnet:
     # ------------------------------------------------------------------------------------------------ entry
     def _ensure_ws(self, B):
         ws = self._ws_by_batch.get(B)                                       # one arena per batch size: captured graphs keep pointing at theirs
-        n = (2 * self._n_gn + 8) * B * 64 * 2                               # norms + statistics produced by a convolution but not consumed
+        n = (2 * self._n_gn + 16) * B * (max(256, self._max_c) // 4) * 2    # one slice per statistics producer (run level) / per norm without one
         if ws is None or ws.numel() != n:
             ws = self._ws_by_batch[B] = torch.zeros(n, dtype=torch.float64, device=self.device)
         self._ws = ws
