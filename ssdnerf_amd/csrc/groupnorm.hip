@@ -187,21 +187,34 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x,
     const uint32_t stpr = second ? tpr - tpr1 : tpr1, scv = second ? cv - tpr1 : cv;
     const size_t sbase = ((size_t)b * HW + row0) * stpr + scv;
     const size_t base = ((size_t)b * HW + row0) * tpr + cv;
-    for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
-        float f[V];
-        GnVec<DT>::load(src, sbase + (size_t)r * stpr, f);
+    // GN_APPLY_UNROLL rows per trip, their 16-byte loads issued before the first is used (r03 A/B, cars UNet forward: 1: 4.32 / 9.13 ms, 2: 4.29 / 9.05,
+    // 4: 4.33 / 9.04 -- bf16 / fp32; one load in flight per thread left the pass at ~55 % of
+    // the HBM rate -- 8 waves per SIMD x 16 bytes is 32 KiB in flight per CU against ~2 us of latency)
+#ifndef GN_APPLY_UNROLL
+#define GN_APPLY_UNROLL 2
+#endif
+    constexpr int UR = GN_APPLY_UNROLL;
+    for (uint32_t r0 = lane_row; r0 < rows_per_block; r0 += rif * UR) {
+        float f[UR][V];
+#pragma unroll
+        for (int k = 0; k < UR; ++k)
+            if (r0 + k * rif < rows_per_block) GnVec<DT>::load(src, sbase + (size_t)(r0 + k * rif) * stpr, f[k]);
         typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < V; i += 2) {                                      // pairs: packed fp32 math around the two transcendentals (SiLU = v / (1 + 2^(-log2(e) v)))
-            f2 v = __builtin_elementwise_fma(f2{f[i], f[i + 1]}, f2{a[i], a[i + 1]}, f2{o[i], o[i + 1]});
-            if (act) {
-                const f2 u = v * f2{-1.4426950408889634f, -1.4426950408889634f};
-                const f2 d = f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + f2{1.0f, 1.0f};
-                v = v * f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        for (int k = 0; k < UR; ++k) {
+            if (r0 + k * rif >= rows_per_block) break;
+#pragma unroll
+            for (int i = 0; i < V; i += 2) {                                  // pairs: packed fp32 math around the two transcendentals (SiLU = v / (1 + 2^(-log2(e) v)))
+                f2 v = __builtin_elementwise_fma(f2{f[k][i], f[k][i + 1]}, f2{a[i], a[i + 1]}, f2{o[i], o[i + 1]});
+                if (act) {
+                    const f2 u = v * f2{-1.4426950408889634f, -1.4426950408889634f};
+                    const f2 d = f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + f2{1.0f, 1.0f};
+                    v = v * f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                }
+                f[k][i] = v.x; f[k][i + 1] = v.y;
             }
-            f[i] = v.x; f[i + 1] = v.y;
+            GnVec<DT>::store(y, base + (size_t)(r0 + k * rif) * tpr, f[k]);
         }
-        GnVec<DT>::store(y, base + (size_t)r * tpr, f);
     }
 }
 
