@@ -91,7 +91,7 @@ SSD_DEV float cv_half_wave_sum(float v) {                                       
     return v;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool F32 = false>
 SSD_DEV void cv_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TN][TM], unsigned char* lds, uint32_t m0, uint32_t n0, uint32_t wm, uint32_t wn) {
     constexpr int BN = 128;
     const uint32_t tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -117,6 +117,20 @@ SSD_DEV void cv_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TN][TM], unsign
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float f[4] = {acc[j][i][4 * q] + bv[q].x, acc[j][i][4 * q + 1] + bv[q].y, acc[j][i][4 * q + 2] + bv[q].z, acc[j][i][4 * q + 3] + bv[q].w};
+                if (F32) {                                                   // fp32 activations (the f32x2 form): a lane's run of four channels is one 16-byte store
+                    const size_t o = row + cb + 8 * q + 4 * half;
+                    if (a.res) {
+                        const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + o);
+                        f[0] += rv.x; f[1] += rv.y; f[2] += rv.z; f[3] += rv.w;
+                    }
+                    if (ok) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + o) = make_float4(f[0], f[1], f[2], f[3]);
+                    if (a.gn_sums && ok) {
+                        gs[q] += (f[0] + f[1]) + (f[2] + f[3]);
+                        gq[q] = __builtin_fmaf(f[0], f[0], gq[q]); gq[q] = __builtin_fmaf(f[1], f[1], gq[q]);
+                        gq[q] = __builtin_fmaf(f[2], f[2], gq[q]); gq[q] = __builtin_fmaf(f[3], f[3], gq[q]);
+                    }
+                    continue;
+                }
                 if (a.res) {
                     const uint2 rv = *reinterpret_cast<const uint2*>(a.res + (row + cb + 8 * q + 4 * half) * 2);
                     f[0] += __uint_as_float(rv.x << 16); f[1] += __uint_as_float(rv.x & 0xffff0000u);
@@ -132,7 +146,7 @@ SSD_DEV void cv_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TN][TM], unsign
                 }
             }
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {                                 // lower half ends up with channels 16 qp .. + 7, upper half with 16 qp + 8 .. + 15 of ITS pixel
+            for (int qp = 0; qp < (F32 ? 0 : 2); ++qp) {                     // lower half ends up with channels 16 qp .. + 7, upper half with 16 qp + 8 .. + 15 of ITS pixel
                 auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * qp].x, pk[2 * qp + 1].x, false, false);
                 auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * qp].y, pk[2 * qp + 1].y, false, false);
                 if (ok) *reinterpret_cast<uint4*>(a.y + (row + cb + 16 * qp + 8 * half) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
@@ -1160,12 +1174,29 @@ SSD_DEV void pp_wait_vm_lgkm_barrier(uint32_t n) {          // n = DMA instructi
     default: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     }
 }
+SSD_DEV void pp_wait_vm_barrier(uint32_t n) {               // the same without the LDS wait (F32 form: that wait sits in front of the operand split)
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+    }
+}
 SSD_DEV void pp_wait_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 SSD_DEV void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <bool ROWS>
+// F32 (r03): the same kernel for fp32 activations with fp32-class products (the "f32x2" arithmetic of k_conv_igemm_f32x2: hi * hi + hi * lo + lo * hi
+// on bf16 pairs).  The tile rows stay 128 bytes, so ring, DMA schedule and barriers are unchanged: an A row is 32 fp32 channels of a pixel (split
+// into the bf16 pair when the fragment is read: 24 VALU instructions per fragment, under the other group's MFMA segment), a B row the 32 hi terms
+// followed by the 32 lo terms of an output channel (w_lo must lie directly behind w_hi in memory: one buffer descriptor serves both); a K-tile is
+// 32 channels, each of its two phases one 16-deep k-step of 12 MFMAs -- 1.5 x the matrix work of the bf16 form per byte moved.
+template <bool ROWS, bool F32 = false>
 __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     constexpr int BM = 256, BN = 128, TM = 2, TN = 2;
+    constexpr uint32_t KCH = F32 ? 32 : 64, AB = F32 ? 4 : 2;                 // channels per K-tile, bytes per activation element
     constexpr int A_ROWS = ROWS ? BM + 8 + 1 : BM;                            // ROWS: up to eight image rows per tile (W = 32) + their zero rows
     constexpr int A_BUF = A_ROWS * CV_ROWB, B_BUF = BN * CV_ROWB;
     constexpr int NA = ROWS ? 2 : 3, NB = 3;                                 // stages per operand
@@ -1180,7 +1211,7 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     const uint32_t group = wave >> 2;                                        // waves 0-3 / 4-7: one wave of each group per SIMD
 
     const uint32_t n_blocks = a.m_tiles * a.n_tiles;
-    const uint32_t taps = a.ksize * a.ksize, kc = a.Cin / CV_BK, KT = taps * kc, Cin2 = a.Cin - a.Cin1;
+    const uint32_t taps = a.ksize * a.ksize, kc = a.Cin / KCH, KT = taps * kc, Cin2 = a.Cin - a.Cin1;
     const uint32_t W = a.W;
     const uint32_t seg_w = ROWS ? (W >= (uint32_t)BM ? (uint32_t)BM : W) : 1u, n_seg = ROWS ? (uint32_t)BM / seg_w : 0u;
     if (ROWS) {
@@ -1189,9 +1220,10 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
             *reinterpret_cast<uint4*>(abuf + buf * A_BUF + row * (seg_w + 1) * CV_ROWB + chunk * 16) = make_uint4(0, 0, 0, 0);
         }
     }
-    const __amdgpu_buffer_rsrc_t rs_x = cv_rsrc(a.x, (uint64_t)a.B * a.H * a.W * a.Cin1 * 2);
-    const __amdgpu_buffer_rsrc_t rs_x2 = cv_rsrc(a.x2 ? a.x2 : a.x, a.x2 ? (uint64_t)a.B * a.H * a.W * Cin2 * 2 : 0);
-    const __amdgpu_buffer_rsrc_t rs_w = cv_rsrc(a.w, (uint64_t)a.Cout * taps * a.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rs_x = cv_rsrc(a.x, (uint64_t)a.B * a.H * a.W * a.Cin1 * AB);
+    const __amdgpu_buffer_rsrc_t rs_x2 = cv_rsrc(a.x2 ? a.x2 : a.x, a.x2 ? (uint64_t)a.B * a.H * a.W * Cin2 * AB : 0);
+    const uint32_t w_term_bytes = a.Cout * taps * a.Cin * 2;                  // one bf16 weight tensor (F32: hi, then lo directly behind it)
+    const __amdgpu_buffer_rsrc_t rs_w = cv_rsrc(a.w, (uint64_t)w_term_bytes * (F32 ? 2 : 1));
 
     // ---- PERSISTENT over tiles: block b takes tiles b, b + gridDim, ... (gridDim = min(tiles, CUs), a multiple of 8).  The stores of a tile's
     // epilogue are posted writes: they drain while the next tile's K loop runs, instead of ending every round of blocks with a chip-wide burst of
@@ -1237,8 +1269,9 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     uint32_t b_voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const uint32_t r = (wave * 2 + i) * 8 + (lane >> 3);
-        b_voff[i] = ((n0 + r) * taps * a.Cin) * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        const uint32_t r = (wave * 2 + i) * 8 + (lane >> 3), sc = (lane & 7) ^ ((r >> 1) & 7);     // sc: the 16-byte chunk of the row this lane fetches
+        b_voff[i] = F32 ? ((n0 + r) * taps * a.Cin) * 2 + (sc & 3) * 16 + (sc >> 2) * w_term_bytes      // chunks 0-3: 32 hi terms, 4-7: the 32 lo terms
+                        : ((n0 + r) * taps * a.Cin) * 2 + sc * 16;
     }
     uint32_t a_voff[4], a_voff2[4];                                          // per tap: byte offset of this lane's 16 bytes in x / x2 at channel 0, or CV_OOB
     auto set_tap = [&](uint32_t tap) {                                          // generic: tap = kh * ksize + kw;  ROWS: tap = kh (the kw shift happens at read time)
@@ -1253,14 +1286,14 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
                 const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
                 pix = a_img[i] + yi * a.W + xi;
             }
-            a_voff[i] = ok ? pix * a.Cin1 * 2 + a_chunk[i] : CV_OOB;
-            a_voff2[i] = ok ? pix * Cin2 * 2 + a_chunk[i] : CV_OOB;
+            a_voff[i] = ok ? pix * a.Cin1 * AB + a_chunk[i] : CV_OOB;
+            a_voff2[i] = ok ? pix * Cin2 * AB + a_chunk[i] : CV_OOB;
         }
     };
     auto issue_a = [&](int i, uint32_t ci0, uint32_t buf) {                      // one A piece of the tap set by set_tap; ci0 is scalar
         unsigned char* dst = abuf + buf * A_BUF + a_lds[i];
-        if (ci0 >= a.Cin1) cv_dma16(rs_x2, dst, a_voff2[i], (ci0 - a.Cin1) * 2);
-        else cv_dma16(rs_x, dst, a_voff[i], ci0 * 2);
+        if (ci0 >= a.Cin1) cv_dma16(rs_x2, dst, a_voff2[i], (ci0 - a.Cin1) * AB);
+        else cv_dma16(rs_x, dst, a_voff[i], ci0 * AB);
     };
     auto issue_b = [&](int i, uint32_t tap, uint32_t ci0, uint32_t buf) {
         cv_dma16(rs_w, bbuf + buf * B_BUF + (wave * 2 + i) * 1024, b_voff[i], (tap * a.Cin + ci0) * 2);
@@ -1275,12 +1308,13 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const uint32_t rho = t0 + (lane & 31) + t0 / seg_w + kw;          // = 1 + seg (seg_w + 1) + x + (kw - 1)
-                a_rd[i][ROWS ? kw : 0] = rho * CV_ROWB + (((lane >> 5) ^ ((rho >> 1) & 7)) * 16);
+                a_rd[i][ROWS ? kw : 0] = rho * CV_ROWB + ((((lane >> 5) << (F32 ? 1 : 0)) ^ ((rho >> 1) & 7)) * 16);
             }
         } else {
-            a_rd[i][0] = (t0 + (lane & 31)) * CV_ROWB + (((lane >> 5) ^ ((lane >> 1) & 7)) * 16);
+            a_rd[i][0] = (t0 + (lane & 31)) * CV_ROWB + ((((lane >> 5) << (F32 ? 1 : 0)) ^ ((lane >> 1) & 7)) * 16);
         }
     }
+    // (F32: a lane's 8 channels of k-step P are the TWO chunks 4 P + 2 half + {0, 1} of the fp32 row: a_rd ^ (P * 64) ^ (e * 16))
     const uint32_t b_rd = (wn * 64 + (lane & 31)) * CV_ROWB + (((lane >> 5) ^ ((lane >> 1) & 7)) * 16);
 
     f32x16 acc[TN][TM];                                                          // TRANSPOSED: [channel tile][pixel tile], rows of a tile = output channels (cv_epilogue_direct)
@@ -1324,8 +1358,8 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
         if (KT > 1) {
             if (l_ci == 0) set_tap(l_tap);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) issue_a(i, l_ci * CV_BK, 1);
-            issue_b(0, l_tap, l_ci * CV_BK, 1); issue_b(1, l_tap, l_ci * CV_BK, 1);
+            for (int i = 0; i < 4; ++i) issue_a(i, l_ci * KCH, 1);
+            issue_b(0, l_tap, l_ci * KCH, 1); issue_b(1, l_tap, l_ci * KCH, 1);
             advance_l();
             in_flight_young = 6;
         }
@@ -1335,85 +1369,154 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
 #ifdef CV_PP_TIMING
     if (tid == 0) stamps[1] = __builtin_amdgcn_s_memtime();
 #endif
+
+    // Fragments are read ONE PHASE AHEAD, in the compute segment (r03): a phase's load segment was twice as long as its MFMA segment -- eight
+    // ds_read_b128 round trips, then the DMA issue, in one wave -- so the two groups alternated at ~50 % matrix-pipe use.  Now the reads of phase
+    // q + 1 are issued at the head of phase q's compute segment and fly under its MFMAs; the load segment is DMA issue, the waits and (F32) the
+    // operand split.  Two register sets, indexed by the phase's k-half.  What changes in the safety argument (pp_phase above):
+    //   RAW  K-tile t + 1 is first read in the compute segment of phase 2 t + 1, so its DMA wait moves ONE phase up: phase 2 t waits
+    //        `vmcnt(pieces issued in phase 2 t)` before its first barrier, which retires every older piece (all of K-tile t + 1; ROWS: the next A
+    //        group too); the other group does the same one barrier later, and phase 2 t + 1's compute segment lies behind both.
+    //   WAR  a stage's last reads now sit in the compute segment of the phase BEFORE the old one -- earlier, not later; they are retired by the
+    //        `lgkmcnt(0)` of the following load segment, i.e. still before the barrier the first DMA into that stage waits behind.
+    bf16x8 fa[2][2][TM], fb[2][2][TN];                                           // [register set = k-half P][bf16: k-step of the phase | F32: hi, lo][tile]
+    float4 xa[F32 ? TM : 1][2];                                                  // F32: the NEXT phase's raw fp32 pixels (split in its load segment)
+    auto load_frags = [&](auto pc, auto kwc, const unsigned char* sa, const unsigned char* sb) {
+        constexpr int P = decltype(pc)::value, KW = decltype(kwc)::value;
+        if (F32) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) xa[F32 ? i : 0][e] = *reinterpret_cast<const float4*>(sa + (a_rd[i][ROWS ? KW : 0] ^ (P * 64) ^ (e * 16)));
+#pragma unroll
+            for (int s = 0; s < 2; ++s)                                      // s = 0: the hi terms (row chunks 0-3), 1: the lo terms (chunks 4-7)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[P][s][j] = *reinterpret_cast<const bf16x8*>(sb + ((b_rd + j * 32 * CV_ROWB) ^ ((P + 2 * s) * 32)));
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[P][s][i] = *reinterpret_cast<const bf16x8*>(sa + (a_rd[i][ROWS ? KW : 0] ^ ((2 * P + s) * 32)));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[P][s][j] = *reinterpret_cast<const bf16x8*>(sb + ((b_rd + j * 32 * CV_ROWB) ^ ((2 * P + s) * 32)));
+            }
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    load_frags(P0{}, K0{}, abuf, bbuf);                                          // phase 0's fragments (K-tile 0 is in place: the barrier above)
     if (group == 1) pp_barrier();                                                // the stagger: group 1 runs one barrier behind
 
-    uint32_t issued_prev = 0;
-    // one phase: P = k-half of the K-tile (compile time), KW = tap column (ROWS; compile time: the K-tiles of a group are unrolled), t = K-tile
-    auto phase = [&](auto pc, auto kwc, uint32_t t, const unsigned char* sa, const unsigned char* sb) {
+    // one phase: P = k-half of the K-tile (compile time), KW = tap column (ROWS; compile time: the K-tiles of a group are unrolled);
+    // (KWN, sa_n, sb_n) = where the NEXT phase reads (has_next: there is one)
+    auto phase = [&](auto pc, auto kwc, auto kwnc, const unsigned char* sa_n, const unsigned char* sb_n, bool has_next) {
         constexpr int P = decltype(pc)::value, KW = decltype(kwc)::value;
-        // ---- load segment: this phase's fragments ...
-        bf16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(sa + (a_rd[i][ROWS ? KW : 0] ^ ((2 * P + s) * 32)));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(sb + ((b_rd + j * 32 * CV_ROWB) ^ ((2 * P + s) * 32)));
-        }
-        // ---- ... and this wave's share of the DMA two K-tiles ahead
+        // ---- load segment: this wave's share of the DMA two K-tiles ahead
         uint32_t issued = 0;
         if (ROWS) {
             if (l_kt < KT) {                                                     // B piece P of K-tile l_kt = t + 2: tap = kh * 3 + kw of group l_kt / 3
                 const uint32_t g = l_kt / 3, bkh = g / kc, bci = g % kc;
-                issue_b(P, bkh * 3 + l_kt % 3, bci * CV_BK, l_kt % NB);
+                issue_b(P, bkh * 3 + l_kt % 3, bci * KCH, l_kt % NB);
                 ++issued;
             }
             constexpr int Q6 = 2 * KW + P;                                       // phase within the group: A piece Q6 of the NEXT group in its first four phases
             if (Q6 < 4 && g_next < 3 * kc) {
                 if (Q6 == 0) set_tap(g_kh);
-                issue_a(Q6 < 4 ? Q6 : 0, g_ci * CV_BK, g_next & 1);
+                issue_a(Q6 < 4 ? Q6 : 0, g_ci * KCH, g_next & 1);
                 ++issued;
                 if (Q6 == 3) { ++g_next; if (++g_ci == kc) { g_ci = 0; ++g_kh; } }
             }
             if (P == 1) ++l_kt;
         } else {
             if (l_kt < KT) {
-                issue_a(2 * P, l_ci * CV_BK, l_kt % NA); issue_a(2 * P + 1, l_ci * CV_BK, l_kt % NA);
-                issue_b(P, l_tap, l_ci * CV_BK, l_kt % NB);
+                issue_a(2 * P, l_ci * KCH, l_kt % NA); issue_a(2 * P + 1, l_ci * KCH, l_kt % NA);
+                issue_b(P, l_tap, l_ci * KCH, l_kt % NB);
                 issued = 3;
                 if (P == 1) { advance_l(); if (l_kt < KT && l_ci == 0) set_tap(l_tap); }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (P == 0) pp_wait_lgkm_barrier();
-        else pp_wait_vm_lgkm_barrier(issued_prev + issued);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- compute segment
-        __builtin_amdgcn_s_setprio(1);
+        if (F32) {
+            // this phase's fragments (read in the previous compute segment) are in: split the pixels' fp32 values -- hi = truncation to bf16,
+            // lo = truncation of the exact remainder -- here, under the other group's MFMA segment
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int i = 0; i < TM; ++i) {
+                const float v[8] = {xa[F32 ? i : 0][0].x, xa[F32 ? i : 0][0].y, xa[F32 ? i : 0][0].z, xa[F32 ? i : 0][0].w,
+                                    xa[F32 ? i : 0][1].x, xa[F32 ? i : 0][1].y, xa[F32 ? i : 0][1].z, xa[F32 ? i : 0][1].w};
+                uint32_t hw[4], lw[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float r0 = v[2 * k] - __uint_as_float(__float_as_uint(v[2 * k]) & 0xffff0000u);
+                    const float r1 = v[2 * k + 1] - __uint_as_float(__float_as_uint(v[2 * k + 1]) & 0xffff0000u);
+                    hw[k] = __builtin_amdgcn_perm(__float_as_uint(v[2 * k + 1]), __float_as_uint(v[2 * k]), 0x07060302u);
+                    lw[k] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                }
+                const uint4 uh = make_uint4(hw[0], hw[1], hw[2], hw[3]), ul = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                fa[P][0][i] = *reinterpret_cast<const bf16x8*>(&uh);
+                fa[P][1][i] = *reinterpret_cast<const bf16x8*>(&ul);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (P == 0) pp_wait_vm_barrier(issued);
+            else pp_barrier();
+        } else if (P == 0) pp_wait_vm_lgkm_barrier(issued);
+        else pp_wait_lgkm_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute segment: the next phase's fragment reads first, then this phase's MFMAs over them
+        __builtin_amdgcn_s_setprio(1);
+        if (has_next) {
+            if (P == 0) load_frags(P1{}, kwc, sa_n, sb_n);
+            else load_frags(P0{}, kwnc, sa_n, sb_n);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (F32) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s][j], fa[s][i], acc[j][i], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[P][1][j], fa[P][0][i], acc[j][i], 0, 0, 0);      // w_lo x_hi
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[P][0][j], fa[P][1][i], acc[j][i], 0, 0, 0);      // w_hi x_lo
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[P][0][j], fa[P][0][i], acc[j][i], 0, 0, 0);      // w_hi x_hi
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[P][s][j], fa[P][s][i], acc[j][i], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        issued_prev = issued;
-        (void)t;
     };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
 #ifdef CV_PP_SKIP_KLOOP
     if (false)
 #endif
     if (ROWS) {
-        for (uint32_t g = 0, t = 0; g < 3 * kc; ++g, t += 3) {                    // group (kh, ci): three K-tiles (kw) from one A stage
+        const uint32_t G = 3 * kc;
+        for (uint32_t g = 0, t = 0; g < G; ++g, t += 3) {                        // group (kh, ci): three K-tiles (kw) from one A stage
             const unsigned char* sa = abuf + (g & 1) * A_BUF;
-            phase(P0{}, std::integral_constant<int, 0>{}, t, sa, bbuf + (t % NB) * B_BUF);
-            phase(P1{}, std::integral_constant<int, 0>{}, t, sa, bbuf + (t % NB) * B_BUF);
-            phase(P0{}, std::integral_constant<int, 1>{}, t + 1, sa, bbuf + ((t + 1) % NB) * B_BUF);
-            phase(P1{}, std::integral_constant<int, 1>{}, t + 1, sa, bbuf + ((t + 1) % NB) * B_BUF);
-            phase(P0{}, std::integral_constant<int, 2>{}, t + 2, sa, bbuf + ((t + 2) % NB) * B_BUF);
-            phase(P1{}, std::integral_constant<int, 2>{}, t + 2, sa, bbuf + ((t + 2) % NB) * B_BUF);
+            const unsigned char* sb0 = bbuf + (t % NB) * B_BUF;
+            const unsigned char* sb1 = bbuf + ((t + 1) % NB) * B_BUF;
+            const unsigned char* sb2 = bbuf + ((t + 2) % NB) * B_BUF;
+            phase(P0{}, K0{}, K0{}, sa, sb0, true);
+            phase(P1{}, K0{}, K1{}, sa, sb1, true);
+            phase(P0{}, K1{}, K1{}, sa, sb1, true);
+            phase(P1{}, K1{}, K2{}, sa, sb2, true);
+            phase(P0{}, K2{}, K2{}, sa, sb2, true);
+            phase(P1{}, K2{}, K0{}, abuf + ((g + 1) & 1) * A_BUF, bbuf + ((t + 3) % NB) * B_BUF, g + 1 < G);
         }
     } else {
         for (uint32_t t = 0; t < KT; ++t) {
             const unsigned char* sa = abuf + (t % NA) * A_BUF;
             const unsigned char* sb = bbuf + (t % NB) * B_BUF;
-            phase(P0{}, P0{}, t, sa, sb);
-            phase(P1{}, P0{}, t, sa, sb);
+            phase(P0{}, K0{}, K0{}, sa, sb, true);
+            phase(P1{}, K0{}, K0{}, abuf + ((t + 1) % NA) * A_BUF, bbuf + ((t + 1) % NB) * B_BUF, t + 1 < KT);
         }
     }
     if (group == 0) pp_barrier();                                                // even out the stagger
@@ -1425,7 +1528,7 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
 #ifdef CV_PP_TIMING
     if (tid == 0) stamps[2] = __builtin_amdgcn_s_memtime();
 #endif
-    cv_epilogue_direct<TM, TN>(a, acc, lds + RING, m0, n0, wm, wn);
+    cv_epilogue_direct<TM, TN, F32>(a, acc, lds + RING, m0, n0, wm, wn);
 #ifdef CV_PP_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // (stamp 3 = this wave's stores acknowledged)
     if (tid == 0) stamps[3] = __builtin_amdgcn_s_memtime();
@@ -1539,6 +1642,34 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
         if (!a.splitk_ws && !y_is_zero && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2: memset failed");
     } else {
         a.splitk_ws = nullptr;
+    }
+    // r03: the two-group 256 x 128 kernel (k_conv_pp_bf16<ROWS, F32 = true>) takes the layers its bf16 form takes (tile_hint 5 / 6 force it);
+    // it needs the lo weights directly behind the hi ones (one buffer descriptor serves both terms)
+    static const bool pp_auto = getenv("SSDNERF_CONV_NO_TWO_GROUP") == nullptr;
+    const bool pp_ok = Cin % 32 == 0 && Cin1 % 32 == 0 && Cout % 128 == 0 && (const unsigned char*)w_lo == (const unsigned char*)w_hi + (size_t)Cout * ksize * ksize * Cin * 2
+                       && (uint64_t)B * H * W * Cin * 4 < (1ull << 31) && (!gn_sums || (a.Ho * a.Wo) % 256 == 0);
+    // (measured, profiles/r03/m_two_group_fp32.txt: the row-reuse form equals k_conv3x3_f32x2_rows on the 128 x 128 level -- 164 vs 166 us per layer --;
+    // the generic form is SLOWER than k_conv_igemm_f32x2<2, 2> on the upsampling layer, 510 vs 447 us, so only the former is picked automatically)
+    if (tile_hint == 0 && pp_auto && pp_ok && splits == 1 && ksize == 3 && stride == 1 && a.M >= 32768 && !upsample && (W == 128 || W == 64) && (H * W) % 256 == 0)
+        tile_hint = 6;
+    if (tile_hint == 5 || tile_hint == 6) {
+        SSD_REQUIRE(pp_ok, "conv2d_nhwc_f32x2: the 256 x 128 kernel needs Cin %% 32 == 0, Cout %% 128 == 0 and w_lo directly behind w_hi");
+        a.splits = 1; a.splitk_ws = nullptr; a.gn_sums = stats;
+        a.m_tiles = (a.M + 255) / 256; a.n_tiles = Cout / 128;
+        const bool pp_rows = tile_hint == 6 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 256 == 0;
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu < 8) n_cu = 256;
+            n_cu &= ~7;
+        }
+        const uint32_t tiles = a.m_tiles * a.n_tiles, grid = tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu;
+        if (pp_rows) hipLaunchKernelGGL((k_conv_pp_bf16<true, true>), dim3(grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_pp_bf16<false, true>), dim3(grid), dim3(512), 0, st, a);
+        SSD_CHECK_LAUNCH("conv2d_nhwc_f32x2");
+        return SSDNERF_OK;
     }
     a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = (Cout + bm - 1) / bm;
     // 3x3 / stride 1 layers whose 128-pixel tiles are whole image rows take the row-reuse kernel (A loaded once per kh, shared by the three kw taps)

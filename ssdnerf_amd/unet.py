@@ -66,7 +66,7 @@ class _Conv2d(nn.Conv2d):
 
     def _split_pair(self, transposed):
         """bf16 (hi, lo) operand pair of the weights, channels_last; ``transposed`` = the backward-data form.  Rebuilt when the weights change."""
-        from .unet_fast import split_bf16x2
+        from .unet_fast import split_bf16x2_adjacent
         w = self.weight
         cache = self.__dict__.setdefault("_f32x2_cache", {})
         key = (w._version, w.data_ptr(), str(w.device))
@@ -75,7 +75,7 @@ class _Conv2d(nn.Conv2d):
             cache["key"] = key
         if transposed not in cache:
             wt = w.detach().flip(2, 3).transpose(0, 1) if transposed else w.detach()
-            cache[transposed] = tuple(t.contiguous(memory_format=torch.channels_last) for t in split_bf16x2(wt.contiguous()))
+            cache[transposed] = split_bf16x2_adjacent(wt.contiguous())
         return cache[transposed]
 
     def forward(self, x):

@@ -169,6 +169,16 @@ def split_bf16x2(w: torch.Tensor):
     return hi, lo
 
 
+def split_bf16x2_adjacent(w: torch.Tensor):
+    """``split_bf16x2`` of a (Cout, Cin, k, k) weight as two channels_last views of ONE buffer, lo directly behind hi: what the two-group fp32
+    kernel needs (csrc/conv_igemm.hip, k_conv_pp_bf16<ROWS, F32>: one buffer descriptor serves both terms)."""
+    hi, lo = split_bf16x2(w)
+    buf = torch.empty((2, w.shape[0], w.shape[2], w.shape[3], w.shape[1]), dtype=torch.bfloat16, device=w.device)
+    buf[0].copy_(hi.permute(0, 2, 3, 1))
+    buf[1].copy_(lo.permute(0, 2, 3, 1))
+    return buf[0].permute(0, 3, 1, 2), buf[1].permute(0, 3, 1, 2)
+
+
 def conv2d_nhwc_f32x2(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                       stride: int = 1, upsample: bool = False, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0, tile_hint: int = 0,
                       x2: Optional[torch.Tensor] = None, splits_hint: int = 0, splitk_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -276,8 +286,7 @@ class _Conv:
                         and C.lib().ssdnerf_conv2d_nhwc_bf16_supported(int(weight.shape[1]), int(weight.shape[0]), k[0], stride[0], 0))
         self.w_lo = None
         if self.own and dtype == torch.float32 and _Conv.F32X2:
-            hi, lo = split_bf16x2(weight.float())
-            self.w_lo = (hi.contiguous(memory_format=torch.channels_last), lo.contiguous(memory_format=torch.channels_last))
+            self.w_lo = split_bf16x2_adjacent(weight.float())
             self.w = self.w_lo[0]                                   # (the fp32 copy is not needed; shape queries go through the hi term)
         elif dtype == torch.float32:
             self.own = False

@@ -474,6 +474,21 @@ F32X2_CASES = [
     (2, 8, 8, 80, 80, 3, 1, True, 0),
     (1, 16, 16, 8, 128, 3, 1, False, 1),
     (2, 32, 96, 80, 80, 3, 1, False, 3),
+    # r03: the two-group 256 x 128 kernel in its fp32 form (hint 5 generic, 6 row reuse where eligible)
+    (2, 16, 16, 128, 128, 3, 1, False, 5),
+    (3, 10, 10, 64, 256, 3, 1, False, 5),      # ragged last tile, every border case
+    (2, 8, 8, 32, 128, 1, 1, False, 5),        # ONE K-tile in all
+    (3, 9, 6, 96, 256, 1, 1, False, 5),        # three K-tiles
+    (2, 16, 16, 128, 128, 3, 2, False, 5),
+    (1, 16, 16, 128, 256, 3, 1, True, 5),
+    (1, 32, 32, 128, 256, 3, 1, False, 6),     # row reuse, eight image rows per tile
+    (1, 64, 64, 128, 128, 3, 1, False, 6),
+    (2, 128, 128, 64, 128, 3, 1, False, 6),
+    (1, 64, 64, 352, 256, 3, 1, False, 6),     # eleven channel tiles per tap row
+    (8, 128, 128, 128, 128, 3, 1, False, 6),   # bench shapes
+    (8, 128, 128, 256, 128, 3, 1, False, 6),
+    (8, 64, 64, 256, 256, 3, 1, True, 5),
+    (8, 128, 128, 256, 128, 1, 1, False, 5),
 ]
 
 
@@ -483,8 +498,7 @@ def test_conv_f32x2_is_fp32_class(B, H, W, Cin, Cout, k, stride, upsample, hint)
     x = torch.randn(B, Cin, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda()
     bias = torch.randn(Cout, generator=g).cuda()
-    hi, lo = unet_fast.split_bf16x2(w)
-    hi, lo = hi.contiguous(memory_format=torch.channels_last), lo.contiguous(memory_format=torch.channels_last)
+    hi, lo = unet_fast.split_bf16x2_adjacent(w)
     xin = F.interpolate(x, scale_factor=2, mode="nearest") if upsample else x
     want = F.conv2d(xin.double(), w.double(), bias.double(), stride, k // 2)
     res = torch.randn(want.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
@@ -494,6 +508,25 @@ def test_conv_f32x2_is_fp32_class(B, H, W, Cin, Cout, k, stride, upsample, hint)
     assert rel < 3e-5, rel                                                    # products carry >= 16 significand bits (bf16 alone: ~4e-3, TF32: ~5e-4)
     lib = F.conv2d(xin, w, bias, stride, k // 2) + res                        # the library's fp32 convolution, for scale
     assert rel < 20 * max(((lib.double() - (want + res.double())).norm() / want.norm()).item(), 1e-7) or rel < 1e-5
+
+
+@pytest.mark.parametrize("hint,H,B", [(5, 16, 2), (6, 64, 1), (6, 128, 8)])
+def test_conv_f32x2_two_group_concat_and_statistics(hint, H, B):
+    """the fp32 two-group kernel: concatenated input, residual, run-level statistics; several tiles per persistent block at the last shape"""
+    g = torch.Generator().manual_seed(19 + H)
+    C1, C2, Cout = 128, 64, 128
+    a = torch.randn(B, C1, H, H, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(B, C2, H, H, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, C1 + C2, 3, 3, generator=g) / 40).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, Cout, H, H, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    hi, lo = unet_fast.split_bf16x2_adjacent(w)
+    runs = torch.zeros(B, Cout // 4, 2, dtype=torch.float64, device="cuda")
+    y = unet_fast.conv2d_nhwc_f32x2(a, hi, lo, bias, res, x2=b, gn_sums=runs, gn_groups=Cout // 4, tile_hint=hint)
+    want = F.conv2d(torch.cat([a, b], 1).double(), w.double(), bias.double(), 1, 1) + res.double()
+    assert ((y.double() - want).norm() / want.norm()).item() < 3e-5
+    yf = y.double().reshape(B, Cout // 4, 4, H * H)
+    assert torch.allclose(runs[..., 0], yf.sum((2, 3)), rtol=1e-6, atol=1e-4) and torch.allclose(runs[..., 1], yf.square().sum((2, 3)), rtol=1e-6, atol=1e-4)
 
 
 def test_conv_f32x2_concat_and_statistics():
