@@ -313,18 +313,19 @@ int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint32_t B, uint32_t HW
 /* The UNet's convolutions (modules.py:51-129; denoising.py:106-187) as an implicit GEMM on the bf16 matrix cores:
  *   y[b][yo][xo][co] = sum_{kh,kw,ci} X[b][yo*stride+kh-pad][xo*stride+kw-pad][ci] * w[co][kh][kw][ci]  (+ bias[co]) (+ residual[b][yo][xo][co])
  * x bf16 [B][H][W][Cin] channel-last -- or, with x2 != NULL, the never-materialised channel concatenation of x [..][Cin1] and
- * x2 [..][Cin - Cin1] (Cin1 % 64 == 0); w bf16 [Cout][ksize][ksize][Cin] (= torch channels_last weight memory); pad = ksize/2;
+ * x2 [..][Cin - Cin1] (both channel counts multiples of 8); w bf16 [Cout][ksize][ksize][Cin] (= torch channels_last weight memory); pad = ksize/2;
  * X = x, or with upsample != 0 the nearest-neighbour 2x upsampling of x, never materialised (DenoisingUpsampleMod);
  * stride 2 = DenoisingDownsampleMod.  bias fp32 [Cout] (nullable), residual / y bf16 [B][Ho][Wo][Cout] (residual nullable,
  * may alias y).  fp32 accumulation; bias and residual are added in fp32 before the single rounding to bf16.
  * gn_sums (nullable): fp64 [B][gn_groups][2], pre-zeroed by the caller; receives sum and sum of squares of the rounded output
  * per (sample, channel group) -- the statistics pass of the GroupNorm that follows (ssdnerf_group_norm_nhwc, workspace_state 2).
  * Needs (Cout / gn_groups) % 4 == 0 and, for layers that are not cut along K, Ho*Wo a multiple of the M tile (256 / 128 / 64).
- * tile_hint: 0 = choose by problem size, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 block tile.
+ * tile_hint: 0 = choose by problem size, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 block tile, 5 / 6 = the two-group 256x128 kernel.
  * splitk_ws (nullable): fp32 scratch of splitk_ws_bytes >= B*Ho*Wo*Cout*4 that is ALL ZERO on entry and is left all zero on
  * return; when given, layers with too few output tiles to fill the chip are cut along K (splits_hint: 0 =
  * choose, n = force n ranges) and reduced through it.
- * ssdnerf_conv2d_nhwc_bf16_supported() tells whether a layer fits (Cin % 64 == 0, Cout % 64 == 0, ksize 1|3, stride 1|2). */
+ * ssdnerf_conv2d_nhwc_bf16_supported() tells whether a layer fits (Cin % 8 == 0, Cout % 8 == 0 -- one 16-byte bf16 chunk; r02: 64 --, ksize 1|3,
+ * stride 1|2).  tile_hint 5 / 6 force the two-group 256 x 128 kernel (6: its row-reuse form where it applies; Cin % 64 == 0, Cout % 128 == 0). */
 int ssdnerf_conv2d_nhwc_bf16_supported(uint32_t Cin, uint32_t Cout, uint32_t ksize, uint32_t stride, uint32_t upsample);
 /* The decomposition ssdnerf_conv2d_nhwc_bf16 will use for M = B*Ho*Wo output pixels: tile choice (1..3) | splits << 8. */
 int ssdnerf_conv2d_nhwc_bf16_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int may_split,
@@ -341,7 +342,8 @@ int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t Cin1, const
  * Ampere, keeps 11).  tile_hint 0 = choose, 1 = 128x128, 3 = 64x64; layers with too few tiles are cut along K (splits_hint 0 = choose) and
  * reduced through splitk_ws (as for the bf16 form: all zero on entry, left all zero) or, without it, straight into the output, which the call
  * zeroes first unless y_is_zero != 0 (ssdnerf_conv2d_nhwc_f32x2_plan tells a caller in advance: tile | splits << 8).  Residual must not alias
- * y.  Other arguments as ssdnerf_conv2d_nhwc_bf16. */
+ * y.  tile_hint 5 / 6: the two-group kernel's fp32 form (needs Cin % 32 == 0, Cout % 128 == 0 and w_lo directly behind w_hi in memory).
+ * Other arguments as ssdnerf_conv2d_nhwc_bf16. */
 int ssdnerf_conv2d_nhwc_f32x2_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int splits_hint);
 int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, const void* w_hi, const void* w_lo, const float* bias,
                               const void* residual, void* y, uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout,

@@ -7,7 +7,7 @@
 thread_local char g_ssdnerf_err[512] = {0};
 
 extern "C" const char* ssdnerf_last_error(void) { return g_ssdnerf_err; }
-extern "C" int ssdnerf_abi_version(void) { return 1; }
+extern "C" int ssdnerf_abi_version(void) { return 2; }   // 2 (r03): conv2d_nhwc_f32x2 takes a split-K scratch; group_norm_nhwc_runs; render workspace holds 8-byte survivor entries
 
 static constexpr unsigned TPB = 256;
 
