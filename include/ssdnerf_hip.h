@@ -358,7 +358,12 @@ int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, cons
 int ssdnerf_attention_qkv_bf16(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
 /* The same for the fp32 configs (the UNet runs without autocast in every paper config but the fp16 one): qkv, out fp32; q, k, v and the
  * probabilities are each split into a bf16 pair and every product is hi*hi + hi*lo + lo*hi in fp32 on the matrix cores (the arithmetic
- * class of ssdnerf_conv2d_nhwc_f32x2), softmax in fp32. */
+ * class of ssdnerf_conv2d_nhwc_f32x2), softmax in fp32.
+ * TOLERANCE CLASS, stated because the name says f32: this is NOT IEEE fp32 arithmetic.  Each factor keeps 16 significand bits (the dropped
+ * lo*lo term and the split's own remainder are both 2^-16 relative), so a logit or an output element carries a relative error of order 1e-5,
+ * two decimal digits better than TF32 and two worse than fp32; the UNet's output differs from the fp32 module by 7e-6 relative at the
+ * benchmarked shape (bench.py, ddim.fp32.rel_err_vs_eager).  Used by the inference executor only: the gradient path (guidance, fine-tuning)
+ * runs the library's fp32 attention (ssdnerf_amd/unet.py, _forward_channel_last). */
 int ssdnerf_attention_qkv_f32(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
 
 #ifdef __cplusplus
