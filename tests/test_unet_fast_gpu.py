@@ -52,6 +52,36 @@ def test_group_norm_kernel(dtype, tol, C, H):
     assert (yt.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C1,C2,G", [(256, 128, 32), (512, 256, 32), (128, 0, 32), (80, 112, 16), (48, 0, 4)])
+def test_group_norm_from_run_level_statistics(dtype, tol, C1, C2, G):
+    """r03: the normalisation pass from statistics kept per run of 4 channels, one array per tensor of a concatenation -- groups of 12 / 24
+    channels that straddle the two tensors (384 / 32, 768 / 32), groups inside one tensor, a single tensor, the 3-D form"""
+    g = torch.Generator().manual_seed(C1 + C2)
+    B, H, W = 2, 8, 12
+    a = (torch.randn(B, C1, H, W, generator=g) * 1.5 + 0.3).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    b = (torch.randn(B, C2, H, W, generator=g) * 0.7 - 0.2).cuda().to(dtype).contiguous(memory_format=torch.channels_last) if C2 else None
+    Cc = C1 + C2
+    gamma, beta = torch.rand(Cc, generator=g).cuda() + 0.5, torch.randn(Cc, generator=g).cuda()
+    ss = torch.randn(B, 2 * Cc, generator=g).cuda() * 0.3
+
+    def runs(t):
+        v = t.double().reshape(B, t.size(1) // 4, 4, H * W)
+        return torch.stack([v.sum((2, 3)), v.square().sum((2, 3))], -1).contiguous()
+    ra, rb = runs(a), (runs(b) if C2 else None)
+    got = unet_fast.group_norm_nhwc(a, G, gamma, beta, ss, 1e-5, True, ra, x2=b, runs=(ra, rb))
+    cat = torch.cat([a, b], 1) if C2 else a
+    e = ss[:, :, None, None]
+    want = F.silu(F.group_norm(cat.float(), G, gamma, beta, 1e-5) * (1 + e[:, :Cc]) + e[:, Cc:])
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    if not C2:                                                                # the (B, T, C) form the attention blocks use
+        at = a.permute(0, 2, 3, 1).reshape(B, H * W, C1).contiguous()
+        got3 = unet_fast.group_norm_nhwc(at, G, gamma, beta, None, 1e-5, False, ra, runs=(ra, None))
+        want3 = F.group_norm(a.float(), G, gamma, beta, 1e-5).permute(0, 2, 3, 1).reshape(B, H * W, C1)
+        assert (got3.float() - want3).abs().max().item() <= tol * max(1.0, want3.abs().max().item())
+
+
 def test_group_norm_rejects_bad_shapes():
     x = torch.randn(1, 36, 4, 4, device="cuda").contiguous(memory_format=torch.channels_last)      # 36 % 32 != 0
     ws = torch.empty(128, dtype=torch.float64, device="cuda")
