@@ -90,11 +90,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # SSDNERF_BENCH_SHARE_DEVICE=1 (test aid, never a measurement): every rank on cuda:0 over gloo, so that the N > 1 control flow can be exercised on
+    # a one-GPU box (RCCL refuses two ranks on one device); the JSON line then says so in config.parallelism
+    share_device = os.environ.get("SSDNERF_BENCH_SHARE_DEVICE", "0") == "1" and world > 1
+    if share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ssdnerf_amd import synthetic as S
     from ssdnerf_amd import nerf
@@ -240,7 +248,7 @@ def main():
         "dtype": "f32" if args.plane_dtype == "float32" else "f32 math / f16 planes", "data": "synthetic",
         "config": {"workload": "ssdnerf_cars_uncond render of cached triplanes (BASELINE.json configs[1])", "scenes_per_gpu": ns,
                    "views_per_scene": nv, "image": f"{hw}x{hw}", "rays_per_step_per_gpu": n_rays, "grid_size": 64, "max_steps": 256,
-                   "T_thresh": 1e-4, "dt_gamma": 0.0, "scene_variant": args.variant, "parallelism": f"scene-parallel x{world}",
+                   "T_thresh": 1e-4, "dt_gamma": 0.0, "scene_variant": args.variant, "parallelism": f"scene-parallel x{world}" + (" (TEST MODE: all ranks share cuda:0 over gloo)" if share_device else ""),
                    "ray_source": "(S,N,3) ray arrays" if args.ray_arrays else "cameras (rays generated in the kernels)",
                    "collective": "all_gather(uint8 views), overlapped with the next step's render" if world > 1 else "none"},
         "views_per_s": rays_per_s / (hw * hw), "samples_per_s": n_samples_all / (elapsed / args.steps),
