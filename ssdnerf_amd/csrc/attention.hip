@@ -134,13 +134,26 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                     *reinterpret_cast<uint16_t*>(dst + e * AT_ROW) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
             }
     };
-    // bf16: K fragments are prefetched one key block ahead (16 B per lane per k-step); fp32: loaded and split at their use (the split pair of a
-    // whole block would not fit the register file next to Q and O)
+    // K fragments are prefetched one key block ahead: bf16 16 B per lane and k-step; fp32 (r03) the RAW 32 B, split into the bf16 pair at their use
+    // -- r02 loaded them at their use, which left an L2 round trip exposed in every key block of a kernel that runs one wave per SIMD
+    // (T = 1024: 107 us per call against 43 us for the bf16 form; one wave per SIMD also means the registers are there)
     bf16x8 kf[F32 ? 1 : KS];
+    float4 kraw[F32 ? KS : 1][2];
     auto k_prefetch = [&](uint32_t kb) {
         if constexpr (!F32) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) { bf16x8 lo; load8(kb * 32 + l31, 1, 2 * s + hf, kf[s], lo); }
+        } else {
+            const uint32_t row = kb * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint32_t c8 = 2 * s + hf;
+                kraw[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); kraw[s][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < T && c8 < nchunk) {
+                    const unsigned char* p = base + (size_t)row * row_bytes + ((size_t)ch + c8 * 8) * ES;
+                    kraw[s][0] = *reinterpret_cast<const float4*>(p); kraw[s][1] = *reinterpret_cast<const float4*>(p + 16);
+                }
+            }
         }
     };
 
@@ -159,9 +172,13 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
     for (uint32_t kb = 0; kb < nkb; ++kb) {
         const uint32_t buf = kb & 1;
         bf16x8 kcur[F32 ? 1 : KS];
+        float4 kcur_raw[F32 ? KS : 1][2];
         if constexpr (!F32) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) kcur[s] = kf[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { kcur_raw[s][0] = kraw[s][0]; kcur_raw[s][1] = kraw[s][1]; }
         }
         if (kb + 1 < nkb) {                                                  // prefetch the next key block (K -> registers, V -> registers)
             v_load(kb + 1);
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
             for (int s = 0; s < KS; ++s) {                                   // S^T[key][query]
                 if constexpr (F32) {
                     bf16x8 khi, klo;
-                    load8(kb * 32 + l31, 1, 2 * s + hf, khi, klo);
+                    at_split8(kcur_raw[s][0], kcur_raw[s][1], khi, klo);
 #ifdef SSD_LEGACY_MFMA_GUARD                                                 // r02 padding in front of MFMAs with VALU-built operands: not the cause (shade_mfma.hip, sm_operand_guard)
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_nop 4");
