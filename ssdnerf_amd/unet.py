@@ -84,6 +84,23 @@ class _Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class _ZeroArena:
+    """One zero-filled fp64 buffer per UNet forward for the statistics workspaces of its fused norms (forward sums and backward sums: two slices
+    per norm) instead of one ``torch.zeros`` -- one fill kernel -- per norm and direction (142 fills of ~4 us in the cars UNet).  Slices are handed
+    out once and never reused, so a slice is all zero when it is taken."""
+    current = None                                  # set by DenoisingUnetMod.forward around the gradient path
+
+    def __init__(self, n, device):
+        self.buf, self.used = torch.zeros(n, dtype=torch.float64, device=device), 0
+
+    def take(self, n):
+        if self.used + n > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float64, device=self.buf.device)
+        out = self.buf[self.used:self.used + n]
+        self.used += n
+        return out
+
+
 class _GroupNormActFn(torch.autograd.Function):
     """y = [silu]( GroupNorm(x) [* (1 + scale) + shift] ) over channel-last activations with FROZEN affine parameters, differentiable
     w.r.t. x only: forward ``ssdnerf_group_norm_nhwc``, backward ``ssdnerf_group_norm_nhwc_backward`` (two passes, recomputing from x and the
@@ -94,7 +111,10 @@ class _GroupNormActFn(torch.autograd.Function):
     def forward(ctx, x, norm, scale_shift, act):
         from . import unet_fast as UF
         xc = x.contiguous(memory_format=torch.channels_last)
-        sums = torch.zeros(x.size(0) * norm.num_groups * 2, dtype=torch.float64, device=x.device)
+        arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
+        n = x.size(0) * norm.num_groups * 2
+        sums = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
+        ctx.arena = arena
         ss = None if scale_shift is None else scale_shift.detach().float().contiguous()
         y = UF.group_norm_nhwc(xc, norm.num_groups, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, sums, workspace_is_zero=True)
         ctx.save_for_backward(xc, sums)
@@ -106,8 +126,9 @@ class _GroupNormActFn(torch.autograd.Function):
         from . import unet_fast as UF
         xc, sums = ctx.saved_tensors
         norm = ctx.norm
+        ws = ctx.arena.take(xc.size(0) * norm.num_groups * 2) if ctx.arena is not None else None
         dx = UF.group_norm_nhwc_backward(xc, dy.contiguous(memory_format=torch.channels_last), norm.num_groups, norm.weight.detach(), norm.bias.detach(),
-                                         ctx.ss, norm.eps, ctx.act, sums)
+                                         ctx.ss, norm.eps, ctx.act, sums, workspace=ws)
         return dx, None, None, None
 
 
@@ -187,7 +208,8 @@ class NormWithEmbedding(nn.Module):
     def forward(self, x, y, fuse_silu=False):
         """``fuse_silu`` (extra): also apply the SiLU that follows in the residual block (only honoured on the fused path; returns
         (tensor, whether the activation was applied))."""
-        e = self.embedding_layer(y)
+        batched = getattr(y, "_ssd_projections", None)                 # DenoisingUnetMod.forward: every block's projection of the time embedding from ONE GEMM
+        e = batched[id(self)] if batched is not None and id(self) in batched else self.embedding_layer(y)
         if self.use_scale_shift and fuse_silu and _gn_act_eligible(x, self.norm, e):
             return _GroupNormActFn.apply(x, self.norm, e, True), True
         e = e[:, :, None, None]
@@ -474,6 +496,33 @@ class DenoisingUnetMod(nn.Module):
         with torch.autocast("cuda", enabled=False):
             return self._fast_executor(dtype).session(x_t.float(), t)
 
+    def _attach_batched_projections(self, embedding):
+        """The residual blocks' projections of the time embedding (NormWithEmbedding.embedding_layer: SiLU -> Linear, modules.py:97-104) do not
+        depend on the activations: with frozen projection weights and an embedding that carries no gradient (guidance, fine-tuning: the gradient
+        goes to x_t only) they are ONE GEMM over the concatenated weights instead of one small GEMM per block -- 61 launches of ~16 us in the cars
+        UNet (profiles/r03/l_finetune_profile.txt).  The result rides on the embedding tensor as an attribute; each block picks its slice."""
+        if embedding.requires_grad or not torch.is_grad_enabled():
+            return
+        mods = [m for m in self.modules() if isinstance(m, NormWithEmbedding)]
+        lins = [m.embedding_layer[1] for m in mods]
+        if not mods or any(not isinstance(m.embedding_layer[0], nn.SiLU) or l.weight.requires_grad or (l.bias is not None and l.bias.requires_grad) or l.bias is None
+                           for m, l in zip(mods, lins)):
+            return
+        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias._version, str(l.weight.device), l.weight.dtype) for l in lins)
+        cache = self.__dict__.setdefault("_proj_cache", {})
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+            cache["w"] = torch.cat([l.weight.detach() for l in lins], 0).contiguous()
+            cache["b"] = torch.cat([l.bias.detach() for l in lins], 0).contiguous()
+        with torch.no_grad():
+            e_all = F.linear(F.silu(embedding), cache["w"].to(embedding.dtype), cache["b"].to(embedding.dtype))
+        out, off = {}, 0
+        for m, l in zip(mods, lins):
+            out[id(m)] = e_all[:, off:off + l.out_features]
+            off += l.out_features
+        embedding._ssd_projections = out
+
     def forward(self, x_t, t, label=None, concat_cond=None, return_noise=False):
         if self._fast_path_ok(x_t, label):
             dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
@@ -484,6 +533,18 @@ class DenoisingUnetMod(nn.Module):
         embedding = self.time_embedding(t)
         if label is not None:
             embedding = self.label_embedding(label) + embedding
+        self._attach_batched_projections(embedding)
+        prev_arena = _ZeroArena.current
+        if x_t.is_cuda and torch.is_grad_enabled() and x_t.requires_grad and GRAD_GN:
+            n_gn = self.__dict__.get("_n_group_norms") or sum(m.num_groups for m in self.modules() if isinstance(m, nn.GroupNorm))
+            self.__dict__["_n_group_norms"] = n_gn
+            _ZeroArena.current = _ZeroArena(4 * x_t.size(0) * n_gn, x_t.device)       # forward + backward sums of every norm
+        try:
+            return self._forward_blocks(x_t, embedding, concat_cond)
+        finally:
+            _ZeroArena.current = prev_arena
+
+    def _forward_blocks(self, x_t, embedding, concat_cond):
         h, hs = x_t, []
         if self.concat_cond_channels > 0:
             h = torch.cat([h, concat_cond], dim=1)
