@@ -250,6 +250,8 @@ def main():
                    "views_per_scene": nv, "image": f"{hw}x{hw}", "rays_per_step_per_gpu": n_rays, "grid_size": 64, "max_steps": 256,
                    "T_thresh": 1e-4, "dt_gamma": 0.0, "scene_variant": args.variant, "parallelism": f"scene-parallel x{world}" + (" (TEST MODE: all ranks share cuda:0 over gloo)" if share_device else ""),
                    "ray_source": "(S,N,3) ray arrays" if args.ray_arrays else "cameras (rays generated in the kernels)",
+                   "mlp_arithmetic": f"fp32 operands split into bf16 terms on the matrix cores: layer 1 all six products (2^-24 class), direction term {dec.shade_dir_products} of 6 "
+                                     "(2^-16 class when 3; image differs by <= 1.6e-6 from the six-product form; SSDNERF_SHADE_DIR_PRODUCTS=6 for all)",
                    "collective": "all_gather(uint8 views), overlapped with the next step's render" if world > 1 else "none"},
         "views_per_s": rays_per_s / (hw * hw), "samples_per_s": n_samples_all / (elapsed / args.steps),
         "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": stats["overflow"],

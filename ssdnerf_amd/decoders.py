@@ -367,6 +367,13 @@ class TriPlaneDecoder(VolumeRenderer):
             self._packed_key = key
         return self._packed
 
+    #: split products of the direction term formed by the MFMA shading kernel: 3 (default: 16 significand bits per factor, <= 1.6e-6 on the image,
+    #: 5 % faster) or 6 (all of them, the fp32 class of the other layers); SSDNERF_SHADE_DIR_PRODUCTS=6 sets the default of new decoders
+    shade_dir_products = 6 if os.environ.get("SSDNERF_SHADE_DIR_PRODUCTS", "3") == "6" else 3
+
+    def _shade_flags(self) -> int:
+        return 0x100 if self.shade_dir_products == 6 else 0          # SSDNERF_SHADE_FULL_DIR_PRODUCTS (include/ssdnerf_hip.h)
+
     def invalidate_packed(self):
         """Forget the packed parameter block (re-packed on the next fused call).  Automatic after ``load_state_dict`` / ``.to()``; needed by hand
         only after writing weights through ``p.data``, which no version counter sees."""
@@ -559,7 +566,7 @@ class TriPlaneDecoder(VolumeRenderer):
                 ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
             shade = C.lib().ssdnerf_render_shade_queue_mfma if self.fused_pipeline == "queue_mfma" else C.lib().ssdnerf_render_shade_queue
             C.check(shade(
-                C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.u32(gs), C.ptr(o), C.ptr(d), C.u32(num_scenes),
+                C.ptr(planes), C.dtype_code(planes) | (self._shade_flags() if self.fused_pipeline == "queue_mfma" else 0), C.u32(hp), C.u32(wp), C.ptr(params), C.u32(gs), C.ptr(o), C.ptr(d), C.u32(num_scenes),
                 C.u32(n), C.f32(self.bound), C.f32(self.min_near), C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(T_thresh),
                 C.f32(blend), C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.ptr(wsp),
                 C.ctypes.c_size_t(wsp.numel()), C.stream()), "render_shade_queue")
@@ -647,7 +654,7 @@ class TriPlaneDecoder(VolumeRenderer):
         if ev is not None:
             ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
         C.check(C.lib().ssdnerf_render_shade_queue_mfma_cams(
-            C.ptr(planes), C.dtype_code(planes), C.u32(hp), C.u32(wp), C.ptr(params), C.u32(gs), C.ptr(pose), C.ptr(k), C.u32(num_scenes), C.u32(nv),
+            C.ptr(planes), C.dtype_code(planes) | self._shade_flags(), C.u32(hp), C.u32(wp), C.ptr(params), C.u32(gs), C.ptr(pose), C.ptr(k), C.u32(num_scenes), C.u32(nv),
             C.u32(h), C.u32(w), C.f32(self.bound), C.f32(self.min_near), C.f32(g0), C.ptr(dtg_dev), C.u32(self.max_steps), C.f32(T_thresh), C.f32(blend),
             C.f32(self.sigmoid_saturation), C.ptr(im), C.ptr(dp), C.ptr(ws), C.ptr(cn), C.ptr(overflow), C.ptr(im8), C.ptr(wsp),
             C.ctypes.c_size_t(wsp.numel()), C.stream()), "render_shade_queue_mfma_cams")

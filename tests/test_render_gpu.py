@@ -367,6 +367,33 @@ def test_fused_decode_backward_matches_autograd_through_the_eager_decode(ns, pla
     assert bool(torch.isfinite(gw).all()) and float(gw.abs().max()) > 0
 
 
+@pytest.mark.parametrize("view,dt_gamma", [(64, 0.0), (200, 0.0038095)])
+def test_direction_term_product_count(scene, decoder, view, dt_gamma):
+    """The MFMA shading kernel forms three of the six split products of the direction term by default (16 significand bits per factor) and all
+    six on request (TriPlaneDecoder.shade_dir_products = 6 -> SSDNERF_SHADE_FULL_DIR_PRODUCTS).  Both settings against the oracle with the
+    SAME tolerance; what does not depend on the direction term -- sample counts, depth, opacity -- bit for bit equal; and how far apart the two
+    images are (the bound quoted in include/ssdnerf_hip.h and DESIGN.md)."""
+    from oracle import render as R
+    ro, rd = _view(view)
+    rgb0, dep0, ws0 = R.render_eval(scene["params"], scene["code"], scene["bits"], ro, rd, dt_gamma=dt_gamma)
+    res = {}
+    for n in (3, 6):
+        decoder.shade_dir_products = n
+        try:
+            res[n] = _render_gpu(decoder, scene, ro, rd, "fused", dt_gamma)
+        finally:
+            decoder.shade_dir_products = 3
+        np.testing.assert_allclose(res[n][0], rgb0, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(res[n][1], dep0, rtol=0, atol=1e-4)
+    assert np.array_equal(res[3][3], res[6][3])
+    assert np.array_equal(res[3][1].view(np.uint32), res[6][1].view(np.uint32)) and np.array_equal(res[3][2].view(np.uint32), res[6][2].view(np.uint32))
+    diff = np.abs(res[3][0] - res[6][0])
+    assert diff.max() > 0.0, "the two settings must be different kernels"
+    assert diff.max() <= 5e-6 and diff.mean() <= 2e-7, (diff.max(), diff.mean())
+    # the full-precision form is the closer one to the oracle
+    assert np.abs(res[6][0] - rgb0).mean() <= np.abs(res[3][0] - rgb0).mean() + 1e-9
+
+
 def test_specialised_shading_kernels_are_bit_identical(tmp_path):
     """k_shade_mfma has three forms: generic (any grid / plane size), the hot-path geometry as compile-time constants (64^3 grid, 128 x 128
     planes, bound 1, 256 steps), and that with dt_gamma == 0 (constant march step).  The specialised forms only turn operands into literals:
