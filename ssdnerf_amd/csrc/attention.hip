@@ -193,11 +193,6 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                 if constexpr (F32) {
                     bf16x8 khi, klo;
                     at_split8(kcur_raw[s][0], kcur_raw[s][1], khi, klo);
-#ifdef SSD_LEGACY_MFMA_GUARD                                                 // r02 padding in front of MFMAs with VALU-built operands: not the cause (shade_mfma.hip, sm_operand_guard)
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_nop 4");
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qf[0][s], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[1][s], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[0][s], sacc, 0, 0, 0);
@@ -243,11 +238,6 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                     pb[1][s] = *reinterpret_cast<const bf16x8*>(&ul);
                 }
             }
-#ifdef SSD_LEGACY_MFMA_GUARD                                                 // (r02 padding between the VALU-built P and the MFMAs that read it; see above)
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 4");
-            __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll

@@ -1494,9 +1494,6 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
         pp_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-#ifdef CV_PP_SKIP_KLOOP
-    if (false)
-#endif
     if (ROWS) {
         const uint32_t G = 3 * kc;
         for (uint32_t g = 0, t = 0; g < G; ++g, t += 3) {                        // group (kh, ci): three K-tiles (kw) from one A stage
@@ -1521,10 +1518,6 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     }
     if (group == 0) pp_barrier();                                                // even out the stagger
     __syncthreads();                                                             // every wave is done with the stages (the epilogue reuses them)
-#ifdef CV_PP_SKIP_EPILOGUE                                                       // (timing experiment: keep the accumulators alive, store nothing)
-    if (acc[0][0][0] == 12345.678f) a.y[0] = 1;
-    continue;
-#endif
 #ifdef CV_PP_TIMING
     if (tid == 0) stamps[2] = __builtin_amdgcn_s_memtime();
 #endif

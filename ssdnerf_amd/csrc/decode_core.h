@@ -22,12 +22,6 @@
 #include "common.h"
 #include "sh_basis.h"
 
-// SSD_GATHER_PAIRS=1: packed form of the bilinear interpolation (see ssd_gather18): identical arithmetic by construction (bit-identical results).
-// r02 measured it at 0 %; since r03 (shading kernel bound by VALU issue, not latency) it is worth 2 % there -- the scalar form is auto-vectorised
-// ACROSS texels, which costs 56 register moves per sample to assemble the operand pairs (profiles/r03/h_shade_valu_diet.txt: 0.537 -> 0.550).
-#ifndef SSD_GATHER_PAIRS
-#define SSD_GATHER_PAIRS 1
-#endif
 
 #define MLP_OFF_WD (64 * 24)
 #define MLP_OFF_BD (64 * 24 + 64 * 16)
@@ -85,9 +79,10 @@ SSD_DEV void ssd_gather18(const PT* __restrict__ planes, const PlaneGeom& g, flo
         Texel<PT>::load6(base + ((uint64_t)y1 * g.Wp + x0) * 8, t10);
         Texel<PT>::load6(base + ((uint64_t)y1 * g.Wp + x1) * 8, t11);
         const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
-#if SSD_GATHER_PAIRS
-        // the same four-term chain per channel, written on channel PAIRS of one texel (adjacent registers of the load, one shared weight)
-        // so that it maps onto v_pk_mul/v_pk_fma without operand assembly; element-wise identical arithmetic, bit-identical results
+        // the four-term chain  t11 w11 + (t10 w10 + (t01 w01 + t00 w00))  per channel, written on channel PAIRS of one texel (adjacent registers of the
+        // load, one shared weight) so that it maps onto v_pk_mul / v_pk_fma without operand assembly.  The scalar form is auto-vectorised ACROSS texels,
+        // which costs 56 register moves per sample to assemble the pairs: -2 % on the shading kernel since it became issue-bound (r03,
+        // profiles/r03/h_shade_valu_diet.txt; r02 had measured the two forms equal); element-wise identical arithmetic, bit-identical results
         typedef float ssd_f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int c = 0; c < 6; c += 2) {
@@ -99,11 +94,6 @@ SSD_DEV void ssd_gather18(const PT* __restrict__ planes, const PlaneGeom& g, flo
             f[c * 3 + p] = r.x;
             f[(c + 1) * 3 + p] = r.y;
         }
-#else
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-            f[c * 3 + p] = ssd_fma(t11[c], w11, ssd_fma(t10[c], w10, ssd_fma(t01[c], w01, t00[c] * w00)));
-#endif
         if (PLANE_BY_PLANE) __builtin_amdgcn_sched_barrier(0);
     }
 }

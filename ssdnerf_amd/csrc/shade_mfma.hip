@@ -51,24 +51,10 @@ SSD_DEV floatx2 sm_silu2(floatx2 h) {
     rcp.y = __builtin_amdgcn_rcpf(d.y);
     return h * rcp;
 }
-// SM_ASM_PK (r03 experiment, OFF): the packed fp32 ops of the heads as inline assembly.  Written as vector arithmetic, ROCm 7.2's backend UNPACKS the
-// packed ops it finds in the shadow of an MFMA into two plain ones (plain VALU ops execute beside the matrix pipe, packed ones do not: 62 of the
-// 467 VALU instructions of the MFMA block are such halves).  Forcing them to stay packed -- fewer issue slots -- measured 7 % SLOWER
-// (profiles/r03/h_shade_valu_diet.txt: roofline fraction 0.550 -> 0.513): the matrix pipe's shadow is worth more than the issue slots.
-#ifndef SM_ASM_PK
-#define SM_ASM_PK 0
-#endif
-#if SM_ASM_PK
-SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { floatx2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "v"(v), "v"(acc)); return r; }
-SSD_DEV floatx2 sm_mul2(floatx2 a, floatx2 b) { floatx2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-SSD_DEV floatx2 sm_add_one2(floatx2 a) { floatx2 r; asm("v_pk_add_f32 %0, %1, 1.0 op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }
-SSD_DEV floatx2 sm_sub2(floatx2 a, floatx2 b) { floatx2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
-#else
+// (r03, measured and dropped: the heads' packed fp32 ops pinned as inline assembly.  Written as vector arithmetic, ROCm 7.2's backend UN-packs the packed
+// ops it finds in the shadow of an MFMA into two plain ones -- plain VALU ops execute beside the matrix pipe, packed ones do not: 62 of the 467 VALU
+// instructions of the MFMA block are such halves.  Forcing them to stay packed, i.e. fewer issue slots, was 7 % SLOWER: profiles/r03/h_shade_valu_diet.txt.)
 SSD_DEV floatx2 sm_fma2(floatx2 w, floatx2 v, floatx2 acc) { return __builtin_elementwise_fma(w, v, acc); }
-SSD_DEV floatx2 sm_mul2(floatx2 a, floatx2 b) { return a * b; }
-SSD_DEV floatx2 sm_add_one2(floatx2 a) { return a + floatx2{1.0f, 1.0f}; }
-SSD_DEV floatx2 sm_sub2(floatx2 a, floatx2 b) { return a - b; }
-#endif
 
 static constexpr unsigned SM_TPB = 256;
 #ifndef SM_SLICE_RAYS
@@ -106,21 +92,6 @@ SSD_DEV void sm_split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     lo = __float_as_uint(r1 - __uint_as_float(mid));           // exact, at most 8 significant bits
 }
 SSD_DEV uint32_t sm_pack2(uint32_t even, uint32_t odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }   // {bf16(even), bf16(odd)}
-// the same split for a feature PAIR with the two exact subtractions as packed ops (r03 experiment, OFF: 0.513 -> 0.509, same file): packed terms
-// {bf16(x0), bf16(x1)} per term
-#ifndef SM_PK_SPLIT
-#define SM_PK_SPLIT 0
-#endif
-SSD_DEV void sm_split3_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    const floatx2 x = {x0, x1};
-    const floatx2 h = {__uint_as_float(__float_as_uint(x0) & 0xffff0000u), __uint_as_float(__float_as_uint(x1) & 0xffff0000u)};
-    const floatx2 r1 = sm_sub2(x, h);
-    const floatx2 m = {__uint_as_float(__float_as_uint(r1.x) & 0xffff0000u), __uint_as_float(__float_as_uint(r1.y) & 0xffff0000u)};
-    const floatx2 r2 = sm_sub2(r1, m);
-    hi = sm_pack2(__float_as_uint(x0), __float_as_uint(x1));      // (the pack takes the upper halves: no mask needed)
-    mid = sm_pack2(__float_as_uint(r1.x), __float_as_uint(r1.y));
-    lo = sm_pack2(__float_as_uint(r2.x), __float_as_uint(r2.y));
-}
 SSD_DEV sm_bf16x8 sm_op(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const uint4 u = make_uint4(a, b, c, d);
     return *reinterpret_cast<const sm_bf16x8*>(&u);
@@ -146,12 +117,7 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 // reads the register before the last 16-lane pass is written.  Evidence: any 4-byte shift of the instruction stream in front of those pairs hid
 // the failure, a 64-byte shift did not; lengthening only the compiler's own `s_nop 0` behind transcendentals to `s_nop 1` IN PLACE (identical code
 // layout) gave 0 differing renders of 200 at every placement, 40 of 40 without.  The fix is therefore not here but in the build: asm_postpass.py
-// gives every transcendental -> use pair of the library two wait states.  -DSSD_LEGACY_MFMA_GUARD restores the r02 barriers (A/B runs only).
-SSD_DEV void sm_operand_guard() {
-#ifdef SSD_LEGACY_MFMA_GUARD
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+// gives every transcendental -> use pair of the library four wait states, and the r02 barriers are gone.
 
 struct FastMarchB {
     float bound, dt_gamma, dt_min, dt_max, mip_bound, rb, half_H, two_rH, Hm1f;
@@ -526,14 +492,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #endif
 #pragma unroll
         for (int p2 = 0; p2 < 9; ++p2) {
-#if SM_PK_SPLIT
-            sm_split3_pair(f[2 * p2], f[2 * p2 + 1], T[0][p2], T[1][p2], T[2][p2]);
-#else
             uint32_t h0, m0, l0, h1, m1, l1;
             sm_split3(f[2 * p2], h0, m0, l0);
             sm_split3(f[2 * p2 + 1], h1, m1, l1);
             T[0][p2] = sm_pack2(h0, h1); T[1][p2] = sm_pack2(m0, m1); T[2][p2] = sm_pack2(l0, l1);
-#endif
         }
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
@@ -568,7 +530,6 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             const int i = TI[pr_i], j = TJ[pr_i];
             const sm_bf16x8 b0 = sm_op(T[j][4 * nt], T[j][4 * nt + 1], T[j][4 * nt + 2], T[j][4 * nt + 3]);
 #if SM_K1_PACK
-            sm_operand_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0, acc[nt][mt], 0, 0, 0);
             if (pr_i == 5) {                                             // rows 16 .. 18 of all six products, after the last (largest) product of rows 0 .. 15
@@ -578,7 +539,6 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             }
 #else
             const sm_bf16x8 b1 = sm_op(nt == 0 ? T[j][8] : Z[j], j == 0 ? bias_pair : 0u, 0u, 0u);
-            sm_operand_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[mt][0][i], b0, acc[nt][mt], 0, 0, 0);
@@ -593,7 +553,6 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         };
         auto dir_term = [&](int nt, int pr_i) {                          // 2 MFMA: h += Wd' SH'(d)
             const int i = TI[pr_i], j = TJ[pr_i];
-            sm_operand_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[mt][i], sb[j], acc[nt][mt], 0, 0, 0);
         };
@@ -623,11 +582,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                 if (COLOUR) w1[i] = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
             }
 #pragma unroll
-            for (int i = 0; i < N; ++i) u[i] = sm_add_one2(v[i]);
+            for (int i = 0; i < N; ++i) u[i] = v[i] + floatx2{1.0f, 1.0f};
 #pragma unroll
             for (int i = 0; i < N; ++i) { v[i].x = __builtin_amdgcn_rcpf(u[i].x); v[i].y = __builtin_amdgcn_rcpf(u[i].y); }
 #pragma unroll
-            for (int i = 0; i < N; ++i) h[i] = sm_mul2(h[i], v[i]);
+            for (int i = 0; i < N; ++i) h[i] = h[i] * v[i];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 if (COLOUR) {
@@ -685,7 +644,6 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
         sm_swap(ps0, ps1); sm_swap(pr0, pr1); sm_swap(pg0, pg1); sm_swap(pb0, pb1);
-        sm_operand_guard();                                              // (both results of every swap are read next)
         const float sigma = ssd_exp(ps0 + ps1 + b_sigma);
         const float sr = ssd_fma(ssd_sigmoid(pr0 + pr1 + bc0), sat_k, -c.sat);
         const float sg = ssd_fma(ssd_sigmoid(pg0 + pg1 + bc1), sat_k, -c.sat);
