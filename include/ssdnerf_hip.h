@@ -370,6 +370,13 @@ int ssdnerf_attention_qkv_bf16(const void* qkv, void* out, uint32_t B, uint32_t 
  * benchmarked shape (bench.py, ddim.fp32.rel_err_vs_eager).  Used by the inference executor only: the gradient path (guidance, fine-tuning)
  * runs the library's fp32 attention (ssdnerf_amd/unet.py, _forward_channel_last). */
 int ssdnerf_attention_qkv_f32(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
+/* Forward that also saves what the backward needs, and the backward itself (r03: the gradient path of rendering guidance / fine-tuning, which r02 ran on
+ * the library's fp32 attention): lse2 fp32 [B][heads][T] = the rows' log-sum-exp in the log2 domain; dout fp32 [B][T][heads*ch] = d loss / d out;
+ * dqkv fp32 [B][T][3*heads*ch] receives d loss / d qkv in qkv's layout; workspace: B*heads*T floats (D = rowsum(dout o out)).  Same arithmetic class
+ * as the forward (see TOLERANCE CLASS above): S and dP are recomputed per 32 x 32 tile, nothing T x T is stored. */
+int ssdnerf_attention_qkv_f32_lse(const void* qkv, void* out, void* lse2, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
+int ssdnerf_attention_qkv_f32_backward(const void* qkv, const void* out, const void* dout, const void* lse2, void* dqkv, void* workspace, uint32_t B,
+                                       uint32_t T, uint32_t heads, uint32_t ch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -68,7 +68,7 @@ SSD_DEV uint32_t at_key_pos(uint32_t kk) {
 
 template <int CHP, bool F32>
 __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restrict__ qkv, unsigned char* __restrict__ out, uint32_t T, uint32_t heads,
-                                                  uint32_t ch, float scale_log2e) {
+                                                  uint32_t ch, float scale_log2e, float* __restrict__ lse2) {
     constexpr int KS = CHP / 16;           // k-steps of the QK^T product
     constexpr int CT = CHP / 32;           // 32-channel tiles of O
     constexpr int VTOT = 32 * CHP / 8;     // 8-channel V chunks per key block
@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
         __syncthreads();
     }
     if (!active || q0 + l31 >= T) return;
-    const float inv_l = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (lse2 && hf == 0) lse2[(size_t)blockIdx.y * T + q0 + l31] = m_run + __builtin_amdgcn_logf(l_tot);      // log2-domain log-sum-exp of the row (backward kernels)
+    const float inv_l = 1.0f / l_tot;
     unsigned char* op = out + ((size_t)(b * T + q0 + l31) * C + h * ch) * ES;
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -274,8 +276,258 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
         }
 }
 
+// ================================================================================================================================
+// Backward of the fp32-class attention (r03): the gradient path -- rendering guidance, the fine-tuning prior -- needs d(attention) / d(qkv) with
+// frozen weights; r02 ran the library's fp32 kernels there (3.1 ms of a 36 ms guided step).  Same arithmetic class as the forward (bf16 pair
+// splits, hi*hi + hi*lo + lo*hi), same layouts, nothing T x T leaves the registers; the forward saves the rows' log-sum-exp (log2 domain).
+//   P = exp2(S c - lse),  dP = dO V^T,  D_i = sum_c dO_ic O_ic,  dS = P o (dP - D),  dQ = s dS K,  dK = s dS^T Q,  dV = P^T dO     (c = s log2 e)
+//   k_attn_bwd_D    D per (sample, head, row)
+//   k_attn_bwd_dq   a wave owns 32 queries and walks the key blocks exactly like the forward: S^T = K Q^T and dP^T = V dO^T (a lane = one query, so lse
+//                   and D are per-lane scalars), dS^T is rounded to the bf16 pair in registers and is the B operand of  dQ^T += K^T dS^T  (K^T through
+//                   LDS in the C-layout key order, as the forward's V^T)
+//   k_attn_bwd_dkv  a wave owns 32 keys and walks the query blocks: S = Q K^T and dP = dO V^T (a lane = one key, 16 queries in its registers; their lse
+//                   and D come from LDS), P and dS are the B operands of  dV^T += dO^T P  and  dK^T += Q^T dS  (Q^T and dO^T through LDS).
+SSD_DEV void at_load_split(const float* p, bool ok, bf16x8& hi, bf16x8& lo) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (ok) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    at_split8(a, b, hi, lo);
+}
+// 16 fp32 values of an MFMA C tile (this lane's column, its 16 rows) -> the B operands of the two 16-deep k-steps over those rows, as a bf16 pair
+SSD_DEV void at_c_to_b(const float (&v)[16], bf16x8 (&hi)[2], bf16x8 (&lo)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint32_t wh[4], wl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wh[k] = at_pack_bf16(v[8 * s + 2 * k], v[8 * s + 2 * k + 1]);
+            wl[k] = at_pack_bf16_rest(v[8 * s + 2 * k], v[8 * s + 2 * k + 1], wh[k]);
+        }
+        const uint4 uh = make_uint4(wh[0], wh[1], wh[2], wh[3]), ul = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+        hi[s] = *reinterpret_cast<const bf16x8*>(&uh);
+        lo[s] = *reinterpret_cast<const bf16x8*>(&ul);
+    }
+}
+// rows [r0, r0 + 32) x ch channels of an fp32 tensor (row stride `rstride` floats, rows >= T read as zeros) -> LDS, TRANSPOSED, as the bf16 pair:
+// dst_hi / dst_lo [channel][AT_ROW bytes], the row index at its C-layout position (at_key_pos).  All 256 threads.
+template <int CHP>
+SSD_DEV void at_stage_T(const float* __restrict__ src, size_t rstride, uint32_t r0, uint32_t T, uint32_t ch, unsigned char* dst_hi, unsigned char* dst_lo, uint32_t tid) {
+    constexpr int TOT = 32 * CHP / 8;
+#pragma unroll
+    for (int i = 0; i < (TOT + 255) / 256; ++i) {
+        const uint32_t id = tid + 256 * i;
+        if (id >= (uint32_t)TOT) break;
+        const uint32_t row = id / (CHP / 8), cc = id % (CHP / 8);
+        bf16x8 hi, lo;
+        at_load_split(src + (size_t)(r0 + row) * rstride + cc * 8, r0 + row < T && cc * 8 < ch, hi, lo);
+        const uint4 uh = *reinterpret_cast<const uint4*>(&hi), ul = *reinterpret_cast<const uint4*>(&lo);
+        const uint32_t wh[4] = {uh.x, uh.y, uh.z, uh.w}, wl[4] = {ul.x, ul.y, ul.z, ul.w};
+        const uint32_t off = (cc * 8) * AT_ROW + at_key_pos(row) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            *reinterpret_cast<uint16_t*>(dst_hi + off + e * AT_ROW) = (uint16_t)((e & 1) ? (wh[e >> 1] >> 16) : (wh[e >> 1] & 0xffffu));
+            *reinterpret_cast<uint16_t*>(dst_lo + off + e * AT_ROW) = (uint16_t)((e & 1) ? (wl[e >> 1] >> 16) : (wl[e >> 1] & 0xffffu));
+        }
+    }
+}
+SSD_DEV f32x16 at_mfma3(const bf16x8& a_hi, const bf16x8& a_lo, const bf16x8& b_hi, const bf16x8& b_lo, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_attn_bwd_D(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ Dv, uint32_t B, uint32_t T,
+                                                    uint32_t heads, uint32_t ch) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;                         // (b, t, h), h fastest: a wave reads consecutive channels of consecutive heads
+    if (i >= B * T * heads) return;
+    const uint32_t h = i % heads, bt = i / heads, b = bt / T, t = bt % T;
+    const float* o = out + (size_t)bt * heads * ch + h * ch;
+    const float* g = dout + (size_t)bt * heads * ch + h * ch;
+    float acc = 0.f;
+    for (uint32_t c = 0; c < ch; c += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(o + c), d = *reinterpret_cast<const float4*>(g + c);
+        acc = __builtin_fmaf(a.x, d.x, acc); acc = __builtin_fmaf(a.y, d.y, acc); acc = __builtin_fmaf(a.z, d.z, acc); acc = __builtin_fmaf(a.w, d.w, acc);
+    }
+    Dv[((size_t)b * heads + h) * T + t] = acc;
+}
+
+template <int CHP>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse2,
+                                                     const float* __restrict__ Dv, float* __restrict__ dqkv, uint32_t T, uint32_t heads, uint32_t ch,
+                                                     float scale, float scale_log2e) {
+    constexpr int KS = CHP / 16, CT = CHP / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char kt[2][2][CHP * AT_ROW];       // K^T of a key block, [buffer][hi | lo]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const uint32_t b = blockIdx.y / heads, h = blockIdx.y % heads, C = heads * ch, nchunk = ch / 8;
+    const size_t rs = (size_t)3 * C;
+    const float* base = qkv + (size_t)b * T * rs + (size_t)h * 3 * ch;             // q of this head; k at + ch, v at + 2 ch
+    const float* dbase = dout + (size_t)b * T * C + (size_t)h * ch;
+    const uint32_t q0 = blockIdx.x * 128 + wave * 32, q = q0 + l31;
+    const bool active = q0 < T, q_ok = q < T;
+    bf16x8 qh[KS], ql[KS], gh[KS], gl[KS];                                          // Q and dO of this lane's query: B operands (column = query)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const uint32_t c8 = 2 * s + hf;
+        at_load_split(base + (size_t)q * rs + c8 * 8, active && q_ok && c8 < nchunk, qh[s], ql[s]);
+        at_load_split(dbase + (size_t)q * C + c8 * 8, active && q_ok && c8 < nchunk, gh[s], gl[s]);
+    }
+    const float lse_q = (active && q_ok) ? lse2[(size_t)blockIdx.y * T + q] : 1e30f;
+    const float D_q = (active && q_ok) ? Dv[(size_t)blockIdx.y * T + q] : 0.f;
+    f32x16 dq[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[c][e] = 0.f;
+    const uint32_t nkb = (T + 31) / 32;
+    at_stage_T<CHP>(base + ch, rs, 0, T, ch, kt[0][0], kt[0][1], tid);
+    __syncthreads();
+    for (uint32_t kb = 0; kb < nkb; ++kb) {
+        const uint32_t buf = kb & 1;
+        if (kb + 1 < nkb) at_stage_T<CHP>(base + ch, rs, (kb + 1) * 32, T, ch, kt[buf ^ 1][0], kt[buf ^ 1][1], tid);
+        if (active) {
+            const uint32_t key = kb * 32 + l31;                                     // the row this lane supplies to the A operands
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint32_t c8 = 2 * s + hf;
+                bf16x8 ah, al;
+                at_load_split(base + (size_t)key * rs + ch + c8 * 8, key < T && c8 < nchunk, ah, al);            // K: S^T[key][query]
+                sacc = at_mfma3(ah, al, qh[s], ql[s], sacc);
+                at_load_split(base + (size_t)key * rs + 2 * ch + c8 * 8, key < T && c8 < nchunk, ah, al);        // V: dP^T[key][query]
+                dpacc = at_mfma3(ah, al, gh[s], gl[s], dpacc);
+            }
+            float ds[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t k_e = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf;     // C layout: register e of lane half hf
+                const float p = k_e < T ? __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[e], scale_log2e, -lse_q)) : 0.f;
+                ds[e] = p * (dpacc[e] - D_q);
+            }
+            bf16x8 dsh[2], dsl[2];
+            at_c_to_b(ds, dsh, dsl);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {                                       // dQ^T[channel][query] += K^T[channel][8 keys of this half] dS^T
+                    const size_t off = (size_t)(c * 32 + l31) * AT_ROW + s * 32 + hf * 16;
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kt[buf][0] + off), kl = *reinterpret_cast<const bf16x8*>(kt[buf][1] + off);
+                    dq[c] = at_mfma3(kh, kl, dsh[s], dsl[s], dq[c]);
+                }
+        }
+        __syncthreads();
+    }
+    if (!active || !q_ok) return;
+    float* op = dqkv + (size_t)(b * T + q) * rs + (size_t)h * 3 * ch;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t c0 = c * 32 + 8 * g + 4 * hf;
+            if (c0 >= ch) continue;
+            *reinterpret_cast<float4*>(op + c0) = make_float4(dq[c][4 * g] * scale, dq[c][4 * g + 1] * scale, dq[c][4 * g + 2] * scale, dq[c][4 * g + 3] * scale);
+        }
+}
+
+template <int CHP>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse2,
+                                                      const float* __restrict__ Dv, float* __restrict__ dqkv, uint32_t T, uint32_t heads, uint32_t ch,
+                                                      float scale, float scale_log2e) {
+    constexpr int KS = CHP / 16, CT = CHP / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char qt[2][2][CHP * AT_ROW];       // Q^T of a query block, [buffer][hi | lo]
+    __shared__ __attribute__((aligned(16))) unsigned char gt[2][2][CHP * AT_ROW];       // dO^T
+    __shared__ __attribute__((aligned(16))) float lse_s[2][32], d_s[2][32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const uint32_t b = blockIdx.y / heads, h = blockIdx.y % heads, C = heads * ch, nchunk = ch / 8;
+    const size_t rs = (size_t)3 * C;
+    const float* base = qkv + (size_t)b * T * rs + (size_t)h * 3 * ch;
+    const float* dbase = dout + (size_t)b * T * C + (size_t)h * ch;
+    const uint32_t k0 = blockIdx.x * 128 + wave * 32, key = k0 + l31;
+    const bool active = k0 < T, k_ok = key < T;
+    bf16x8 kh[KS], kl[KS], vh[KS], vl[KS];                                          // K and V of this lane's key: B operands (column = key)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const uint32_t c8 = 2 * s + hf;
+        at_load_split(base + (size_t)key * rs + ch + c8 * 8, active && k_ok && c8 < nchunk, kh[s], kl[s]);
+        at_load_split(base + (size_t)key * rs + 2 * ch + c8 * 8, active && k_ok && c8 < nchunk, vh[s], vl[s]);
+    }
+    f32x16 dk[CT], dv[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[c][e] = 0.f; dv[c][e] = 0.f; }
+    const uint32_t nqb = (T + 31) / 32;
+    auto stage = [&](uint32_t qb, uint32_t buf) {
+        at_stage_T<CHP>(base, rs, qb * 32, T, ch, qt[buf][0], qt[buf][1], tid);
+        at_stage_T<CHP>(dbase, (size_t)C, qb * 32, T, ch, gt[buf][0], gt[buf][1], tid);
+        if (tid < 32) {
+            const uint32_t qi = qb * 32 + tid;
+            lse_s[buf][tid] = qi < T ? lse2[(size_t)blockIdx.y * T + qi] : 1e30f;   // rows past T: P = exp2(-huge) = 0
+            d_s[buf][tid] = qi < T ? Dv[(size_t)blockIdx.y * T + qi] : 0.f;
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (uint32_t qb = 0; qb < nqb; ++qb) {
+        const uint32_t buf = qb & 1;
+        if (qb + 1 < nqb) stage(qb + 1, buf ^ 1);
+        if (active) {
+            const uint32_t qrow = qb * 32 + l31;                                    // the row this lane supplies to the A operands
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint32_t c8 = 2 * s + hf;
+                bf16x8 ah, al;
+                at_load_split(base + (size_t)qrow * rs + c8 * 8, qrow < T && c8 < nchunk, ah, al);               // Q: S[query][key]
+                sacc = at_mfma3(ah, al, kh[s], kl[s], sacc);
+                at_load_split(dbase + (size_t)qrow * C + c8 * 8, qrow < T && c8 < nchunk, ah, al);               // dO: dP[query][key]
+                dpacc = at_mfma3(ah, al, vh[s], vl[s], dpacc);
+            }
+            float p[16], ds[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                                           // registers 4 g .. 4 g + 3 = queries 8 g + 4 hf + {0 .. 3} of the block
+                const float4 lq = *reinterpret_cast<const float4*>(&lse_s[buf][8 * g + 4 * hf]), dq4 = *reinterpret_cast<const float4*>(&d_s[buf][8 * g + 4 * hf]);
+                const float lv[4] = {lq.x, lq.y, lq.z, lq.w}, dvv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = 4 * g + r;
+                    p[e] = k_ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[e], scale_log2e, -lv[r])) : 0.f;
+                    ds[e] = p[e] * (dpacc[e] - dvv[r]);
+                }
+            }
+            bf16x8 ph[2], pl[2], dsh[2], dsl[2];
+            at_c_to_b(p, ph, pl);
+            at_c_to_b(ds, dsh, dsl);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const size_t off = (size_t)(c * 32 + l31) * AT_ROW + s * 32 + hf * 16;
+                    const bf16x8 g_h = *reinterpret_cast<const bf16x8*>(gt[buf][0] + off), g_l = *reinterpret_cast<const bf16x8*>(gt[buf][1] + off);
+                    dv[c] = at_mfma3(g_h, g_l, ph[s], pl[s], dv[c]);                 // dV^T[channel][key] += dO^T[channel][8 queries of this half] P
+                    const bf16x8 q_h = *reinterpret_cast<const bf16x8*>(qt[buf][0] + off), q_l = *reinterpret_cast<const bf16x8*>(qt[buf][1] + off);
+                    dk[c] = at_mfma3(q_h, q_l, dsh[s], dsl[s], dk[c]);               // dK^T[channel][key] += Q^T[channel][8 queries of this half] dS
+                }
+        }
+        __syncthreads();
+    }
+    if (!active || !k_ok) return;
+    float* op = dqkv + (size_t)(b * T + key) * rs + (size_t)h * 3 * ch;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t c0 = c * 32 + 8 * g + 4 * hf;
+            if (c0 >= ch) continue;
+            *reinterpret_cast<float4*>(op + ch + c0) = make_float4(dk[c][4 * g] * scale, dk[c][4 * g + 1] * scale, dk[c][4 * g + 2] * scale, dk[c][4 * g + 3] * scale);
+            *reinterpret_cast<float4*>(op + 2 * ch + c0) = make_float4(dv[c][4 * g], dv[c][4 * g + 1], dv[c][4 * g + 2], dv[c][4 * g + 3]);
+        }
+}
+
 template <bool F32>
-int at_launch(const char* who, const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream) {
+int at_launch(const char* who, const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream, float* lse2 = nullptr) {
     if (B == 0 || T == 0) return SSDNERF_OK;
     SSD_REQUIRE(qkv && out, "%s: null pointer", who);
     SSD_REQUIRE(ch >= 8 && ch <= 128 && ch % 8 == 0, "%s: head width must be a multiple of 8 in [8, 128]", who);
@@ -285,10 +537,10 @@ int at_launch(const char* who, const void* qkv, void* out, uint32_t B, uint32_t 
     hipStream_t st = (hipStream_t)stream;
     const unsigned char* in = (const unsigned char*)qkv;
     unsigned char* o = (unsigned char*)out;
-    if (ch <= 32) hipLaunchKernelGGL((k_attn_fwd<32, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e);
-    else if (ch <= 64) hipLaunchKernelGGL((k_attn_fwd<64, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e);
-    else if (ch <= 96) hipLaunchKernelGGL((k_attn_fwd<96, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e);
-    else hipLaunchKernelGGL((k_attn_fwd<128, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e);
+    if (ch <= 32) hipLaunchKernelGGL((k_attn_fwd<32, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
+    else if (ch <= 64) hipLaunchKernelGGL((k_attn_fwd<64, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
+    else if (ch <= 96) hipLaunchKernelGGL((k_attn_fwd<96, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
+    else hipLaunchKernelGGL((k_attn_fwd<128, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
     SSD_CHECK_LAUNCH(who);
     return SSDNERF_OK;
 }
@@ -301,4 +553,34 @@ extern "C" int ssdnerf_attention_qkv_bf16(const void* qkv, void* out, uint32_t B
 
 extern "C" int ssdnerf_attention_qkv_f32(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream) {
     return at_launch<true>("attention_qkv_f32", qkv, out, B, T, heads, ch, stream);
+}
+
+// Forward that also saves the rows' log-sum-exp (log2 domain) for ssdnerf_attention_qkv_f32_backward: lse2 fp32 [B][heads][T].
+extern "C" int ssdnerf_attention_qkv_f32_lse(const void* qkv, void* out, void* lse2, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream) {
+    SSD_REQUIRE(lse2, "attention_qkv_f32_lse: null pointer");
+    return at_launch<true>("attention_qkv_f32_lse", qkv, out, B, T, heads, ch, stream, (float*)lse2);
+}
+
+extern "C" int ssdnerf_attention_qkv_f32_backward(const void* qkv, const void* out, const void* dout, const void* lse2, void* dqkv, void* workspace, uint32_t B, uint32_t T,
+                                                  uint32_t heads, uint32_t ch, void* stream) {
+    if (B == 0 || T == 0) return SSDNERF_OK;
+    SSD_REQUIRE(qkv && out && dout && lse2 && dqkv && workspace, "attention_qkv_f32_backward: null pointer");
+    SSD_REQUIRE(ch >= 8 && ch <= 128 && ch % 8 == 0, "attention_qkv_f32_backward: head width must be a multiple of 8 in [8, 128]");
+    SSD_REQUIRE(heads > 0 && (uint64_t)B * heads <= 65535, "attention_qkv_f32_backward: B*heads <= 65535");
+    const float scale = 1.0f / sqrtf((float)ch), scale_log2e = 1.4426950408889634f * scale;
+    hipStream_t st = (hipStream_t)stream;
+    const float* q = (const float*)qkv;
+    const float* g = (const float*)dout;
+    const float* l = (const float*)lse2;
+    float* Dv = (float*)workspace;                                            // B * heads * T floats
+    float* d = (float*)dqkv;
+    hipLaunchKernelGGL(k_attn_bwd_D, dim3((B * T * heads + 255) / 256), dim3(256), 0, st, (const float*)out, g, Dv, B, T, heads, ch);
+    const dim3 grid((T + 127) / 128, B * heads), block(256);
+#define AT_BWD(CHP)                                                                                                                     \
+    hipLaunchKernelGGL((k_attn_bwd_dq<CHP>), grid, block, 0, st, q, g, l, (const float*)Dv, d, T, heads, ch, scale, scale_log2e);        \
+    hipLaunchKernelGGL((k_attn_bwd_dkv<CHP>), grid, block, 0, st, q, g, l, (const float*)Dv, d, T, heads, ch, scale, scale_log2e);
+    if (ch <= 32) { AT_BWD(32) } else if (ch <= 64) { AT_BWD(64) } else if (ch <= 96) { AT_BWD(96) } else { AT_BWD(128) }
+#undef AT_BWD
+    SSD_CHECK_LAUNCH("attention_qkv_f32_backward");
+    return SSDNERF_OK;
 }

@@ -84,6 +84,30 @@ class _Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class _AttentionF32Fn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(ch)) v over a (B, T, 3C) qkv projection (channel order [head][q | k | v][ch]) on the hand-written fp32-class kernels, forward
+    (saving the rows' log-sum-exp) and backward (csrc/attention.hip: k_attn_fwd, k_attn_bwd_D / _dq / _dkv) -- r02 ran the library's fp32 attention here."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        from . import unet_fast as UF
+        qkv = qkv.contiguous()
+        out, lse = UF.attention_qkv_f32_with_lse(qkv, heads)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import unet_fast as UF
+        qkv, out, lse = ctx.saved_tensors
+        return UF.attention_qkv_f32_backward(qkv, out, dout.contiguous(), lse, ctx.heads), None
+
+
+#: SSDNERF_UNET_GRAD_ATT_KERNEL=0: the library's scaled_dot_product_attention in the gradient path (A/B runs, true-fp32 parity runs)
+GRAD_ATT_KERNEL = os.environ.get("SSDNERF_UNET_GRAD_ATT_KERNEL", "1") != "0"
+
+
 class _ZeroArena:
     """One zero-filled fp64 buffer per UNet forward for the statistics workspaces of its fused norms (forward sums and backward sums: two slices
     per norm) instead of one ``torch.zeros`` -- one fill kernel -- per norm and direction (142 fills of ~4 us in the cars UNet).  Slices are handed
@@ -296,8 +320,11 @@ class MultiHeadAttentionMod(nn.Module):
         xc = x.contiguous(memory_format=torch.channels_last)
         xn = _GroupNormActFn.apply(xc, self.norm, None, False)
         qkv = F.linear(xn.permute(0, 2, 3, 1).reshape(b, t, c), self.qkv.weight[:, :, 0], self.qkv.bias)      # channel = head*3ch + {q,k,v}*ch + i
-        q, k, v = qkv.view(b, t, heads, 3, ch).permute(3, 0, 2, 1, 4)                                         # each (b, heads, t, ch)
-        a = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(b, t, c)
+        if GRAD_ATT_KERNEL and qkv.is_cuda and qkv.dtype == torch.float32 and ch % 8 == 0 and 8 <= ch <= 128:
+            a = _AttentionF32Fn.apply(qkv, heads)                                                             # (b, t, c)
+        else:
+            q, k, v = qkv.view(b, t, heads, 3, ch).permute(3, 0, 2, 1, 4)                                     # each (b, heads, t, ch)
+            a = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(b, t, c)
         out = F.linear(a, self.proj.weight[:, :, 0], self.proj.bias) + xc.permute(0, 2, 3, 1).reshape(b, t, c)
         return out.view(b, h, w, c).permute(0, 3, 1, 2)                                                       # a channels_last (B, C, H, W) view
 

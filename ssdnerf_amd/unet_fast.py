@@ -239,6 +239,32 @@ def attention_qkv_f32(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     return out
 
 
+def attention_qkv_f32_with_lse(qkv: torch.Tensor, heads: int):
+    """``attention_qkv_f32`` that also returns the rows' log-sum-exp (log2 domain, (B, heads, T) fp32) for ``attention_qkv_f32_backward``."""
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    if qkv.dtype != torch.float32 or not qkv.is_contiguous():
+        raise RuntimeError("attention_qkv_f32_with_lse: contiguous fp32 input only")
+    out = torch.empty((B, T, Cc), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
+    C.check(C.lib().ssdnerf_attention_qkv_f32_lse(C.ptr(qkv), C.ptr(out), C.ptr(lse), C.u32(B), C.u32(T), C.u32(heads), C.u32(Cc // heads), C.stream()),
+            "attention_qkv_f32_lse")
+    return out, lse
+
+
+def attention_qkv_f32_backward(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, heads: int) -> torch.Tensor:
+    """d loss / d qkv of ``attention_qkv_f32`` (csrc/attention.hip: k_attn_bwd_D, k_attn_bwd_dq, k_attn_bwd_dkv); everything (B, T, .) fp32 contiguous."""
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in (qkv, out, dout, lse)) or out.shape != (B, T, Cc) or dout.shape != out.shape:
+        raise RuntimeError("attention_qkv_f32_backward: contiguous fp32 tensors of matching shapes only")
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)
+    C.check(C.lib().ssdnerf_attention_qkv_f32_backward(C.ptr(qkv), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(ws), C.u32(B), C.u32(T), C.u32(heads),
+                                                        C.u32(Cc // heads), C.stream()), "attention_qkv_f32_backward")
+    return dqkv
+
+
 def attention_supported(dtype, T: int, ch: int) -> bool:
     """shapes the hand-written attention kernels take (csrc/attention.hip): any T, head width a multiple of 8 up to 128"""
     return dtype in (torch.bfloat16, torch.float32) and ch % 8 == 0 and 8 <= ch <= 128 and T >= 1

@@ -726,3 +726,30 @@ def test_input_gradient_norms_fused_on_the_gpu():
     y, gx = grad_of()
     assert float((y - y_ref).abs().max()) <= 1e-4 * float(y_ref.abs().max())
     assert float((gx - g_ref).abs().max()) <= 1e-4 * float(g_ref.abs().max())
+
+
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 1024, 4, 64), (2, 256, 4, 128), (1, 64, 4, 128), (1, 96, 2, 40), (2, 160, 1, 80), (1, 33, 2, 8)])
+def test_attention_backward_kernels_match_autograd(B, T, heads, ch):
+    """d(attention) / d(qkv) of the fp32-class kernels (k_attn_bwd_D / _dq / _dkv) against autograd through the fp64 formula; the forward's saved
+    log-sum-exp against the formula's; ragged T (33, 96, 160) and head widths that are not multiples of 32"""
+    g = torch.Generator().manual_seed(T + ch + heads)
+    C = heads * ch
+    qkv = (torch.randn(B, T, 3 * C, generator=g) * 1.1).cuda()
+    dout = torch.randn(B, T, C, generator=g).cuda()
+    out, lse = unet_fast.attention_qkv_f32_with_lse(qkv, heads)
+    dqkv = unet_fast.attention_qkv_f32_backward(qkv, out, dout.contiguous(), lse, heads)
+    x = qkv.double().clone().requires_grad_(True)
+    q, k, v = x.view(B, T, heads, 3, ch).permute(3, 0, 2, 1, 4)                       # (B, heads, T, ch), reference channel order [head][q|k|v][ch]
+    s = q @ k.transpose(-1, -2) / ch ** 0.5
+    want_out = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, T, C)
+    want_lse2 = torch.logsumexp(s, dim=-1) / 0.6931471805599453
+    (want,) = torch.autograd.grad((want_out * dout.double()).sum(), x)
+    assert ((out.double() - want_out).norm() / want_out.norm()).item() < 3e-5
+    assert (lse.double() - want_lse2).abs().max().item() < 1e-3
+    rel = ((dqkv.double() - want).norm() / want.norm()).item()
+    assert rel < 5e-5, rel
+    for name, sl in (("dq", 0), ("dk", 1), ("dv", 2)):                                 # each of the three gradients on its own (a zero one would hide in the norm)
+        a = dqkv.view(B, T, heads, 3, ch)[:, :, :, sl].double()
+        w = want.view(B, T, heads, 3, ch)[:, :, :, sl]
+        assert ((a - w).norm() / w.norm()).item() < 1e-4, name
+        assert (a - w).abs().max().item() < 2e-4 * w.abs().max().item(), name
