@@ -308,26 +308,49 @@ SSD_DEV void at_c_to_b(const float (&v)[16], bf16x8 (&hi)[2], bf16x8 (&lo)[2]) {
     }
 }
 // rows [r0, r0 + 32) x ch channels of an fp32 tensor (row stride `rstride` floats, rows >= T read as zeros) -> LDS, TRANSPOSED, as the bf16 pair:
-// dst_hi / dst_lo [channel][AT_ROW bytes], the row index at its C-layout position (at_key_pos).  All 256 threads.
+// dst_hi / dst_lo [channel][AT_ROW bytes], the row index at its C-layout position (at_key_pos).  All 256 threads.  A thread takes TWO adjacent rows
+// (2 j, 2 j + 1: adjacent positions as well) and four channels, so that every LDS store is a whole dword {row 2 j, row 2 j + 1} of one channel
+// (16 two-byte stores per thread in the first version of this function: the staging, not the products, was most of a key block's time).
+template <int CHP> struct AtStage {                                              // one tile's items of this thread, between the global loads and the LDS stores
+    static constexpr int TOT = 16 * CHP / 4, N = (TOT + 255) / 256;               // (row pair, 4-channel group) items; per thread
+    float4 a[N], b[N];
+};
+// load half: issued at the head of a block's iteration, so that the round trip runs under the block's products ...
 template <int CHP>
-SSD_DEV void at_stage_T(const float* __restrict__ src, size_t rstride, uint32_t r0, uint32_t T, uint32_t ch, unsigned char* dst_hi, unsigned char* dst_lo, uint32_t tid) {
-    constexpr int TOT = 32 * CHP / 8;
+SSD_DEV void at_stage_load(AtStage<CHP>& st, const float* __restrict__ src, size_t rstride, uint32_t r0, uint32_t T, uint32_t ch, uint32_t tid) {
 #pragma unroll
-    for (int i = 0; i < (TOT + 255) / 256; ++i) {
-        const uint32_t id = tid + 256 * i;
-        if (id >= (uint32_t)TOT) break;
-        const uint32_t row = id / (CHP / 8), cc = id % (CHP / 8);
-        bf16x8 hi, lo;
-        at_load_split(src + (size_t)(r0 + row) * rstride + cc * 8, r0 + row < T && cc * 8 < ch, hi, lo);
-        const uint4 uh = *reinterpret_cast<const uint4*>(&hi), ul = *reinterpret_cast<const uint4*>(&lo);
-        const uint32_t wh[4] = {uh.x, uh.y, uh.z, uh.w}, wl[4] = {ul.x, ul.y, ul.z, ul.w};
-        const uint32_t off = (cc * 8) * AT_ROW + at_key_pos(row) * 2;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            *reinterpret_cast<uint16_t*>(dst_hi + off + e * AT_ROW) = (uint16_t)((e & 1) ? (wh[e >> 1] >> 16) : (wh[e >> 1] & 0xffffu));
-            *reinterpret_cast<uint16_t*>(dst_lo + off + e * AT_ROW) = (uint16_t)((e & 1) ? (wl[e >> 1] >> 16) : (wl[e >> 1] & 0xffffu));
+    for (int i = 0; i < AtStage<CHP>::N; ++i) {
+        const uint32_t id = tid + 256 * i, rp = id / (CHP / 4), cg = id % (CHP / 4), ra = r0 + 2 * rp;
+        st.a[i] = make_float4(0.f, 0.f, 0.f, 0.f); st.b[i] = st.a[i];
+        if (id < (uint32_t)AtStage<CHP>::TOT && cg * 4 < ch) {
+            if (ra < T) st.a[i] = *reinterpret_cast<const float4*>(src + (size_t)ra * rstride + cg * 4);
+            if (ra + 1 < T) st.b[i] = *reinterpret_cast<const float4*>(src + (size_t)(ra + 1) * rstride + cg * 4);
         }
     }
+}
+// ... store half: split and write, at the iteration's end
+template <int CHP>
+SSD_DEV void at_stage_store(const AtStage<CHP>& st, unsigned char* dst_hi, unsigned char* dst_lo, uint32_t tid) {
+#pragma unroll
+    for (int i = 0; i < AtStage<CHP>::N; ++i) {
+        const uint32_t id = tid + 256 * i, rp = id / (CHP / 4), cg = id % (CHP / 4);
+        if (id >= (uint32_t)AtStage<CHP>::TOT) break;
+        const float va[4] = {st.a[i].x, st.a[i].y, st.a[i].z, st.a[i].w}, vb[4] = {st.b[i].x, st.b[i].y, st.b[i].z, st.b[i].w};
+        const uint32_t off = (cg * 4) * AT_ROW + at_key_pos(2 * rp) * 2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t wh = at_pack_bf16(va[c], vb[c]);
+            *reinterpret_cast<uint32_t*>(dst_hi + off + c * AT_ROW) = wh;
+            *reinterpret_cast<uint32_t*>(dst_lo + off + c * AT_ROW) = at_pack_bf16_rest(va[c], vb[c], wh);
+        }
+    }
+}
+struct AtRaw8 { float4 a, b; };                                                  // 8 fp32 channels of one row, as loaded (split at their use)
+SSD_DEV AtRaw8 at_load_raw(const float* p, bool ok) {
+    AtRaw8 r;
+    r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = r.a;
+    if (ok) { r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); }
+    return r;
 }
 SSD_DEV f32x16 at_mfma3(const bf16x8& a_hi, const bf16x8& a_lo, const bf16x8& b_hi, const bf16x8& b_lo, f32x16 acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);
@@ -378,23 +401,48 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ q
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[c][e] = 0.f;
     const uint32_t nkb = (T + 31) / 32;
-    at_stage_T<CHP>(base + ch, rs, 0, T, ch, kt[0][0], kt[0][1], tid);
+    // the A-operand rows of K and V (row = key kb * 32 + l31) are fetched ONE KEY BLOCK AHEAD as raw fp32 (one wave per SIMD: nothing else hides the L2
+    // round trip) -- up to 64-wide heads; wider ones (T <= 256 in the UNet) would spill
+    constexpr bool PF = CHP <= 64;
+    AtRaw8 kraw[PF ? KS : 1], vraw[PF ? KS : 1];
+    auto prefetch = [&](uint32_t kb) {
+        if constexpr (PF) {
+            const uint32_t key = kb * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint32_t c8 = 2 * s + hf;
+                const bool ok = active && key < T && c8 < nchunk;
+                kraw[s] = at_load_raw(base + (size_t)key * rs + ch + c8 * 8, ok);
+                vraw[s] = at_load_raw(base + (size_t)key * rs + 2 * ch + c8 * 8, ok);
+            }
+        }
+    };
+    AtStage<CHP> st;
+    prefetch(0);
+    at_stage_load<CHP>(st, base + ch, rs, 0, T, ch, tid);
+    at_stage_store<CHP>(st, kt[0][0], kt[0][1], tid);
     __syncthreads();
     for (uint32_t kb = 0; kb < nkb; ++kb) {
         const uint32_t buf = kb & 1;
-        if (kb + 1 < nkb) at_stage_T<CHP>(base + ch, rs, (kb + 1) * 32, T, ch, kt[buf ^ 1][0], kt[buf ^ 1][1], tid);
+        AtRaw8 kcur[PF ? KS : 1], vcur[PF ? KS : 1];
+        if constexpr (PF) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { kcur[s] = kraw[s]; vcur[s] = vraw[s]; }
+        }
+        if (kb + 1 < nkb) { prefetch(kb + 1); at_stage_load<CHP>(st, base + ch, rs, (kb + 1) * 32, T, ch, tid); }
         if (active) {
-            const uint32_t key = kb * 32 + l31;                                     // the row this lane supplies to the A operands
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const uint32_t c8 = 2 * s + hf;
+                const uint32_t key = kb * 32 + l31, c8 = 2 * s + hf;                  // the row this lane supplies to the A operands
                 bf16x8 ah, al;
-                at_load_split(base + (size_t)key * rs + ch + c8 * 8, key < T && c8 < nchunk, ah, al);            // K: S^T[key][query]
+                if constexpr (PF) at_split8(kcur[s].a, kcur[s].b, ah, al);
+                else at_load_split(base + (size_t)key * rs + ch + c8 * 8, key < T && c8 < nchunk, ah, al);        // K: S^T[key][query]
                 sacc = at_mfma3(ah, al, qh[s], ql[s], sacc);
-                at_load_split(base + (size_t)key * rs + 2 * ch + c8 * 8, key < T && c8 < nchunk, ah, al);        // V: dP^T[key][query]
+                if constexpr (PF) at_split8(vcur[s].a, vcur[s].b, ah, al);
+                else at_load_split(base + (size_t)key * rs + 2 * ch + c8 * 8, key < T && c8 < nchunk, ah, al);    // V: dP^T[key][query]
                 dpacc = at_mfma3(ah, al, gh[s], gl[s], dpacc);
             }
             float ds[16];
@@ -415,6 +463,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ q
                     dq[c] = at_mfma3(kh, kl, dsh[s], dsl[s], dq[c]);
                 }
         }
+        if (kb + 1 < nkb) at_stage_store<CHP>(st, kt[buf ^ 1][0], kt[buf ^ 1][1], tid);
         __syncthreads();
     }
     if (!active || !q_ok) return;
@@ -457,20 +506,49 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[c][e] = 0.f; dv[c][e] = 0.f; }
     const uint32_t nqb = (T + 31) / 32;
-    auto stage = [&](uint32_t qb, uint32_t buf) {
-        at_stage_T<CHP>(base, rs, qb * 32, T, ch, qt[buf][0], qt[buf][1], tid);
-        at_stage_T<CHP>(dbase, (size_t)C, qb * 32, T, ch, gt[buf][0], gt[buf][1], tid);
+    AtStage<CHP> sq, sg;
+    float s_lse = 0.f, s_d = 0.f;
+    auto stage_load = [&](uint32_t qb) {
+        at_stage_load<CHP>(sq, base, rs, qb * 32, T, ch, tid);
+        at_stage_load<CHP>(sg, dbase, (size_t)C, qb * 32, T, ch, tid);
         if (tid < 32) {
             const uint32_t qi = qb * 32 + tid;
-            lse_s[buf][tid] = qi < T ? lse2[(size_t)blockIdx.y * T + qi] : 1e30f;   // rows past T: P = exp2(-huge) = 0
-            d_s[buf][tid] = qi < T ? Dv[(size_t)blockIdx.y * T + qi] : 0.f;
+            s_lse = qi < T ? lse2[(size_t)blockIdx.y * T + qi] : 1e30f;             // rows past T: P = exp2(-huge) = 0
+            s_d = qi < T ? Dv[(size_t)blockIdx.y * T + qi] : 0.f;
         }
     };
-    stage(0, 0);
+    auto stage_store = [&](uint32_t buf) {
+        at_stage_store<CHP>(sq, qt[buf][0], qt[buf][1], tid);
+        at_stage_store<CHP>(sg, gt[buf][0], gt[buf][1], tid);
+        if (tid < 32) { lse_s[buf][tid] = s_lse; d_s[buf][tid] = s_d; }
+    };
+    // the A-operand rows of Q and dO (row = query qb * 32 + l31) one query block ahead as raw fp32, up to 64-wide heads (see k_attn_bwd_dq)
+    constexpr bool PF = CHP <= 64;
+    AtRaw8 qraw[PF ? KS : 1], graw[PF ? KS : 1];
+    auto prefetch = [&](uint32_t qb) {
+        if constexpr (PF) {
+            const uint32_t qrow = qb * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint32_t c8 = 2 * s + hf;
+                const bool ok = active && qrow < T && c8 < nchunk;
+                qraw[s] = at_load_raw(base + (size_t)qrow * rs + c8 * 8, ok);
+                graw[s] = at_load_raw(dbase + (size_t)qrow * C + c8 * 8, ok);
+            }
+        }
+    };
+    prefetch(0);
+    stage_load(0);
+    stage_store(0);
     __syncthreads();
     for (uint32_t qb = 0; qb < nqb; ++qb) {
         const uint32_t buf = qb & 1;
-        if (qb + 1 < nqb) stage(qb + 1, buf ^ 1);
+        AtRaw8 qcur[PF ? KS : 1], gcur[PF ? KS : 1];
+        if constexpr (PF) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { qcur[s] = qraw[s]; gcur[s] = graw[s]; }
+        }
+        if (qb + 1 < nqb) { prefetch(qb + 1); stage_load(qb + 1); }
         if (active) {
             const uint32_t qrow = qb * 32 + l31;                                    // the row this lane supplies to the A operands
             f32x16 sacc, dpacc;
@@ -480,9 +558,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
             for (int s = 0; s < KS; ++s) {
                 const uint32_t c8 = 2 * s + hf;
                 bf16x8 ah, al;
-                at_load_split(base + (size_t)qrow * rs + c8 * 8, qrow < T && c8 < nchunk, ah, al);               // Q: S[query][key]
+                if constexpr (PF) at_split8(qcur[s].a, qcur[s].b, ah, al);
+                else at_load_split(base + (size_t)qrow * rs + c8 * 8, qrow < T && c8 < nchunk, ah, al);          // Q: S[query][key]
                 sacc = at_mfma3(ah, al, kh[s], kl[s], sacc);
-                at_load_split(dbase + (size_t)qrow * C + c8 * 8, qrow < T && c8 < nchunk, ah, al);               // dO: dP[query][key]
+                if constexpr (PF) at_split8(gcur[s].a, gcur[s].b, ah, al);
+                else at_load_split(dbase + (size_t)qrow * C + c8 * 8, qrow < T && c8 < nchunk, ah, al);          // dO: dP[query][key]
                 dpacc = at_mfma3(ah, al, vh[s], vl[s], dpacc);
             }
             float p[16], ds[16];
@@ -511,6 +591,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
                     dk[c] = at_mfma3(q_h, q_l, dsh[s], dsl[s], dk[c]);               // dK^T[channel][key] += Q^T[channel][8 queries of this half] dS
                 }
         }
+        if (qb + 1 < nqb) stage_store(buf ^ 1);
         __syncthreads();
     }
     if (!active || !k_ok) return;
