@@ -166,10 +166,16 @@ __global__ void __launch_bounds__(RQ_TPB) k_bitfield_coarsen(const uint8_t* __re
 // The margins cover the fp32 differences between this test and the rays the kernels build; what it removes are rays the coarse pre-test would
 // have finished with the same outputs.  A view whose pose is not rigid, or with a set block that is not entirely in front of the camera,
 // gets a full mask (no cull).
-__global__ void __launch_bounds__(RQ_TPB) k_view_masks(FastMarch m, RaySrc src, uint32_t views_cap, const uint8_t* __restrict__ coarse_all,
-                                                        uint32_t* __restrict__ view_masks) {
+// r03: the same pass records, per tile, the CAMERA-DEPTH RANGE of the (grown) set blocks that project into it.  Camera depth is linear along a ray
+// (z_c(o + t d) = t (e_z . d), e_z the camera's viewing axis in world coordinates), so a ray of that tile can test an occupied cell only for
+// t in [z_lo, z_hi] / (e_z . d): k_ray_cull scans its test points inside that range instead of from the box's near to its far face
+// (a car fills about a third of the box's depth).  Stored as two bf16, rounded outwards.
+__global__ void __launch_bounds__(RQ_TPB) k_view_masks(FastMarch m, RaySrc src, uint32_t views_cap, uint32_t zr_cap, const uint8_t* __restrict__ coarse_all,
+                                                        uint32_t* __restrict__ view_masks, uint32_t* __restrict__ view_zr) {
     __shared__ uint32_t mask[8];
     __shared__ uint32_t give_up;
+    __shared__ uint32_t z_lo[256], z_hi[256];                                // fp32 bit patterns of positive depths: unsigned order == float order
+    z_lo[threadIdx.x] = 0xffffffffu; z_hi[threadIdx.x] = 0u;
     const uint32_t view = blockIdx.x, scene = blockIdx.y;
     const uint32_t Hc = m.H >> RQ_COARSE_LOG2B, log2Hc = m.log2H - RQ_COARSE_LOG2B, n_blocks = Hc * Hc * Hc;
     if (threadIdx.x < 8) mask[threadIdx.x] = 0u;
@@ -191,7 +197,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_view_masks(FastMarch m, RaySrc src, 
         const uint32_t bx = i & (Hc - 1), by = (i >> log2Hc) & (Hc - 1), bz = i >> (2 * log2Hc);
         const float lo[3] = {(float)bx * blockw - m.mip_bound - cell, (float)by * blockw - m.mip_bound - cell, (float)bz * blockw - m.mip_bound - cell};
         const float span = blockw + 2.0f * cell;
-        float ulo = 3.0e38f, uhi = -3.0e38f, vlo = 3.0e38f, vhi = -3.0e38f;
+        float ulo = 3.0e38f, uhi = -3.0e38f, vlo = 3.0e38f, vhi = -3.0e38f, zmin = 3.0e38f, zmax = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float rx = lo[0] + ((k & 1) ? span : 0.0f) - M[3], ry = lo[1] + ((k & 2) ? span : 0.0f) - M[7], rz = lo[2] + ((k & 4) ? span : 0.0f) - M[11];
@@ -200,6 +206,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_view_masks(FastMarch m, RaySrc src, 
             if (!(zc > 1e-3f)) { bad = true; break; }
             const float u = ssd_fma(K[0], xc / zc, K[2]), v = ssd_fma(K[1], yc / zc, K[3]);   // pixel-centre coordinates (pixel p has centre p + 0.5)
             ulo = fminf(ulo, u); uhi = fmaxf(uhi, u); vlo = fminf(vlo, v); vhi = fmaxf(vhi, v);
+            zmin = fminf(zmin, zc); zmax = fmaxf(zmax, zc);
         }
         if (bad) break;
         // pixels whose centre lies in [ulo - 1.5, uhi + 1.5]: p + 0.5 >= ulo - 1.5  ->  p >= ulo - 2
@@ -208,14 +215,24 @@ __global__ void __launch_bounds__(RQ_TPB) k_view_masks(FastMarch m, RaySrc src, 
         const uint32_t tx0 = (uint32_t)fmaxf(p0, 0.0f) / tw, tx1 = min((uint32_t)fminf(p1, (float)(src.w - 1u)) / tw, 15u);
         const uint32_t ty0 = (uint32_t)fmaxf(q0, 0.0f) / th, ty1 = min((uint32_t)fminf(q1, (float)(h - 1u)) / th, 15u);
         const uint32_t row = ((2u << tx1) - 1u) & ~((1u << tx0) - 1u);       // bits tx0 .. tx1 of a 16-bit tile row
-        for (uint32_t ty = ty0; ty <= ty1; ++ty) atomicOr(&mask[ty >> 1], row << ((ty & 1u) * 16u));
+        for (uint32_t ty = ty0; ty <= ty1; ++ty) {
+            atomicOr(&mask[ty >> 1], row << ((ty & 1u) * 16u));
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                atomicMin(&z_lo[ty * 16u + tx], __float_as_uint(zmin));
+                atomicMax(&z_hi[ty * 16u + tx], __float_as_uint(zmax));
+            }
+        }
     }
     if (bad) give_up = 1u;
     __syncthreads();
     if (threadIdx.x < 8) view_masks[((uint64_t)scene * views_cap + view) * 8 + threadIdx.x] = give_up ? 0xffffffffu : mask[threadIdx.x];
+    {   // bf16 halves, rounded outwards; no cull -> [0, inf)
+        const uint32_t lo16 = give_up ? 0u : (z_lo[threadIdx.x] >> 16), hi16 = give_up ? 0x7f80u : min((z_hi[threadIdx.x] >> 16) + 1u, 0x7f80u);
+        view_zr[((uint64_t)scene * zr_cap + view) * 256 + threadIdx.x] = lo16 | (hi16 << 16);
+    }
 }
 
-struct CullGrid { uint32_t group; uint32_t views_cap; };   // rays per blockIdx.y group: hw (one view per y, cameras) or N (arrays, gridDim.y == 1)
+struct CullGrid { uint32_t group; uint32_t views_cap; uint32_t zr_cap; };   // rays per blockIdx.y group: hw (one view per y, cameras) or N (arrays, gridDim.y == 1)
 #ifndef RQ_LONG_STEPS
 #define RQ_LONG_STEPS 48                       // a hitting ray whose remaining segment (first hit .. tail bound) is longer than this many minimum steps goes to the FRONT of the queue
 #endif
@@ -245,11 +262,14 @@ SSD_DEV void rq_flush(const T* list, const uint32_t* list_count, uint32_t* slot 
 __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, CullGrid cg, const uint8_t* __restrict__ coarse_bits,
                                                       float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
                                                       int32_t* __restrict__ sample_counts, uint2* __restrict__ survivors,
-                                                      uint32_t* __restrict__ counters, const uint32_t* __restrict__ view_masks) {
+                                                      uint32_t* __restrict__ counters, const uint32_t* __restrict__ view_masks,
+                                                      const uint32_t* __restrict__ view_zr) {
     const uint32_t scene = blockIdx.z;
     __shared__ uint32_t tile_mask[8];                                         // this block's view (cameras: one view per blockIdx.y), k_view_masks
+    __shared__ uint32_t tile_zr[256];                                         // ... and its tiles' depth ranges
     const bool view_cull = view_masks != nullptr;
     if (view_cull && threadIdx.x < 8) tile_mask[threadIdx.x] = view_masks[((uint64_t)scene * cg.views_cap + blockIdx.y) * 8 + threadIdx.x];
+    if (view_cull) tile_zr[threadIdx.x] = view_zr[((uint64_t)scene * cg.zr_cap + blockIdx.y) * 256 + threadIdx.x];
     const uint32_t tile_w = view_cull ? (src.w + 15u) / 16u : 1u, tile_h = view_cull ? (src.hw / src.w + 15u) / 16u : 1u;
     const bool tiled = view_cull && (src.w & 7u) == 0 && ((src.hw / src.w) & 7u) == 0;
     // this scene's coarse bitfield -> LDS ((H/4)^3 bits; 512 B for H = 64)
@@ -280,6 +300,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
         if (in_group < cg.group && n < c.N) {
             RayGeom r = {};
             bool outside = false;
+            float t_zlo = 0.0f, t_zhi = 3.0e38f;                             // the tile's depth range as ray parameters (view cull only)
             if (src.c2w != nullptr) {       // the view is uniform over the block (blockIdx.y): pose and intrinsics are scalar loads
                 const uint64_t cam = (uint64_t)scene * src.V + blockIdx.y;
                 const uint32_t py = src.w_shift >= 0 ? in_group >> src.w_shift : in_group / src.w;
@@ -292,6 +313,17 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
                     float o[3], d[3];
                     ssd_cam_ray(src.c2w + cam * 16, src.intr + cam * 4, px, py, o, d);
                     r = ssd_ray_geom(o[0], o[1], o[2], d[0], d[1], d[2]);
+                    if (view_cull) {
+                        const uint32_t tile = (py / tile_h) * 16u + px / tile_w;
+                        const uint32_t zr = tile_zr[tile];
+                        const float* M = src.c2w + cam * 16;
+                        const float ez_d = ssd_fma(M[2], d[0], ssd_fma(M[6], d[1], M[10] * d[2]));     // z_c of the point o + t d is t * ez_d (k_view_masks' own formula)
+                        if (ez_d > 1e-6f) {
+                            const float rz = 1.0f / ez_d;
+                            t_zlo = __uint_as_float(zr << 16) * rz * 0.998f;                        // (rounding of the division / of k_view_masks' products: far below the margin)
+                            t_zhi = __uint_as_float(zr & 0xffff0000u) * rz * 1.002f;
+                        }
+                    }
                 }
             } else {
                 r = ssd_load_ray(src.rays_o + 3 * gi, src.rays_d + 3 * gi);
@@ -312,18 +344,30 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
                       qz = ssd_fma(ssd_fma(t, r.dz, r.oz), c.m.rb, 1.0f) * hb;
                 const float sx = step_t * r.dx * c.m.rb * hb, sy = step_t * r.dy * c.m.rb * hb, sz = step_t * r.dz * c.m.rb * hb;
                 const uint32_t top = Hc - 1;
+                const float topf = (float)top;
                 auto occupied = [&](float x, float y, float z) {
-                    const uint32_t bx = min((uint32_t)fmaxf(x, 0.0f), top), by = min((uint32_t)fmaxf(y, 0.0f), top), bz = min((uint32_t)fmaxf(z, 0.0f), top);
+                    const uint32_t bx = (uint32_t)__builtin_amdgcn_fmed3f(x, 0.0f, topf), by = (uint32_t)__builtin_amdgcn_fmed3f(y, 0.0f, topf),
+                                   bz = (uint32_t)__builtin_amdgcn_fmed3f(z, 0.0f, topf);
                     const uint32_t ci = (((bz << log2Hc) + by) << log2Hc) + bx;
                     return ((coarse_lds[ci >> 3] >> (ci & 7u)) & 1u) != 0;
                 };
                 int j_last = -1, j_first = -1, j = 0;
-                for (float tc = t; tc < far_; tc += step_t, ++j) {                // test points near, near + step, ... below far
+                float tc = t;
+                // test points in front of / behind the tile's depth range lie in no set block (a set block the ray passes through projects onto
+                // the ray's pixel, hence into its tile, and is part of the range): they are clear without being looked up.  One step of slack each side.
+                if (t_zlo > t + 2.0f * step_t) {
+                    j = (int)((t_zlo - t) / step_t) - 1;
+                    const float fj = (float)j;
+                    tc = ssd_fma(fj, step_t, t); qx = ssd_fma(fj, sx, qx); qy = ssd_fma(fj, sy, qy); qz = ssd_fma(fj, sz, qz);
+                }
+                const float t_scan_end = fminf(far_, t_zhi + step_t);
+                for (; tc < t_scan_end; tc += step_t, ++j) {                      // test points near, near + step, ... below far
                     if (occupied(qx, qy, qz)) { j_last = j; if (j_first < 0) j_first = j; }
                     qx += sx; qy += sy; qz += sz;
                 }
-                // ... and the segment's end point itself
-                if (occupied(ssd_fma(ssd_fma(far_, r.dx, r.ox), c.m.rb, 1.0f) * hb, ssd_fma(ssd_fma(far_, r.dy, r.oy), c.m.rb, 1.0f) * hb,
+                // ... and the segment's end point itself (when the range reaches it)
+                if (t_scan_end >= far_ &&
+                    occupied(ssd_fma(ssd_fma(far_, r.dx, r.ox), c.m.rb, 1.0f) * hb, ssd_fma(ssd_fma(far_, r.dy, r.oy), c.m.rb, 1.0f) * hb,
                              ssd_fma(ssd_fma(far_, r.dz, r.oz), c.m.rb, 1.0f) * hb)) j_last = j;
                 alive = j_last >= 0;                                             // nothing within a cell of this ray: no march
                 // every test point after j_last is clear: past near + (j_last + 1) steps no cell the march could test is occupied, so the
@@ -663,14 +707,15 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
         hipLaunchKernelGGL(k_bitfield_coarsen, dim3(ssd_blocks(hc * hc * hc * 8, RQ_TPB), S), dim3(RQ_TPB), 0, s, w.lin_bits, grid_size, c.m.log2H, c.bitfield_stride, w.coarse);
     CullGrid cg;
     cg.views_cap = N / 64 + 1;
+    cg.zr_cap = N / 256 + 1;
     dim3 grid;
     if (src.c2w != nullptr) { cg.group = src.hw; grid = dim3(ssd_blocks(src.hw, RQ_TPB * RQ_CHUNKS), src.V, S); }      // one view per blockIdx.y: camera loads are scalar
     else { cg.group = N; grid = dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), 1, S); }
     const bool view_cull = coarse_ok && src.c2w != nullptr && src.hw >= 64 && src.w >= 16 && src.hw / src.w >= 16 && src.hw % src.w == 0;
     if (view_cull)
-        hipLaunchKernelGGL(k_view_masks, dim3(src.V, S), dim3(RQ_TPB), 0, s, c.m, src, cg.views_cap, w.coarse, w.view_masks);
+        hipLaunchKernelGGL(k_view_masks, dim3(src.V, S), dim3(RQ_TPB), 0, s, c.m, src, cg.views_cap, cg.zr_cap, w.coarse, w.view_masks, w.view_zr);
     hipLaunchKernelGGL(k_ray_cull, grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
-                       w.survivors, w.counters, view_cull ? w.view_masks : (const uint32_t*)nullptr);
+                       w.survivors, w.counters, view_cull ? w.view_masks : (const uint32_t*)nullptr, w.view_zr);
     if (dt_gammas == nullptr && dt_gamma == 0.0f)
         hipLaunchKernelGGL(k_survivor_march<true>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum,
                            sample_counts, w.queue, w.counters);
