@@ -237,7 +237,7 @@ __host__ __device__ static inline uint32_t ssd_counter(uint32_t kind, uint32_t S
 //   view_masks [S][<= N/64 views][8] u32: per view, a 16 x 16-tile mask of the image tiles that a set coarse block projects into (k_view_masks)
 //   view_zr [S][<= N/256 views][256] u32: per image tile, the camera-depth range of the set coarse blocks that project into it, as two bf16
 //              (low half: lower end rounded down, high half: upper end rounded up): k_ray_cull scans a ray's test points inside that range only
-struct RenderWs { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; uint2* survivors; uint32_t* view_masks; uint32_t* view_zr; size_t counter_bytes, bytes; };
+struct RenderWs { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; uint2* survivors; uint32_t* view_masks; uint32_t* view_zr; uint64_t* blocks64; size_t counter_bytes, bytes; };
 static inline RenderWs ssd_render_ws(void* base, uint32_t S, uint32_t N, uint32_t grid_size) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t counters = up((size_t)SSD_CNT_KINDS * S * SSD_COUNTER_STRIDE * 4), bits = up((size_t)S * grid_size * grid_size * grid_size / 8);
@@ -253,8 +253,10 @@ static inline RenderWs ssd_render_ws(void* base, uint32_t S, uint32_t N, uint32_
     w.view_masks = (uint32_t*)(b + counters + bits + coarse + queue + surv);
     const size_t masks = up((size_t)S * (N / 64 + 1) * 32);
     w.view_zr = (uint32_t*)(b + counters + bits + coarse + queue + surv + masks);
+    const size_t zr = up((size_t)S * (N / 256 + 1) * 1024);
+    w.blocks64 = (uint64_t*)(b + counters + bits + coarse + queue + surv + masks + zr);      // [S][(H/4)^3] u64: the 64 cells of a 4^3 block in one word (k_survivor_march)
     w.counter_bytes = counters;
-    w.bytes = counters + bits + coarse + queue + surv + masks + up((size_t)S * (N / 256 + 1) * 1024);
+    w.bytes = counters + bits + coarse + queue + surv + masks + zr + bits;
     return w;
 }
 

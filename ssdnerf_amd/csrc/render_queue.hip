@@ -107,6 +107,34 @@ __global__ void k_bitfield_linearize(const uint8_t* __restrict__ morton_bits, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// The bitfield once more, BLOCK-MAJOR: the 64 cells of a 4^3 block in one 64-bit word (bit = (z & 3) << 4 | (y & 3) << 2 | (x & 3), words in linear
+// z/y/x block order).  One 8-byte load tells k_survivor_march whether the whole block, the 2^3 sub-block or the cell at a position is occupied.
+__global__ void __launch_bounds__(RQ_TPB) k_bitfield_blocks64(const uint8_t* __restrict__ lin_bits_all, uint32_t H, uint32_t log2H, uint32_t bytes_per_scene,
+                                                              uint64_t* __restrict__ blocks_all) {
+    const uint32_t Hb = H >> 2, lb = log2H - 2, n_blocks = Hb * Hb * Hb;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint8_t* lin = lin_bits_all + (uint64_t)blockIdx.y * bytes_per_scene;
+    const uint32_t bx = b & (Hb - 1), by = (b >> lb) & (Hb - 1), bz = b >> (2 * lb);
+    uint64_t w = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {                                       // row (z, y) of the block: 4 bits at a bit offset that is a multiple of 4
+        const uint32_t bit = ((((4 * bz + (k >> 2)) << log2H) + 4 * by + (k & 3u)) << log2H) + 4 * bx;
+        w |= (uint64_t)((lin[bit >> 3] >> (bit & 4u)) & 0xfu) << (4 * k);
+    }
+    blocks_all[(uint64_t)blockIdx.y * n_blocks + b] = w;
+}
+
+// exit parameter of the SZ^3-cell block around probe p, `eps` inside the exit face (see k_survivor_march)
+template <int SZ>
+SSD_DEV float rq_block_exit(const FastMarch& m, const RayGeom& r, const FastProbe& p, float sgx, float sgy, float sgz, float ex, float ey, float ez, float t) {
+    const float tx = (ssd_fma(ssd_fma((float)(p.nx & ~(SZ - 1)) + (float)SZ * sgx, m.two_rH, -1.0f), m.mip_bound, -p.x) - ex) * r.rdx;
+    const float ty = (ssd_fma(ssd_fma((float)(p.ny & ~(SZ - 1)) + (float)SZ * sgy, m.two_rH, -1.0f), m.mip_bound, -p.y) - ey) * r.rdy;
+    const float tz = (ssd_fma(ssd_fma((float)(p.nz & ~(SZ - 1)) + (float)SZ * sgz, m.two_rH, -1.0f), m.mip_bound, -p.z) - ez) * r.rdz;
+    return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+}
+
+// ------------------------------------------------------------------------------------------------
 // Conservative coarse occupancy: one bit per block of B^3 cells (B = 2^RQ_COARSE_LOG2B), set if ANY cell of the block dilated by B/2 cells
 // is occupied.  k_ray_cull walks it with points RQ_COARSE_STEP = B - 0.1 cells apart: every point q of the segment is then within
 // (B - 0.1)/2 cells, per axis, of a test point p, so the cell of q -- and the neighbour the reference's fp32 rounding may pick instead --
@@ -398,6 +426,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
 // LDS-latency probes.)
 template <bool DTG0>
 __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc src, const uint8_t* __restrict__ lin_bits,
+                                                            const uint64_t* __restrict__ blocks64 /* k_bitfield_blocks64 or null */,
                                                             const uint2* __restrict__ survivors, float* __restrict__ image,
                                                             float* __restrict__ depth, float* __restrict__ weights_sum,
                                                             int32_t* __restrict__ sample_counts, uint2* __restrict__ queue,
@@ -410,6 +439,9 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
     if (threadIdx.x == 0) { list_count = 0; short_count = 0; }
     __syncthreads();
     lin_bits += (uint64_t)scene * c.bitfield_stride;
+    const uint32_t lb = c.m.log2H - 2;
+    if (blocks64) blocks64 += (uint64_t)scene * (c.bitfield_stride >> 3);
+    const float blk_eps = c.m.two_rH * c.m.mip_bound * (1.0f / 4096.0f);      // 2^-12 cell: >> the fp32 error of a position (<= 3e-5 cell up to H = 512)
     if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
     const bool packing = c.N <= SSD_RAY_ID_MASK + 1u;
 #pragma unroll 1
@@ -442,10 +474,42 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
             } else {
                 while (t < head) t += rq_dt<DTG0>(c.m, t);
             }
-            while (t < far_) {
-                const FastProbe p = rq_probe<DTG0>(c.m, lin_bits, r, t);
-                if (p.occ) { hit = true; break; }
-                t = rq_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
+            if (blocks64) {
+                // BLOCK SKIP (r03).  The march's parameters t_k do not depend on the cells (see the head skip), and the first sample is the first t_k whose
+                // cell is occupied.  If the 4^3-cell block (or its 2^3 sub-block) around the current position holds no occupied cell, every t_k whose
+                // position is still inside it -- positions are monotone per axis in t, and `blk_eps` inside the exit face covers their rounding -- tests
+                // an empty cell: those parameters are run through without probes (the rays that graze the object, 2/3 of the survivors, walk ~30 cells
+                // of its hull).  One 8-byte load per probe serves all three levels.
+                const float ex = blk_eps * ssd_sign1(r.dx), ey = blk_eps * ssd_sign1(r.dy), ez = blk_eps * ssd_sign1(r.dz);
+                while (t < far_) {
+                    FastProbe p;
+                    p.x = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dx, r.ox), -c.m.bound, c.m.bound);
+                    p.y = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dy, r.oy), -c.m.bound, c.m.bound);
+                    p.z = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dz, r.oz), -c.m.bound, c.m.bound);
+                    p.nx = rq_cell(c.m, ssd_fma(p.x, c.m.rb, 1.0f)); p.ny = rq_cell(c.m, ssd_fma(p.y, c.m.rb, 1.0f)); p.nz = rq_cell(c.m, ssd_fma(p.z, c.m.rb, 1.0f));
+                    const uint32_t bi = (((((uint32_t)p.nz >> 2) << lb) + ((uint32_t)p.ny >> 2)) << lb) + ((uint32_t)p.nx >> 2);
+                    const uint64_t w = blocks64[bi];
+                    float tt;
+                    if (w == 0) {
+                        tt = rq_block_exit<4>(c.m, r, p, sgx, sgy, sgz, ex, ey, ez, t);
+                    } else {
+                        const uint64_t sub = w >> ((((uint32_t)p.nz & 2u) << 4) | (((uint32_t)p.ny & 2u) << 2) | ((uint32_t)p.nx & 2u));
+                        if ((sub & 0x00330033ull) == 0) {
+                            tt = rq_block_exit<2>(c.m, r, p, sgx, sgy, sgz, ex, ey, ez, t);
+                        } else {
+                            if ((sub >> ((((uint32_t)p.nz & 1u) << 4) | (((uint32_t)p.ny & 1u) << 2) | ((uint32_t)p.nx & 1u))) & 1ull) { hit = true; break; }
+                            t = rq_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
+                            continue;
+                        }
+                    }
+                    do { t += rq_dt<DTG0>(c.m, t); } while (t < tt);
+                }
+            } else {
+                while (t < far_) {
+                    const FastProbe p = rq_probe<DTG0>(c.m, lin_bits, r, t);
+                    if (p.occ) { hit = true; break; }
+                    t = rq_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
+                }
             }
             if (!hit) {  // the ray left the object's neighbourhood without a sample: background only
                 image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
@@ -705,6 +769,12 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     const bool coarse_ok = hc >= 8 && (hc * hc * hc / 8) <= RQ_COARSE_MAX_BYTES && (hc * hc * hc / 8) % 16 == 0 && bound <= 1.0f && getenv("SSDNERF_NO_COARSE") == nullptr;
     if (coarse_ok)
         hipLaunchKernelGGL(k_bitfield_coarsen, dim3(ssd_blocks(hc * hc * hc * 8, RQ_TPB), S), dim3(RQ_TPB), 0, s, w.lin_bits, grid_size, c.m.log2H, c.bitfield_stride, w.coarse);
+    const uint64_t* blocks64 = nullptr;
+    if (grid_size >= 16 && getenv("SSDNERF_NO_COARSE") == nullptr) {
+        const uint32_t hb = grid_size >> 2;
+        hipLaunchKernelGGL(k_bitfield_blocks64, dim3(ssd_blocks(hb * hb * hb, RQ_TPB), S), dim3(RQ_TPB), 0, s, w.lin_bits, grid_size, c.m.log2H, c.bitfield_stride, w.blocks64);
+        blocks64 = w.blocks64;
+    }
     CullGrid cg;
     cg.views_cap = N / 64 + 1;
     cg.zr_cap = N / 256 + 1;
@@ -717,10 +787,10 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     hipLaunchKernelGGL(k_ray_cull, grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
                        w.survivors, w.counters, view_cull ? w.view_masks : (const uint32_t*)nullptr, w.view_zr);
     if (dt_gammas == nullptr && dt_gamma == 0.0f)
-        hipLaunchKernelGGL(k_survivor_march<true>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum,
+        hipLaunchKernelGGL(k_survivor_march<true>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, blocks64, w.survivors, image, depth, weights_sum,
                            sample_counts, w.queue, w.counters);
     else
-        hipLaunchKernelGGL(k_survivor_march<false>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, w.survivors, image, depth, weights_sum,
+        hipLaunchKernelGGL(k_survivor_march<false>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, blocks64, w.survivors, image, depth, weights_sum,
                            sample_counts, w.queue, w.counters);
     hipLaunchKernelGGL(k_queue_close, dim3(ssd_blocks(N / 2 + 1, RQ_TPB), S), dim3(RQ_TPB), 0, s, S, N, (uint2*)w.queue, w.counters);   // moves <= N/2 entries
     hipLaunchKernelGGL(k_queue_total, dim3(ssd_blocks(S, 64)), dim3(64), 0, s, S, w.counters);
