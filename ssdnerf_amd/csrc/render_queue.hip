@@ -48,7 +48,6 @@ struct QueueCfg {
     uint64_t plane_stride;      // elements per scene
     uint32_t bitfield_stride;   // bytes per scene
     const float* dt_gammas;     // [S] on device or null
-    uint32_t dbg;
     uint8_t* image_u8;          // [S][N][3] or null: the quantised image, written next to the float one (saves the separate quantisation pass)
 };
 
@@ -363,7 +362,6 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
                 alive = t < far_;
                 t_start = t;
             }
-            if (c.dbg & 16u) alive = false;
             if (use_coarse && alive) {
                 const float step_t = ssd_coarse_step_t(r, c.m.two_rH * c.m.mip_bound);          // RQ_COARSE_STEP cells of world length, in t
                 // The test points run in COARSE-BLOCK coordinates, advanced by one add per axis: q(u) = ((o + u d) rb + 1) half_H / B.  The
@@ -411,7 +409,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
                 // ~10 cells in front of the object instead of ~45 cells away at the box (k_survivor_march 0.68 -> 0.41 ms, profiles/r03).
                 if (alive && j_first >= 2) t_start = fminf(ssd_fma((float)j_first - 1.5f, step_t, t), far_);
             }
-            if (!alive && !(c.dbg & 32u)) {  // misses the box, or nothing within a cell of the ray: background only
+            if (!alive) {  // misses the box, or nothing within a cell of the ray: background only
                 image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
                 if (c.image_u8) { const uint8_t q8 = ssd_quant_u8(c.bg); c.image_u8[3 * gi + 0] = q8; c.image_u8[3 * gi + 1] = q8; c.image_u8[3 * gi + 2] = q8; }
                 depth[gi] = 0.f; weights_sum[gi] = 0.f;
@@ -464,9 +462,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
             far_b = far_;
             const float sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f), sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f), sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
             t = near_;
-            float head = __uint_as_float(sv.y);
-            if (c.dbg & 2u) head = near_;
-            if (c.dbg & 1u) far_ = near_;                        // k_ray_cull's head skip: nothing the march could test is occupied before it
+            const float head = __uint_as_float(sv.y);                        // k_ray_cull's head skip: nothing the march could test is occupied before it
             if (DTG0) {                                                      // the march's own parameter sequence, without the probes: four additions per test
                 const float dt = c.m.dt_min;
                 while (t < head) {
@@ -515,7 +511,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
                     t = rq_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
                 }
             }
-            if (!hit && !(c.dbg & 4u)) {  // the ray left the object's neighbourhood without a sample: background only
+            if (!hit) {  // the ray left the object's neighbourhood without a sample: background only
                 image[3 * gi + 0] = c.bg; image[3 * gi + 1] = c.bg; image[3 * gi + 2] = c.bg;
                 if (c.image_u8) { const uint8_t q8 = ssd_quant_u8(c.bg); c.image_u8[3 * gi + 0] = q8; c.image_u8[3 * gi + 1] = q8; c.image_u8[3 * gi + 2] = q8; }
                 depth[gi] = 0.f; weights_sum[gi] = 0.f;
@@ -719,7 +715,6 @@ static int rq_make_cfg(QueueCfg& c, uint32_t Hp, uint32_t Wp, uint32_t grid_size
     SSD_REQUIRE(rq_is_pow2(grid_size) && grid_size >= 8 && grid_size <= 512, "render (queued): grid_size must be a power of two in [8, 512]");
     const MarchCfg mc = ssd_make_march_cfg(bound, dt_gamma, max_steps, 1, grid_size, nullptr);
     c.m.bound = bound; c.m.dt_gamma = dt_gamma; c.m.dt_min = mc.dt_min; c.m.dt_max = mc.dt_max;
-    c.dbg = 0;
     c.m.mip_bound = fminf(1.0f, bound);
     c.m.rb = 1.0f / c.m.mip_bound;
     c.m.half_H = 0.5f * (float)grid_size;
@@ -766,7 +761,6 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     int rc = rq_make_cfg(c, 1, 1, grid_size, S, N, bound, min_near, dt_gamma, dt_gammas, max_steps, 0.f, bg_color, 0.f);
     if (rc) return rc;
     c.image_u8 = image_u8;
-    c.dbg = getenv("SSDNERF_RQ_DBG") ? (uint32_t)atoi(getenv("SSDNERF_RQ_DBG")) : 0u;
     hipStream_t s = (hipStream_t)stream;
     const RenderWs w = ssd_render_ws(workspace, S, N, grid_size);
     if (hipMemsetAsync(w.counters, 0, w.counter_bytes, s) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "render_first_hit: memset failed");   // hit counts, slice tickets, survivor counts, boundary tests
