@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_view_masks(FastMarch m, RaySrc src, 
     }
 }
 
-struct CullGrid { uint32_t group; uint32_t views_cap; uint32_t zr_cap; };   // rays per blockIdx.y group: hw (one view per y, cameras) or N (arrays, gridDim.y == 1)
+struct CullGrid { uint32_t group; uint32_t views_cap; uint32_t zr_cap; int32_t tile_w_shift, tile_h_shift; };   // shifts: log2 of the tile size in pixels, or -1   // rays per blockIdx.y group: hw (one view per y, cameras) or N (arrays, gridDim.y == 1)
 #ifndef RQ_LONG_STEPS
 #define RQ_LONG_STEPS 48                       // a hitting ray whose remaining segment (first hit .. tail bound) is longer than this many minimum steps goes to the FRONT of the queue
 #endif
@@ -300,6 +300,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
     if (view_cull) tile_zr[threadIdx.x] = view_zr[((uint64_t)scene * cg.zr_cap + blockIdx.y) * 256 + threadIdx.x];
     const uint32_t tile_w = view_cull ? (src.w + 15u) / 16u : 1u, tile_h = view_cull ? (src.hw / src.w + 15u) / 16u : 1u;
     const bool tiled = view_cull && (src.w & 7u) == 0 && ((src.hw / src.w) & 7u) == 0;
+    const bool pow2 = src.w_shift >= 3 && cg.tile_w_shift >= 0 && cg.tile_h_shift >= 0;          // power-of-two view and tile sizes: shifts instead of divisions
     // this scene's coarse bitfield -> LDS ((H/4)^3 bits; 512 B for H = 64)
     __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
     __shared__ uint2 list[RQ_CHUNKS * RQ_TPB];
@@ -316,9 +317,12 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
 #pragma unroll 1
     for (uint32_t chunk = 0; chunk < RQ_CHUNKS; ++chunk) {
         uint32_t in_group = (blockIdx.x * RQ_CHUNKS + chunk) * RQ_TPB + threadIdx.x;
+        uint32_t px = 0, py = 0;
         if (tiled && in_group < cg.group) {      // a wave takes an 8 x 8 pixel block of the view instead of 64 pixels of a row: whole waves fall in unmarked tiles
             const uint32_t blk = in_group >> 6, l = in_group & 63u, bpr = src.w >> 3;
-            in_group = ((blk / bpr) * 8u + (l >> 3)) * src.w + (blk % bpr) * 8u + (l & 7u);
+            const uint32_t by = pow2 ? blk >> (src.w_shift - 3) : blk / bpr, bx = blk - by * bpr;       // (runtime divisions were ~100 of the ~190 instructions of a ray here)
+            py = by * 8u + (l >> 3); px = bx * 8u + (l & 7u);
+            in_group = py * src.w + px;
         }
         const uint32_t n = blockIdx.y * cg.group + in_group;
         const uint64_t gi = (uint64_t)scene * c.N + n;
@@ -331,10 +335,13 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
             float t_zlo = 0.0f, t_zhi = 3.0e38f;                             // the tile's depth range as ray parameters (view cull only)
             if (src.c2w != nullptr) {       // the view is uniform over the block (blockIdx.y): pose and intrinsics are scalar loads
                 const uint64_t cam = (uint64_t)scene * src.V + blockIdx.y;
-                const uint32_t py = src.w_shift >= 0 ? in_group >> src.w_shift : in_group / src.w;
-                const uint32_t px = in_group - py * src.w;
+                if (!tiled) {
+                    py = src.w_shift >= 0 ? in_group >> src.w_shift : in_group / src.w;
+                    px = in_group - py * src.w;
+                }
+                uint32_t tile = 0;
                 if (view_cull) {
-                    const uint32_t tile = (py / tile_h) * 16u + px / tile_w;
+                    tile = pow2 ? ((py >> cg.tile_h_shift) << 4) + (px >> cg.tile_w_shift) : (py / tile_h) * 16u + px / tile_w;
                     outside = !((tile_mask[tile >> 5] >> (tile & 31u)) & 1u);
                 }
                 if (!outside) {
@@ -342,7 +349,6 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
                     ssd_cam_ray(src.c2w + cam * 16, src.intr + cam * 4, px, py, o, d);
                     r = ssd_ray_geom(o[0], o[1], o[2], d[0], d[1], d[2]);
                     if (view_cull) {
-                        const uint32_t tile = (py / tile_h) * 16u + px / tile_w;
                         const uint32_t zr = tile_zr[tile];
                         const float* M = src.c2w + cam * 16;
                         const float ez_d = ssd_fma(M[2], d[0], ssd_fma(M[6], d[1], M[10] * d[2]));     // z_c of the point o + t d is t * ez_d (k_view_masks' own formula)
@@ -778,6 +784,12 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     CullGrid cg;
     cg.views_cap = N / 64 + 1;
     cg.zr_cap = N / 256 + 1;
+    cg.tile_w_shift = cg.tile_h_shift = -1;
+    if (src.c2w != nullptr && src.w > 0) {
+        const uint32_t tw = (src.w + 15u) / 16u, th = (src.hw / src.w + 15u) / 16u;
+        if (tw && !(tw & (tw - 1))) cg.tile_w_shift = __builtin_ctz(tw);
+        if (th && !(th & (th - 1))) cg.tile_h_shift = __builtin_ctz(th);
+    }
     dim3 grid;
     if (src.c2w != nullptr) { cg.group = src.hw; grid = dim3(ssd_blocks(src.hw, RQ_TPB * RQ_CHUNKS), src.V, S); }      // one view per blockIdx.y: camera loads are scalar
     else { cg.group = N; grid = dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), 1, S); }
