@@ -430,14 +430,17 @@ template <typename T> SSD_DEV float ssd_grid_max();
 template <> SSD_DEV float ssd_grid_max<float>() { return 3.402823466e+38f; }
 template <> SSD_DEV float ssd_grid_max<__half>() { return 65504.0f; }
 
+static constexpr uint32_t DU_CHUNKS = 8;          // 256-cell chunks per block of k_density_update
 template <typename PT, typename GT>
 __global__ void __launch_bounds__(DEC_TPB) k_density_update(const PT* __restrict__ planes, PlaneGeom g, const float* __restrict__ P, uint32_t H,
                                                              float centre, float cell, float half_cell, const float* __restrict__ jitter,
                                                              float decay, GT* __restrict__ grid, float inv_count, float* __restrict__ mean_out) {
     const uint32_t H3 = H * H * H;
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;  // cell in x-major order (custom_meshgrid ij)
     const uint32_t s = blockIdx.y;
     float contrib = 0.0f;
+#pragma unroll 1
+    for (uint32_t chunk = 0; chunk < DU_CHUNKS; ++chunk) {
+    const uint32_t n = (blockIdx.x * DU_CHUNKS + chunk) * blockDim.x + threadIdx.x;  // cell in x-major order (custom_meshgrid ij)
     if (n < H3) {
         const uint32_t cz = n % H, cy = (n / H) % H, cx = n / (H * H);
         float xyz[3];
@@ -463,13 +466,23 @@ __global__ void __launch_bounds__(DEC_TPB) k_density_update(const PT* __restrict
             out = fmaxf(decayed, fresh);
             *cellp = ssd_grid_round<GT>(out);
         }
-        contrib = fmaxf(out, 0.0f);
+        contrib += fmaxf(out, 0.0f);
+    }
     }
     if (mean_out) {
-        // wave reduce, then one atomic per wave
+        // ONE atomic per block of DU_CHUNKS x 256 cells (r03).  Every wave used to add its sum to the one address: 32 768 same-address device-scope
+        // atomics per refresh of 8 scenes, resolved one after the other at ~10 ns each -- 330 of the kernel's 434 us (profiles/r03/s_pmc_final.txt:
+        // 1 883 VALU instructions per wave in 154 k cycles).
+        __shared__ float wave_sum[DEC_TPB / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(mean_out, contrib * inv_count);
+        if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = contrib;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.0f;
+            for (uint32_t w = 0; w < DEC_TPB / 64; ++w) t += wave_sum[w];
+            atomicAdd(mean_out, t * inv_count);
+        }
     }
 }
 
@@ -486,7 +499,7 @@ extern "C" int ssdnerf_density_grid_update(const void* planes, int planes_dtype,
     const float cell = (float)(2.0 * (double)bound / (double)grid_size);
     const float half_cell = (float)((double)bound / (double)grid_size);
     const float inv_count = (float)(1.0 / ((double)S * (double)H3));
-    dim3 gr(ssd_blocks(H3, DEC_TPB), S), b(DEC_TPB);
+    dim3 gr(ssd_blocks(H3, DEC_TPB * DU_CHUNKS), S), b(DEC_TPB);
     hipStream_t s = (hipStream_t)stream;
 #define SSD_LAUNCH_DU(PT, GT) hipLaunchKernelGGL((k_density_update<PT, GT>), gr, b, 0, s, (const PT*)planes, g, mlp_params, grid_size, centre, cell, \
                                                  half_cell, jitter, decay, (GT*)density_grid, inv_count, mean_out)
