@@ -138,6 +138,28 @@ def test_reference_configs_load_and_build_unchanged():
     assert t.code_diff_pr(x).shape == (1, 6, 128, 384) and t.code_diff_pr_inv(t.code_diff_pr(x)).shape == x.shape
 
 
+def test_render_queue_workspace_size_host_side():
+    """``ssdnerf_render_queue_workspace`` (common.h: ssd_render_ws) is host arithmetic: every region of the two-stage renderer's scratch is in it
+    -- counters, the bitfield in linear and in block-major order, coarse bits, 8-byte survivor and hit-queue entries, per-view tile masks and
+    tile depth ranges -- regions are 256-byte aligned, and the size grows with the scene and ray counts."""
+    import ctypes
+    from ssdnerf_amd import _cabi as C
+    lib = C.lib()
+    u32 = ctypes.c_uint32
+
+    def size(S, N, H):
+        return lib.ssdnerf_render_queue_workspace(u32(S), u32(N), u32(H))
+    S, N, H = 8, 251 * 128 * 128, 64
+    got = size(S, N, H)
+    lists = 2 * S * N * 8                                   # survivors + hit queue
+    bitfields = 2 * S * H ** 3 // 8                         # linear + block-major (one u64 per 4^3 cells)
+    tiles = S * (N // 64 + 1) * 32 + S * (N // 256 + 1) * 1024
+    assert got % 256 == 0
+    assert lists + bitfields + tiles <= got <= lists + bitfields + tiles + S * (H // 2) ** 3 // 8 + 5 * S * 128 + 16 * 256
+    assert size(S + 1, N, H) > got and size(S, N + 4096, H) > got and size(S, N, 128) > got
+    assert size(1, 1, 8) >= 256 and size(1, 1, 8) % 256 == 0
+
+
 def test_conv_plans_and_operand_split_host_side():
     """Host-only pieces of the UNet convolution path: the decomposition the C ABI reports for a layer, and the bf16 x 2 weight split."""
     import ctypes
