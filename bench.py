@@ -228,7 +228,8 @@ def main():
     # dominant kernel = k_shade_mfma (gather + MLP + composite).  Its algorithmic bytes: 288 B per sample it shades plus,
     # per hitting ray, 8 B queue entry + 20 B outputs (+ 24 B ray when ray arrays are read).
     n_hit = stats["n_hit"]
-    algo_bytes = n_samples * BYTES_PER_SAMPLE + n_hit * bytes_per_hit_ray
+    bytes_per_sample = BYTES_PER_SAMPLE if args.plane_dtype == "float32" else BYTES_PER_SAMPLE // 2     # 288 B per sample in fp32, 144 B with fp16 planes
+    algo_bytes = n_samples * bytes_per_sample + n_hit * bytes_per_hit_ray
     achieved = algo_bytes / (shade_ms * 1e-3) / 1e9
     first_hit_bytes = n_rays * (24 if args.ray_arrays else 0) + (n_rays - n_hit) * 20 + n_hit * 8
 
@@ -248,7 +249,7 @@ def main():
         "dtype": "f32" if args.plane_dtype == "float32" else "f32 math / f16 planes", "data": "synthetic",
         "config": {"workload": "ssdnerf_cars_uncond render of cached triplanes (BASELINE.json configs[1])", "scenes_per_gpu": ns,
                    "views_per_scene": nv, "image": f"{hw}x{hw}", "rays_per_step_per_gpu": n_rays, "grid_size": 64, "max_steps": 256,
-                   "T_thresh": 1e-4, "dt_gamma": 0.0, "scene_variant": args.variant, "parallelism": f"scene-parallel x{world}" + (" (TEST MODE: all ranks share cuda:0 over gloo)" if share_device else ""),
+                   "T_thresh": 1e-4, "dt_gamma": 0.0, "scene_variant": args.variant, "plane_dtype": args.plane_dtype, "parallelism": f"scene-parallel x{world}" + (" (TEST MODE: all ranks share cuda:0 over gloo)" if share_device else ""),
                    "ray_source": "(S,N,3) ray arrays" if args.ray_arrays else "cameras (rays generated in the kernels)",
                    "mlp_arithmetic": f"fp32 operands split into bf16 terms on the matrix cores: layer 1 all six products (2^-24 class), direction term {dec.shade_dir_products} of 6 "
                                      "(2^-16 class when 3; image differs by <= 1.6e-6 from the six-product form; SSDNERF_SHADE_DIR_PRODUCTS=6 for all)",
@@ -258,7 +259,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_shade_mfma", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                      "launch_ms": shade_ms, "launches_per_step": 1,
-                     "note": f"algorithmic = 288 B/sample + {bytes_per_hit_ray} B per hitting ray; planes (1.5 MiB/scene) are L2-resident, so real HBM "
+                     "note": f"algorithmic = {bytes_per_sample} B/sample + {bytes_per_hit_ray} B per hitting ray; planes (1.5 MiB/scene) are L2-resident, so real HBM "
                              "traffic is far below this (PMC numbers in DESIGN.md / profiles/)",
                      "other_kernels": {"first_hit (k_ray_cull + k_survivor_march)": {
                          "launch_ms": first_hit_ms, "algorithmic_bytes_per_launch": first_hit_bytes,
