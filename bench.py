@@ -49,8 +49,10 @@ UNET_FLOP_PER_SCENE = 2.18e11  # cars UNet forward
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: 10 untimed + 20 timed steps (0.2 s).  With 2 + 5 the timed region still sits on the clock ramp of a cold device: 5.94-6.07 ms per step
+    # against 5.79-5.87 ms with 10 + 20 and 5.79 ms with 20 + 50 in one session on one box (profiles/r03/z_warmup_ab.txt)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scenes", type=int, default=8, help="scenes per GPU per batch (samples_per_gpu in the cars config)")
     ap.add_argument("--views", type=int, default=251, help="views per scene (cars test set: 251)")
     ap.add_argument("--size", type=int, default=128)
