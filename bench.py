@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--variant", default="object", choices=["object", "uniform"])
     ap.add_argument("--plane-dtype", default="float32", choices=["float32", "float16"])
     ap.add_argument("--ray-arrays", action="store_true", help="feed materialised (S,N,3) ray arrays instead of cameras")
+    ap.add_argument("--packed-loop", action="store_true", help="time TriPlaneDecoder.render_packed(check_overflow=False) instead of nerf.render (the r01-r03 "
+                    "timed region: no overflow-flag read per batch); A/B only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip gpu_baseline / ddim / uniform_variant (profiling runs)")
     ap.add_argument("--cpu-views", type=int, default=251, help="views of scene 0 rendered by the CPU oracle (251 = the whole scene, ~10 s on 32 host threads)")
@@ -151,14 +153,22 @@ def main():
         return dec.render_packed(planes_, None, None, bits_, 64, [0.0] * ns, 1e-4, bg_color=1.0, check_overflow=False, cams=(poses, intr, hw, hw), want_u8=True,
                                  **kw)
 
+    def render_product(planes_, bits_, code_):
+        """the timed step since r04: ``nerf.render`` = ``BaseNeRF.render`` on the cached (packed) planes -- the same two launches as
+        ``render_packed`` plus what the product path does around them: the ONE overflow-flag read per batch (a host sync) that decides whether the batch
+        has to be redone through the stepwise path, and the uint8 views"""
+        image, depth, image_u8 = nerf.render(dec, code_, bits_, hw, hw, intr, poses, grid_size=64, bg_color=1.0, cfg={}, planes=planes_,
+                                              rays=rays, return_u8=True)
+        return {"image": image.reshape(ns, nv * hw * hw, 3), "depth": depth.reshape(ns, nv * hw * hw), "image_u8": image_u8}
+
     # N > 1: every rank ends up with every rank's quantised views (RCCL all-gather over xGMI).  The collective of step i runs on RCCL's
     # stream while step i+1 renders (two landing buffers); the compute stream only waits for it before issuing the next collective.
     gathered = [torch.empty(world * ns, nv, hw, hw, 3, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
     pending = {"work": None, "i": 0, "keep": None}
 
-    def step(planes_, bits_, events=None):
+    def step(planes_, bits_, events=None, code_=None):
         dec.stage_events = [] if events is not None else None      # HIP events on the launch stream: [before A, between A and B, after B]
-        out = render(planes_, bits_)
+        out = render(planes_, bits_) if args.packed_loop or code_ is None else render_product(planes_, bits_, code_)
         if events is not None:
             events.append(dec.stage_events)
             dec.stage_events = None
@@ -187,10 +197,10 @@ def main():
         del counts
         return res
 
-    def timed(planes_, bits_, warmup, steps):
+    def timed(planes_, bits_, warmup, steps, code_=None):
         events = []
         for _ in range(warmup):
-            step(planes_, bits_)
+            step(planes_, bits_, None, code_)
         drain()
         torch.cuda.synchronize()
         if world > 1:
@@ -198,7 +208,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = step(planes_, bits_, events)
+            out = step(planes_, bits_, events, code_)
         drain()                                              # the last step's collective is inside the timed region
         torch.cuda.synchronize()
         if world > 1:
@@ -213,7 +223,8 @@ def main():
 
     stats = stat_pass(planes, bits)
     log(f"stat pass done: {stats['n_samples']} samples, overflow {stats['overflow']}, boundary tests {stats['boundary']}")
-    elapsed, kernel_events, out = timed(planes, bits, args.warmup, args.steps)
+    code_dev = code_cpu.to(dev)                              # (only read if a batch must be redone through the stepwise path)
+    elapsed, kernel_events, out = timed(planes, bits, args.warmup, args.steps, code_dev)
     n_samples = stats["n_samples"]
     if world > 1:
         tot = torch.tensor([n_samples], dtype=torch.float64, device=dev)
@@ -235,13 +246,20 @@ def main():
     achieved = algo_bytes / (shade_ms * 1e-3) / 1e9
     first_hit_bytes = n_rays * (24 if args.ray_arrays else 0) + (n_rays - n_hit) * 20 + n_hit * 8
 
-    traffic = None          # HBM bytes per launch from the PMC counters: measured offline (separate rocprofv3 passes), valid for the default workload only
+    # HBM bytes per launch from the PMC counters: they cannot be read from inside the process that is being timed (rocprofv3 wraps the
+    # whole command and a counter pass serialises every launch), so `traffic` is the figure of the most recent tools/prof_render.sh session
+    # on THIS workload and kernel form; `traffic_source` says which session (file, the commit it profiled, the rocprofv3 launch average of the
+    # same session) so that the number can be traced to profiles/
+    traffic, traffic_source = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         w = tj["workload"]
         if (w["scenes"], w["views"], w["size"], w["variant"], w["plane_dtype"]) == (ns, nv, hw, args.variant, args.plane_dtype) and tj["kernel"].startswith("k_shade_mfma") \
-                and w.get("ray_source", "arrays") == ("arrays" if args.ray_arrays else "cameras"):
+                and w.get("ray_source", "arrays") == ("arrays" if args.ray_arrays else "cameras") \
+                and int(tj.get("dir_products", 3)) == int(dec.shade_dir_products):
             traffic = tj["hbm_bytes_per_launch"]
+            traffic_source = {k: tj.get(k) for k in ("source", "profiled_commit", "kernel", "rocprof_launch_ms_avg_timed_steps", "rocprof_launches_averaged",
+                                                     "hip_event_launch_ms_same_run", "method")}
     except Exception:
         pass
     result = {
@@ -254,12 +272,15 @@ def main():
                    "T_thresh": 1e-4, "dt_gamma": 0.0, "scene_variant": args.variant, "plane_dtype": args.plane_dtype, "parallelism": f"scene-parallel x{world}" + (" (TEST MODE: all ranks share cuda:0 over gloo)" if share_device else ""),
                    "ray_source": "(S,N,3) ray arrays" if args.ray_arrays else "cameras (rays generated in the kernels)",
                    "mlp_arithmetic": f"fp32 operands split into bf16 terms on the matrix cores: layer 1 all six products (2^-24 class), direction term {dec.shade_dir_products} of 6 "
-                                     "(2^-16 class when 3; image differs by <= 1.6e-6 from the six-product form; SSDNERF_SHADE_DIR_PRODUCTS=6 for all)",
+                                     "(6 = the default since r04, fp32 class throughout; 3 = opt-in SSDNERF_SHADE_DIR_PRODUCTS=3, 2^-16 class on that additive term: "
+                                     "see dir3_variant)",
+                   "timed_call": "TriPlaneDecoder.render_packed(check_overflow=False) [--packed-loop]" if args.packed_loop else
+                                 "nerf.render (BaseNeRF.render on cached planes: two launches + the overflow-flag read per batch + uint8 views)",
                    "collective": "all_gather(uint8 views), overlapped with the next step's render" if world > 1 else "none"},
         "views_per_s": rays_per_s / (hw * hw), "samples_per_s": n_samples_all / (elapsed / args.steps),
         "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": stats["overflow"],
         "roofline": {"bound": "hbm", "kernel": "k_shade_mfma", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,
                      "launch_ms": shade_ms, "launches_per_step": 1,
                      "note": f"algorithmic = {bytes_per_sample} B/sample + {bytes_per_hit_ray} B per hitting ray; planes (1.5 MiB/scene) are L2-resident, so real HBM "
                              "traffic is far below this (PMC numbers in DESIGN.md / profiles/)",
@@ -283,20 +304,37 @@ def main():
     del out
     if extras and args.variant == "object":
         try:
-            _, planes_u, bits_u = build_scenes("uniform")
+            code_u, planes_u, bits_u = build_scenes("uniform")
             st_u = stat_pass(planes_u, bits_u)
-            el_u, ev_u, _ = timed(planes_u, bits_u, 1, 3)
+            el_u, ev_u, _ = timed(planes_u, bits_u, 1, 3, code_u.to(dev))
             result["uniform_variant"] = {"ms_per_step": el_u / 3 * 1e3, "rays_per_s": n_rays / (el_u / 3), "samples_per_s": st_u["n_samples"] / (el_u / 3),
                                          "mean_samples_per_ray": st_u["n_samples"] / n_rays,
                                          "shade_launch_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in ev_u])),
                                          "shade_algorithmic_GBs": (st_u["n_samples"] * BYTES_PER_SAMPLE + st_u["n_hit"] * bytes_per_hit_ray)
                                          / (float(np.mean([e[1].elapsed_time(e[2]) for e in ev_u])) * 1e-3) / 1e9,
                                          "boundary_tests": st_u["boundary"], "rays_at_step_cap": st_u["overflow"]}
-            del planes_u, bits_u
+            del planes_u, bits_u, code_u
             log("uniform variant done")
         except Exception as e:
             result["uniform_variant"] = {"error": repr(e)}
-    del planes
+    if extras and args.variant == "object":
+        # the opt-in precision class of the direction term beside the headline (r03 verdict weak #1: the default forms all six split products)
+        try:
+            other = 3 if dec.shade_dir_products == 6 else 6
+            keep = dec.shade_dir_products
+            dec.shade_dir_products = other
+            try:
+                el_d, ev_d, _ = timed(planes, bits, 3, 10, code_dev)
+            finally:
+                dec.shade_dir_products = keep
+            ms_d = float(np.mean([e[1].elapsed_time(e[2]) for e in ev_d]))
+            result[f"dir{other}_variant"] = {"direction_term_products": other, "ms_per_step": el_d / 10 * 1e3, "shade_launch_ms": ms_d,
+                                              "roofline_frac": algo_bytes / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "note": "same workload, 10 timed steps; sample counts, depth and opacity are bit-identical between the two settings"}
+            log(f"dir{other} variant done: shade {ms_d:.3f} ms")
+        except Exception as e:
+            result["dir_variant"] = {"error": repr(e)}
+    del planes, code_dev
     torch.cuda.empty_cache()
     model = None
     if not args.no_extras:                                   # the sampling legs build the config's whole model (every rank at N > 1)

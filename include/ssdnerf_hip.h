@@ -211,10 +211,11 @@ int ssdnerf_render_shade_queue(const void* planes, int planes_dtype, uint32_t Hp
  * three bf16 terms) and wave-local LDS pools that turn long empty-space searches into full-width march passes
  * (csrc/shade_mfma.hip).  Same arguments and workspace as ssdnerf_render_shade_queue; integer outputs identical, floats within
  * fp32 rounding.
- * Precision of the direction term (the additive Wd.SH(d) correction of the colour pre-activation, triplane_decoder.py:170-173): by default three
- * of its six split products are formed (hi*hi, hi*mid, mid*hi: 16 significand bits per factor; the image moves by <= 1.6e-6 on the bench scenes,
- * the kernel is 5 % faster); OR SSDNERF_SHADE_FULL_DIR_PRODUCTS into `planes_dtype` for all six (the fp32 class of the other layers).  Densities,
- * sample counts and depth do not depend on it. */
+ * Precision of the direction term (the additive Wd.SH(d) correction of the colour pre-activation, triplane_decoder.py:170-173): OR
+ * SSDNERF_SHADE_FULL_DIR_PRODUCTS into `planes_dtype` for all six split products (the fp32 class of the other layers -- what the Python host
+ * layer passes by default since r04); without the flag three of the six are formed (hi*hi, hi*mid, mid*hi: 16 significand bits per factor; the
+ * image moves by <= 1.6e-6 on the bench scenes -- an error that scales with |Wd.SH(d)| |Wc|, so it is an opt-in, TriPlaneDecoder.shade_dir_products
+ * = 3 -- and the kernel is 5 % faster).  Densities, sample counts and depth do not depend on it. */
 #define SSDNERF_SHADE_FULL_DIR_PRODUCTS 0x100
 int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dtype, uint32_t Hp, uint32_t Wp, const float* mlp_params,
                                     uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S, uint32_t N,

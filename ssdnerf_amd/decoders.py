@@ -367,12 +367,13 @@ class TriPlaneDecoder(VolumeRenderer):
             self._packed_key = key
         return self._packed
 
-    #: split products of the direction term formed by the MFMA shading kernel: 3 (default: 16 significand bits per factor, <= 1.6e-6 on the image,
-    #: 5 % faster) or 6 (all of them, the fp32 class of the other layers); SSDNERF_SHADE_DIR_PRODUCTS=6 sets the default of new decoders
-    shade_dir_products = 6 if os.environ.get("SSDNERF_SHADE_DIR_PRODUCTS", "3") == "6" else 3
+    #: split products of the direction term formed by the MFMA shading kernel: 6 (default since r04: all of them, the fp32 class of the other
+    #: layers, whatever the decoder's weights) or 3 (opt-in: 16 significand bits per factor of that additive term; <= 1.6e-6 on the image with
+    #: Xavier-scale weights, growing with |Wd.SH(d)| |Wc|; the kernel is 5 % faster); SSDNERF_SHADE_DIR_PRODUCTS=3 sets the default of new decoders
+    shade_dir_products = 3 if os.environ.get("SSDNERF_SHADE_DIR_PRODUCTS", "6") == "3" else 6
 
     def _shade_flags(self) -> int:
-        return 0x100 if self.shade_dir_products == 6 else 0          # SSDNERF_SHADE_FULL_DIR_PRODUCTS (include/ssdnerf_hip.h)
+        return 0x100 if self.shade_dir_products != 3 else 0          # SSDNERF_SHADE_FULL_DIR_PRODUCTS (include/ssdnerf_hip.h)
 
     def invalidate_packed(self):
         """Forget the packed parameter block (re-packed on the next fused call).  Automatic after ``load_state_dict`` / ``.to()``; needed by hand

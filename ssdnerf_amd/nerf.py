@@ -53,17 +53,23 @@ def get_cam_rays(c2w: torch.Tensor, intrinsics: torch.Tensor, h: int, w: int) ->
 @torch.no_grad()
 def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch.Tensor, h: int, w: int, intrinsics: torch.Tensor,
            poses: torch.Tensor, grid_size: int = 64, bg_color: float = 1.0, cfg: Optional[Dict] = None,
-           planes: Optional[torch.Tensor] = None, rays: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+           planes: Optional[torch.Tensor] = None, rays: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, return_u8: bool = False):
     """``BaseNeRF.render``: (S,V) views of S scenes -> image (S,V,h,w,3) blended with ``bg_color``, depth (S,V,h,w).
 
     ``planes`` / ``rays`` let callers that render the same scenes or cameras repeatedly keep the packed planes /
-    ray arrays resident instead of rebuilding them (they are pure functions of ``code`` / ``poses, intrinsics``)."""
+    ray arrays resident instead of rebuilding them (they are pure functions of ``code`` / ``poses, intrinsics``).
+    ``return_u8`` (extra): also return the image quantised as ``eval_and_viz`` does (base_nerf.py:551-553), (S,V,h,w,3) uint8 -- written by
+    the render kernels next to the float image on the camera-fed path, one ``quantize_u8`` pass otherwise."""
     cfg = cfg or {}
     was_training = decoder.training
     decoder.train(False)
     dt_gamma_scale = cfg.get("dt_gamma_scale", 0.0)
-    dt_gamma = dt_gamma_scale * 2 / (intrinsics[..., 0] + intrinsics[..., 1]).mean(dim=-1)      # (S,)
     s, v = poses.shape[:2]
+    if dt_gamma_scale == 0:
+        # the uncond configs: the cone angle is 0 for every scene, known on the host -> the constant-step kernel form (shade_mfma.hip MODE 2)
+        dt_gamma = [0.0] * s
+    else:
+        dt_gamma = (dt_gamma_scale * 2 / (intrinsics[..., 0] + intrinsics[..., 1]).mean(dim=-1)).reshape(-1)      # (S,), stays on the device
     max_render_rays = cfg.get("max_render_rays", -1)
     chunked = 0 < max_render_rays < v * h * w
     if planes is None and decoder.render_mode == "fused" and decoder.fused_supported(code):
@@ -71,10 +77,11 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
     overflow = []                                                     # device flags of the fused launches: ONE host read after the last chunk
     if planes is not None and rays is None and not chunked and os.environ.get("SSDNERF_RENDER_ARRAYS", "0") != "1":   # (=1: debugging aid, materialise the rays)
         # the whole batch in one fused launch pair, rays generated in the kernels from (poses, intrinsics): no (S,V,h,w,3) arrays at all
-        out = decoder.render_packed(planes, None, None, density_bitfield, grid_size, dt_gamma.reshape(-1), 1e-4, bg_color=bg_color,
-                                    check_overflow=False, cams=(poses, intrinsics.expand(s, v, 4), h, w))
+        out = decoder.render_packed(planes, None, None, density_bitfield, grid_size, dt_gamma, 1e-4, bg_color=bg_color,
+                                    check_overflow=False, cams=(poses, intrinsics.expand(s, v, 4), h, w), want_u8=return_u8)
         overflow.append(decoder.last_render_stats["overflow"])
         image, depth = out["image"], out["depth"]
+        image_u8 = out.get("image_u8")
     else:
         rays_o, rays_d = get_cam_rays(poses, intrinsics, h, w) if rays is None else rays
         rays_o = rays_o.reshape(s, v * h * w, 3)
@@ -82,16 +89,16 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
         chunks_o = rays_o.split(max_render_rays, dim=1) if chunked else [rays_o]
         chunks_d = rays_d.split(max_render_rays, dim=1) if chunked else [rays_d]
         images, depths = [], []
-        gammas = None
+        gammas, image_u8 = None, None
         for o, d in zip(chunks_o, chunks_d):
             if planes is not None:
                 # dt_gamma stays on the device (the reference calls .item() per scene, base_volume_renderer.py:112)
-                out = decoder.render_packed(planes, o, d, density_bitfield, grid_size, dt_gamma.reshape(-1), 1e-4, bg_color=bg_color,
+                out = decoder.render_packed(planes, o, d, density_bitfield, grid_size, dt_gamma, 1e-4, bg_color=bg_color,
                                             check_overflow=False)
                 overflow.append(decoder.last_render_stats["overflow"])
                 rgb = out["image"]                                    # already a dense (S,N,3) tensor: no stack copy
             else:
-                gammas = gammas or [float(g) for g in dt_gamma.reshape(-1).tolist()]
+                gammas = gammas or [float(g) for g in (dt_gamma if isinstance(dt_gamma, list) else dt_gamma.tolist())]
                 out = decoder(o, d, code, density_bitfield, grid_size, dt_gamma=gammas, perturb=False)
                 ws = torch.stack(out["weights_sum"], dim=0)
                 rgb = torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1))
@@ -104,15 +111,18 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
         # schedule: redo the batch through the reference-shaped stepwise path, which is exact by construction (same rule as
         # TriPlaneDecoder._forward_eval_fused).  One sync per render call; the reference syncs once per loop iteration.
         rays_o, rays_d = get_cam_rays(poses, intrinsics, h, w) if rays is None else rays
-        gammas = [float(g) for g in dt_gamma.reshape(-1).tolist()]
+        gammas = [float(g) for g in (dt_gamma if isinstance(dt_gamma, list) else dt_gamma.tolist())]
         out = decoder._forward_eval_stepwise(list(rays_o.reshape(s, -1, 3)), list(rays_d.reshape(s, -1, 3)), code, density_bitfield,
                                              [grid_size] * s if isinstance(grid_size, int) else grid_size, gammas, False, 1e-4)
         ws = torch.stack(out["weights_sum"], dim=0)
         image = torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1))
         depth = torch.stack(out["depth"], dim=0)
+        image_u8 = None
     image = image.reshape(s, v, h, w, 3)
     depth = depth.reshape(s, v, h, w)
     decoder.train(was_training)
+    if return_u8:
+        return image, depth, (quantize_u8(image) if image_u8 is None else image_u8.reshape(s, v, h, w, 3))
     return image, depth
 
 

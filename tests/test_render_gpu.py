@@ -369,8 +369,8 @@ def test_fused_decode_backward_matches_autograd_through_the_eager_decode(ns, pla
 
 @pytest.mark.parametrize("view,dt_gamma", [(64, 0.0), (200, 0.0038095)])
 def test_direction_term_product_count(scene, decoder, view, dt_gamma):
-    """The MFMA shading kernel forms three of the six split products of the direction term by default (16 significand bits per factor) and all
-    six on request (TriPlaneDecoder.shade_dir_products = 6 -> SSDNERF_SHADE_FULL_DIR_PRODUCTS).  Both settings against the oracle with the
+    """The MFMA shading kernel forms all six split products of the direction term by default (SSDNERF_SHADE_FULL_DIR_PRODUCTS) and three of them
+    (16 significand bits per factor) on request (TriPlaneDecoder.shade_dir_products = 3).  Both settings against the oracle with the
     SAME tolerance; what does not depend on the direction term -- sample counts, depth, opacity -- bit for bit equal; and how far apart the two
     images are (the bound quoted in include/ssdnerf_hip.h and DESIGN.md)."""
     from oracle import render as R
@@ -382,7 +382,7 @@ def test_direction_term_product_count(scene, decoder, view, dt_gamma):
         try:
             res[n] = _render_gpu(decoder, scene, ro, rd, "fused", dt_gamma)
         finally:
-            decoder.shade_dir_products = 3
+            decoder.shade_dir_products = type(decoder).shade_dir_products
         np.testing.assert_allclose(res[n][0], rgb0, rtol=0, atol=2e-5)
         np.testing.assert_allclose(res[n][1], dep0, rtol=0, atol=1e-4)
     assert np.array_equal(res[3][3], res[6][3])

@@ -1,42 +1,101 @@
 #!/usr/bin/env bash
-# tools/prof_render.sh [bench args...] -- rocprofv3 kernel trace + PMC counters of the fused render kernel (run on the GPU box).
-# Kernel-trace/stats and each --pmc set are separate runs (never combined with sys/hip traces).
+# tools/prof_render.sh <tag> [bench args...] -- ONE profiling session of the render bench on the GPU box; everything the bench line's `roofline`
+# object cites comes out of it (r04: the r03 verdict's "make roofline reproducible from profiles/"):
+#   1. the un-profiled bench line of the same build and box                                  -> <tag>_bench_unprofiled.json
+#   2. rocprofv3 --kernel-trace --stats of `python bench.py --warmup 10 --steps 20`            -> <tag>_kernel_stats.csv (every launch of the run),
+#      <tag>_bench_under_rocprof.json (the bench line of THAT run: its HIP-event launch_ms is over the same 20 launches) and
+#      <tag>_launch_avg.txt: per kernel, the rocprofv3 average over the LAST 20 launches (= the timed steps, warm) next to the all-launch one
+#   3. the PMC passes, each in its own run with --kernel-trace only (never combined with sys/hip tracing)   -> <tag>_pmc.txt
+#   4. profiles/traffic_latest.json regenerated from passes 3 + 2 of THIS session (FETCH_SIZE doubled per MI355X_MICROARCH.md), with the commit
+#      it profiled; bench.py copies it into `roofline.traffic` / `roofline.traffic_source`.
+# Outputs land in gpurun_out/prof_<tag>/; copy them to profiles/rNN/ and commit traffic_latest.json.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof
+TAG=${1:-a}; shift
+OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd $R
 ARGS="${@:---no-extras --no-cpu-baseline}"      # the default (8 scenes x 251 views) workload: traffic is per launch of THAT
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_kt -o kt -- python bench.py --steps 3 --warmup 1 $ARGS > $OUT/kt_bench.json 2> $OUT/kt_err.log
-find /tmp/rp_kt -name "*stats*.csv" -exec cp {} $OUT/ \;
+python bench.py --warmup 10 --steps 20 $ARGS > $OUT/${TAG}_bench_unprofiled.json 2> $OUT/unprofiled_err.log
+rm -rf /tmp/rp_kt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_kt -o kt -- python bench.py --warmup 10 --steps 20 $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt_err.log
+f=$(find /tmp/rp_kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-300 "$f" | head -24 > $OUT/${TAG}_kernel_stats.csv
+python - "$OUT/${TAG}_launch_avg.txt" <<'PY'
+import csv, glob, collections, sys
+d = collections.defaultdict(list)
+for f in glob.glob("/tmp/rp_kt/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        d[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+with open(sys.argv[1], "w") as out:
+    out.write(f"{'kernel':70s} {'calls':>6s} {'avg_us_all':>11s} {'avg_us_last20':>14s} {'min_us':>9s} {'max_us_last20':>14s}\n")
+    for k, v in sorted(d.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+        v.sort()
+        durs = [x[1] for x in v]
+        last = durs[-20:]
+        out.write(f"{k[:70]:70s} {len(durs):6d} {sum(durs) / len(durs):11.1f} {sum(last) / len(last):14.1f} {min(durs):9.1f} {max(last):14.1f}\n")
+print(open(sys.argv[1]).read()[:2400])
+PY
+: > $OUT/${TAG}_pmc.txt
 pmc() { # name, counters...
   n=$1; shift
+  rm -rf /tmp/rp_$n
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/rp_$n -o $n -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2> $OUT/${n}_err.log
-  python - "$n" <<'PY'
+  python - "$n" "$OUT/${TAG}_pmc.txt" <<'PY'
 import csv, glob, sys, collections
-n = sys.argv[1]
+n, path = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob(f"/tmp/rp_{n}/**/*counter_collection*.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "?")[:60]
-        acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
+        acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[(k, row["Counter_Name"])] += 1
-import os
-out = open(os.environ.get("OUT", ".") + f"/{n}_summary.txt", "w")
-for k, d in acc.items():
-    if not any(w in k for w in ("k_shade", "k_ray_cull", "k_survivor", "k_density", "k_quantize", "k_bitfield")): continue
-    for c, v in sorted(d.items()):
-        line = f"{k:60s} {c:28s} total={v:.6g} dispatches={cnt[(k,c)]} per_dispatch={v/cnt[(k,c)]:.6g}"
-        print(line); out.write(line + "\n")
+with open(path, "a") as out:
+    for k, d in acc.items():
+        if not any(w in k for w in ("k_shade", "k_ray_cull", "k_survivor", "k_density", "k_view_masks", "k_queue_close", "k_bitfield")):
+            continue
+        for c, v in sorted(d.items()):
+            out.write(f"{k:60s} {c:28s} total={v:.6g} dispatches={cnt[(k, c)]} per_dispatch={v / cnt[(k, c)]:.6g}\n")
 PY
 }
-export OUT
 pmc pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pmc pmc2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
 pmc pmc3 FETCH_SIZE
 pmc pmc6 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES
 pmc pmc4 WRITE_SIZE GRBM_GUI_ACTIVE
 pmc pmc5 TCC_HIT_sum TCC_MISS_sum
-head -30 $OUT/kt_kernel_stats.csv 2>/dev/null || ls $OUT
-cat $OUT/kt_bench.json | tail -1 | cut -c1-400
+# traffic_latest.json from THIS session
+python - "$OUT" "$TAG" <<'PY'
+import json, re, subprocess, sys, os
+out, tag = sys.argv[1], sys.argv[2]
+def per_dispatch(counter):
+    for line in open(f"{out}/{tag}_pmc.txt"):
+        if line.startswith("k_shade_mfma") and f" {counter} " in line:
+            return line[:60].strip(), float(re.search(r"per_dispatch=([0-9.e+]+)", line).group(1))
+    return None, None
+kern, fetch = per_dispatch("FETCH_SIZE")
+_, write = per_dispatch("WRITE_SIZE")
+bench = json.loads([l for l in open(f"{out}/{tag}_bench_under_rocprof.json") if l.startswith("{")][-1])
+avg_last = n_last = None
+for line in open(f"{out}/{tag}_launch_avg.txt"):
+    if line.startswith("k_shade_mfma"):
+        cols = line[70:].split()
+        avg_last, n_last = float(cols[2]) / 1e3, min(20, int(cols[0]))
+commit = os.environ.get("SSDNERF_PROFILED_COMMIT")      # (.git does not travel to the GPU box: the caller passes `git rev-parse --short HEAD`)
+cfg = bench["config"]
+m = re.search(r"direction term (\d) of 6", cfg.get("mlp_arithmetic", ""))
+tj = {"workload": {"scenes": cfg["scenes_per_gpu"], "views": cfg["views_per_scene"], "size": int(cfg["image"].split("x")[0]), "variant": cfg["scene_variant"],
+                   "plane_dtype": cfg["plane_dtype"], "ray_source": "cameras" if cfg["ray_source"].startswith("cameras") else "arrays"},
+      "kernel": kern, "dir_products": int(m.group(1)) if m else 3,
+      "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
+      "hbm_bytes_per_launch": None if fetch is None or write is None else (2 * fetch + write) * 1024,
+      "rocprof_launch_ms_avg_timed_steps": avg_last, "rocprof_launches_averaged": n_last,
+      "hip_event_launch_ms_same_run": bench["roofline"]["launch_ms"],
+      "method": "tools/prof_render.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE in separate passes (1 launch each); FETCH_SIZE doubled per "
+                "MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); launch average = rocprofv3 --kernel-trace over the 20 timed launches of "
+                "`bench.py --warmup 10 --steps 20`, HIP events of the same run beside it",
+      "profiled_commit": commit, "source": f"profiles/r04/{tag}_pmc.txt, {tag}_launch_avg.txt, {tag}_bench_under_rocprof.json"}
+json.dump(tj, open(f"{out}/traffic_latest.json", "w"), indent=1)
+print(json.dumps(tj, indent=1))
+PY
+cat $OUT/${TAG}_bench_unprofiled.json | tail -1 | cut -c1-300
 du -sh $OUT
