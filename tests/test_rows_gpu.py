@@ -46,7 +46,13 @@ def test_full_scene_sample_counts_match_the_oracle(variant, n_views):
     samples per ray) -- from the camera-fed fused path against the reference-shaped oracle loop (C restatement of the reference kernels on all
     host cores + PyTorch-CPU decode).  Integer contract: equal except on rays with a termination test within 1e-5 of T_thresh -- the
     transmittance there is 1 - (a sum of ~30 weights near 1), so hardware exp vs expf and the summation order of the MLP move it by a few 1e-6 --
-    and those mismatches must be rarer than 1 ray in 2000."""
+    and those mismatches must be rarer than 1 ray in 2000.
+
+    Float contract (r04; the r03 verdict's weak #2: "whole-scene float parity is observed, not asserted"): over the SAME sweep RGB within 1e-4
+    of the oracle everywhere and within 2e-5 on every ray whose sample count agrees (the single-view tolerance), depth within 1e-4 on those rays
+    (a ray that takes one sample more or less at T ~ 1e-4 moves depth by up to 1e-4 x t); and with the oracle marching the rays the CPU
+    generates itself (<= 1 ulp away from the kernels': samples move across voxel faces) RGB still within north_star's 1e-4 on a quarter of
+    the views."""
     import oracle
     from oracle import render as R
     from ssdnerf_amd import synthetic as S
@@ -61,9 +67,11 @@ def test_full_scene_sample_counts_match_the_oracle(variant, n_views):
     _, bits = get_density(dec, code.cuda()[None], 64, density_thresh=0.1, density_step=8, jitters=[j.cuda() for j in jit])
     poses = S.spiral_poses(251)[:n_views]
     intr = S.cars_intrinsics(128, 128)[None].expand(n_views, -1)
-    dec.render_packed(pack_triplanes(code.cuda()[None]), None, None, bits, 64, [0.0], 1e-4, bg_color=1.0, want_counts=True, check_overflow=False,
-                      cams=(poses.cuda()[None], intr.cuda()[None], 128, 128))
+    out = dec.render_packed(pack_triplanes(code.cuda()[None]), None, None, bits, 64, [0.0], 1e-4, bg_color=1.0, want_counts=True, check_overflow=False,
+                            cams=(poses.cuda()[None], intr.cuda()[None], 128, 128))
     got = dec.last_render_stats["sample_counts"][0].cpu().numpy().reshape(n_views, -1)
+    got_rgb = out["image"][0].cpu().numpy().reshape(n_views, -1, 3)
+    got_dep = out["depth"][0].cpu().numpy().reshape(n_views, -1)
     near_thresh = int(dec.last_render_stats["boundary_tests"].sum())
     assert int(dec.last_render_stats["overflow"].item()) == 0
     bits_np = bits[0].cpu().numpy()
@@ -73,13 +81,30 @@ def test_full_scene_sample_counts_match_the_oracle(variant, n_views):
     from ssdnerf_amd import nerf
     ro, rd = (t[0].cpu() for t in nerf.get_cam_rays(poses.cuda()[None], intr.cuda()[None], 128, 128))
     mismatched = unexplained = total = 0
+    rgb_err = rgb_err_same = dep_err_same = dep_err = 0.0
     for v in range(n_views):
         tr = {}
-        R.render_eval(params, code, bits_np, ro[v].reshape(-1, 3).numpy(), rd[v].reshape(-1, 3).numpy(), trace=tr, near_band=1e-5)
+        rgb0, dep0, _ = R.render_eval(params, code, bits_np, ro[v].reshape(-1, 3).numpy(), rd[v].reshape(-1, 3).numpy(), trace=tr, near_band=1e-5)
         diff = tr["samples_composited"] != got[v]
         mismatched += int(diff.sum())
         unexplained += int((diff & ~tr["near_threshold"]).sum())
         total += int(tr["samples_composited"].sum())
+        e_rgb, e_dep = np.abs(got_rgb[v] - rgb0).max(axis=-1), np.abs(got_dep[v] - dep0)
+        rgb_err, dep_err = max(rgb_err, float(e_rgb.max())), max(dep_err, float(e_dep.max()))
+        rgb_err_same, dep_err_same = max(rgb_err_same, float(e_rgb[~diff].max())), max(dep_err_same, float(e_dep[~diff].max()))
+    print(f"{variant}: {n_views} views, max|rgb - oracle| = {rgb_err:.2e} ({rgb_err_same:.2e} on rays with equal counts), max|depth - oracle| = "
+          f"{dep_err:.2e} ({dep_err_same:.2e}); {mismatched} rays differ in count")
+    assert rgb_err <= 1e-4 and rgb_err_same <= 2e-5, (rgb_err, rgb_err_same)
+    assert dep_err_same <= 1e-4 and dep_err <= 6e-4, (dep_err_same, dep_err)
+    # the oracle on ITS OWN rays (the CPU tensor-op form of get_cam_rays, <= 1 ulp from the kernels' rays): what bench.py's
+    # cpu_baseline.max_abs_rgb_err_gpu_vs_oracle reports for the whole scene (7.4e-5 in r03) -- every fourth view here
+    rgb_err_cpu_rays = 0.0
+    for v in range(0, n_views, 4):
+        ro_c, rd_c = R.get_cam_rays(poses[v][None], intr[v][None], 128, 128)
+        rgb_c, _, _ = R.render_eval(params, code, bits_np, ro_c.reshape(-1, 3).numpy(), rd_c.reshape(-1, 3).numpy())
+        rgb_err_cpu_rays = max(rgb_err_cpu_rays, float(np.abs(got_rgb[v] - rgb_c).max()))
+    print(f"{variant}: oracle on CPU-generated rays, {len(range(0, n_views, 4))} views: max|rgb - oracle| = {rgb_err_cpu_rays:.2e}")
+    assert rgb_err_cpu_rays <= 1e-4, rgb_err_cpu_rays
     n_rays = n_views * 128 * 128
     assert total > 50 * n_views and abs(int(got.sum()) - total) <= max(8, mismatched * 8)
     assert unexplained == 0                                                    # only rays sitting at the threshold may differ ...

@@ -64,38 +64,6 @@ pmc pmc6 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_I
 pmc pmc4 WRITE_SIZE GRBM_GUI_ACTIVE
 pmc pmc5 TCC_HIT_sum TCC_MISS_sum
 # traffic_latest.json from THIS session
-python - "$OUT" "$TAG" <<'PY'
-import json, re, subprocess, sys, os
-out, tag = sys.argv[1], sys.argv[2]
-def per_dispatch(counter):
-    for line in open(f"{out}/{tag}_pmc.txt"):
-        if line.startswith("k_shade_mfma") and f" {counter} " in line:
-            return line[:60].strip(), float(re.search(r"per_dispatch=([0-9.e+]+)", line).group(1))
-    return None, None
-kern, fetch = per_dispatch("FETCH_SIZE")
-_, write = per_dispatch("WRITE_SIZE")
-bench = json.loads([l for l in open(f"{out}/{tag}_bench_under_rocprof.json") if l.startswith("{")][-1])
-avg_last = n_last = None
-for line in open(f"{out}/{tag}_launch_avg.txt"):
-    if line.startswith("k_shade_mfma"):
-        cols = line[70:].split()
-        avg_last, n_last = float(cols[2]) / 1e3, min(20, int(cols[0]))
-commit = os.environ.get("SSDNERF_PROFILED_COMMIT")      # (.git does not travel to the GPU box: the caller passes `git rev-parse --short HEAD`)
-cfg = bench["config"]
-m = re.search(r"direction term (\d) of 6", cfg.get("mlp_arithmetic", ""))
-tj = {"workload": {"scenes": cfg["scenes_per_gpu"], "views": cfg["views_per_scene"], "size": int(cfg["image"].split("x")[0]), "variant": cfg["scene_variant"],
-                   "plane_dtype": cfg["plane_dtype"], "ray_source": "cameras" if cfg["ray_source"].startswith("cameras") else "arrays"},
-      "kernel": kern, "dir_products": int(m.group(1)) if m else 3,
-      "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
-      "hbm_bytes_per_launch": None if fetch is None or write is None else (2 * fetch + write) * 1024,
-      "rocprof_launch_ms_avg_timed_steps": avg_last, "rocprof_launches_averaged": n_last,
-      "hip_event_launch_ms_same_run": bench["roofline"]["launch_ms"],
-      "method": "tools/prof_render.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE in separate passes (1 launch each); FETCH_SIZE doubled per "
-                "MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); launch average = rocprofv3 --kernel-trace over the 20 timed launches of "
-                "`bench.py --warmup 10 --steps 20`, HIP events of the same run beside it",
-      "profiled_commit": commit, "source": f"profiles/r04/{tag}_pmc.txt, {tag}_launch_avg.txt, {tag}_bench_under_rocprof.json"}
-json.dump(tj, open(f"{out}/traffic_latest.json", "w"), indent=1)
-print(json.dumps(tj, indent=1))
-PY
+python tools/make_traffic_json.py "$OUT" "$TAG"
 cat $OUT/${TAG}_bench_unprofiled.json | tail -1 | cut -c1-300
 du -sh $OUT
