@@ -472,12 +472,18 @@ class DiffusionNeRF(MultiSceneNeRF):
         diffusion = self._eval_diffusion()
         with self._autocast():
             latent = diffusion(self.code_diff_pr(noise), return_loss=False, show_pbar=show_pbar, **kwargs)
-        code = self.code_diff_pr_inv(latent.float())
+        points = latent if isinstance(latent, list) else [latent]          # save_intermediates: the sampler returns its trajectory
         n_refine = self.test_cfg.get("n_inverse_steps", 0)
-        if n_refine > 0:
-            code = self._refine_under_prior(diffusion, code, n_refine, prior_timesteps, prior_noises)
-        grid, bits = self.get_density(self._modules_for_eval(), code, cfg=self.test_cfg, jitters=density_jitters)
-        return code, grid, bits
+        codes, grids, bitfields = [], [], []
+        for i, point in enumerate(points):
+            code = self.code_diff_pr_inv(point.float())
+            if n_refine > 0 and i == len(points) - 1:                        # only the final sample is polished under the prior (diffusion_nerf.py:213-231)
+                code = self._refine_under_prior(diffusion, code, n_refine, prior_timesteps, prior_noises)
+            grid, bits = self.get_density(self._modules_for_eval(), code, cfg=self.test_cfg, jitters=density_jitters)
+            codes.append(code); grids.append(grid); bitfields.append(bits)
+        if isinstance(latent, list):                                         # one (code, grid, bitfield) per trajectory point, like the reference (:236-237)
+            return codes, grids, bitfields
+        return codes[-1], grids[-1], bitfields[-1]
 
     def _refine_under_prior(self, diffusion, code, n_steps, timesteps=None, noises=None):
         """``test_cfg['n_inverse_steps']`` on a batch WITHOUT conditioning views (every recons config sets it, and the reference's val_uncond then
@@ -490,9 +496,10 @@ class DiffusionNeRF(MultiSceneNeRF):
             sch = self.build_scheduler(opt, cfg)
             for k in range(n_steps):
                 opt.zero_grad()
-                with self._autocast():
-                    prior, _ = diffusion(self.code_diff_pr(self.code_activation(leaf)), return_loss=True, cfg=cfg,
-                                         timesteps=None if timesteps is None else timesteps[k], noise=None if noises is None else noises[k])
+                # fp32 here: the reference wraps only the SAMPLING of val_uncond in autocast and evaluates this loss outside it
+                # (diffusion_nerf.py:212-229; r03 advisor)
+                prior, _ = diffusion(self.code_diff_pr(self.code_activation(leaf)), return_loss=True, cfg=cfg,
+                                     timesteps=None if timesteps is None else timesteps[k], noise=None if noises is None else noises[k])
                 prior.backward()
                 opt.step()
                 if sch is not None:

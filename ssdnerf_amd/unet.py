@@ -104,8 +104,17 @@ class _AttentionF32Fn(torch.autograd.Function):
         return UF.attention_qkv_f32_backward(qkv, out, dout.contiguous(), lse, ctx.heads), None
 
 
-#: SSDNERF_UNET_GRAD_ATT_KERNEL=0: the library's scaled_dot_product_attention in the gradient path (A/B runs, true-fp32 parity runs)
+#: SSDNERF_UNET_GRAD_ATT_KERNEL=0: the library's scaled_dot_product_attention in the gradient path (A/B runs, true-fp32 parity runs; covered by
+#: tests/test_recons_gpu.py::test_gradient_path_attention_library_fp32_is_reachable_and_agrees)
 GRAD_ATT_KERNEL = os.environ.get("SSDNERF_UNET_GRAD_ATT_KERNEL", "1") != "0"
+
+
+def attention_kernel_ok(qkv: torch.Tensor, heads: int) -> bool:
+    """(B, T, 3C) projection that the hand-written fp32-class attention kernels (forward + backward) take: head width a multiple of 8 in [8, 128]
+    and at most 65 535 (batch, head) pairs -- the second grid dimension of csrc/attention.hip's launches; anything else runs the library's
+    scaled_dot_product_attention instead of raising."""
+    ch = qkv.size(-1) // (3 * heads)
+    return bool(GRAD_ATT_KERNEL and qkv.is_cuda and qkv.dtype == torch.float32 and ch % 8 == 0 and 8 <= ch <= 128 and qkv.size(0) * heads <= 65535)
 
 
 class _ZeroArena:
@@ -320,7 +329,7 @@ class MultiHeadAttentionMod(nn.Module):
         xc = x.contiguous(memory_format=torch.channels_last)
         xn = _GroupNormActFn.apply(xc, self.norm, None, False)
         qkv = F.linear(xn.permute(0, 2, 3, 1).reshape(b, t, c), self.qkv.weight[:, :, 0], self.qkv.bias)      # channel = head*3ch + {q,k,v}*ch + i
-        if GRAD_ATT_KERNEL and qkv.is_cuda and qkv.dtype == torch.float32 and ch % 8 == 0 and 8 <= ch <= 128:
+        if attention_kernel_ok(qkv, heads):
             a = _AttentionF32Fn.apply(qkv, heads)                                                             # (b, t, c)
         else:
             q, k, v = qkv.view(b, t, heads, 3, ch).permute(3, 0, 2, 1, 4)                                     # each (b, heads, t, ch)
@@ -550,11 +559,21 @@ class DenoisingUnetMod(nn.Module):
             off += l.out_features
         embedding._ssd_projections = out
 
+    #: Input-gradient calls with FROZEN weights under autocast (config 5's guided / Langevin / fine-tuning steps with ``autocast_dtype='bfloat16'``):
+    #: True (default) runs them on the fp32-class matrix-core kernels of the gradient path with autocast switched off for the call -- a compute
+    #: type >= the requested one, and faster than the eager modules under autocast (library bf16 convolutions, casts around every norm; r04 A/B in
+    #: profiles/r04).  SSDNERF_UNET_GRAD_AUTOCAST=1 keeps the eager autocast modules (the reference's arithmetic for that config).
+    grad_path_fp32_under_autocast = os.environ.get("SSDNERF_UNET_GRAD_AUTOCAST", "0") != "1"
+
     def forward(self, x_t, t, label=None, concat_cond=None, return_noise=False):
         if self._fast_path_ok(x_t, label):
             dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
             with torch.autocast("cuda", enabled=False):
                 return self._fast_executor(dtype)(x_t.float(), t)
+        if (self.grad_path_fp32_under_autocast and x_t.is_cuda and torch.is_grad_enabled() and x_t.requires_grad and torch.is_autocast_enabled("cuda")
+                and not self.out.conv.weight.requires_grad and not self.time_embedding.blocks[0].weight.requires_grad):
+            with torch.autocast("cuda", enabled=False):
+                return self.forward(x_t.float(), t, label, None if concat_cond is None else concat_cond.float(), return_noise)
         if self.use_rescale_timesteps:
             t = t.float() * (1000.0 / self.num_timesteps)
         embedding = self.time_embedding(t)

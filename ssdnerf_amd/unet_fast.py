@@ -319,13 +319,14 @@ class _Conv:
         if not self.own and (pin or pout):                          # no kernel for it after all: keep the layer's true shape for the library
             self.__init__(conv, dtype)
 
-    splitk_ws: Optional[torch.Tensor] = None        # shared all-zero fp32 scratch for the small layers' split-K (set by the executor)
+    splitk_ws_by_device: dict = {}                  # device index -> all-zero fp32 scratch for the small layers' split-K (shared_splitk_ws)
     F32X2 = os.environ.get("SSDNERF_UNET_F32X2", "1") != "0"      # fp32 executor: own bf16 x 2 convolution (default) or the library's fp32 one
 
     def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0, x2=None):
         if self.w_lo is not None:
-            return conv2d_nhwc_f32x2(x, self.w_lo[0], self.w_lo[1], bias, residual, self.stride[0], upsample, gn_sums, gn_groups, x2=x2, splitk_ws=_Conv.splitk_ws)
-        return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups, splitk_ws=_Conv.splitk_ws, x2=x2)
+            return conv2d_nhwc_f32x2(x, self.w_lo[0], self.w_lo[1], bias, residual, self.stride[0], upsample, gn_sums, gn_groups, x2=x2,
+                                     splitk_ws=shared_splitk_ws(x.device))
+        return conv2d_nhwc_bf16(x, self.w, bias, residual, self.stride[0], upsample, gn_sums, gn_groups, splitk_ws=shared_splitk_ws(x.device), x2=x2)
 
     def _w_lib(self):                                               # weight for the library path of a block whose other convolutions do not fit the own kernel
         return self.w if self.w_lo is None else (self.w_lo[0].float() + self.w_lo[1].float()).contiguous(memory_format=torch.channels_last)
@@ -345,11 +346,20 @@ class _Conv:
         return bias_residual_nhwc(self.mm(x), self.bias, None)
 
 
-def shared_splitk_ws(device) -> torch.Tensor:
-    """The all-zero fp32 scratch the split-K convolutions reduce through (every call leaves it all zero again; one per process, one stream)."""
-    if _Conv.splitk_ws is None or _Conv.splitk_ws.device != torch.device(device):
-        _Conv.splitk_ws = torch.zeros(_Conv.SPLITK_BYTES // 4, dtype=torch.float32, device=device)
-    return _Conv.splitk_ws
+def shared_splitk_ws(device) -> Optional[torch.Tensor]:
+    """The all-zero fp32 scratch the split-K convolutions of ``device`` reduce through (every call leaves it all zero again).  One buffer PER
+    DEVICE, created on first use and never dropped: captured hipGraphs and executors of that device hold its pointer (r03 advisor: one
+    process-global buffer that was re-created whenever the device changed left graphs of the first device with a freed pointer and could hand a
+    kernel another GPU's memory).  Users of one device share it, so they must be ordered on one stream -- the executor's graph replays and the
+    autograd path's eager launches both run on torch's current stream."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return None                                                 # (CPU tensors only reach here under the CPU suite's stand-in kernels)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _Conv.splitk_ws_by_device.get(idx)
+    if ws is None:
+        ws = _Conv.splitk_ws_by_device[idx] = torch.zeros(_Conv.SPLITK_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+    return ws
 
 
 class _GN:
@@ -493,7 +503,7 @@ class FastUnet:
             if plan >> 8 != 1:
                 return True                                                 # split along K: the finishing pass takes the statistics
             return hw % (128 if (plan & 0xff) == 1 else 64) == 0
-        plan = C.lib().ssdnerf_conv2d_nhwc_bf16_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, int(_Conv.splitk_ws is not None), 0)
+        plan = C.lib().ssdnerf_conv2d_nhwc_bf16_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, 1, 0)
         if plan >> 8 != 1:
             return True                                                     # a split-K layer: its finishing pass takes the statistics
         return hw % (256 if (plan & 0xff) == 4 else 128 if (plan & 0xff) == 1 else 64) == 0   # unsplit: the M tile must lie inside one sample

@@ -1,0 +1,237 @@
+"""GPU parity of the reconstruction path as a WHOLE (r03 verdict, missing #3 / #4; BASELINE.json configs[2] and configs[4]):
+
+  * a multi-step rendering-guided DDIM trajectory (UNet backward -> renderer backward -> density refresh with decay, every step) against
+    ``oracle/diffusion.py::ddim_sample`` + ``oracle/guidance.py::guidance_loss`` with CPU autograd (diffusion_nerf.py:241-311,
+    gaussian_diffusion.py:193-227);
+  * config 5's combination -- guided Langevin corrections under bf16 autocast with fp16 planes -- against the fp32 path (PSNR floor);
+  * the direction term of the fused shading kernel with decoder weights far outside the Xavier range;
+  * the true-fp32 attention of the gradient path (SSDNERF_UNET_GRAD_ATT_KERNEL=0) stays reachable and agrees with the fp32-class kernels.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEC = dict(type="TriPlaneDecoder", interp_mode="bilinear", base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], use_dir_enc=True,
+           dir_layers=[16, 64], activation="silu", sigma_activation="trunc_exp", sigmoid_saturation=0.001, max_steps=256)
+UNET = dict(type="DenoisingUnetMod", image_size=128, in_channels=18, base_channels=32, channels_cfg=[1, 1, 2], resblocks_per_downsample=1, dropout=0.0,
+            use_scale_shift_norm=True, num_heads=4, attention_res=[32], norm_cfg=dict(type="GN", num_groups=8))
+UNET_ORACLE = dict(image_size=128, base_channels=32, channels_cfg=(1, 1, 2), resblocks_per_downsample=1, num_heads=4, attention_res=(32,), norm_groups=8)
+# a LOW-noise schedule (alpha_bar_999 = 0.99): x_T = a code + b z is a noised object, so every guided step renders real geometry.  With the
+# configs' schedule and random UNet weights the predicted x0 holds no occupied voxels and guidance would have nothing to push against.
+BETAS = dict(type="linear", beta_0=1e-6, beta_T=2e-5)
+
+
+def _randomize(module, seed, scale=0.2):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (scale / max(1.0, p[0].numel() ** 0.5) if p.dim() > 1 else 0.1))
+
+
+def _model(test_cfg, autocast_dtype=None, plane_dtype="float32", betas=BETAS, unet=UNET):
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.registry import MODELS
+    m = MODELS.build(dict(
+        type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64,
+        autocast_dtype=autocast_dtype,
+        diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(betas), denoising=dict(unet)),
+        decoder=dict(DEC, plane_dtype=plane_dtype), decoder_use_ema=True, freeze_decoder=False, bg_color=1,
+        pixel_loss=dict(type="MSELoss", loss_weight=20.0), reg_loss=dict(type="RegLoss", power=2, loss_weight=3e-3), cache_size=0, test_cfg=test_cfg))
+    _randomize(m.diffusion_ema.denoising, 9)
+    m.decoder_ema.load_state_dict(S.make_decoder_params(), strict=False)
+    return m.cuda().eval()
+
+
+def _noised_objects(seeds, g, tables_a_b):
+    from ssdnerf_amd import synthetic as S
+    a, b = tables_a_b
+    code = torch.stack([S.make_triplane(sd) for sd in seeds])                  # |code| <= 2; the tests clip x0 to [-3, 3], which stays inactive
+    z = torch.randn(code.shape, generator=g).clamp(-3, 3)
+    return (a * code + b * z).float()
+
+
+# ---------------------------------------------------------------------------------------------- guided DDIM, several steps, against the oracle
+def test_guided_ddim_trajectory_matches_oracle():
+    """Three rendering-guided DDIM steps of two scenes (diffusion_nerf.py:241-311: per step x0 <- UNet(x_t), density grid refreshed from x0 with decay
+    0.9, train-branch render of the 64x64 conditioning view with jitter, pixel + regularisation loss, its gradient w.r.t. x_t THROUGH the UNet,
+    x0 <- x0 - grad * b^(2-2w) a^(2w-1) * gain, DDIM update) with every random draw injected, against the CPU restatement (oracle UNet + C march /
+    composite + PyTorch-CPU decode, autograd end to end).  Compared: the final codes, and the guided trajectory must differ from the unguided one
+    by orders of magnitude more than the product differs from the oracle."""
+    from oracle import diffusion as OD, guidance as OG, render as R
+    from ssdnerf_amd import synthetic as S
+    n_steps, S_, hw = 3, 2, 64
+    gain = 0.4 * (2 ** 14)                                                       # (the chairs config's lambda_gd; with the cars value 3.2 * 2^14 single entries move by > 1)
+    # clip_range [-3, 3] instead of the configs' [-2, 2]: the synthetic object code saturates at +-2, and an entry that sits within rounding of an
+    # ACTIVE clip has gradient 0 on one side of the comparison and 1 on the other; the clip arithmetic itself is pinned by the DDIM fixtures
+    cfg = dict(img_size=(hw, hw), num_timesteps=n_steps, clip_range=[-3, 3], density_thresh=0.1, dt_gamma_scale=0.5, n_inverse_rays=2 ** 14,
+               loss_coef=0.1 / (128 * 128), guidance_gain=gain, cond_mode="guide")
+    m = _model(cfg)
+    tables = OD.schedule_tables(1000, "linear", beta_0=BETAS["beta_0"], beta_T=BETAS["beta_T"])
+    g = torch.Generator().manual_seed(77)
+    x_T = _noised_objects([31, 32], g, (tables["sqrt_alphas_bar"][999], tables["sqrt_one_minus_alphas_bar"][999]))
+    targets = torch.rand(S_, hw * hw, 3, generator=g)
+    marches = [torch.rand(S_, hw * hw, generator=g) for _ in range(n_steps)]
+    jits = [torch.rand(64 ** 3, 3, generator=g) for _ in range(n_steps)]
+    pose, intr = S.spiral_poses()[[64]], S.cars_intrinsics(hw, hw)
+    params = S.make_decoder_params()
+
+    # ---- product
+    data = dict(cond_imgs=targets.reshape(S_, 1, hw, hw, 3).cuda(), cond_intrinsics=intr.cuda()[None, None].expand(S_, 1, -1),
+                cond_poses=pose.cuda()[None].expand(S_, -1, -1, -1), noise=x_T.cuda())
+    with torch.enable_grad():
+        code, grid, bits = m.val_guide(data, guide_noises=[n.cuda() for n in marches], density_jitters=[j.cuda() for j in jits])
+    with torch.no_grad():
+        plain = m.diffusion_ema(m.code_diff_pr(x_T.cuda()), return_loss=False)                   # the same trajectory without guidance
+
+    # ---- oracle
+    sd = {k: v.cpu() for k, v in m.diffusion_ema.denoising.state_dict().items()}
+    den = lambda x, t: OD.unet_forward(sd, x, t, **UNET_ORACLE)
+    ro, rd = R.get_cam_rays(pose, intr[None], hw, hw)
+    ro, rd = ro.reshape(-1, 3).numpy(), rd.reshape(-1, 3).numpy()
+    dt_gamma = 0.5 / float(intr[:2].mean())
+    grids = [np.zeros(64 ** 3, np.float32) for _ in range(S_)]
+    k = [0]
+    points = []
+
+    def guide(x0):
+        codes = x0.reshape(S_, 3, 6, 128, 128)
+        total = 0
+        for s in range(S_):
+            b_s, _ = R.update_extra_state(params, codes[s].detach(), grids[s], jits[k[0]].numpy(), density_thresh=0.1, decay=0.9)
+            loss, rec = OG.guidance_loss(params, codes[s], b_s, ro, rd, targets[s], marches[k[0]][s].numpy(), dt_gamma, scale_num_ray=hw * hw)
+            points.append(rec["num_points"])
+            total = total + loss
+        k[0] += 1
+        return total                                                             # = (mean over scenes) x num_scenes, diffusion_nerf.py:294
+
+    want = OD.ddim_sample(den, x_T.reshape(S_, 18, 128, 128), tables, n_steps, clip_range=(-3, 3), grad_guide_fn=guide, guidance_gain=gain)
+    want_plain = OD.ddim_sample(den, x_T.reshape(S_, 18, 128, 128), tables, n_steps, clip_range=(-3, 3))
+    want, want_plain = want.reshape(S_, 3, 6, 128, 128), want_plain.reshape(S_, 3, 6, 128, 128)
+
+    assert k[0] == n_steps and min(points) > 2000, points                       # every step marched real geometry
+    assert float(want.abs().max()) < 2.99                                       # the clip never engaged: gradients flow everywhere on both sides
+    moved = float((want - want_plain).abs().max())
+    err = float((code.cpu() - want).abs().max())
+    err_plain = float((plain.reshape(S_, 3, 6, 128, 128).cpu() - want_plain).abs().max())
+    rms_moved = float((want - want_plain).square().mean().sqrt())
+    rms_err = float((code.cpu() - want).square().mean().sqrt())
+    print(f"guided trajectory: max|code - oracle| = {err:.3e} (rms {rms_err:.3e}); guidance moved the result by {moved:.3e} (rms {rms_moved:.3e}); "
+          f"unguided max|code - oracle| = {err_plain:.3e}; samples per guided render {points}")
+    assert moved > 1e-2, "guidance must move the trajectory measurably for this comparison to mean anything"
+    assert err_plain <= 2e-4
+    assert err <= 2e-3 * moved + 2e-4 and rms_err <= 2e-3 * rms_moved + 2e-5
+    for s in range(S_):                                                          # the occupancy state the objective owns, after its last refresh
+        np.testing.assert_allclose(grid[s].cpu().numpy(), grids[s], rtol=2e-3, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- config 5: Langevin x guidance under bf16 + fp16 planes
+def test_config5_guided_langevin_bf16_fp16_against_fp32():
+    """BASELINE.json configs[4] (ssdnerf_chairs_recons1v.py:79-97 with bf16 UNet + fp16 triplane cache): rendering-guided DDIM with Langevin
+    correction steps (gaussian_diffusion.py:242-262, 318-323), snr_weight_power 0.25, then one fine-tuning iteration, then a render -- once in fp32,
+    once with ``autocast_dtype='bfloat16'`` and fp16 planes, same injected draws.  Mixed-precision tolerance: PSNR of every rendered view against
+    the fp32 run, and the codes' relative distance."""
+    from oracle import diffusion as OD
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.nerf import eval_psnr
+    hw, S_ = 64, 2
+    cfg = dict(img_size=(hw, hw), num_timesteps=3, clip_range=[-2, 2], density_thresh=0.1, dt_gamma_scale=0.5, n_inverse_rays=2 ** 14,
+               loss_coef=0.1 / (128 * 128), guidance_gain=0.4 * (2 ** 14), snr_weight_power=0.25, cond_mode="guide_optim", n_inverse_steps=1,
+               extra_scene_step=1, optimizer=dict(type="Adam", lr=0.005, weight_decay=0.0), lr_scheduler=dict(type="ExponentialLR", gamma=0.998),
+               langevin_steps=2, langevin_delta=0.4)
+    tables = OD.schedule_tables(1000, "linear", beta_0=BETAS["beta_0"], beta_T=BETAS["beta_T"])
+    g = torch.Generator().manual_seed(78)
+    x_T = _noised_objects([33, 34], g, (tables["sqrt_alphas_bar"][999], tables["sqrt_one_minus_alphas_bar"][999]))
+    targets = torch.rand(S_, 1, hw, hw, 3, generator=g)
+    n_eval = 3 + 2 * 2                                                             # DDIM steps + Langevin corrections behind the first two
+    marches = [torch.rand(S_, hw * hw, generator=g) for _ in range(n_eval)]
+    jits = [torch.rand(64 ** 3, 3, generator=g) for _ in range(n_eval)]
+    opt_marches = [torch.rand(S_, hw * hw, generator=g) for _ in range(2)]
+    opt_jits = [torch.rand(64 ** 3, 3, generator=g) for _ in range(1)]
+    pose, intr = S.spiral_poses()[[64, 100]], S.cars_intrinsics(hw, hw)
+    out = {}
+    for name, ac, pd in (("fp32", None, "float32"), ("mixed", "bfloat16", "float16")):
+        m = _model(dict(cfg), autocast_dtype=ac, plane_dtype=pd)
+        assert len(m.diffusion_ema.sampling_plan("ddim")) == n_eval
+        data = dict(cond_imgs=targets.cuda(), cond_intrinsics=intr.cuda()[None, None].expand(S_, 1, -1), cond_poses=pose[:1].cuda()[None].expand(S_, -1, -1, -1),
+                    noise=x_T.cuda(), test_poses=pose.cuda()[None].expand(S_, -1, -1, -1), test_intrinsics=intr.cuda()[None, None].expand(S_, 2, -1))
+        torch.manual_seed(5); np.random.seed(5)                                    # the Langevin z draws and the prior's (t, noise): host generators
+        res = m.val_step(data, guide_noises=[n.cuda() for n in marches], guide_density_jitters=[j.cuda() for j in jits],
+                         march_noises=[n.cuda() for n in opt_marches], optim_density_jitters=[j.cuda() for j in opt_jits])
+        out[name] = (res["code"].float().cpu(), res["pred_imgs"].float().cpu())
+        assert bool(torch.isfinite(res["code"]).all())
+    rel = float((out["mixed"][0] - out["fp32"][0]).norm() / out["fp32"][0].norm())
+    psnr = eval_psnr(out["mixed"][1].flatten(0, 1), out["fp32"][1].flatten(0, 1))
+    print(f"config 5 mix vs fp32: code rel distance {rel:.3e}, PSNR per view {[round(float(p), 1) for p in psnr]}")
+    assert rel < 2e-2 and float(psnr.min()) > 30.0
+
+
+# ---------------------------------------------------------------------------------------------- direction term, weights outside the Xavier range
+@pytest.mark.parametrize("scale", [8.0, 16.0])
+def test_direction_term_with_large_decoder_weights(scale):
+    """r03 verdict weak #1: the error of a reduced-precision direction term scales with |Wd.SH(d)| |Wc|, and trained decoders are not bounded by
+    Xavier.  With ``dir_net`` and ``color_net`` scaled x8 / x16 the DEFAULT kernel (all six split products) must still meet the single-view
+    tolerance against the oracle; the opt-in three-product form is measured beside it (and is allowed to miss it)."""
+    from oracle import render as R
+    from ssdnerf_amd import synthetic as S
+    from ssdnerf_amd.decoders import TriPlaneDecoder, pack_triplanes
+    from ssdnerf_amd.density import get_density
+    params = S.make_decoder_params()
+    params["dir_net.0.weight"] = params["dir_net.0.weight"] * scale
+    params["dir_net.0.bias"] = torch.linspace(-0.5, 0.5, 64) * scale
+    params["color_net.0.weight"] = params["color_net.0.weight"] * scale
+    dec = TriPlaneDecoder(**{k: v for k, v in DEC.items() if k != "type"})
+    dec.load_state_dict(params, strict=False)
+    dec = dec.cuda().eval()
+    assert dec.shade_dir_products == 6
+    code = S.make_triplane(2021)
+    g = torch.Generator().manual_seed(7)
+    jit = [torch.rand(64 ** 3, 3, generator=g) for _ in range(4)]
+    _, bits = get_density(dec, code.cuda()[None], 64, density_thresh=0.1, density_step=4, jitters=[j.cuda() for j in jit])
+    from ssdnerf_amd import nerf
+    poses, intr = S.spiral_poses()[[64, 200]].cuda()[None], S.cars_intrinsics(128, 128).cuda()[None, None].expand(1, 2, -1)
+    ro, rd = (t[0].cpu() for t in nerf.get_cam_rays(poses, intr, 128, 128))
+    planes = pack_triplanes(code.cuda()[None])
+    errs = {}
+    for n in (6, 3):
+        dec.shade_dir_products = n
+        out = dec.render_packed(planes, None, None, bits, 64, [0.0], 1e-4, bg_color=1.0, check_overflow=False, cams=(poses, intr, 128, 128))
+        rgb = out["image"][0].cpu().numpy().reshape(2, -1, 3)
+        errs[n] = max(float(np.abs(rgb[v] - R.render_eval(params, code, bits[0].cpu().numpy(), ro[v].reshape(-1, 3).numpy(), rd[v].reshape(-1, 3).numpy())[0]).max())
+                      for v in range(2))
+    dec.shade_dir_products = 6
+    print(f"decoder weights x{scale:g}: max|rgb - oracle| = {errs[6]:.2e} with six direction products, {errs[3]:.2e} with three")
+    assert errs[6] <= 2e-5, errs
+
+
+# ---------------------------------------------------------------------------------------------- gradient-path attention: library fp32 reachable, kernels agree
+def test_gradient_path_attention_library_fp32_is_reachable_and_agrees(monkeypatch):
+    """The gradient path's attention runs on the hand-written fp32-CLASS kernels by default (three bf16-pair products per matrix product);
+    ``SSDNERF_UNET_GRAD_ATT_KERNEL=0`` (module flag ``unet.GRAD_ATT_KERNEL``) keeps the library's true-fp32 scaled_dot_product_attention reachable.
+    Both at the bench's attention shapes (8 scenes x 4 heads; T = 1024 / 256 / 64, head width 64 / 128 / 128): outputs and input gradients agree to
+    the stated tolerance (2e-4 of the largest entry: the three-product class), and a batch x heads product beyond the kernels' grid limit takes the
+    library path instead of raising."""
+    from ssdnerf_amd import unet as U
+    g = torch.Generator().manual_seed(3)
+    for c, hw in ((256, 32), (512, 16), (512, 8)):
+        blk = U.MultiHeadAttentionMod(c, num_heads=4).cuda()
+        _randomize(blk, 11, scale=1.0)
+        blk.requires_grad_(False)
+        x = torch.randn(8, c, hw, hw, generator=g).cuda()
+        res = {}
+        for flag in (True, False):
+            monkeypatch.setattr(U, "GRAD_ATT_KERNEL", flag)
+            xi = x.clone().requires_grad_(True)
+            y = blk(xi)
+            (gx,) = torch.autograd.grad((y * torch.cos(y.detach())).sum(), xi)
+            res[flag] = (y.detach(), gx)
+        for a, b, what in ((res[True][0], res[False][0], "output"), (res[True][1], res[False][1], "input gradient")):
+            tol = 2e-4 * float(b.abs().max())
+            assert float((a - b).abs().max()) <= tol, (c, hw, what, float((a - b).abs().max()), tol)
+    monkeypatch.setattr(U, "GRAD_ATT_KERNEL", True)
+    assert U.attention_kernel_ok(torch.empty(1, 64, 3 * 256, device="cuda"), heads=4)
+    assert not U.attention_kernel_ok(torch.empty(20000, 4, 3 * 32, device="cuda"), heads=4)      # 80 000 (batch, head) pairs > 65 535 grid rows
