@@ -39,7 +39,10 @@ def _model(test_cfg, autocast_dtype=None, plane_dtype="float32", betas=BETAS, un
     m = MODELS.build(dict(
         type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64,
         autocast_dtype=autocast_dtype,
-        diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(betas), denoising=dict(unet)),
+        diffusion=dict(type="GaussianDiffusion", num_timesteps=1000, betas_cfg=dict(betas), denoising=dict(unet), denoising_mean_mode="V",
+                       timestep_sampler=dict(type="SNRWeightedTimeStepSampler", power=0.5),
+                       ddpm_loss=dict(type="DDPMMSELossMod", rescale_mode="timestep_weight", data_info=dict(pred="v_t_pred", target="v_t"),
+                                      weight_scale=4.0, scale_norm=True)),
         decoder=dict(DEC, plane_dtype=plane_dtype), decoder_use_ema=True, freeze_decoder=False, bg_color=1,
         pixel_loss=dict(type="MSELoss", loss_weight=20.0), reg_loss=dict(type="RegLoss", power=2, loss_weight=3e-3), cache_size=0, test_cfg=test_cfg))
     _randomize(m.diffusion_ema.denoising, 9)
@@ -123,8 +126,9 @@ def test_guided_ddim_trajectory_matches_oracle():
     print(f"guided trajectory: max|code - oracle| = {err:.3e} (rms {rms_err:.3e}); guidance moved the result by {moved:.3e} (rms {rms_moved:.3e}); "
           f"unguided max|code - oracle| = {err_plain:.3e}; samples per guided render {points}")
     assert moved > 1e-2, "guidance must move the trajectory measurably for this comparison to mean anything"
-    assert err_plain <= 2e-4
-    assert err <= 2e-3 * moved + 2e-4 and rms_err <= 2e-3 * rms_moved + 2e-5
+    # measured on the MI355X (r04): err 1.4e-6 / rms 3.2e-8 for a guidance displacement of 1.7e-1 / rms 1.5e-3, unguided 7e-7
+    assert err_plain <= 2e-5
+    assert err <= 2e-4 * moved + 1e-5 and rms_err <= 2e-4 * rms_moved + 1e-6
     for s in range(S_):                                                          # the occupancy state the objective owns, after its last refresh
         np.testing.assert_allclose(grid[s].cpu().numpy(), grids[s], rtol=2e-3, atol=2e-5)
 
@@ -154,8 +158,13 @@ def test_config5_guided_langevin_bf16_fp16_against_fp32():
     opt_jits = [torch.rand(64 ** 3, 3, generator=g) for _ in range(1)]
     pose, intr = S.spiral_poses()[[64, 100]], S.cars_intrinsics(hw, hw)
     out = {}
-    for name, ac, pd in (("fp32", None, "float32"), ("mixed", "bfloat16", "float16")):
+    # "mixed": the shipped form -- under autocast the guided / fine-tuning UNet calls run the fp32-class gradient kernels (unet.DenoisingUnetMod.
+    # grad_path_fp32_under_autocast), so only the fp16 planes separate it from fp32.  "mixed_bf16_unet": the eager modules under bf16 autocast
+    # (SSDNERF_UNET_GRAD_AUTOCAST=1, the reference's arithmetic for this config) -- the real mixed-precision tolerance check.
+    for name, ac, pd, eager in (("fp32", None, "float32", False), ("mixed", "bfloat16", "float16", False), ("mixed_bf16_unet", "bfloat16", "float16", True)):
         m = _model(dict(cfg), autocast_dtype=ac, plane_dtype=pd)
+        if eager:
+            m.diffusion_ema.denoising.grad_path_fp32_under_autocast = False
         assert len(m.diffusion_ema.sampling_plan("ddim")) == n_eval
         data = dict(cond_imgs=targets.cuda(), cond_intrinsics=intr.cuda()[None, None].expand(S_, 1, -1), cond_poses=pose[:1].cuda()[None].expand(S_, -1, -1, -1),
                     noise=x_T.cuda(), test_poses=pose.cuda()[None].expand(S_, -1, -1, -1), test_intrinsics=intr.cuda()[None, None].expand(S_, 2, -1))
@@ -164,10 +173,11 @@ def test_config5_guided_langevin_bf16_fp16_against_fp32():
                          march_noises=[n.cuda() for n in opt_marches], optim_density_jitters=[j.cuda() for j in opt_jits])
         out[name] = (res["code"].float().cpu(), res["pred_imgs"].float().cpu())
         assert bool(torch.isfinite(res["code"]).all())
-    rel = float((out["mixed"][0] - out["fp32"][0]).norm() / out["fp32"][0].norm())
-    psnr = eval_psnr(out["mixed"][1].flatten(0, 1), out["fp32"][1].flatten(0, 1))
-    print(f"config 5 mix vs fp32: code rel distance {rel:.3e}, PSNR per view {[round(float(p), 1) for p in psnr]}")
-    assert rel < 2e-2 and float(psnr.min()) > 30.0
+    for name, rel_max, psnr_min in (("mixed", 1e-4, 45.0), ("mixed_bf16_unet", 2e-2, 30.0)):
+        rel = float((out[name][0] - out["fp32"][0]).norm() / out["fp32"][0].norm())
+        psnr = eval_psnr(out[name][1].flatten(0, 1), out["fp32"][1].flatten(0, 1))
+        print(f"config 5 {name} vs fp32: code rel distance {rel:.3e}, PSNR per view {[round(float(p), 1) for p in psnr]}")
+        assert rel < rel_max and float(psnr.min()) > psnr_min, (name, rel, psnr)
 
 
 # ---------------------------------------------------------------------------------------------- direction term, weights outside the Xavier range
