@@ -166,7 +166,7 @@ def main():
     # N > 1: every rank ends up with every rank's quantised views (RCCL all-gather over xGMI).  The collective of step i runs on RCCL's
     # stream while step i+1 renders (two landing buffers); the compute stream only waits for it before issuing the next collective.
     gathered = [torch.empty(world * ns, nv, hw, hw, 3, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
-    pending = {"work": None, "i": 0, "keep": None}
+    pending = {"work": None, "i": 0, "keep": None, "waits": []}   # waits: HIP event pairs around every wait of the compute stream for a collective
 
     def step(planes_, bits_, events=None, code_=None):
         dec.stage_events = [] if events is not None else None      # HIP events on the launch stream: [before A, between A and B, after B]
@@ -178,15 +178,22 @@ def main():
         img_u8 = (out["image_u8"] if "image_u8" in out else nerf.quantize_u8(out["image"])).reshape(ns, nv, hw, hw, 3)
         if world > 1:
             if pending["work"] is not None:
-                pending["work"].wait()
+                wait_collective()
             pending["keep"] = img_u8                     # the source must stay alive until the collective has run
             pending["work"] = dist.all_gather_into_tensor(gathered[pending["i"] & 1], img_u8, async_op=True)
             pending["i"] += 1
         return out
 
+    def wait_collective():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        pending["work"].wait()                           # (the compute STREAM waits; the host does not)
+        e1.record()
+        pending["waits"].append((e0, e1))
+
     def drain():
         if pending["work"] is not None:
-            pending["work"].wait()
+            wait_collective()
             pending["work"] = None
 
     def stat_pass(planes_, bits_):
@@ -205,6 +212,7 @@ def main():
             step(planes_, bits_, None, code_)
         drain()
         torch.cuda.synchronize()
+        del pending["waits"][:]
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -218,6 +226,12 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if world > 1:
+            # per-rank breakdown (r04): this rank's own wall time, its render launches and how long its compute stream stood waiting for collectives
+            mine = torch.tensor([elapsed / steps * 1e3, float(np.mean([e[0].elapsed_time(e[2]) for e in events])),
+                                 sum(a.elapsed_time(b) for a, b in pending["waits"]) / steps], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            pending["per_rank"] = [dict(rank=r, ms_per_step=float(v[0]), render_ms=float(v[1]), gather_wait_ms=float(v[2])) for r, v in enumerate(every)]
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -227,6 +241,7 @@ def main():
     log(f"stat pass done: {stats['n_samples']} samples, overflow {stats['overflow']}, boundary tests {stats['boundary']}")
     code_dev = code_cpu.to(dev)                              # (only read if a batch must be redone through the stepwise path)
     elapsed, kernel_events, out = timed(planes, bits, args.warmup, args.steps, code_dev)
+    per_rank = pending.get("per_rank")
     n_samples = stats["n_samples"]
     if world > 1:
         tot = torch.tensor([n_samples], dtype=torch.float64, device=dev)
@@ -290,6 +305,11 @@ def main():
                          "launch_ms": first_hit_ms, "algorithmic_bytes_per_launch": first_hit_bytes,
                          "achieved_GBs": first_hit_bytes / (first_hit_ms * 1e-3) / 1e9}}},
         "hit_rays_per_step_per_gpu": n_hit,
+        "per_rank": None if per_rank is None else {
+            "ranks": per_rank, "slowest_rank": max(per_rank, key=lambda r: r["ms_per_step"])["rank"],
+            "note": "ms_per_step: the rank's own wall clock over the timed steps (the line's ms_per_step is the max); render_ms: HIP events around its two "
+                    "render launches; gather_wait_ms: HIP events around every wait of its compute stream for an all-gather (0 when the collective hides "
+                    "behind the next render)"},
         "boundary_rays": {"termination_tests_within_2e-6_of_T_thresh": stats["boundary"], "samples_per_step_per_gpu": n_samples},
     }
 
@@ -545,13 +565,20 @@ def sampling_leg(model, dev, ns, nv, hw, n_steps, dtype_name, rank, world, dist,
                 dist.barrier()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+            ranks = None
             if world > 1:
+                mine = torch.tensor([el * 1e3, e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)], dtype=torch.float64, device=dev)
+                every = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                ranks = [dict(rank=r, total_ms=float(v[0]), ddim_ms=float(v[1]), density_ms=float(v[2]), render_ms=float(v[3])) for r, v in enumerate(every)]
                 t = torch.tensor([el], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = float(t.item())
             if rep and (best is None or el < best["total_s"]):
                 best = dict(total_s=el, ddim_ms=e0.elapsed_time(e1), density_ms=e1.elapsed_time(e2), render_ms=e2.elapsed_time(e3),
                             finite=bool(torch.isfinite(image).all()))
+                if ranks is not None:
+                    best.update(per_rank=ranks, slowest_rank=max(ranks, key=lambda r: r["total_ms"])["rank"])
     finally:
         model.autocast_dtype = None
     out = dict(scenes_per_s=world * ns / best["total_s"], scenes_per_rank=ns, n_gpus=world, unet_dtype=dtype_name, **best)

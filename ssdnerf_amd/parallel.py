@@ -59,3 +59,22 @@ def reduce_mean(x: torch.Tensor) -> torch.Tensor:
     x = x.clone().div_(dist.get_world_size())
     dist.all_reduce(x, op=dist.ReduceOp.SUM)
     return x
+
+
+def weighted_log_vars(log_vars: dict, batch_sizes: List[int], device=None) -> dict:
+    """The closing reduction of a scene-parallel evaluation (lib/apis/test.py:58-73): every logged scalar is averaged over ALL scenes of all
+    ranks, weighted by the number of scenes of the batch it came from -- sum_ranks(sum_batches(value * n)) / sum_ranks(sum_batches(n)) -- with one
+    scalar all_reduce per key plus one for the denominator.  ``log_vars``: key -> list of per-batch values of THIS rank; ``batch_sizes``: scenes per
+    batch of this rank (ranks may hold different numbers of batches and ragged last batches)."""
+    n = torch.tensor(batch_sizes, dtype=torch.float, device=device)
+    total = n.sum()
+    distributed = dist.is_available() and dist.is_initialized()
+    if distributed:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    out = {}
+    for key, values in log_vars.items():
+        acc = (torch.tensor([float(v) for v in values], dtype=torch.float, device=device) * n).sum()
+        if distributed:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        out[key] = float(acc / total)
+    return out

@@ -100,3 +100,61 @@ def test_two_rank_cache_shards_and_averaged_training_statistics():
     # running_mean: 0.5 * mean_ranks(rank) = 0.25; running_var: 0.5 * 0.25 + 0.5 * mean_ranks(var) with var = 0.8 on both ranks
     assert res[0][3] == pytest.approx(0.25) and res[1][3] == pytest.approx(0.25)
     assert res[0][4] == pytest.approx(0.5 * 0.25 + 0.5 * 0.8) and res[1][4] == pytest.approx(res[0][4])
+
+
+# ---------------------------------------------------------------------------------------------- world_size 8: the node the north star names
+def _worker_node(rank, world, port, n_scenes, per_gpu, q):
+    """One rank of an 8-rank scene-parallel evaluation shaped like lib/apis/test.py:12-73 over lib/datasets/samplers/distributed_sampler.py:27-40:
+    the rank walks ITS shard of the scene list in batches of ``per_gpu`` scenes (ragged last batch), "renders" them (scene s -> views filled with
+    s mod 251, a PSNR-like scalar 20 + s), all ranks exchange the rendered views of the batch, and the logged scalar is reduced at the end."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssdnerf_amd import parallel
+    bounds = parallel.shard_bounds(n_scenes, world)
+    mine = list(parallel.shard_scenes(n_scenes, rank, world))
+    n_batches = max(-(-int(bounds[r + 1] - bounds[r]) // per_gpu) for r in range(world))      # every rank runs the same number of batches (the sampler pads)
+    ok, log, sizes = True, [], []
+    for b in range(n_batches):
+        ids = mine[b * per_gpu:(b + 1) * per_gpu]
+        views = (torch.stack([torch.full((1, 2, 2, 3), s % 251, dtype=torch.uint8) for s in ids]) if ids
+                 else torch.zeros(0, 1, 2, 2, 3, dtype=torch.uint8))
+        equal = all(min(per_gpu, max(0, int(bounds[r + 1] - bounds[r]) - b * per_gpu)) == len(ids) for r in range(world))
+        parts = [parallel.all_gather_views(views).reshape(world, len(ids), 1, 2, 2, 3)[r] for r in range(world)] if equal and ids \
+            else parallel.all_gather_ragged_views(views)
+        for r, part in enumerate(parts):                                       # what every rank holds after the exchange: rank r's scenes of this batch
+            want = list(range(int(bounds[r]), int(bounds[r + 1])))[b * per_gpu:(b + 1) * per_gpu]
+            ok = ok and part.shape[0] == len(want) and all(int(part[i].min()) == want[i] % 251 == int(part[i].max()) for i in range(len(want)))
+        if ids:
+            log.append(sum(20.0 + s for s in ids) / len(ids))
+            sizes.append(len(ids))
+    red = parallel.weighted_log_vars(dict(psnr=log), sizes)
+    q.put((rank, mine[0] if mine else -1, len(mine), ok, red["psnr"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scenes", [704, 701])
+def test_eight_rank_scene_parallel_evaluation(n_scenes):
+    """The 8-GPU node of north_star on gloo: 704 test scenes (SRN cars) -> the reference's 88-scene shards, 8 scenes per rank per batch, 11 batches;
+    701 scenes -> shards of 88 / 87 / 88 / ... with ragged last batches.  Every rank must end up with every rank's views of every batch, and the
+    sample-weighted metric must equal the plain mean over all scenes."""
+    world, per_gpu = 8, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_node, args=(r, world, port, n_scenes, per_gpu, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    from ssdnerf_amd.parallel import shard_bounds
+    b = shard_bounds(n_scenes, world)
+    assert [r[1] for r in res] == [int(v) for v in b[:-1]] and [r[2] for r in res] == [int(b[i + 1] - b[i]) for i in range(world)]
+    if n_scenes == 704:
+        assert all(r[2] == 88 for r in res)
+    assert all(r[3] for r in res)
+    want = 20.0 + (n_scenes - 1) / 2
+    assert all(abs(r[4] - want) < 1e-3 for r in res), ([r[4] for r in res], want)
