@@ -561,13 +561,14 @@ def sampling_leg(model, dev, ns, nv, hw, n_steps, dtype_name, rank, world, dist,
                 if world > 1:
                     dist.all_gather_into_tensor(gathered, img_u8)
             torch.cuda.synchronize()
+            own = time.perf_counter() - t0                   # this rank's own time (the all-gather included), before it waits for the others
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             ranks = None
             if world > 1:
-                mine = torch.tensor([el * 1e3, e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)], dtype=torch.float64, device=dev)
+                mine = torch.tensor([own * 1e3, e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)], dtype=torch.float64, device=dev)
                 every = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(every, mine)
                 ranks = [dict(rank=r, total_ms=float(v[0]), ddim_ms=float(v[1]), density_ms=float(v[2]), render_ms=float(v[3])) for r, v in enumerate(every)]

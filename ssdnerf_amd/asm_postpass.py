@@ -18,6 +18,13 @@ most recent writer (within the window) is a transcendental, make the number of i
 lengthening an `s_nop` that already sits directly in front of the reader (the usual case: no code moves), else by inserting one.  `s_nop N`
 counts N + 1 slots, every other instruction 1.  The pass is idempotent.  ``build.py`` runs it on every source of the library (the rule is a
 property of the hardware, not of one kernel) and records the counts in ``lib/postpass_report.json``.
+
+r04 (the r03 advisor's holes): (1) a call (`s_swappc`) or a function entry leaves EVERY VGPR pending -- the callee / caller may have produced any of
+them with a transcendental -- instead of clearing the history; (2) the per-label pending sets are iterated to a fixpoint, so what a predecessor's
+predecessor left in flight reaches a block through a short intermediate block; (3) the single-index register syntax `v[7]` is parsed; (4) LDS-DMA
+loads (`buffer_load ... lds`, `global_load_lds_*`) have no VGPR destination: their first operand is an address that is READ; (5) the invariant is
+re-checked on the LINKED CODE OBJECT by ``verify_code_object`` -- `llvm-objdump -d` of what the device will run, tokenised by a second, deliberately
+dumb scanner (any mention of the register by a VALU instruction counts, whichever operand) that shares no code with the listing parser.
 """
 from __future__ import annotations
 
@@ -25,7 +32,8 @@ import re
 from typing import Dict, List, Set, Tuple
 
 TRANS = ("v_exp_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_log_", "v_sin_", "v_cos_")
-_REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+_REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]|\bv\[(\d+)\]")
+ALL_VGPRS = frozenset(range(512))
 _LABEL = re.compile(r"^[A-Za-z_.$][\w.$]*:")
 
 
@@ -34,6 +42,8 @@ def _vregs(tok: str) -> Set[int]:
     for m in _REG.finditer(tok):
         if m.group(1) is not None:
             out.add(int(m.group(1)))
+        elif m.group(4) is not None:
+            out.add(int(m.group(4)))
         else:
             out.update(range(int(m.group(2)), int(m.group(3)) + 1))
     return out
@@ -68,7 +78,8 @@ def _parse(line: str):
         return op, set(), set(), 1
     stores = op.startswith(("ds_write", "ds_add", "global_store", "buffer_store", "flat_store", "scratch_store", "global_atomic", "buffer_atomic"))
     swaps = op.startswith(("v_permlane32_swap", "v_permlane16_swap", "v_swap"))
-    no_vdst = stores or op.startswith(("v_cmp", "v_cmpx", "v_nop", "v_readlane", "v_readfirstlane"))
+    lds_dma = op.startswith("global_load_lds") or (op.startswith(("buffer_load", "global_load")) and re.search(r"\blds\b", text.split(None, 1)[1] if len(parts) > 1 else ""))
+    no_vdst = stores or lds_dma or op.startswith(("v_cmp", "v_cmpx", "v_nop", "v_readlane", "v_readfirstlane"))
     writes: Set[int] = set()
     reads: Set[int] = set()
     for i, o in enumerate(ops):
@@ -85,7 +96,13 @@ def _parse(line: str):
 
 
 _BRANCH = ("s_cbranch", "s_branch")
-_NO_FALLTHROUGH = ("s_branch", "s_endpgm", "s_setpc", "s_swappc")
+_NO_FALLTHROUGH = ("s_branch", "s_endpgm", "s_setpc")
+_CALL = ("s_swappc",)
+
+
+def _all_pending() -> list:
+    """history entry for 'any VGPR may just have been written by a transcendental' (function entry, return from a call)"""
+    return ["v_exp_(unknown code)", set(ALL_VGPRS), set(), 0, -1]
 
 
 def _pending_trans(run: List[list], window: int, extra_slots: int = 0) -> Dict[int, int]:
@@ -127,26 +144,49 @@ def _walk(listing: str, wait_states: int, edit: bool):
     """one walk over the kernels of a listing, control flow included: a block that is entered by a branch (loop back-edges too) or by fall-through
     starts with the transcendental results its predecessors may have left in flight.  edit=False: only measure (returns the closest pair)."""
     lines = listing.split("\n")
-    # pass 1: what is pending at every branch, per target label (the branch itself is one issue slot)
-    at_label: Dict[str, List[Dict[int, int]]] = {}
-    run: List[list] = []
-    for raw in lines:
-        t = raw.strip()
-        m = _LABEL.match(t)
-        if m:
-            continue                                            # (fall-through keeps the run; pass 2 merges the branch predecessors in)
-        ins = _parse(raw)
-        if ins is None:
-            continue
-        op, writes, reads, slots = ins
-        run.append([op, writes, reads, slots, -1])
-        if op.startswith(_BRANCH):
-            target = t.split()[-1]
-            pend = _pending_trans(run, wait_states + 8)
-            if pend:
-                at_label.setdefault(target, []).append(pend)
-        if op.startswith(_NO_FALLTHROUGH):
-            run = []
+    kernels = {m.group(1) for m in re.finditer(r"^\s*\.amdhsa_kernel\s+(\S+)", listing, re.M)}   # entry points: the hardware starts them with nothing in flight
+
+    def entry_state(label_line: str) -> list:
+        return [] if label_line.split(":")[0] in kernels else [_all_pending()]
+    # pass 1: what is pending at every branch, per target label (the branch itself is one issue slot).  A block's own start state depends on the
+    # pending sets of ITS predecessors, so the sets are iterated to a fixpoint (distances only shrink and are bounded by the window)
+    window = wait_states + 8
+    at_label: Dict[str, Dict[int, int]] = {}
+    for _ in range(16):
+        new_at: Dict[str, Dict[int, int]] = {}
+        run: List[list] = []
+        for raw in lines:
+            t = raw.strip()
+            if _LABEL.match(t):
+                name = t.split(":")[0]
+                if re.match(r"^[\w$.]+:\s*(;.*)?$", t) and not t.startswith(".L"):
+                    run = entry_state(t)                        # a function / kernel entry
+                else:
+                    preds = [at_label[name]] if name in at_label else []
+                    fall = _pending_trans(run, window)
+                    if fall:
+                        preds.append(fall)
+                    run = _history(preds)
+                continue
+            ins = _parse(raw)
+            if ins is None:
+                continue
+            op, writes, reads, slots = ins
+            run.append([op, writes, reads, slots, -1])
+            if op.startswith(_CALL):
+                run = [_all_pending()]
+            if op.startswith(_BRANCH):
+                target = t.split(";")[0].split()[-1]
+                pend = _pending_trans(run, window)
+                if pend:
+                    cur = new_at.setdefault(target, {})
+                    for r, d in pend.items():
+                        cur[r] = min(d, cur.get(r, 1 << 30))
+            if op.startswith(_NO_FALLTHROUGH):
+                run = []
+        if new_at == at_label:
+            break
+        at_label = new_at
     # pass 2
     out: List[str] = []
     run = []
@@ -158,15 +198,17 @@ def _walk(listing: str, wait_states: int, edit: bool):
         if t.startswith((".amdhsa_kernel", ".end_amdhsa_kernel")):
             in_kernel = False
         elif re.match(r"^[\w$.]+:\s*(;.*)?$", t) and not t.startswith(".L"):
-            in_kernel, run = True, []                           # a function / kernel entry label
+            in_kernel, run = True, entry_state(t)               # a device FUNCTION's caller may have left anything in flight; a kernel starts clean
+            out.append(raw)
+            continue
         if not in_kernel:
             out.append(raw)
             continue
         m = _LABEL.match(t)
         if m:
             name = t.split(":")[0]
-            preds = list(at_label.get(name, []))
-            fall = _pending_trans(run, wait_states + 8)
+            preds = [at_label[name]] if name in at_label else []
+            fall = _pending_trans(run, window)
             if fall:
                 preds.append(fall)
             run = _history(preds)
@@ -205,12 +247,14 @@ def _walk(listing: str, wait_states: int, edit: bool):
                 stats["inserted"] += 1
         out.append(raw)
         run.append([op, writes, reads, slots, len(out) - 1])
+        if op.startswith(_CALL):
+            run = [_all_pending()]                              # whatever the callee did last
         if op.startswith(_NO_FALLTHROUGH):
             run = []
     return "\n".join(out), stats, closest
 
 
-def pad_trans_use(listing: str, wait_states: int = 2) -> Tuple[str, Dict[str, int]]:
+def pad_trans_use(listing: str, wait_states: int = 4) -> Tuple[str, Dict[str, int]]:
     out, stats, _ = _walk(listing, wait_states, True)
     return out, stats
 
@@ -219,3 +263,85 @@ def closest_trans_use(listing: str) -> int:
     """smallest number of issue slots between a transcendental and the first VALU reader of its result in the listing, across branches and
     fall-through as well (a large number if there is no such pair): the invariant the build asserts after the pass"""
     return _walk(listing, 0, False)[2]
+
+
+# ---------------------------------------------------------------------------------------------- independent check on the linked code object
+_DIS_REG = re.compile(r"(?<![\w.])v(\d+)(?![\w\[])|(?<![\w.])v\[(\d+)(?::(\d+))?\]")
+
+
+def _mentions(operands: str) -> Set[int]:
+    regs: Set[int] = set()
+    for a, lo, hi in _DIS_REG.findall(operands):
+        if a:
+            regs.add(int(a))
+        else:
+            regs.update(range(int(lo), int(hi or lo) + 1))
+    return regs
+
+
+def verify_code_object(path: str, wait_states: int, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump") -> Dict[str, int]:
+    """Check the trans -> use rule on the instructions the device will execute: `llvm-objdump -d --symbolize-operands` of the linked code object.
+    Deliberately NOT the listing parser: every instruction is (mnemonic, set of VGPRs it mentions anywhere); from each transcendental, every
+    control-flow path (both sides of conditional branches, back-edges included) is followed for ``wait_states`` issue slots, and the first VALU
+    instruction on a path that mentions a destination register of the transcendental must not be closer than that.  Mentions as a destination count
+    too (conservative: an overwrite this close would be flagged; none exists in the library).  Returns counts; raises RuntimeError on a violation."""
+    import subprocess
+    text = subprocess.run([objdump, "-d", "--symbolize-operands", path], check=True, capture_output=True, text=True).stdout
+    ins: List[Tuple[str, str]] = []
+    labels: Dict[str, int] = {}
+    for line in text.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        body = line.split("//")[0].strip()
+        if not body or not line.startswith(("\t", " ")):
+            continue
+        parts = body.split(None, 1)
+        ins.append((parts[0], parts[1] if len(parts) > 1 else ""))
+    n_trans = closest = 0
+    closest = 1 << 30
+    worst = None
+    for i, (op, operands) in enumerate(ins):
+        if not op.startswith(TRANS):
+            continue
+        n_trans += 1
+        first = operands.split(",")[0]
+        dst = _mentions(first)
+        stack = [(i + 1, 0, frozenset(dst))]
+        seen = set()
+        while stack:
+            j, used, live = stack.pop()
+            while j < len(ins) and used < wait_states + 4 and live:           # (4 slots beyond the rule, so that the report shows the actual margin)
+                if (j, used, live) in seen:
+                    break
+                seen.add((j, used, live))
+                o, args = ins[j]
+                if o == "s_nop":
+                    used += int(args.strip(), 0) + 1
+                    j += 1
+                    continue
+                if o.startswith("v_"):
+                    hit = _mentions(args) & live
+                    if hit:
+                        if used < closest:
+                            closest, worst = used, (i, j)
+                        live = live - hit
+                if o.startswith(("s_endpgm", "s_setpc")):
+                    break
+                if o.startswith("s_branch"):
+                    tgt = args.split()[0]
+                    j = labels.get(tgt, len(ins))
+                    used += 1
+                    continue
+                if o.startswith("s_cbranch"):
+                    tgt = args.split()[0]
+                    if tgt in labels:
+                        stack.append((labels[tgt], used + 1, live))
+                used += 1
+                j += 1
+    if closest < wait_states:
+        a, b = worst
+        raise RuntimeError(f"{path}: `{ins[a][0]} {ins[a][1]}` is read {closest} issue slots later by `{ins[b][0]} {ins[b][1]}` in the linked code object "
+                           f"(instructions {a} and {b}); the build requires {wait_states}")
+    return dict(trans_instructions=n_trans, closest_pair=None if closest == 1 << 30 else closest)

@@ -4,10 +4,16 @@
 where the sources call ``__builtin_fmaf``, so integer outputs (sample counts, alive flags) are
 reproducible bit for bit against the CPU oracle.
 
-Every source goes  hipcc -S (device listing) -> ``asm_postpass.pad_trans_use`` (two wait states behind every transcendental instruction:
-the toolchain pads that hazard to one, which is not always enough on gfx950 with two waves on a SIMD -- see asm_postpass.py and
-profiles/r03/hazard.txt) -> assembler -> lld -> offload bundle -> host object that embeds it.  ``SSDNERF_NO_POSTPASS=1`` builds the
-compiler's own code (A/B runs only).  ``lib/postpass_report.json`` records what the pass did per source.
+Every source goes  hipcc -S (device listing) -> ``asm_postpass.pad_trans_use`` (FOUR issue slots, ``TRANS_USE_WAIT_STATES``, behind every
+transcendental instruction before its result is read: the toolchain pads that hazard to one, which is not always enough on gfx950 with two waves
+on a SIMD -- see asm_postpass.py and profiles/r03/hazard.txt) -> assembler -> lld -> ``asm_postpass.verify_code_object`` (the rule re-checked on
+the LINKED code object with an independent scanner) -> offload bundle -> host object that embeds it.  ``SSDNERF_NO_POSTPASS=1`` builds the
+compiler's own code (A/B runs only).  ``lib/postpass_report.json`` records what the pass did per source, the settings, and the toolchain.
+
+The pass parses the device listing syntax of ROCm 7.2 and re-states `hipcc -c`'s internal device steps, so it is PINNED to the toolchains it was
+validated on (``VALIDATED_HIP_VERSIONS``): another `hipcc --version` fails the build loudly (``SSDNERF_ALLOW_UNVALIDATED_TOOLCHAIN=1`` overrides
+after the hazard runs of tools/ubench/gen_trans_use_hazard.py and tests/test_render_gpu.py::test_fused_render_is_reproducible_bit_for_bit have been
+repeated on it).
 """
 from __future__ import annotations
 
@@ -24,6 +30,7 @@ SOURCES = ["raymarching_ops.hip", "shencoder.hip", "decode.hip", "render_fused.h
 LLVM_BIN = os.environ.get("SSDNERF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 TRANS_USE_WAIT_STATES = int(os.environ.get("SSDNERF_TRANS_USE_WAIT_STATES", "4"))
 HEADERS = ["common.h", "sh_basis.h", "decode_core.h", "decode_bwd_math.h", "gn_bwd_math.h", os.path.join("..", "..", "include", "ssdnerf_hip.h")]
+VALIDATED_HIP_VERSIONS = ("7.2.",)              # prefixes of `hipcc --version`'s "HIP version:" the post-pass + hazard analysis were validated on (r03 / r04)
 FLAGS = os.environ.get("SSDNERF_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-result"]
 
 
@@ -34,8 +41,30 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+def _settings() -> dict:
+    """what, besides the sources, decides the bytes of the library: compared with the shipped report by needs_build()"""
+    return {"wait_states": TRANS_USE_WAIT_STATES if os.environ.get("SSDNERF_NO_POSTPASS", "0") != "1" else None,
+            "extra_flags": os.environ.get("SSDNERF_EXTRA_FLAGS", "")}
+
+
+def toolchain() -> dict:
+    try:
+        text = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, check=True).stdout
+    except Exception as e:                                           # noqa: BLE001
+        return {"hip_version": None, "validated": False, "error": repr(e)}
+    hip = next((l.split(":", 1)[1].strip() for l in text.splitlines() if l.startswith("HIP version")), None)
+    clang = next((l.strip() for l in text.splitlines() if "clang version" in l), None)
+    return {"hip_version": hip, "clang": clang, "validated": bool(hip) and hip.startswith(VALIDATED_HIP_VERSIONS)}
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
+        return True
+    try:
+        with open(os.path.join(LIB_DIR, "postpass_report.json")) as f:
+            if json.load(f).get("settings") != _settings():
+                return True                                          # SSDNERF_TRANS_USE_WAIT_STATES / SSDNERF_NO_POSTPASS / SSDNERF_EXTRA_FLAGS changed
+    except Exception:                                                # noqa: BLE001
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "asm_postpass.py")]
@@ -48,10 +77,17 @@ def _run(cmd, verbose):
     subprocess.check_call(cmd)
 
 
+def assemble_and_link(dev_s: str, dev_o: str, dev_out: str, verbose: bool = False) -> None:
+    """device listing -> device object -> linked code object (the two device steps `hipcc -c` runs internally after its -S stage)"""
+    _run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", dev_s, "-o", dev_o], verbose)
+    _run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-plugin-opt=-amdgpu-internalize-symbols",
+          "-plugin-opt=mcpu=gfx950", "-o", dev_out, dev_o], verbose)
+
+
 def _compile_with_postpass(src: str, obj: str, verbose: bool) -> dict:
     """device listing -> post-pass -> device object -> code object -> fat binary -> host object embedding it (the steps `hipcc -c` runs
     internally, with the listing edited in between); returns the post-pass statistics of this source"""
-    from .asm_postpass import closest_trans_use, pad_trans_use
+    from .asm_postpass import closest_trans_use, pad_trans_use, verify_code_object
     stem = obj[:-2]
     dev_s, dev_o, dev_out, fatbin = stem + ".dev.s", stem + ".dev.o", stem + ".dev.out", stem + ".hipfb"
     _run([_hipcc()] + FLAGS + ["-S", "--cuda-device-only", src, "-o", dev_s], verbose)
@@ -59,13 +95,14 @@ def _compile_with_postpass(src: str, obj: str, verbose: bool) -> dict:
         listing = f.read()
     patched, stats = pad_trans_use(listing, TRANS_USE_WAIT_STATES)
     closest = closest_trans_use(patched)
-    assert closest >= TRANS_USE_WAIT_STATES, f"{src}: a transcendental -> use pair is still {closest} slots apart after the post-pass"
+    if closest < TRANS_USE_WAIT_STATES:                              # (an explicit raise: `python -O` drops asserts)
+        raise RuntimeError(f"{src}: a transcendental -> use pair is still {closest} slots apart after the post-pass")
     stats["closest_pair_after"] = closest if closest < (1 << 30) else None
     with open(dev_s, "w") as f:
         f.write(patched)
-    _run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", dev_s, "-o", dev_o], verbose)
-    _run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-plugin-opt=-amdgpu-internalize-symbols",
-          "-plugin-opt=mcpu=gfx950", "-o", dev_out, dev_o], verbose)
+    assemble_and_link(dev_s, dev_o, dev_out, verbose)
+    # the same rule on what the device will execute, by a scanner that shares nothing with the listing parser (raises on a violation)
+    stats["code_object_check"] = verify_code_object(dev_out, TRANS_USE_WAIT_STATES, os.path.join(LLVM_BIN, "llvm-objdump"))
     _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
           "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={dev_out}", f"-output={fatbin}"], verbose)
     _run([_hipcc()] + FLAGS + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", src, "-o", obj], verbose)
@@ -79,7 +116,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     postpass = os.environ.get("SSDNERF_NO_POSTPASS", "0") != "1"
-    objs, report = [], {"wait_states": TRANS_USE_WAIT_STATES if postpass else None, "sources": {}}
+    tc = toolchain()
+    if postpass and not tc["validated"] and os.environ.get("SSDNERF_ALLOW_UNVALIDATED_TOOLCHAIN", "0") != "1":
+        raise RuntimeError(f"ssdnerf_amd.build: the assembly post-pass was validated on HIP {VALIDATED_HIP_VERSIONS}*, this hipcc reports "
+                           f"{tc.get('hip_version')!r} ({tc.get('clang')}).  The pass parses the device listing and re-states hipcc's device link line; "
+                           "re-run the hazard checks on this toolchain (build.py docstring), then set SSDNERF_ALLOW_UNVALIDATED_TOOLCHAIN=1 or extend "
+                           "VALIDATED_HIP_VERSIONS.")
+    objs, report = [], {"wait_states": TRANS_USE_WAIT_STATES if postpass else None, "settings": _settings(), "toolchain": tc, "sources": {}}
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         if postpass:
@@ -93,5 +136,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_variant(name: str, source: str, extra_flags) -> str:
+    """Side build for A/B runs (no GPU needed): recompile ONE source with extra flags -- through the same post-pass -- and link it with the
+    in-tree objects into <repo>/.variants/<name>/libssdnerf_hip.so (git-ignored, shipped by gpurun).  Use on the GPU box with
+    SSDNERF_HIP_LIB=.variants/<name>/libssdnerf_hip.so."""
+    global FLAGS
+    build()
+    out_dir = os.path.join(os.path.dirname(HERE), ".variants", name)
+    os.makedirs(out_dir, exist_ok=True)
+    obj = os.path.join(out_dir, source.replace(".hip", ".o"))
+    saved = FLAGS
+    FLAGS = list(extra_flags) + FLAGS
+    try:
+        stats = _compile_with_postpass(os.path.join(CSRC, source), obj, False)
+    finally:
+        FLAGS = saved
+    objs = [obj if s == source else os.path.join(LIB_DIR, s.replace(".hip", ".o")) for s in SOURCES]
+    lib = os.path.join(out_dir, "libssdnerf_hip.so")
+    _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-o", lib] + objs, False)
+    os.remove(obj)
+    print(f"built {lib} ({source} {' '.join(extra_flags)}): {stats}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:                                      # python -m ssdnerf_amd.build --variant NAME --source shade_mfma.hip -- -DSM_X=1 ...
+        i = sys.argv.index("--variant")
+        extra = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []
+        build_variant(sys.argv[i + 1], sys.argv[sys.argv.index("--source") + 1], extra)
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

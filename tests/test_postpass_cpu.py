@@ -71,7 +71,76 @@ def test_real_listing_of_a_library_source_meets_the_invariant(tmp_path):
 def test_shipped_library_was_built_with_the_post_pass():
     import json
     report = json.load(open(os.path.join(B.LIB_DIR, "postpass_report.json")))
-    assert report["wait_states"] == B.TRANS_USE_WAIT_STATES >= 2
+    assert report["wait_states"] == B.TRANS_USE_WAIT_STATES >= 2 and report["toolchain"]["validated"] is True
     assert set(report["sources"]) == set(B.SOURCES)
     shade = report["sources"]["shade_mfma.hip"]
     assert shade["trans_instructions"] > 1000 and shade["closest_pair_after"] >= B.TRANS_USE_WAIT_STATES
+    # the same rule re-checked on the linked code object by the independent scanner (asm_postpass.verify_code_object)
+    assert shade["code_object_check"]["trans_instructions"] == shade["trans_instructions"] and shade["code_object_check"]["closest_pair"] >= B.TRANS_USE_WAIT_STATES
+
+
+HOLES = """
+	.text
+helper:                                 ; a device FUNCTION (not an .amdhsa_kernel): its caller may have left anything in flight
+	v_mul_f32_e32 v3, v0, v0
+	v_sqrt_f32_e32 v7, v0
+	v_pk_mul_f32 v[8:9], v[7], v[7]
+	v_exp_f32_e32 v12, v0
+	s_setpc_b64 s[30:31]
+_Z1kPf:
+	v_mul_f32_e32 v30, v0, v0
+	v_rcp_f32_e32 v5, v0
+	global_load_lds_dwordx4 v[5:6], off
+	v_mul_f32_e32 v6, v5, v0
+	v_exp_f32_e32 v10, v0
+	s_cbranch_scc1 .LBB0_1
+	s_nop 0
+.LBB0_1:
+	s_cbranch_scc0 .LBB0_2
+	s_nop 0
+.LBB0_2:
+	v_mul_f32_e32 v11, v10, v0
+	v_log_f32_e32 v20, v0
+	s_swappc_b64 s[30:31], s[4:5]
+	v_mul_f32_e32 v21, v12, v0
+	s_endpgm
+	.amdhsa_kernel _Z1kPf
+	.end_amdhsa_kernel
+"""
+
+
+def test_post_pass_handles_the_r03_advisor_holes():
+    """(1) function entries / returns from calls leave every VGPR pending, a KERNEL entry none; (2) pending sets reach a block through a short
+    intermediate block (fixpoint over labels); (3) `v[7]`; (4) the first operand of an LDS-DMA load is read, not written."""
+    out, st = pad_trans_use(HOLES, 4)
+    lines = [l.strip() for l in out.split("\n")]
+    assert lines[lines.index("v_mul_f32_e32 v3, v0, v0") - 1] == "s_nop 3"                  # function entry: v0 may be a fresh transcendental result
+    assert lines[lines.index("v_mul_f32_e32 v30, v0, v0") - 1] == "_Z1kPf:"                 # kernel entry: nothing in flight
+    assert lines[lines.index("v_pk_mul_f32 v[8:9], v[7], v[7]") - 1] == "s_nop 3"           # v[7] is v7
+    assert lines[lines.index("v_mul_f32_e32 v6, v5, v0") - 1] == "s_nop 2"                  # the LDS-DMA load did not overwrite v5 (it is one slot)
+    # exp v10 -> branch (1 slot) -> .LBB0_1 -> branch (1 slot) -> .LBB0_2 -> reader: 2 slots on the all-taken path
+    assert lines[lines.index("v_mul_f32_e32 v11, v10, v0") - 1] == "s_nop 1"
+    assert lines[lines.index("v_mul_f32_e32 v21, v12, v0") - 1] == "s_nop 3"                # after the call: v12 may come from the callee's v_exp
+    assert closest_trans_use(out) >= 4
+    again, st2 = pad_trans_use(out, 4)
+    assert again == out
+
+
+def test_linked_code_object_is_verified_independently(tmp_path):
+    """``verify_code_object`` disassembles the LINKED device code object and re-checks the rule with its own scanner: the compiler's own code
+    object of a library source violates it (one wait state), the post-passed one passes, and both see the same transcendental count."""
+    from ssdnerf_amd.asm_postpass import verify_code_object
+    import pytest
+    src = os.path.join(B.CSRC, "raygen.hip")
+    raw_s, fixed_s = tmp_path / "raw.s", tmp_path / "fixed.s"
+    subprocess.check_call([B._hipcc()] + B.FLAGS + ["-S", "--cuda-device-only", src, "-o", str(raw_s)], stderr=subprocess.DEVNULL)
+    fixed_s.write_text(pad_trans_use(raw_s.read_text(), B.TRANS_USE_WAIT_STATES)[0])
+    outs = {}
+    for name, path in (("raw", raw_s), ("fixed", fixed_s)):
+        obj, out = tmp_path / f"{name}.o", tmp_path / f"{name}.out"
+        B.assemble_and_link(str(path), str(obj), str(out))
+        outs[name] = str(out)
+    with pytest.raises(RuntimeError, match="issue slots later"):
+        verify_code_object(outs["raw"], B.TRANS_USE_WAIT_STATES)
+    rep = verify_code_object(outs["fixed"], B.TRANS_USE_WAIT_STATES)
+    assert rep["trans_instructions"] > 0 and (rep["closest_pair"] is None or rep["closest_pair"] >= B.TRANS_USE_WAIT_STATES)
