@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/ab
 one() { # label, env...
   l=$1; shift
-  env "$@" timeout 120 python bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline > gpurun_out/ab/$l.json 2> gpurun_out/ab/$l.err < /dev/null
+  env "$@" timeout 120 python bench.py --steps 20 --warmup 10 --no-extras --no-cpu-baseline > gpurun_out/ab/$l.json 2> gpurun_out/ab/$l.err < /dev/null
   python - "$l" <<'PY'
 import json, sys
 l = sys.argv[1]
