@@ -368,8 +368,10 @@ int ssdnerf_attention_qkv_bf16(const void* qkv, void* out, uint32_t B, uint32_t 
  * TOLERANCE CLASS, stated because the name says f32: this is NOT IEEE fp32 arithmetic.  Each factor keeps 16 significand bits (the dropped
  * lo*lo term and the split's own remainder are both 2^-16 relative), so a logit or an output element carries a relative error of order 1e-5,
  * two decimal digits better than TF32 and two worse than fp32; the UNet's output differs from the fp32 module by 7e-6 relative at the
- * benchmarked shape (bench.py, ddim.fp32.rel_err_vs_eager).  Used by the inference executor only: the gradient path (guidance, fine-tuning)
- * runs the library's fp32 attention (ssdnerf_amd/unet.py, _forward_channel_last). */
+ * benchmarked shape (bench.py, ddim.fp32.rel_err_vs_eager).  Used by the inference executor and -- since r03, through the _lse / _backward entry
+ * points below -- by the gradient path (guidance, fine-tuning) as well: the reference computes those gradients in IEEE fp32, this path in the
+ * class above (tests: test_attention_backward_kernels_match_autograd, 5e-5 vs fp64 autograd).  SSDNERF_UNET_GRAD_ATT_KERNEL=0 keeps the library's
+ * true-fp32 scaled_dot_product_attention for the gradient path (tests/test_recons_gpu.py covers both), and B * heads > 65 535 falls back to it. */
 int ssdnerf_attention_qkv_f32(const void* qkv, void* out, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
 /* Forward that also saves what the backward needs, and the backward itself (r03: the gradient path of rendering guidance / fine-tuning, which r02 ran on
  * the library's fp32 attention): lse2 fp32 [B][heads][T] = the rows' log-sum-exp in the log2 domain; dout fp32 [B][T][heads*ch] = d loss / d out;
@@ -378,6 +380,21 @@ int ssdnerf_attention_qkv_f32(const void* qkv, void* out, uint32_t B, uint32_t T
 int ssdnerf_attention_qkv_f32_lse(const void* qkv, void* out, void* lse2, uint32_t B, uint32_t T, uint32_t heads, uint32_t ch, void* stream);
 int ssdnerf_attention_qkv_f32_backward(const void* qkv, const void* out, const void* dout, const void* lse2, void* dqkv, void* workspace, uint32_t B,
                                        uint32_t T, uint32_t heads, uint32_t ch, void* stream);
+
+/* ---- iso-surface extraction (replaces the PyMCubes call of lib/core/utils/nerf_utils.py:103-105) -----------------
+ * Marching cubes over volume fp32 [nx][ny][nz] (x-major, PyMCubes' indexing) at `iso` in two kernels around two prefix sums the caller runs:
+ *   _count : per lattice point p = (x*ny + y)*nz + z:  point_mask[p] = which of its owned edges (+x: bit 0, +y: bit 1, +z: bit 2) cross the
+ *            iso-value, point_verts[p] = their number, cell_tris[p] = triangles of the cell whose minimum corner is p (0 on the last layers).
+ *            tri_count: uint8 [256] triangles per corner-sign case (corner i INSIDE when its value > iso; ssdnerf_amd/mesh.py triangle_table).
+ *   _emit  : tri_offsets / vert_offsets = INCLUSIVE prefix sums of cell_tris / point_verts; tri_edges int8 [256][15] = cube-edge ids of every
+ *            case's triangles.  Writes vertices fp32 [V][3] in index coordinates (one per crossing lattice edge, linearly interpolated:
+ *            coordinate + (iso - a) / (b - a) along the edge) and triangles int32 [T][3] (indices into vertices; counter-clockwise seen from the
+ *            low-density side).  The mesh is watertight by construction of the table. */
+int ssdnerf_marching_cubes_count(const float* volume, uint32_t nx, uint32_t ny, uint32_t nz, float iso, const uint8_t* tri_count,
+                                 int32_t* cell_tris, int32_t* point_verts, uint8_t* point_mask, void* stream);
+int ssdnerf_marching_cubes_emit(const float* volume, uint32_t nx, uint32_t ny, uint32_t nz, float iso, const uint8_t* tri_count,
+                                const int8_t* tri_edges, const int32_t* tri_offsets, const int32_t* vert_offsets, const uint8_t* point_mask,
+                                float* vertices, int32_t* triangles, void* stream);
 
 #ifdef __cplusplus
 }

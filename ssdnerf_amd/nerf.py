@@ -175,16 +175,19 @@ def extract_density_volume(decoder: TriPlaneDecoder, code_single: torch.Tensor, 
     return extract_fields(aabb[:3] - 0.1, aabb[3:] + 0.1, resolution, query, device=code_single.device)
 
 
-def extract_geometry(decoder: TriPlaneDecoder, code_single: torch.Tensor, resolution: int = 256, threshold: float = 10):
-    """``vertices, triangles`` of the density iso-surface (nerf_utils.py:82-112).  The marching-cubes step is PyMCubes in the reference;
-    it is imported on use - the package is an optional dependency, everything up to the density volume is native."""
-    try:
-        import mcubes
-    except ImportError as e:
-        raise ImportError("extract_geometry needs PyMCubes (`mcubes`) for the marching-cubes step; `extract_density_volume` provides the "
-                          "volume it runs on") from e
+def extract_geometry(decoder: TriPlaneDecoder, code_single: torch.Tensor, resolution: int = 256, threshold: float = 10, backend: str = "native"):
+    """``vertices, triangles`` of the density iso-surface in world coordinates (nerf_utils.py:82-112).  The marching-cubes step is PyMCubes in
+    the reference; here it is native and runs on the GPU over the volume the fused density decode has just assembled there (``mesh.py``,
+    csrc/marching_cubes.hip): no 256^3 copy to the host.  ``backend='mcubes'`` calls PyMCubes instead where it is installed (same vertex rule;
+    the triangulation of ambiguous cells may differ).  Returns numpy arrays like the reference (vertices float, triangles int)."""
     u = extract_density_volume(decoder, code_single, resolution)
-    vertices, triangles = mcubes.marching_cubes(u.cpu().numpy(), threshold)
+    if backend == "mcubes":
+        import mcubes
+        vertices, triangles = mcubes.marching_cubes(u.cpu().numpy(), threshold)
+    else:
+        from .mesh import marching_cubes
+        v, t = marching_cubes(u, threshold)
+        vertices, triangles = v.cpu().numpy().astype("float64"), t.cpu().numpy()
     b_min = (decoder.aabb[:3] - 0.1).cpu().numpy()
     b_max = (decoder.aabb[3:] + 0.1).cpu().numpy()
     return vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :], triangles

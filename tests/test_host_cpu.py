@@ -309,5 +309,7 @@ def test_density_volume_for_mesh_extraction_matches_oracle_decode():
     sig[((pts.abs() > 1).any(dim=-1)).reshape(res, res, res)] = 0
     np.testing.assert_allclose(u.numpy(), sig.numpy(), rtol=2e-5, atol=1e-6)
     assert float(u[0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u.max()) > 1.0
+    # the marching-cubes step is native since r04 (ssdnerf_amd/mesh.py + csrc/marching_cubes.hip: GPU only, tests/test_mesh_gpu.py); PyMCubes, the
+    # reference's backend, stays an optional one and is not installed here
     with pytest.raises(ImportError):
-        nerf.extract_geometry(dec, code, resolution=res)
+        nerf.extract_geometry(dec, code, resolution=res, backend="mcubes")
