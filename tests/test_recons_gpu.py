@@ -173,7 +173,9 @@ def test_config5_guided_langevin_bf16_fp16_against_fp32():
                          march_noises=[n.cuda() for n in opt_marches], optim_density_jitters=[j.cuda() for j in opt_jits])
         out[name] = (res["code"].float().cpu(), res["pred_imgs"].float().cpu())
         assert bool(torch.isfinite(res["code"]).all())
-    for name, rel_max, psnr_min in (("mixed", 1e-4, 45.0), ("mixed_bf16_unet", 2e-2, 30.0)):
+    # measured on the MI355X (r04): 6.1e-6 / 2.2e-5 relative, every view equal after the k/255 rounding (the PSNR formula's epsilon caps at 60 dB);
+    # the schedule of this test is the low-noise one (x0 = a x_t - 0.1 v), so the bf16 UNet's 2e-3 reaches the code divided by ten
+    for name, rel_max, psnr_min in (("mixed", 1e-4, 45.0), ("mixed_bf16_unet", 1e-3, 40.0)):
         rel = float((out[name][0] - out["fp32"][0]).norm() / out["fp32"][0].norm())
         psnr = eval_psnr(out[name][1].flatten(0, 1), out["fp32"][1].flatten(0, 1))
         print(f"config 5 {name} vs fp32: code rel distance {rel:.3e}, PSNR per view {[round(float(p), 1) for p in psnr]}")
