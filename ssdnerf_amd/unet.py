@@ -31,23 +31,52 @@ def _device_ok(x: torch.Tensor) -> bool:
     return x.is_cuda
 
 
+def _runs_fusable(x: torch.Tensor, conv) -> bool:
+    """whether the fp32-class convolution kernel can leave the GroupNorm sums of its OUTPUT, per run of 4 channels, in its epilogue (the rule of
+    unet_fast.FastUnet._can_fuse_stats: every output tile inside one sample, or a split-K layer whose finishing pass takes them)"""
+    from . import _cabi as C
+    cout, cin, k = conv.out_channels, conv.in_channels, conv.kernel_size[0]
+    hw = x.size(2) * x.size(3)
+    if cout % 4 != 0 or hw > 128 * 256:
+        return False
+    plan = C.lib().ssdnerf_conv2d_nhwc_f32x2_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, 0)
+    if plan >> 8 != 1:
+        return True
+    return hw % (128 if (plan & 0xff) == 1 else 64) == 0
+
+
 class _ConvF32x2Fn(torch.autograd.Function):
-    """y = conv2d(x, W) + b for a stride-1, 'same'-padded 1x1 / 3x3 convolution with FROZEN weights, differentiable w.r.t. x only.
-    Forward and backward are the same implicit-GEMM kernel: d/dx is the convolution of dy with the spatially flipped, in/out-swapped
-    weights (W'[ci, co, i, j] = W[co, ci, k-1-i, k-1-j])."""
+    """y = conv2d(x, W) + b (+ residual) for a stride-1, 'same'-padded 1x1 / 3x3 convolution with FROZEN weights, differentiable w.r.t. x (and the
+    residual).  Forward and backward are the same implicit-GEMM kernel: d/dx is the convolution of dy with the spatially flipped, in/out-swapped
+    weights (W'[ci, co, i, j] = W[co, ci, k-1-i, k-1-j]).  r04: ``residual`` is added in the kernel's epilogue (a residual block's `conv_2 + skip`
+    costs no extra pass; its gradient is dy itself), and ``box`` (a dict) receives ``box['runs']`` = the sums / sums of squares of the OUTPUT per run
+    of 4 channels (fp64 (B, Cout/4, 2)) from the same epilogue, or None where the kernel cannot take them -- the GroupNorm that reads the output
+    then needs no statistics pass (``_GroupNormActFn``)."""
 
     @staticmethod
-    def forward(ctx, x, conv):
+    def forward(ctx, x, conv, residual=None, box=None):
         from . import unet_fast as UF
         hi, lo = conv._split_pair(False)
         ctx.conv = conv
-        return UF.conv2d_nhwc_f32x2(x.contiguous(memory_format=torch.channels_last), hi, lo, bias=conv.bias, splitk_ws=UF.shared_splitk_ws(x.device))
+        ctx.has_residual = residual is not None
+        xc = x.contiguous(memory_format=torch.channels_last)
+        runs = None
+        if box is not None and _runs_fusable(xc, conv):
+            n = xc.size(0) * (conv.out_channels // 4) * 2
+            arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
+            runs = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
+        if box is not None:
+            box["runs"] = runs
+        return UF.conv2d_nhwc_f32x2(xc, hi, lo, bias=conv.bias, residual=None if residual is None else residual.contiguous(memory_format=torch.channels_last),
+                                    gn_sums=runs, gn_groups=conv.out_channels // 4 if runs is not None else 0, splitk_ws=UF.shared_splitk_ws(x.device))
 
     @staticmethod
     def backward(ctx, gy):
         from . import unet_fast as UF
         hi, lo = ctx.conv._split_pair(True)
-        return UF.conv2d_nhwc_f32x2(gy.contiguous(memory_format=torch.channels_last), hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)), None
+        gyc = gy.contiguous(memory_format=torch.channels_last)
+        gx = UF.conv2d_nhwc_f32x2(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
+        return gx, None, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None), None
 
 
 class _Conv2d(nn.Conv2d):
@@ -78,10 +107,51 @@ class _Conv2d(nn.Conv2d):
             cache[transposed] = split_bf16x2_adjacent(wt.contiguous())
         return cache[transposed]
 
-    def forward(self, x):
+    #: SSDNERF_UNET_GRAD_FUSE=0: residual adds and GroupNorm statistics as separate passes again (the r03 gradient path; A/B runs)
+    fuse_epilogues = os.environ.get("SSDNERF_UNET_GRAD_FUSE", "1") != "0"
+
+    def forward(self, x, residual=None, box=None):
+        """``residual`` / ``box`` (extras of the input-gradient path, see ``_ConvF32x2Fn``): y + residual in the kernel's epilogue; box['runs'] = the
+        output's GroupNorm sums per run of 4 channels where the kernel can leave them."""
         if self._eligible(x):
-            return _ConvF32x2Fn.apply(x, self)
-        return super().forward(x)
+            if not self.fuse_epilogues:
+                y = _ConvF32x2Fn.apply(x, self, None, None)
+                return y if residual is None else y + residual
+            return _ConvF32x2Fn.apply(x, self, residual, box)
+        y = super().forward(x)
+        return y if residual is None else y + residual
+
+
+class _Pointwise:
+    """A 1x1 ``nn.Conv1d`` (the attention block's qkv / proj) seen as the 1x1 convolution ``_ConvF32x2Fn`` takes: same attribute names as
+    ``_Conv2d``, operand pairs cached per weight version."""
+
+    kernel_size = (1, 1)
+
+    def __init__(self, conv1d: nn.Conv1d):
+        self.m = conv1d
+        self.in_channels, self.out_channels = conv1d.in_channels, conv1d.out_channels
+        self._cache = {}
+
+    @property
+    def bias(self):
+        return self.m.bias
+
+    def ok(self) -> bool:
+        m = self.m
+        return (m.groups == 1 and m.kernel_size == (1,) and m.stride == (1,) and m.in_channels % 8 == 0 and m.out_channels % 8 == 0
+                and not m.weight.requires_grad and (m.bias is None or not m.bias.requires_grad))
+
+    def _split_pair(self, transposed):
+        from .unet_fast import split_bf16x2_adjacent
+        w = self.m.weight
+        key = (w._version, w.data_ptr(), str(w.device))
+        if self._cache.get("key") != key:
+            self._cache = {"key": key}
+        if transposed not in self._cache:
+            w4 = w.detach()[:, :, :, None]                          # (Cout, Cin, 1, 1)
+            self._cache[transposed] = split_bf16x2_adjacent((w4.transpose(0, 1) if transposed else w4).contiguous())
+        return self._cache[transposed]
 
 
 class _AttentionF32Fn(torch.autograd.Function):
@@ -107,6 +177,10 @@ class _AttentionF32Fn(torch.autograd.Function):
 #: SSDNERF_UNET_GRAD_ATT_KERNEL=0: the library's scaled_dot_product_attention in the gradient path (A/B runs, true-fp32 parity runs; covered by
 #: tests/test_recons_gpu.py::test_gradient_path_attention_library_fp32_is_reachable_and_agrees)
 GRAD_ATT_KERNEL = os.environ.get("SSDNERF_UNET_GRAD_ATT_KERNEL", "1") != "0"
+
+
+#: SSDNERF_UNET_GRAD_ATT_POINTWISE=0: the attention blocks' qkv / proj projections of the gradient path stay on the library's fp32 GEMMs (A/B runs)
+GRAD_ATT_POINTWISE = os.environ.get("SSDNERF_UNET_GRAD_ATT_POINTWISE", "1") != "0"
 
 
 def attention_kernel_ok(qkv: torch.Tensor, heads: int) -> bool:
@@ -138,18 +212,25 @@ class _GroupNormActFn(torch.autograd.Function):
     """y = [silu]( GroupNorm(x) [* (1 + scale) + shift] ) over channel-last activations with FROZEN affine parameters, differentiable
     w.r.t. x only: forward ``ssdnerf_group_norm_nhwc``, backward ``ssdnerf_group_norm_nhwc_backward`` (two passes, recomputing from x and the
     forward's per-group sums).  Keeps the whole residual block channel-last between the matrix-core convolutions, which removes the
-    NCHW <-> NHWC copies eager GroupNorm forces around each of them."""
+    NCHW <-> NHWC copies eager GroupNorm forces around each of them.  r04: ``runs`` = the statistics of x per run of 4 channels, left by the
+    epilogue of the convolution that produced x (``_ConvF32x2Fn``): only the normalisation pass runs (``ssdnerf_group_norm_nhwc_runs``), as in the
+    inference executor."""
 
     @staticmethod
-    def forward(ctx, x, norm, scale_shift, act):
+    def forward(ctx, x, norm, scale_shift, act, runs=None):
         from . import unet_fast as UF
         xc = x.contiguous(memory_format=torch.channels_last)
         arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
-        n = x.size(0) * norm.num_groups * 2
-        sums = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
         ctx.arena = arena
         ss = None if scale_shift is None else scale_shift.detach().float().contiguous()
-        y = UF.group_norm_nhwc(xc, norm.num_groups, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, sums, workspace_is_zero=True)
+        B, Cc, G = x.size(0), x.size(1), norm.num_groups
+        if runs is not None and (Cc // G) % 4 == 0 and runs.numel() == B * (Cc // 4) * 2:
+            y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, None, runs=(runs, None))
+            sums = runs.view(B, G, Cc // (4 * G), 2).sum(dim=2).reshape(-1)                  # per-group sums for the backward (a few hundred doubles)
+        else:
+            n = B * G * 2
+            sums = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
+            y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, sums, workspace_is_zero=True)
         ctx.save_for_backward(xc, sums)
         ctx.norm, ctx.ss, ctx.act = norm, ss, act
         return y
@@ -162,7 +243,12 @@ class _GroupNormActFn(torch.autograd.Function):
         ws = ctx.arena.take(xc.size(0) * norm.num_groups * 2) if ctx.arena is not None else None
         dx = UF.group_norm_nhwc_backward(xc, dy.contiguous(memory_format=torch.channels_last), norm.num_groups, norm.weight.detach(), norm.bias.detach(),
                                          ctx.ss, norm.eps, ctx.act, sums, workspace=ws)
-        return dx, None, None, None
+        return dx, None, None, None, None
+
+
+def _runs_of(x):
+    """the run-level GroupNorm statistics a producing convolution attached to ``x`` (or None)"""
+    return getattr(x, "_ssd_runs", None)
 
 
 #: The norms of the input-gradient path go through ``_GroupNormActFn`` and its attention blocks run channel-last (``_forward_channel_last``):
@@ -238,13 +324,13 @@ class NormWithEmbedding(nn.Module):
         out = in_channels * 2 if use_scale_shift else in_channels
         self.embedding_layer = nn.Sequential(_build_act(act_cfg), nn.Linear(embedding_channels, out))
 
-    def forward(self, x, y, fuse_silu=False):
+    def forward(self, x, y, fuse_silu=False, runs=None):
         """``fuse_silu`` (extra): also apply the SiLU that follows in the residual block (only honoured on the fused path; returns
-        (tensor, whether the activation was applied))."""
+        (tensor, whether the activation was applied)).  ``runs`` (extra): x's statistics from the producing convolution's epilogue."""
         batched = getattr(y, "_ssd_projections", None)                 # DenoisingUnetMod.forward: every block's projection of the time embedding from ONE GEMM
         e = batched[id(self)] if batched is not None and id(self) in batched else self.embedding_layer(y)
         if self.use_scale_shift and fuse_silu and _gn_act_eligible(x, self.norm, e):
-            return _GroupNormActFn.apply(x, self.norm, e, True), True
+            return _GroupNormActFn.apply(x, self.norm, e, True, runs), True
         e = e[:, :, None, None]
         if self.use_scale_shift:
             scale, shift = torch.chunk(e, 2, dim=1)
@@ -283,11 +369,15 @@ class DenoisingResBlockMod(nn.Module):
         s = self.shortcut(x) if self.learnable_shortcut else x
         if _gn_act_eligible(x, self.conv_1[0]) and isinstance(self.conv_1[1], nn.SiLU) and isinstance(self.conv_2[0], nn.SiLU) \
                 and not (self.training and len(self.conv_2) > 2):
-            # input-gradient path: GroupNorm + SiLU (and the scale/shift norm + SiLU) as one fused, channel-last op each
-            h = self.conv_1[-1](_GroupNormActFn.apply(x, self.conv_1[0], None, True))
-            h, activated = self.norm_with_embedding(h, y, fuse_silu=True)
-            h = self.conv_2[-1](h if activated else self.conv_2[0](h))
-            return h + s
+            # input-gradient path: GroupNorm + SiLU (and the scale/shift norm + SiLU) as one fused, channel-last op each; r04: the norms take their
+            # statistics from the epilogue of the convolution that produced their input (no statistics pass), `+ s` rides in conv_2's epilogue
+            box1, box2 = {}, {}
+            h = self.conv_1[-1](_GroupNormActFn.apply(x, self.conv_1[0], None, True, _runs_of(x)), None, box1)
+            h, activated = self.norm_with_embedding(h, y, fuse_silu=True, runs=box1.get("runs"))
+            out = self.conv_2[-1](h if activated else self.conv_2[0](h), s, box2)
+            if box2.get("runs") is not None:
+                out._ssd_runs = box2["runs"]
+            return out
         h = self.conv_1(x)
         h = self.norm_with_embedding(h, y)
         h = self.conv_2(h)
@@ -327,15 +417,32 @@ class MultiHeadAttentionMod(nn.Module):
         t, heads = h * w, self.num_heads
         ch = c // heads
         xc = x.contiguous(memory_format=torch.channels_last)
-        xn = _GroupNormActFn.apply(xc, self.norm, None, False)
+        xn = _GroupNormActFn.apply(xc, self.norm, None, False, _runs_of(x))
+        pw = self.__dict__.get("_pointwise")
+        if pw is None:
+            pw = self.__dict__["_pointwise"] = (_Pointwise(self.qkv), _Pointwise(self.proj))
+        if GRAD_ATT_POINTWISE and _Conv2d.grad_conv and _Conv2d.fuse_epilogues and pw[0].ok() and pw[1].ok():
+            # r04: the two projections on the fp32-class 1x1 convolution kernel of the residual blocks (the inference executor's choice) instead of the
+            # library's fp32 GEMMs: `proj(a) + x` and the statistics of the sum for the next block's norm come out of ONE epilogue
+            qkv = _ConvF32x2Fn.apply(xn, pw[0], None, None).permute(0, 2, 3, 1).reshape(b, t, 3 * c)          # channel = head*3ch + {q,k,v}*ch + i
+            a = _AttentionF32Fn.apply(qkv, heads) if attention_kernel_ok(qkv, heads) else self._sdpa(qkv, b, t, heads, ch)
+            box = {}
+            out = _ConvF32x2Fn.apply(a.view(b, h, w, c).permute(0, 3, 1, 2), pw[1], xc, box)
+            if box.get("runs") is not None:
+                out._ssd_runs = box["runs"]
+            return out
         qkv = F.linear(xn.permute(0, 2, 3, 1).reshape(b, t, c), self.qkv.weight[:, :, 0], self.qkv.bias)      # channel = head*3ch + {q,k,v}*ch + i
         if attention_kernel_ok(qkv, heads):
             a = _AttentionF32Fn.apply(qkv, heads)                                                             # (b, t, c)
         else:
-            q, k, v = qkv.view(b, t, heads, 3, ch).permute(3, 0, 2, 1, 4)                                     # each (b, heads, t, ch)
-            a = F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(b, t, c)
+            a = self._sdpa(qkv, b, t, heads, ch)
         out = F.linear(a, self.proj.weight[:, :, 0], self.proj.bias) + xc.permute(0, 2, 3, 1).reshape(b, t, c)
         return out.view(b, h, w, c).permute(0, 3, 1, 2)                                                       # a channels_last (B, C, H, W) view
+
+    @staticmethod
+    def _sdpa(qkv, b, t, heads, ch):
+        q, k, v = qkv.view(b, t, heads, 3, ch).permute(3, 0, 2, 1, 4)                                         # each (b, heads, t, ch)
+        return F.scaled_dot_product_attention(q, k, v, scale=1.0 / math.sqrt(ch)).permute(0, 2, 1, 3).reshape(b, t, heads * ch)
 
     def forward(self, x):
         if GRAD_ATT and x.dim() == 4 and self.groups == 1 and _gn_act_eligible(x, self.norm) and not self.qkv.weight.requires_grad \
@@ -372,7 +479,13 @@ class DenoisingUpsampleMod(nn.Module):
 
     def forward(self, x):
         x = F.interpolate(x, scale_factor=2, mode="nearest")
-        return self.conv(x) if self.with_conv else x
+        if not self.with_conv:
+            return x
+        box = {}
+        out = self.conv(x, None, box)
+        if box.get("runs") is not None:
+            out._ssd_runs = box["runs"]
+        return out
 
 
 class _NormActConv(nn.Module):
@@ -386,7 +499,7 @@ class _NormActConv(nn.Module):
 
     def forward(self, x):
         if _gn_act_eligible(x, self.gn) and isinstance(self.activate, nn.SiLU):
-            return self.conv(_GroupNormActFn.apply(x, self.gn, None, True))
+            return self.conv(_GroupNormActFn.apply(x, self.gn, None, True, _runs_of(x)))
         return self.conv(self.activate(self.gn(x)))
 
 
@@ -583,8 +696,10 @@ class DenoisingUnetMod(nn.Module):
         prev_arena = _ZeroArena.current
         if x_t.is_cuda and torch.is_grad_enabled() and x_t.requires_grad and GRAD_GN:
             n_gn = self.__dict__.get("_n_group_norms") or sum(m.num_groups for m in self.modules() if isinstance(m, nn.GroupNorm))
-            self.__dict__["_n_group_norms"] = n_gn
-            _ZeroArena.current = _ZeroArena(4 * x_t.size(0) * n_gn, x_t.device)       # forward + backward sums of every norm
+            n_runs = self.__dict__.get("_n_conv_runs") or sum(m.out_channels // 2 for m in self.modules() if isinstance(m, _Conv2d))
+            self.__dict__["_n_group_norms"], self.__dict__["_n_conv_runs"] = n_gn, n_runs
+            # forward + backward sums of every norm, and the run-level sums (Cout / 4 runs x 2) the convolutions' epilogues leave for them
+            _ZeroArena.current = _ZeroArena(x_t.size(0) * (4 * n_gn + n_runs), x_t.device)
         try:
             return self._forward_blocks(x_t, embedding, concat_cond)
         finally:
@@ -599,5 +714,11 @@ class DenoisingUnetMod(nn.Module):
             hs.append(h)
         h = self.mid_blocks(h, embedding)
         for block in self.out_blocks:
-            h = block(torch.cat([h, hs.pop()], dim=1), embedding)
+            skip = hs.pop()
+            cat = torch.cat([h, skip], dim=1)
+            ra, rb = _runs_of(h), _runs_of(skip)
+            if ra is not None and rb is not None:                # (B, C/4, 2) each: the concatenation's runs are the two lists, one behind the other
+                B = h.size(0)
+                cat._ssd_runs = torch.cat([ra.view(B, -1, 2), rb.view(B, -1, 2)], dim=1).reshape(-1)
+            h = block(cat, embedding)
         return self.out(h)
