@@ -387,6 +387,11 @@ def main():
                 # BASELINE.json configs[3] (ssdnerf_abotables_uncond.py:103-111): the same sampler, but val_uncond renders 10 views per scene, so the
                 # leg is UNet-bound (the N > 1 form of this config is the `sampling` leg itself: every rank samples, renders and all-gathers)
                 samp["abo_10_views_fp32"] = sampling_leg(model, dev, ns, 10, hw, args.ddim_steps, "fp32", rank, world, None, log)
+                # a throughput-oriented batch: the configs sample 8 scenes per GPU per batch (samples_per_gpu=8), which leaves the UNet's low-resolution
+                # half latency-bound (<= 32^2 pixels x 8 scenes per launch); 288 GB of HBM hold far more, and at 32 scenes per batch the same kernels
+                # run 25-30 % faster per scene (tools/bench_unet.py --scenes 32: 12.1 ms bf16 / 28.2 ms fp32 per step).  Same sampler, same render.
+                for name in ("fp32", "bf16"):
+                    samp[f"batch32_{name}"] = sampling_leg(model, dev, 32, nv, hw, args.ddim_steps, name, rank, world, None, log)
             samp.update(scenes_per_s=samp["fp32"]["scenes_per_s"], config="uncond sampling as ssdnerf_cars_uncond runs it "
                         f"(fp32 UNet, {args.ddim_steps}-step DDIM, 8 density-grid refreshes, {nv} views of {hw}x{hw} per scene; abo_10_views_fp32: 10 views per "
                         "scene as ssdnerf_abotables_uncond renders), random UNet weights (fog-like scenes: the render leg's slow case)")
