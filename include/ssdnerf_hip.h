@@ -276,7 +276,7 @@ int ssdnerf_quantize_u8(const float* x, uint64_t n, uint8_t* y, void* stream);
 /* ---- Part 3: denoising-UNet glue (lib/models/architecture/ddpm/modules.py:12-129, denoising.py:178-187) ------------------
  * Activations are channel-last: x, y are [B][HW][C] of dtype 0 = fp32, 1 = fp16, 2 = bf16.
  *
- * y = act( GroupNorm_G(X + pre_bias) * gamma + beta  [ * (1 + scale[b]) + shift[b] ] ),  act = 0 none / 1 SiLU,
+ * y = act( GroupNorm_G(X + pre_bias) * gamma + beta  [ * (1 + scale[b]) + shift[b] ] ),  act bit 0: SiLU; bit 1 (r04, fp32 only): write y PRE-SPLIT for ssdnerf_conv2d_nhwc_f32x2_presplit (see there),
  * where X = x, or -- with x2 != NULL -- the channel concatenation [x (C1 channels) | x2 (C - C1 channels)] of two tensors, which
  * is never materialised (the decoder half's `torch.cat([h, skip], dim=1)`, denoising.py:209-213).
  * pre_bias (nullable, fp32 [C]) is the bias of the convolution that produced x, folded in here so the producer needs no
@@ -355,6 +355,16 @@ int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, cons
                               const void* residual, void* y, uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout,
                               uint32_t ksize, uint32_t stride, uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint,
                               int splits_hint, int y_is_zero, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+
+/* r04: the large 3 x 3 layers of the fp32 configs on PRE-SPLIT activations.  ssdnerf_group_norm_nhwc / _runs with bit 1 of `act` set (act | 2; fp32,
+ * C % 32 == 0) write their result not as fp32 but as its bf16 pair split in the layout the two-group convolution kernel's K-tiles take -- per pixel and
+ * block of 32 channels 128 bytes = [32 hi terms | 32 lo terms], hi = truncation to bf16, lo = truncation of the exact remainder: the same bytes per element
+ * and the same arithmetic as the split ssdnerf_conv2d_nhwc_f32x2 does on the fly, so the convolution's result is bit-identical -- and
+ * ssdnerf_conv2d_nhwc_f32x2_presplit convolves such a tensor (3 x 3, stride 1, pad 1; w_lo directly behind w_hi; bias / residual / y / gn_sums as in
+ * ssdnerf_conv2d_nhwc_f32x2).  _supported: whether a layer is one the kernel takes (then, and only then, ask the producing norm for the split output). */
+int ssdnerf_conv2d_nhwc_f32x2_presplit_supported(uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, int with_gn_sums);
+int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const void* w_hi, const void* w_lo, const float* bias, const void* residual, void* y, uint32_t B,
+                                       uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, void* gn_sums, uint32_t gn_groups, void* stream);
 
 /* Self-attention of MultiHeadAttentionMod (modules.py:12-48; mmgen QKVAttention) over the qkv projection of a channel-last
  * activation: qkv bf16 [B][T][3*heads*ch] with the reference's channel order [head][q | k | v][ch], out bf16 [B][T][heads*ch]

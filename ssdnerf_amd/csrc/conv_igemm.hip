@@ -1193,8 +1193,15 @@ SSD_DEV void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 // into the bf16 pair when the fragment is read: 24 VALU instructions per fragment, under the other group's MFMA segment), a B row the 32 hi terms
 // followed by the 32 lo terms of an output channel (w_lo must lie directly behind w_hi in memory: one buffer descriptor serves both); a K-tile is
 // 32 channels, each of its two phases one 16-deep k-step of 12 MFMAs -- 1.5 x the matrix work of the bf16 form per byte moved.
-template <bool ROWS, bool F32 = false>
+// PS (r04, F32 only): the activations arrive PRE-SPLIT -- per pixel and block of 32 channels 128 bytes = [32 hi terms | 32 lo terms] in bf16, written
+// by the GroupNorm pass that produced them (groupnorm.hip, GnVec<GN_F32>::store_split; same bytes per element as fp32, so ring, DMA schedule and
+// addressing are those of the F32 form).  An A row then has exactly the layout of a B row, the fragments are read as bf16x8 like the weights', and the
+// split leaves the K loop: in the F32 form every wave split every pixel fragment it read -- 48 VALU instructions per phase in the load segment, the
+// same pixels again in the wave of the other channel half and (ROWS) for each of the three kw taps, six times in all.  Same products, same order:
+// bit-identical results.
+template <bool ROWS, bool F32 = false, bool PS = false>
 __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
+    static_assert(!PS || F32, "pre-split activations are a form of the fp32-class kernel");
     constexpr int BM = 256, BN = 128, TM = 2, TN = 2;
     constexpr uint32_t KCH = F32 ? 32 : 64, AB = F32 ? 4 : 2;                 // channels per K-tile, bytes per activation element
     constexpr int A_ROWS = ROWS ? BM + 8 + 1 : BM;                            // ROWS: up to eight image rows per tile (W = 32) + their zero rows
@@ -1308,10 +1315,10 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const uint32_t rho = t0 + (lane & 31) + t0 / seg_w + kw;          // = 1 + seg (seg_w + 1) + x + (kw - 1)
-                a_rd[i][ROWS ? kw : 0] = rho * CV_ROWB + ((((lane >> 5) << (F32 ? 1 : 0)) ^ ((rho >> 1) & 7)) * 16);
+                a_rd[i][ROWS ? kw : 0] = rho * CV_ROWB + ((((lane >> 5) << (F32 && !PS ? 1 : 0)) ^ ((rho >> 1) & 7)) * 16);
             }
         } else {
-            a_rd[i][0] = (t0 + (lane & 31)) * CV_ROWB + ((((lane >> 5) << (F32 ? 1 : 0)) ^ ((lane >> 1) & 7)) * 16);
+            a_rd[i][0] = (t0 + (lane & 31)) * CV_ROWB + ((((lane >> 5) << (F32 && !PS ? 1 : 0)) ^ ((lane >> 1) & 7)) * 16);
         }
     }
     // (F32: a lane's 8 channels of k-step P are the TWO chunks 4 P + 2 half + {0, 1} of the fp32 row: a_rd ^ (P * 64) ^ (e * 16))
@@ -1384,10 +1391,17 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
     auto load_frags = [&](auto pc, auto kwc, const unsigned char* sa, const unsigned char* sb) {
         constexpr int P = decltype(pc)::value, KW = decltype(kwc)::value;
         if (F32) {
+            if (PS) {                                                        // pre-split pixels: hi / lo chunks exactly like the weights'
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) xa[F32 ? i : 0][e] = *reinterpret_cast<const float4*>(sa + (a_rd[i][ROWS ? KW : 0] ^ (P * 64) ^ (e * 16)));
+                    for (int i = 0; i < TM; ++i) fa[P][s][i] = *reinterpret_cast<const bf16x8*>(sa + (a_rd[i][ROWS ? KW : 0] ^ ((P + 2 * s) * 32)));
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) xa[F32 ? i : 0][e] = *reinterpret_cast<const float4*>(sa + (a_rd[i][ROWS ? KW : 0] ^ (P * 64) ^ (e * 16)));
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s)                                      // s = 0: the hi terms (row chunks 0-3), 1: the lo terms (chunks 4-7)
 #pragma unroll
@@ -1439,7 +1453,10 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (F32) {
+        if (F32 && PS) {                                                     // nothing to split: the load segment is DMA issue and the waits, as in the bf16 form
+            if (P == 0) pp_wait_vm_lgkm_barrier(issued);
+            else pp_wait_lgkm_barrier();
+        } else if (F32) {
             // this phase's fragments (read in the previous compute segment) are in: split the pixels' fp32 values -- hi = truncation to bf16,
             // lo = truncation of the exact remainder -- here, under the other group's MFMA segment
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1684,6 +1701,46 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
         hipLaunchKernelGGL(k_conv_f32_finish, dim3((HWo + rows - 1) / rows, B), dim3(256), 0, st, (float*)y, a.splitk_ws, bias, (const float*)residual, HWo, cpr, rows, stats, a.G);
     }
     SSD_CHECK_LAUNCH("conv2d_nhwc_f32x2");
+    return SSDNERF_OK;
+}
+
+// The two-group kernel on PRE-SPLIT activations (k_conv_pp_bf16<true, true, true>): x = what ssdnerf_group_norm_nhwc(..., act | 2) wrote.  Only the layers
+// the row-reuse form of the fp32 two-group kernel takes on its own (3 x 3, stride 1, W in {64, 128}, >= 32768 output pixels, Cin % 32 == 0, Cout % 128 == 0):
+// _supported says whether a layer is one, so that the host asks its GroupNorm for the split output exactly then.
+extern "C" int ssdnerf_conv2d_nhwc_f32x2_presplit_supported(uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, int with_gn_sums) {
+    static const bool pp_auto = getenv("SSDNERF_CONV_NO_TWO_GROUP") == nullptr && getenv("SSDNERF_CONV_NO_PRESPLIT") == nullptr;
+    const uint64_t M = (uint64_t)B * H * W;
+    return pp_auto && ksize == 3 && Cin % 32 == 0 && Cout % 128 == 0 && (W == 128 || W == 64) && (H * W) % 256 == 0 && M >= 32768 && M < (1ull << 31)
+           && (uint64_t)B * H * W * Cin * 4 < (1ull << 31) && (uint64_t)Cout * 9 * Cin * 2 < (1ull << 31) && (!with_gn_sums || (H * W) % 256 == 0);
+}
+
+extern "C" int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const void* w_hi, const void* w_lo, const float* bias, const void* residual, void* y, uint32_t B,
+                                                  uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, void* gn_sums, uint32_t gn_groups, void* stream) {
+    if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x_split && w_hi && w_lo && y, "conv2d_nhwc_f32x2_presplit: null pointer");
+    SSD_REQUIRE(ssdnerf_conv2d_nhwc_f32x2_presplit_supported(B, H, W, Cin, Cout, 3, gn_sums != nullptr), "conv2d_nhwc_f32x2_presplit: layer not taken by the two-group row kernel");
+    SSD_REQUIRE((const unsigned char*)w_lo == (const unsigned char*)w_hi + (size_t)Cout * 9 * Cin * 2, "conv2d_nhwc_f32x2_presplit: w_lo must lie directly behind w_hi");
+    SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0), "conv2d_nhwc_f32x2_presplit: fused GroupNorm statistics need groups of a multiple of 4 channels");
+    ConvArgs a;
+    a.x2 = nullptr; a.Cin1 = Cin;
+    a.x = (const unsigned char*)x_split; a.w = (const unsigned char*)w_hi; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
+    a.gn_sums = (double*)gn_sums; a.G = gn_groups ? gn_groups : 1;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.ksize = 3; a.stride = 1; a.pad = 1; a.upsample = 0;
+    a.Ho = H; a.Wo = W; a.M = B * H * W;
+    a.splits = 1; a.splitk_ws = nullptr;
+    a.m_tiles = (a.M + 255) / 256; a.n_tiles = Cout / 128;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu < 8) n_cu = 256;
+        n_cu &= ~7;
+    }
+    const uint32_t tiles = a.m_tiles * a.n_tiles, grid = tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu;
+    hipLaunchKernelGGL((k_conv_pp_bf16<true, true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    SSD_CHECK_LAUNCH("conv2d_nhwc_f32x2_presplit");
     return SSDNERF_OK;
 }
 

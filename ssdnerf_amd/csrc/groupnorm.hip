@@ -31,6 +31,20 @@ template <> struct GnVec<GN_F32> {
     }
     __device__ static void store(void* p, size_t idx, const float* f) { reinterpret_cast<float4*>(p)[idx] = make_float4(f[0], f[1], f[2], f[3]); }
     __device__ static float round(float x) { return x; }               // value as it reads back from storage
+    // PRE-SPLIT store (r04): the four fp32 values leave as their bf16 pair split -- hi = truncation to bf16, lo = truncation of the exact remainder,
+    // the arithmetic of the fp32-class convolution kernels (conv_igemm.hip) -- in the layout the two-group kernel's K-tiles take: per pixel and block
+    // of 32 channels, 128 bytes = [32 hi terms | 32 lo terms].  Same bytes per element as fp32; `idx` is the 4-channel vector index as in store().
+    __device__ static void store_split(void* p, size_t idx, const float* f) {
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hi[i] = __float_as_uint(f[i]) & 0xffff0000u;
+            lo[i] = __float_as_uint(f[i] - __uint_as_float(hi[i]));
+        }
+        unsigned char* base = reinterpret_cast<unsigned char*>(p) + (idx >> 3) * 128 + (idx & 7) * 8;      // 8 vectors of 4 channels per 32-channel block
+        *reinterpret_cast<uint2*>(base) = make_uint2(__builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u), __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u));
+        *reinterpret_cast<uint2*>(base + 64) = make_uint2(__builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u), __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u));
+    }
 };
 template <> struct GnVec<GN_BF16> {
     static constexpr int V = 8;
@@ -206,12 +220,15 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_apply(const void* __restrict__ x,
 #pragma unroll
             for (int i = 0; i < V; i += 2) {                                  // pairs: packed fp32 math around the two transcendentals (SiLU = v / (1 + 2^(-log2(e) v)))
                 f2 v = __builtin_elementwise_fma(f2{f[k][i], f[k][i + 1]}, f2{a[i], a[i + 1]}, f2{o[i], o[i + 1]});
-                if (act) {
+                if (act & 1) {
                     const f2 u = v * f2{-1.4426950408889634f, -1.4426950408889634f};
                     const f2 d = f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + f2{1.0f, 1.0f};
                     v = v * f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
                 }
                 f[k][i] = v.x; f[k][i + 1] = v.y;
+            }
+            if constexpr (DT == GN_F32) {
+                if (act & 2) { GnVec<DT>::store_split(y, base + (size_t)(r0 + k * rif) * tpr, f[k]); continue; }     // (host: C % 32 == 0)
             }
             GnVec<DT>::store(y, base + (size_t)(r0 + k * rif) * tpr, f[k]);
         }
@@ -402,6 +419,7 @@ extern "C" int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
     if (!x2) C1 = C;
     SSD_REQUIRE(C1 <= C && C1 % V == 0 && (x2 || C1 == C), "group_norm_nhwc: the first tensor's channel count must be a multiple of the 16-byte vector and <= C");
+    SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc: the pre-split output (act & 2) needs fp32 and C % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t rows_s = gn_rows_per_block(B, HW, 1024, 64), rows_a = gn_rows_per_block(B, HW, 2048, 16);
     const dim3 grid_s(HW / rows_s, B), grid_a(HW / rows_a, B), block(GN_TPB);
@@ -433,6 +451,7 @@ extern "C" int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint3
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc_runs: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
     if (!x2) C1 = C;
     SSD_REQUIRE(C1 <= C && C1 % V == 0 && (x2 || C1 == C), "group_norm_nhwc_runs: the first tensor's channel count must be a multiple of the 16-byte vector and <= C");
+    SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc_runs: the pre-split output (act & 2) needs fp32 and C % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t rows_a = gn_rows_per_block(B, HW, 2048, 16);
     const dim3 grid_a(HW / rows_a, B), block(GN_TPB);

@@ -45,13 +45,15 @@ def _lib_call(what: str):
 def group_norm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, scale_shift: Optional[torch.Tensor], eps: float,
                     act: bool, workspace: torch.Tensor, out: Optional[torch.Tensor] = None, pre_bias: Optional[torch.Tensor] = None,
                     workspace_is_zero: bool = False, stats_ready: bool = False, x2: Optional[torch.Tensor] = None,
-                    runs: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> torch.Tensor:
+                    runs: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, split_out: bool = False) -> torch.Tensor:
     """``x``: (B, C, H, W) tensor in channels_last memory format, or (B, T, C) contiguous.  ``scale_shift``: fp32 view (B, 2C) whose
     rows may be strided.  ``pre_bias``: fp32 (C,) added to x before the norm.  ``stats_ready``: ``workspace`` already holds the sums
     (written by the producing convolution's epilogue).  ``x2``: normalise the channel concatenation [x | x2] without building it
     (4-D only).  ``runs`` = (runs of x, runs of x2 or None): statistics per run of 4 channels (fp64 (B, C/4, 2) each, what the convolutions
-    write with ``gn_groups = Cout // 4``) instead of ``workspace``; only the normalisation pass runs.
+    write with ``gn_groups = Cout // 4``) instead of ``workspace``; only the normalisation pass runs.  ``split_out`` (fp32, C % 32 == 0): the
+    result is written PRE-SPLIT for ``conv2d_nhwc_f32x2_presplit`` (its bytes are not fp32 values any more; same shape and size).
     Returns a tensor of the input's shape/strides (of the concatenation's shape with ``x2``)."""
+    act_bits = int(bool(act)) | (2 if split_out else 0)
     if x.dim() == 4:
         B, C1, H, W = x.shape
         HW = H * W
@@ -80,11 +82,11 @@ def group_norm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: tor
     if runs is not None:
         assert pre_bias is None and (x2 is None) == (runs[1] is None)
         C.check(C.lib().ssdnerf_group_norm_nhwc_runs(C.ptr(x), C.ptr(x2), C.u32(C1), _GN_DTYPE[x.dtype], C.u32(B), C.u32(HW), C.u32(Cc), C.u32(groups), C.ptr(gamma),
-                                                      C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)), C.ptr(runs[0]), C.ptr(runs[1]),
+                                                      C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), act_bits, C.ptr(runs[0]), C.ptr(runs[1]),
                                                       C.ptr(y), C.stream()), "group_norm_nhwc_runs")
         return y
     C.check(C.lib().ssdnerf_group_norm_nhwc(C.ptr(x), C.ptr(x2), C.u32(C1), _GN_DTYPE[x.dtype], C.u32(B), C.u32(HW), C.u32(Cc), C.u32(groups), C.ptr(pre_bias), C.ptr(gamma),
-                                             C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)), C.ptr(workspace),
+                                             C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), act_bits, C.ptr(workspace),
                                              2 if stats_ready else int(bool(workspace_is_zero)), C.ptr(y), C.stream()),
             "group_norm_nhwc")
     return y
@@ -177,6 +179,29 @@ def split_bf16x2_adjacent(w: torch.Tensor):
     buf[0].copy_(hi.permute(0, 2, 3, 1))
     buf[1].copy_(lo.permute(0, 2, 3, 1))
     return buf[0].permute(0, 3, 1, 2), buf[1].permute(0, 3, 1, 2)
+
+
+def presplit_supported(x: torch.Tensor, cout: int, k: int, with_stats: bool = False) -> bool:
+    """whether the 3 x 3 / stride 1 convolution of the channels_last fp32 tensor ``x`` to ``cout`` channels is a layer the two-group kernel takes on
+    PRE-SPLIT activations (``conv2d_nhwc_f32x2_presplit``): the norm that produces x then writes its result with ``split_out=True``"""
+    return bool(x.is_cuda and x.dtype == torch.float32 and C.lib().ssdnerf_conv2d_nhwc_f32x2_presplit_supported(
+        C.u32(x.size(0)), C.u32(x.size(2)), C.u32(x.size(3)), C.u32(x.size(1)), C.u32(cout), C.u32(k), int(with_stats)))
+
+
+def conv2d_nhwc_f32x2_presplit(x_split: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                               residual: Optional[torch.Tensor] = None, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0) -> torch.Tensor:
+    """``conv2d_nhwc_f32x2`` (3 x 3, stride 1) of an activation that ``group_norm_nhwc(..., split_out=True)`` wrote pre-split (csrc/conv_igemm.hip,
+    k_conv_pp_bf16<ROWS, F32, PS>): bit-identical result, the operand split is out of the K loop.  ``w_hi`` / ``w_lo`` from ``split_bf16x2_adjacent``."""
+    B, Cin, H, W = x_split.shape
+    Cout = w_hi.shape[0]
+    if not x_split.is_contiguous(memory_format=torch.channels_last) or x_split.dtype != torch.float32 or tuple(w_hi.shape[1:]) != (Cin, 3, 3):
+        raise RuntimeError("conv2d_nhwc_f32x2_presplit: (B, Cin, H, W) channels_last carrier tensor and a (Cout, Cin, 3, 3) weight pair")
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_split.device, memory_format=torch.channels_last)
+    if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("conv2d_nhwc_f32x2_presplit: residual must match the output's shape, dtype and layout")
+    C.check(C.lib().ssdnerf_conv2d_nhwc_f32x2_presplit(C.ptr(x_split), C.ptr(w_hi), C.ptr(w_lo), C.ptr(bias), C.ptr(residual), C.ptr(y), C.u32(B), C.u32(H), C.u32(W),
+                                                        C.u32(Cin), C.u32(Cout), C.ptr(gn_sums), C.u32(gn_groups), C.stream()), "conv2d_nhwc_f32x2_presplit")
+    return y
 
 
 def conv2d_nhwc_f32x2(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -322,7 +347,16 @@ class _Conv:
     splitk_ws_by_device: dict = {}                  # device index -> all-zero fp32 scratch for the small layers' split-K (shared_splitk_ws)
     F32X2 = os.environ.get("SSDNERF_UNET_F32X2", "1") != "0"      # fp32 executor: own bf16 x 2 convolution (default) or the library's fp32 one
 
-    def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0, x2=None):
+    def takes_presplit(self, x, with_stats=False) -> bool:
+        """the norm that feeds this convolution may hand its result over pre-split (fp32 executor, large 3 x 3 layers)"""
+        return (self.w_lo is not None and self.own and _Conv.PRESPLIT and self.stride[0] == 1 and self.w.shape[2] == 3
+                and presplit_supported(x, int(self.w.shape[0]), 3, with_stats))
+
+    PRESPLIT = os.environ.get("SSDNERF_UNET_PRESPLIT", "1") != "0"   # 0: the fp32 two-group kernel splits its pixels on the fly again (A/B runs)
+
+    def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0, x2=None, presplit=False):
+        if presplit:
+            return conv2d_nhwc_f32x2_presplit(x, self.w_lo[0], self.w_lo[1], bias, residual, gn_sums, gn_groups)
         if self.w_lo is not None:
             return conv2d_nhwc_f32x2(x, self.w_lo[0], self.w_lo[1], bias, residual, self.stride[0], upsample, gn_sums, gn_groups, x2=x2,
                                      splitk_ws=shared_splitk_ws(x.device))
@@ -344,6 +378,20 @@ class _Conv:
             _lib_call(f"conv2d {tuple(self.w.shape)}")
             return F.conv2d(x, self.w, self.bias.to(self.w.dtype), self.stride, self.padding)
         return bias_residual_nhwc(self.mm(x), self.bias, None)
+
+
+class _like:
+    """shape / dtype / device stand-in for a (B, C, H, W) tensor with another channel count (the concatenation a norm is about to produce)"""
+    __slots__ = ("_x", "_c")
+
+    def __init__(self, x, channels):
+        self._x, self._c = x, channels
+
+    is_cuda = property(lambda self: self._x.is_cuda)
+    dtype = property(lambda self: self._x.dtype)
+
+    def size(self, i):
+        return self._c if i == 1 else self._x.size(i)
 
 
 def shared_splitk_ws(device) -> Optional[torch.Tensor]:
@@ -481,12 +529,12 @@ class FastUnet:
         assert ws.numel() == n, "GroupNorm statistics arena exhausted"
         return ws
 
-    def _gn(self, x, gn: _GN, ss, act, pre_bias=None, stats=None, x2=None, stats2=None):
+    def _gn(self, x, gn: _GN, ss, act, pre_bias=None, stats=None, x2=None, stats2=None, split=False):
         Cc = (x.size(1) if x.dim() == 4 else x.size(2)) + (x2.size(1) if x2 is not None else 0)
         if stats is not None and (x2 is None or stats2 is not None) and (Cc // gn.groups) % 4 == 0:
-            return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, stats, x2=x2, runs=(stats, stats2))
+            return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, stats, x2=x2, runs=(stats, stats2), split_out=split)
         return group_norm_nhwc(x, gn.groups, gn.gamma, gn.beta, ss, gn.eps, act, self._stats_slice(x.size(0)), pre_bias=pre_bias, workspace_is_zero=True,
-                               x2=x2)
+                               x2=x2, split_out=split)
 
     def _can_fuse_stats(self, conv: _Conv, x, upsample=False):
         if not conv.own:
@@ -508,10 +556,10 @@ class FastUnet:
             return True                                                     # a split-K layer: its finishing pass takes the statistics
         return hw % (256 if (plan & 0xff) == 4 else 128 if (plan & 0xff) == 1 else 64) == 0   # unsplit: the M tile must lie inside one sample
 
-    def _conv_stats(self, conv: _Conv, x, bias=None, residual=None, upsample=False, x2=None):
+    def _conv_stats(self, conv: _Conv, x, bias=None, residual=None, upsample=False, x2=None, presplit=False):
         """An own convolution with the run-level statistics of its output where the kernel can take them (else None)."""
         st = self._stats_slice(x.size(0), conv.w.size(0)) if self._can_fuse_stats(conv, x, upsample) else None
-        return conv.igemm(x, bias, residual, upsample=upsample, gn_sums=st, gn_groups=conv.w.size(0) // 4 if st is not None else 0, x2=x2), st
+        return conv.igemm(x, bias, residual, upsample=upsample, gn_sums=st, gn_groups=conv.w.size(0) // 4 if st is not None else 0, x2=x2, presplit=presplit), st
 
     def _res(self, x, stats, op, ss_all, x2=None, stats2=None):
         """One residual block.  ``x2``: the block's input is the concatenation [x | x2] (decoder half) and is never built."""
@@ -520,12 +568,18 @@ class FastUnet:
         own = conv1.own and conv2.own and (shortcut is None or shortcut.own)
         if x2 is not None and not (own and shortcut is not None and x.size(1) % 8 == 0 and x2.size(1) % 8 == 0):
             x, x2, stats, stats2 = torch.cat([x, x2], dim=1).contiguous(memory_format=torch.channels_last), None, None, None
-        g1 = self._gn(x, gn1, None, True, stats=stats, x2=x2, stats2=stats2)
         if own:
-            h, st1 = self._conv_stats(conv1, g1, conv1.bias)                                # conv + bias (+ statistics for gn2)
-            g2 = self._gn(h, gn2, ss, True, stats=st1)
+            # r04 (fp32 executor): the norms in front of the LARGE 3 x 3 layers write their result pre-split for the two-group kernel (bit-identical
+            # products; the operand split leaves the convolution's K loop, where every pixel was split six times)
+            cin1 = x.size(1) + (x2.size(1) if x2 is not None else 0)
+            ps1 = conv1.w_lo is not None and conv1.takes_presplit(_like(x, cin1), with_stats=True)
+            g1 = self._gn(x, gn1, None, True, stats=stats, x2=x2, stats2=stats2, split=ps1)
+            h, st1 = self._conv_stats(conv1, g1, conv1.bias, presplit=ps1)                  # conv + bias (+ statistics for gn2)
+            ps2 = conv2.w_lo is not None and conv2.takes_presplit(h, with_stats=True)
+            g2 = self._gn(h, gn2, ss, True, stats=st1, split=ps2)
             skip = shortcut.igemm(x, x2=x2) if shortcut is not None else x                  # the shortcut's bias rides in out_bias
-            return self._conv_stats(conv2, g2, out_bias, skip)                              # conv + bias + skip (+ statistics for whatever reads it next)
+            return self._conv_stats(conv2, g2, out_bias, skip, presplit=ps2)                # conv + bias + skip (+ statistics for whatever reads it next)
+        g1 = self._gn(x, gn1, None, True, stats=stats, x2=x2, stats2=stats2)
         h = conv1.mm(g1)
         h = conv2.mm(self._gn(h, gn2, ss, True, pre_bias=conv1.bias))
         return bias_residual_nhwc(h, out_bias, shortcut.mm(x) if shortcut is not None else x), None   # + b_conv2 (+ b_shortcut) + skip

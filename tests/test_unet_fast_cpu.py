@@ -14,7 +14,8 @@ from ssdnerf_amd.registry import MODULES
 
 
 def _gn_standin(x, groups, gamma, beta, scale_shift, eps, act, workspace, out=None, pre_bias=None, workspace_is_zero=False, stats_ready=False, x2=None,
-                runs=None):
+                runs=None, split_out=False):
+    assert not split_out                                                 # (pre-split outputs only exist for the GPU's large fp32 layers)
     if x2 is not None:
         x = torch.cat([x, x2], dim=1)
     xc = x if x.dim() == 4 else x.transpose(1, 2)                       # (B, C, ...)

@@ -753,3 +753,45 @@ def test_attention_backward_kernels_match_autograd(B, T, heads, ch):
         w = want.view(B, T, heads, 3, ch)[:, :, :, sl]
         assert ((a - w).norm() / w.norm()).item() < 1e-4, name
         assert (a - w).abs().max().item() < 2e-4 * w.abs().max().item(), name
+
+
+# ---------------------------------------------------------------------------------------------- r04: pre-split activations for the fp32 two-group kernel
+@pytest.mark.parametrize("B,cin,cout,hw", [(8, 128, 128, 128), (8, 256, 128, 128), (8, 256, 256, 64), (2, 128, 256, 128)])
+def test_presplit_convolution_is_bit_identical_to_the_on_the_fly_split(B, cin, cout, hw):
+    """GroupNorm writes its fp32 result pre-split (``split_out``: per pixel and 32 channels [32 hi | 32 lo] bf16 terms) and the two-group kernel's PS
+    form convolves it (csrc/conv_igemm.hip k_conv_pp_bf16<ROWS, F32, PS>): the same hi / lo terms, the same products in the same order as the F32
+    form that splits every fragment when it reads it -- so output AND the epilogue's GroupNorm sums must be equal bit for bit, with bias, residual
+    and scale-shift in play."""
+    from ssdnerf_amd import unet_fast as UF
+    g = torch.Generator().manual_seed(cin + cout + hw)
+    x = torch.randn(B, cin, hw, hw, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    res = torch.randn(B, cout, hw, hw, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    gamma, beta = (torch.rand(cin, generator=g) + 0.5).cuda(), torch.randn(cin, generator=g).cuda()
+    ss = (torch.randn(B, 2 * cin, generator=g) * 0.3).cuda()
+    hi, lo = UF.split_bf16x2_adjacent(w)
+    assert UF.presplit_supported(x, cout, 3, True)
+    outs = []
+    for split in (False, True):
+        ws = torch.zeros(B * 32 * 2, dtype=torch.float64, device="cuda")
+        gn = UF.group_norm_nhwc(x, 32, gamma, beta, ss, 1e-5, True, ws, workspace_is_zero=True, split_out=split)
+        runs = torch.zeros(B * (cout // 4) * 2, dtype=torch.float64, device="cuda")
+        if split:
+            y = UF.conv2d_nhwc_f32x2_presplit(gn, hi, lo, bias, res, runs, cout // 4)
+        else:
+            y = UF.conv2d_nhwc_f32x2(gn, hi, lo, bias, res, gn_sums=runs, gn_groups=cout // 4, tile_hint=6)      # the F32 two-group row kernel
+        outs.append((gn, y, runs))
+    assert not torch.equal(outs[0][0], outs[1][0])                                       # the carrier tensor really holds something else
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    ref = F.conv2d(outs[0][0], w, bias, padding=1) + res
+    assert float((outs[1][1] - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+def test_presplit_is_not_offered_for_layers_the_row_kernel_does_not_take():
+    from ssdnerf_amd import unet_fast as UF
+    x = torch.empty(8, 512, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert not UF.presplit_supported(x, 512, 3)                                          # low resolution: the generic kernel (split once, in its loader)
+    assert not UF.presplit_supported(torch.empty(8, 128, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last), 128, 1)
+    assert not UF.presplit_supported(torch.empty(8, 24, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last), 128, 3)
