@@ -54,12 +54,21 @@ class _ConvF32x2Fn(torch.autograd.Function):
     then needs no statistics pass (``_GroupNormActFn``)."""
 
     @staticmethod
-    def forward(ctx, x, conv, residual=None, box=None):
+    def forward(ctx, x, conv, residual=None, box=None, presplit=False):
         from . import unet_fast as UF
         hi, lo = conv._split_pair(False)
         ctx.conv = conv
         ctx.has_residual = residual is not None
         xc = x.contiguous(memory_format=torch.channels_last)
+        if presplit:                                                # x is what the norm in front wrote pre-split for the two-group kernel (see _GroupNormActFn)
+            runs = None
+            if box is not None:
+                n = xc.size(0) * (conv.out_channels // 4) * 2
+                arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
+                runs = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
+                box["runs"] = runs
+            return UF.conv2d_nhwc_f32x2_presplit(xc, hi, lo, conv.bias, None if residual is None else residual.contiguous(memory_format=torch.channels_last),
+                                                 runs, conv.out_channels // 4 if runs is not None else 0)
         runs = None
         if box is not None and _runs_fusable(xc, conv):
             n = xc.size(0) * (conv.out_channels // 4) * 2
@@ -76,7 +85,7 @@ class _ConvF32x2Fn(torch.autograd.Function):
         hi, lo = ctx.conv._split_pair(True)
         gyc = gy.contiguous(memory_format=torch.channels_last)
         gx = UF.conv2d_nhwc_f32x2(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
-        return gx, None, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None), None
+        return gx, None, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None
 
 
 class _Conv2d(nn.Conv2d):
@@ -92,6 +101,13 @@ class _Conv2d(nn.Conv2d):
                 and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.dilation == (1, 1) and self.padding == (k // 2, k // 2)
                 and self.padding_mode == "zeros" and self.in_channels % 8 == 0 and self.out_channels % 8 == 0
                 and (self.bias is None or not self.bias.requires_grad))
+
+    def wants_presplit(self, x) -> bool:
+        """the norm in front of this convolution may write its result pre-split: a large 3 x 3 layer of the fp32 gradient path that the two-group
+        kernel's PS form takes (``unet_fast.presplit_supported``), fused epilogues on"""
+        from . import unet_fast as UF
+        return bool(self.fuse_epilogues and UF._Conv.PRESPLIT and self.kernel_size == (3, 3) and self._eligible(x)
+                    and UF.presplit_supported(x, self.out_channels, 3, True))
 
     def _split_pair(self, transposed):
         """bf16 (hi, lo) operand pair of the weights, channels_last; ``transposed`` = the backward-data form.  Rebuilt when the weights change."""
@@ -117,7 +133,7 @@ class _Conv2d(nn.Conv2d):
             if not self.fuse_epilogues:
                 y = _ConvF32x2Fn.apply(x, self, None, None)
                 return y if residual is None else y + residual
-            return _ConvF32x2Fn.apply(x, self, residual, box)
+            return _ConvF32x2Fn.apply(x, self, residual, box, bool(getattr(x, "_ssd_presplit", False)))
         y = super().forward(x)
         return y if residual is None else y + residual
 
@@ -217,7 +233,9 @@ class _GroupNormActFn(torch.autograd.Function):
     inference executor."""
 
     @staticmethod
-    def forward(ctx, x, norm, scale_shift, act, runs=None):
+    def forward(ctx, x, norm, scale_shift, act, runs=None, split_out=False):
+        """``split_out``: the result goes to a large 3 x 3 convolution of the fp32 gradient path and is written PRE-SPLIT for it (bf16 hi / lo pairs in
+        the carrier tensor, ``unet_fast.group_norm_nhwc``); the caller tags the tensor ``_ssd_presplit`` and hands it to that convolution only."""
         from . import unet_fast as UF
         xc = x.contiguous(memory_format=torch.channels_last)
         arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
@@ -225,12 +243,12 @@ class _GroupNormActFn(torch.autograd.Function):
         ss = None if scale_shift is None else scale_shift.detach().float().contiguous()
         B, Cc, G = x.size(0), x.size(1), norm.num_groups
         if runs is not None and (Cc // G) % 4 == 0 and runs.numel() == B * (Cc // 4) * 2:
-            y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, None, runs=(runs, None))
+            y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, None, runs=(runs, None), split_out=split_out)
             sums = runs.view(B, G, Cc // (4 * G), 2).sum(dim=2).reshape(-1)                  # per-group sums for the backward (a few hundred doubles)
         else:
             n = B * G * 2
             sums = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
-            y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, sums, workspace_is_zero=True)
+            y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, sums, workspace_is_zero=True, split_out=split_out)
         ctx.save_for_backward(xc, sums)
         ctx.norm, ctx.ss, ctx.act = norm, ss, act
         return y
@@ -243,7 +261,13 @@ class _GroupNormActFn(torch.autograd.Function):
         ws = ctx.arena.take(xc.size(0) * norm.num_groups * 2) if ctx.arena is not None else None
         dx = UF.group_norm_nhwc_backward(xc, dy.contiguous(memory_format=torch.channels_last), norm.num_groups, norm.weight.detach(), norm.bias.detach(),
                                          ctx.ss, norm.eps, ctx.act, sums, workspace=ws)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
+
+
+def _tag_presplit(y, on: bool):
+    if on:
+        y._ssd_presplit = True
+    return y
 
 
 def _runs_of(x):
@@ -324,13 +348,14 @@ class NormWithEmbedding(nn.Module):
         out = in_channels * 2 if use_scale_shift else in_channels
         self.embedding_layer = nn.Sequential(_build_act(act_cfg), nn.Linear(embedding_channels, out))
 
-    def forward(self, x, y, fuse_silu=False, runs=None):
+    def forward(self, x, y, fuse_silu=False, runs=None, split_for=None):
         """``fuse_silu`` (extra): also apply the SiLU that follows in the residual block (only honoured on the fused path; returns
         (tensor, whether the activation was applied)).  ``runs`` (extra): x's statistics from the producing convolution's epilogue."""
         batched = getattr(y, "_ssd_projections", None)                 # DenoisingUnetMod.forward: every block's projection of the time embedding from ONE GEMM
         e = batched[id(self)] if batched is not None and id(self) in batched else self.embedding_layer(y)
         if self.use_scale_shift and fuse_silu and _gn_act_eligible(x, self.norm, e):
-            return _GroupNormActFn.apply(x, self.norm, e, True, runs), True
+            ps = split_for is not None and split_for.wants_presplit(x)
+            return _tag_presplit(_GroupNormActFn.apply(x, self.norm, e, True, runs, ps), ps), True
         e = e[:, :, None, None]
         if self.use_scale_shift:
             scale, shift = torch.chunk(e, 2, dim=1)
@@ -372,8 +397,9 @@ class DenoisingResBlockMod(nn.Module):
             # input-gradient path: GroupNorm + SiLU (and the scale/shift norm + SiLU) as one fused, channel-last op each; r04: the norms take their
             # statistics from the epilogue of the convolution that produced their input (no statistics pass), `+ s` rides in conv_2's epilogue
             box1, box2 = {}, {}
-            h = self.conv_1[-1](_GroupNormActFn.apply(x, self.conv_1[0], None, True, _runs_of(x)), None, box1)
-            h, activated = self.norm_with_embedding(h, y, fuse_silu=True, runs=box1.get("runs"))
+            ps1 = self.conv_1[-1].wants_presplit(x)                    # (r04: the norm writes the operand pair the large 3 x 3 layers multiply)
+            h = self.conv_1[-1](_tag_presplit(_GroupNormActFn.apply(x, self.conv_1[0], None, True, _runs_of(x), ps1), ps1), None, box1)
+            h, activated = self.norm_with_embedding(h, y, fuse_silu=True, runs=box1.get("runs"), split_for=self.conv_2[-1])
             out = self.conv_2[-1](h if activated else self.conv_2[0](h), s, box2)
             if box2.get("runs") is not None:
                 out._ssd_runs = box2["runs"]
