@@ -760,7 +760,7 @@ def test_attention_backward_kernels_match_autograd(B, T, heads, ch):
 def test_presplit_convolution_is_bit_identical_to_the_on_the_fly_split(B, cin, cout, hw):
     """GroupNorm writes its fp32 result pre-split (``split_out``: per pixel and 32 channels [32 hi | 32 lo] bf16 terms) and the two-group kernel's PS
     form convolves it (csrc/conv_igemm.hip k_conv_pp_bf16<ROWS, F32, PS>): the same hi / lo terms, the same products in the same order as the F32
-    form that splits every fragment when it reads it -- so the output must be equal bit for bit (and the epilogue's GroupNorm sums to fp64 rounding),
+    form that splits every fragment when it reads it -- so the output must be equal bit for bit (and the epilogue's GroupNorm sums to accumulation order),
     with bias, residual and scale-shift in play."""
     from ssdnerf_amd import unet_fast as UF
     g = torch.Generator().manual_seed(cin + cout + hw)
@@ -784,8 +784,9 @@ def test_presplit_convolution_is_bit_identical_to_the_on_the_fly_split(B, cin, c
         outs.append((gn, y, runs))
     assert not torch.equal(outs[0][0], outs[1][0])                                       # the carrier tensor really holds something else
     assert torch.equal(outs[0][1], outs[1][1])
-    # (the statistics are sums of the same fp32 values, added across tiles by fp64 atomics in whatever order the tiles finish)
-    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-11, atol=1e-6)
+    # (the statistics are sums of the same fp32 values: fp32 LDS atomics inside a tile, fp64 atomics across tiles, in whatever order waves and tiles
+    # finish -- two runs of ONE kernel differ by as much)
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-3)
     ref = F.conv2d(outs[0][0], w, bias, padding=1) + res
     assert float((outs[1][1] - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
