@@ -356,15 +356,18 @@ int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, cons
                               uint32_t ksize, uint32_t stride, uint32_t upsample, void* gn_sums, uint32_t gn_groups, int tile_hint,
                               int splits_hint, int y_is_zero, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
-/* r04: the large 3 x 3 layers of the fp32 configs on PRE-SPLIT activations.  ssdnerf_group_norm_nhwc / _runs with bit 1 of `act` set (act | 2; fp32,
- * C % 32 == 0) write their result not as fp32 but as its bf16 pair split in the layout the two-group convolution kernel's K-tiles take -- per pixel and
- * block of 32 channels 128 bytes = [32 hi terms | 32 lo terms], hi = truncation to bf16, lo = truncation of the exact remainder: the same bytes per element
- * and the same arithmetic as the split ssdnerf_conv2d_nhwc_f32x2 does on the fly, so the convolution's result is bit-identical -- and
- * ssdnerf_conv2d_nhwc_f32x2_presplit convolves such a tensor (3 x 3, stride 1, pad 1; w_lo directly behind w_hi; bias / residual / y / gn_sums as in
- * ssdnerf_conv2d_nhwc_f32x2).  _supported: whether a layer is one the kernel takes (then, and only then, ask the producing norm for the split output). */
+/* r04: the fp32 configs' convolutions on PRE-SPLIT activations.  ssdnerf_group_norm_nhwc / _runs with bit 1 of `act` set (act | 2; fp32, C % 32 == 0)
+ * write their result not as fp32 but as its bf16 pair split in the layout the convolution kernels' K-tiles take -- per pixel and block of 32 channels
+ * 128 bytes = [32 hi terms | 32 lo terms], hi = truncation to bf16, lo = truncation of the exact remainder: the same bytes per element and the same
+ * arithmetic as the split ssdnerf_conv2d_nhwc_f32x2 does on the fly -- and ssdnerf_conv2d_nhwc_f32x2_presplit convolves such a tensor (ksize 1 | 3,
+ * stride 1, pad ksize / 2; w_lo directly behind w_hi; bias / residual / y / gn_sums / splitk_ws as in ssdnerf_conv2d_nhwc_f32x2).
+ * _supported: 1 = the two-group row kernel takes the layer (large 3 x 3 layers; bit-identical to the on-the-fly split), 2 = the generic kernel's PS form
+ * does (any other stride-1 layer with Cin % 32 == 0, Cout % 64 == 0; same products, another summation order), 0 = neither: ask the producing norm for the
+ * split output only when it is non-zero.  tile_hint 1 / 2 / 3 (128 x 128, 64 x 128, 64 x 64) and splits_hint > 0 force the generic form's plan (sweeps); 0 = auto. */
 int ssdnerf_conv2d_nhwc_f32x2_presplit_supported(uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, int with_gn_sums);
 int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const void* w_hi, const void* w_lo, const float* bias, const void* residual, void* y, uint32_t B,
-                                       uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, void* gn_sums, uint32_t gn_groups, void* stream);
+                                       uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, void* gn_sums, uint32_t gn_groups,
+                                       int tile_hint, int splits_hint, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
 /* Self-attention of MultiHeadAttentionMod (modules.py:12-48; mmgen QKVAttention) over the qkv projection of a channel-last
  * activation: qkv bf16 [B][T][3*heads*ch] with the reference's channel order [head][q | k | v][ch], out bf16 [B][T][heads*ch]

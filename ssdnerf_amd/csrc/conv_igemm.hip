@@ -281,8 +281,18 @@ SSD_DEV void cv_epilogue_bf16(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned
 // 8 instead of 64 / the N tile -- the last K-tile of a tensor and the last N tile may be partly empty (the tiled UNet's 80 / 160 / 240 / 480-channel
 // layers, the 18 -> 24-channel stem and head).  A separate instantiation: the masks cost the small layers of the cars UNet (4 MFMAs per K-tile and
 // wave on the 64 x 64 tile) up to 30 % when they were unconditional (profiles/r03/f_partial_tiles_ab.txt).
-template <int TM, int TN, int WM, int WN, int NS, bool PT>
+template <int TM, int TN, bool PT = false> SSD_DEV void cv_epilogue_f32(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* lds, uint32_t m0, uint32_t n0);
+
+// PS (r04): the fp32-class form on PRE-SPLIT activations (what ssdnerf_group_norm_nhwc(..., act | 2) writes: per pixel and 32-channel block 32 bf16 hi
+// terms, then the 32 lo terms -- the bytes of the fp32 tensor).  A K-tile is then 32 channels: its 128-byte A row is [hi | lo] straight from memory, its B
+// row is fetched as [w_hi | w_lo] (w_lo lies directly behind w_hi), and a k-step pair multiplies lo * hi + hi * lo + hi * hi.  Same DMA ring, no
+// register pass over the operands (k_conv_igemm_f32x2 loads fp32, splits in registers and writes LDS by hand -- per K-tile, per block).  fp32 output
+// through cv_epilogue_f32 (bias, residual, GroupNorm sums) or fp32 split-K atomics + k_conv_f32_finish.
+template <int TM, int TN, int WM, int WN, int NS, bool PT, bool PS = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs a) {
+    static_assert(!PS || (WM == 2 && WN == 2 && !PT), "the pre-split form shares cv_epilogue_f32's 2 x 2 wave grid and takes whole tiles only");
+    constexpr int KCH = PS ? 32 : CV_BK;                                     // channels per K-tile
+    constexpr int XB = PS ? 4 : 2;                                           // activation bytes per channel
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;                // global_load_lds instructions per wave per K-tile (8 rows each)
@@ -330,14 +340,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
     for (int i = 0; i < B_INST; ++i) {
         const uint32_t r = (wave * B_INST + i) * 8 + (lane >> 3);
         b_sc[i] = (lane & 7) ^ ((r >> 1) & 7);
-        b_off[i] = (!PT || n0 + r < a.Cout) ? ((n0 + r) * taps * a.Cin) * 2 + b_sc[i] * 16 : CV_OOB;   // (PT: rows past Cout read zeros)
+        if (PS) b_off[i] = ((n0 + r) * taps * a.Cin) * 2 + (b_sc[i] & 3) * 16 + (b_sc[i] >> 2) * (a.Cout * taps * a.Cin * 2);   // chunks 0-3: 32 hi terms, 4-7: the lo terms
+        else b_off[i] = (!PT || n0 + r < a.Cout) ? ((n0 + r) * taps * a.Cin) * 2 + b_sc[i] * 16 : CV_OOB;   // (PT: rows past Cout read zeros)
     }
 
     // r03: LDS-DMA through buffer descriptors (see cv_rsrc): one 32-bit offset per piece and tap, the channel tile as the scalar offset, padding taps
     // as an out-of-range offset that reads zeros -- the 64-bit source selects of r02 were most of the ~190 address instructions per K-tile
-    const __amdgpu_buffer_rsrc_t rs_x = cv_rsrc(a.x, (uint64_t)a.B * a.H * a.W * a.Cin1 * 2);
+    const __amdgpu_buffer_rsrc_t rs_x = cv_rsrc(a.x, (uint64_t)a.B * a.H * a.W * a.Cin1 * XB);
     const __amdgpu_buffer_rsrc_t rs_x2 = cv_rsrc(a.x2 ? a.x2 : a.x, a.x2 ? (uint64_t)a.B * a.H * a.W * (a.Cin - a.Cin1) * 2 : 0);
-    const __amdgpu_buffer_rsrc_t rs_w = cv_rsrc(a.w, (uint64_t)a.Cout * taps * a.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rs_w = cv_rsrc(a.w, (uint64_t)a.Cout * taps * a.Cin * 2 * (PS ? 2 : 1));
     uint32_t a_voff[A_INST], a_voff2[A_INST];
     const uint32_t Cin2 = a.Cin - a.Cin1;
     auto set_tap = [&](uint32_t tap) {
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
             const bool ok = a_ok[i] && yv >= 0 && xv >= 0 && yv < (int32_t)Hv && xv < (int32_t)Wv;
             const uint32_t yi = a.upsample ? (uint32_t)yv >> 1 : (uint32_t)yv, xi = a.upsample ? (uint32_t)xv >> 1 : (uint32_t)xv;
             const uint32_t pix = a_img[i] + yi * a.W + xi;
-            a_voff[i] = ok ? pix * a.Cin1 * 2 + a_sc[i] * 16 : CV_OOB;
+            a_voff[i] = ok ? pix * a.Cin1 * XB + a_sc[i] * 16 : CV_OOB;
             a_voff2[i] = ok ? pix * Cin2 * 2 + a_sc[i] * 16 : CV_OOB;
         }
     };
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
     // K-tiles of a tap: kc1 over the first tensor's channels, then kc2 over the second's; a tensor's LAST tile may hold fewer than 64 channels
     // (channel counts are multiples of 8, e.g. the 80 / 160 / 240 / 480-channel layers of the tiled UNet): its missing 16-byte chunks read zeros on
     // both operands, and the multiply loop runs only the 16-deep k-steps that hold channels
-    const uint32_t kc1 = (a.Cin1 + CV_BK - 1) / CV_BK, kc = kc1 + (Cin2 + CV_BK - 1) / CV_BK;
+    const uint32_t kc1 = (a.Cin1 + KCH - 1) / KCH, kc = kc1 + (Cin2 + CV_BK - 1) / CV_BK;        // (PS: one tensor, whole 32-channel tiles)
     auto tile_channels = [&](uint32_t ci) {                                  // channels in K-tile ci of a tap
         if (!PT) return (uint32_t)CV_BK;
         const uint32_t left = ci >= kc1 ? Cin2 - (ci - kc1) * CV_BK : a.Cin1 - ci * CV_BK;
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
         unsigned char* sa = lds + buf * STAGE;
         unsigned char* sb = sa + BM * CV_ROWB;
         const bool second = ci >= kc1;                                       // K-tiles never straddle the two tensors
-        const uint32_t cb = (second ? ci - kc1 : ci) * CV_BK, coff = cb * 2, nchunk = tile_channels(ci) >> 3;
+        const uint32_t cb = (second ? ci - kc1 : ci) * KCH, coff = cb * XB, nchunk = tile_channels(ci) >> 3;
 #pragma unroll
         for (int i = 0; i < A_INST; ++i) {
             unsigned char* dst = sa + (wave * A_INST + i) * 1024;
@@ -426,12 +437,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
                 for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(st + ((b_rd + j * 32 * CV_ROWB) ^ (s * 32)));
             }
             __builtin_amdgcn_sched_barrier(0);                               // keep the reads clustered ahead of the MFMAs (the scheduler would re-serialise them)
+            if (PS) {                                                        // k-steps 0, 1: the hi terms of channels 0-15, 16-31; 2, 3: their lo terms
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 + s][i], fb[s][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[2 + s][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+                        }
+            } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+            }
         } else {
             for (uint32_t s = 0; s < ksteps; ++s) {
                 bf16x8 fa[TM], fb[TN];
@@ -463,11 +487,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
         return;
     }
 
-    cv_epilogue_bf16<TM, TN, WM, WN, PT>(a, acc, lds, m0, n0);
+    if constexpr (PS) cv_epilogue_f32<TM, TN, false>(a, acc, lds, m0, n0);
+    else cv_epilogue_bf16<TM, TN, WM, WN, PT>(a, acc, lds, m0, n0);
 }
 
 // fp32 epilogue shared by the fp32-class kernels: accumulators -> fp32 tile in LDS -> (+bias, +residual) -> fp32 rows (+ GroupNorm sums)
-template <int TM, int TN, bool PT = false>
+template <int TM, int TN, bool PT>
 SSD_DEV void cv_epilogue_f32(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* lds, uint32_t m0, uint32_t n0) {
     constexpr int BM = 64 * TM, BN = 64 * TN, EPI = BM * BN * 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -1704,31 +1729,93 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
     return SSDNERF_OK;
 }
 
-// The two-group kernel on PRE-SPLIT activations (k_conv_pp_bf16<true, true, true>): x = what ssdnerf_group_norm_nhwc(..., act | 2) wrote.  Only the layers
-// the row-reuse form of the fp32 two-group kernel takes on its own (3 x 3, stride 1, W in {64, 128}, >= 32768 output pixels, Cin % 32 == 0, Cout % 128 == 0):
-// _supported says whether a layer is one, so that the host asks its GroupNorm for the split output exactly then.
+// tile (1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64) | splits << 8 of the generic kernel's PS form.  Its own rule, from the r04 sweep of the low-resolution
+// layers over (tile, splits) (profiles/r04/k_ps_small_layer_sweep.jsonl): without the register pass of k_conv_igemm_f32x2 a block is short enough that
+// ~512 blocks (two per CU) are the target, not 1024, and a K of fewer than 64 tiles (every 1 x 1 layer) is fastest unsplit -- the fp32 atomics and the
+// finishing pass cost more than the half-empty chip.
+static int cv_ps_plan(uint32_t M, uint32_t Cin, uint32_t Cout, uint32_t ksize, int tile_hint, int splits_hint) {
+    int choice = tile_hint;
+    if (choice < 1 || choice > 3) choice = (Cout % 128 == 0 && (uint64_t)((M + 127) / 128) * (Cout / 128) >= 384) ? 1 : 3;
+    const uint32_t bm = choice == 1 ? 128 : 64, bn = choice == 3 ? 64 : 128, tiles = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn), KT = ksize * ksize * (Cin / 32);
+    uint32_t splits = 1;
+    if (splits_hint > 0) splits = (uint32_t)splits_hint;
+    else if (tiles < 384 && KT >= 64 && (uint64_t)M * Cout <= (1u << 21) && Cout <= 1024) {
+        splits = (512 + tiles / 2) / tiles;
+        if (splits > 8) splits = 8;
+        while (splits > 1 && KT / splits < 16) --splits;
+    }
+    if (splits > 16) splits = 16;
+    if (splits > KT / 2) splits = KT / 2 ? KT / 2 : 1;
+    return choice | (int)(splits << 8);
+}
+
+// Convolutions on PRE-SPLIT activations: x = what ssdnerf_group_norm_nhwc(..., act | 2) wrote.  Two kernels take them:
+//   1  the two-group row kernel (k_conv_pp_bf16<true, true, true>) on the layers its fp32 form takes on its own (3 x 3, W in {64, 128}, >= 32768 output pixels,
+//      Cin % 32 == 0, Cout % 128 == 0) -- bit-identical to the on-the-fly split;
+//   2  (r04) the generic DMA-ring kernel's PS form (k_conv_igemm_bf16<..., PS = true>) on every other stride-1 layer with Cin % 32 == 0, Cout % 64 == 0
+//      (tile and split-K from ssdnerf_conv2d_nhwc_f32x2_plan): same fp32-class products as k_conv_igemm_f32x2, summed in another order.
+// _supported returns which (0 = neither), so that the host asks its GroupNorm for the split output exactly then.
 extern "C" int ssdnerf_conv2d_nhwc_f32x2_presplit_supported(uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, int with_gn_sums) {
     static const bool pp_auto = getenv("SSDNERF_CONV_NO_TWO_GROUP") == nullptr && getenv("SSDNERF_CONV_NO_PRESPLIT") == nullptr;
+    static const bool small_auto = getenv("SSDNERF_CONV_NO_PRESPLIT") == nullptr && getenv("SSDNERF_CONV_NO_PRESPLIT_SMALL") == nullptr;
     const uint64_t M = (uint64_t)B * H * W;
-    return pp_auto && ksize == 3 && Cin % 32 == 0 && Cout % 128 == 0 && (W == 128 || W == 64) && (H * W) % 256 == 0 && M >= 32768 && M < (1ull << 31)
-           && (uint64_t)B * H * W * Cin * 4 < (1ull << 31) && (uint64_t)Cout * 9 * Cin * 2 < (1ull << 31) && (!with_gn_sums || (H * W) % 256 == 0);
+    if (B == 0 || H == 0 || W == 0 || (ksize != 1 && ksize != 3) || Cin % 32 != 0 || M >= (1ull << 31) || M * Cin * 4 >= (1ull << 31)
+        || (uint64_t)Cout * ksize * ksize * Cin * 4 >= (1ull << 31)) return 0;
+    if (pp_auto && ksize == 3 && Cout % 128 == 0 && (W == 128 || W == 64) && (H * W) % 256 == 0 && M >= 32768) return 1;
+    if (!small_auto || Cout % 64 != 0 || M * Cout * 4 >= (1ull << 31)) return 0;
+    const int plan = cv_ps_plan((uint32_t)M, Cin, Cout, ksize, 0, 0);
+    const uint32_t bm = (plan & 0xff) == 1 ? 128 : 64, splits = (uint32_t)plan >> 8;
+    if (with_gn_sums && splits == 1 && (H * W) % bm != 0) return 0;
+    return 2;
 }
 
 extern "C" int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const void* w_hi, const void* w_lo, const float* bias, const void* residual, void* y, uint32_t B,
-                                                  uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, void* gn_sums, uint32_t gn_groups, void* stream) {
+                                                  uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, void* gn_sums, uint32_t gn_groups,
+                                                  int tile_hint, int splits_hint, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if (B == 0 || H == 0 || W == 0) return SSDNERF_OK;
     SSD_REQUIRE(x_split && w_hi && w_lo && y, "conv2d_nhwc_f32x2_presplit: null pointer");
-    SSD_REQUIRE(ssdnerf_conv2d_nhwc_f32x2_presplit_supported(B, H, W, Cin, Cout, 3, gn_sums != nullptr), "conv2d_nhwc_f32x2_presplit: layer not taken by the two-group row kernel");
-    SSD_REQUIRE((const unsigned char*)w_lo == (const unsigned char*)w_hi + (size_t)Cout * 9 * Cin * 2, "conv2d_nhwc_f32x2_presplit: w_lo must lie directly behind w_hi");
+    int kind = ssdnerf_conv2d_nhwc_f32x2_presplit_supported(B, H, W, Cin, Cout, ksize, gn_sums != nullptr);
+    if (tile_hint >= 1 && tile_hint <= 3 && ssdnerf_conv2d_nhwc_f32x2_presplit_supported(B, H, W, Cin, tile_hint == 3 ? 64 : 128, ksize, 0) && Cout % (tile_hint == 3 ? 64 : 128) == 0)
+        kind = 2;                                                            // (sweeps: force the generic kernel's PS form with this tile)
+    SSD_REQUIRE(kind != 0, "conv2d_nhwc_f32x2_presplit: layer not taken by a pre-split kernel (ask ssdnerf_conv2d_nhwc_f32x2_presplit_supported first)");
+    SSD_REQUIRE((const unsigned char*)w_lo == (const unsigned char*)w_hi + (size_t)Cout * ksize * ksize * Cin * 2, "conv2d_nhwc_f32x2_presplit: w_lo must lie directly behind w_hi");
     SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0), "conv2d_nhwc_f32x2_presplit: fused GroupNorm statistics need groups of a multiple of 4 channels");
+    hipStream_t st = (hipStream_t)stream;
     ConvArgs a;
     a.x2 = nullptr; a.Cin1 = Cin;
     a.x = (const unsigned char*)x_split; a.w = (const unsigned char*)w_hi; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
     a.gn_sums = (double*)gn_sums; a.G = gn_groups ? gn_groups : 1;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.ksize = 3; a.stride = 1; a.pad = 1; a.upsample = 0;
+    a.ksize = ksize; a.stride = 1; a.pad = ksize / 2; a.upsample = 0;
     a.Ho = H; a.Wo = W; a.M = B * H * W;
     a.splits = 1; a.splitk_ws = nullptr;
+    if (kind == 2) {
+        const int plan = cv_ps_plan(a.M, Cin, Cout, ksize, tile_hint, splits_hint);
+        const int choice = plan & 0xff;
+        const uint32_t bm = choice == 1 ? 128 : 64, bn = choice == 3 ? 64 : 128;
+        a.splits = (uint32_t)plan >> 8;
+        SSD_REQUIRE(!gn_sums || a.splits > 1 || (H * W) % bm == 0, "conv2d_nhwc_f32x2_presplit: fused GroupNorm statistics need H*W to be a multiple of the M tile");
+        a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = Cout / bn;
+        float* ws = (splitk_ws && splitk_ws_bytes >= (size_t)a.M * Cout * 4) ? (float*)splitk_ws : nullptr;
+        double* stats = a.gn_sums;
+        if (a.splits > 1) {
+            a.gn_sums = nullptr;
+            if (!ws && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2_presplit: memset failed");
+            a.splitk_ws = ws ? ws : (float*)y;
+        }
+        const dim3 grid(a.m_tiles * a.n_tiles * a.splits);
+        if (choice == 1) hipLaunchKernelGGL((k_conv_igemm_bf16<2, 2, 2, 2, 2, false, true>), grid, dim3(256), 0, st, a);
+        else if (choice == 2) hipLaunchKernelGGL((k_conv_igemm_bf16<1, 2, 2, 2, 3, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_igemm_bf16<1, 1, 2, 2, 4, false, true>), grid, dim3(256), 0, st, a);
+        if (a.splits > 1) {
+            const uint32_t HWo = H * W, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
+            uint32_t rows = HWo;
+            while (rows > rstep && rows % 2 == 0 && (uint64_t)B * (HWo / rows) < 1024) rows /= 2;
+            hipLaunchKernelGGL(k_conv_f32_finish, dim3((HWo + rows - 1) / rows, B), dim3(256), 0, st, (float*)y, ws, bias, (const float*)residual, HWo, cpr, rows, stats, a.G);
+        }
+        SSD_CHECK_LAUNCH("conv2d_nhwc_f32x2_presplit");
+        return SSDNERF_OK;
+    }
     a.m_tiles = (a.M + 255) / 256; a.n_tiles = Cout / 128;
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -1739,7 +1826,7 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const voi
         n_cu &= ~7;
     }
     const uint32_t tiles = a.m_tiles * a.n_tiles, grid = tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu;
-    hipLaunchKernelGGL((k_conv_pp_bf16<true, true, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_conv_pp_bf16<true, true, true>), dim3(grid), dim3(512), 0, st, a);
     SSD_CHECK_LAUNCH("conv2d_nhwc_f32x2_presplit");
     return SSDNERF_OK;
 }

@@ -68,7 +68,7 @@ class _ConvF32x2Fn(torch.autograd.Function):
                 runs = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
                 box["runs"] = runs
             return UF.conv2d_nhwc_f32x2_presplit(xc, hi, lo, conv.bias, None if residual is None else residual.contiguous(memory_format=torch.channels_last),
-                                                 runs, conv.out_channels // 4 if runs is not None else 0)
+                                                 runs, conv.out_channels // 4 if runs is not None else 0, splitk_ws=UF.shared_splitk_ws(x.device))
         runs = None
         if box is not None and _runs_fusable(xc, conv):
             n = xc.size(0) * (conv.out_channels // 4) * 2

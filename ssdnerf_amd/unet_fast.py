@@ -181,26 +181,33 @@ def split_bf16x2_adjacent(w: torch.Tensor):
     return buf[0].permute(0, 3, 1, 2), buf[1].permute(0, 3, 1, 2)
 
 
-def presplit_supported(x: torch.Tensor, cout: int, k: int, with_stats: bool = False) -> bool:
-    """whether the 3 x 3 / stride 1 convolution of the channels_last fp32 tensor ``x`` to ``cout`` channels is a layer the two-group kernel takes on
-    PRE-SPLIT activations (``conv2d_nhwc_f32x2_presplit``): the norm that produces x then writes its result with ``split_out=True``"""
-    return bool(x.is_cuda and x.dtype == torch.float32 and C.lib().ssdnerf_conv2d_nhwc_f32x2_presplit_supported(
+def presplit_supported(x: torch.Tensor, cout: int, k: int, with_stats: bool = False) -> int:
+    """whether the k x k / stride 1 convolution of the channels_last fp32 tensor ``x`` to ``cout`` channels is a layer a kernel takes on PRE-SPLIT
+    activations (``conv2d_nhwc_f32x2_presplit``; 1: the two-group row kernel, 2: the generic DMA-ring kernel's PS form, 0: none): the norm that
+    produces x then writes its result with ``split_out=True``"""
+    if not (x.is_cuda and x.dtype == torch.float32):
+        return 0
+    return int(C.lib().ssdnerf_conv2d_nhwc_f32x2_presplit_supported(
         C.u32(x.size(0)), C.u32(x.size(2)), C.u32(x.size(3)), C.u32(x.size(1)), C.u32(cout), C.u32(k), int(with_stats)))
 
 
 def conv2d_nhwc_f32x2_presplit(x_split: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                               residual: Optional[torch.Tensor] = None, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0) -> torch.Tensor:
-    """``conv2d_nhwc_f32x2`` (3 x 3, stride 1) of an activation that ``group_norm_nhwc(..., split_out=True)`` wrote pre-split (csrc/conv_igemm.hip,
-    k_conv_pp_bf16<ROWS, F32, PS>): bit-identical result, the operand split is out of the K loop.  ``w_hi`` / ``w_lo`` from ``split_bf16x2_adjacent``."""
+                               residual: Optional[torch.Tensor] = None, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0,
+                               splitk_ws: Optional[torch.Tensor] = None, tile_hint: int = 0, splits_hint: int = 0) -> torch.Tensor:
+    """``conv2d_nhwc_f32x2`` (1 x 1 or 3 x 3, stride 1) of an activation that ``group_norm_nhwc(..., split_out=True)`` wrote pre-split (csrc/conv_igemm.hip,
+    k_conv_pp_bf16<ROWS, F32, PS> -- bit-identical to the on-the-fly split -- or k_conv_igemm_bf16<..., PS> on the small layers): the operand split is out
+    of the K loop.  ``w_hi`` / ``w_lo`` from ``split_bf16x2_adjacent``; ``splitk_ws``: the all-zero scratch of ``shared_splitk_ws``."""
     B, Cin, H, W = x_split.shape
-    Cout = w_hi.shape[0]
-    if not x_split.is_contiguous(memory_format=torch.channels_last) or x_split.dtype != torch.float32 or tuple(w_hi.shape[1:]) != (Cin, 3, 3):
-        raise RuntimeError("conv2d_nhwc_f32x2_presplit: (B, Cin, H, W) channels_last carrier tensor and a (Cout, Cin, 3, 3) weight pair")
+    Cout, k = w_hi.shape[0], w_hi.shape[2]
+    if not x_split.is_contiguous(memory_format=torch.channels_last) or x_split.dtype != torch.float32 or tuple(w_hi.shape[1:]) != (Cin, k, k) or k not in (1, 3):
+        raise RuntimeError("conv2d_nhwc_f32x2_presplit: (B, Cin, H, W) channels_last carrier tensor and a (Cout, Cin, k, k) weight pair, k 1 | 3")
     y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_split.device, memory_format=torch.channels_last)
     if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or not residual.is_contiguous(memory_format=torch.channels_last)):
         raise RuntimeError("conv2d_nhwc_f32x2_presplit: residual must match the output's shape, dtype and layout")
     C.check(C.lib().ssdnerf_conv2d_nhwc_f32x2_presplit(C.ptr(x_split), C.ptr(w_hi), C.ptr(w_lo), C.ptr(bias), C.ptr(residual), C.ptr(y), C.u32(B), C.u32(H), C.u32(W),
-                                                        C.u32(Cin), C.u32(Cout), C.ptr(gn_sums), C.u32(gn_groups), C.stream()), "conv2d_nhwc_f32x2_presplit")
+                                                        C.u32(Cin), C.u32(Cout), C.u32(k), C.ptr(gn_sums), C.u32(gn_groups), int(tile_hint), int(splits_hint), C.ptr(splitk_ws),
+                                                        ctypes.c_size_t(0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size()), C.stream()),
+            "conv2d_nhwc_f32x2_presplit")
     return y
 
 
@@ -349,14 +356,14 @@ class _Conv:
 
     def takes_presplit(self, x, with_stats=False) -> bool:
         """the norm that feeds this convolution may hand its result over pre-split (fp32 executor, large 3 x 3 layers)"""
-        return (self.w_lo is not None and self.own and _Conv.PRESPLIT and self.stride[0] == 1 and self.w.shape[2] == 3
-                and presplit_supported(x, int(self.w.shape[0]), 3, with_stats))
+        return bool(self.w_lo is not None and self.own and _Conv.PRESPLIT and self.stride[0] == 1 and int(self.w.shape[1]) == int(x.size(1))
+                    and presplit_supported(x, int(self.w.shape[0]), int(self.w.shape[2]), with_stats))
 
     PRESPLIT = os.environ.get("SSDNERF_UNET_PRESPLIT", "1") != "0"   # 0: the fp32 two-group kernel splits its pixels on the fly again (A/B runs)
 
     def igemm(self, x, bias=None, residual=None, upsample=False, gn_sums=None, gn_groups=0, x2=None, presplit=False):
         if presplit:
-            return conv2d_nhwc_f32x2_presplit(x, self.w_lo[0], self.w_lo[1], bias, residual, gn_sums, gn_groups)
+            return conv2d_nhwc_f32x2_presplit(x, self.w_lo[0], self.w_lo[1], bias, residual, gn_sums, gn_groups, splitk_ws=shared_splitk_ws(x.device))
         if self.w_lo is not None:
             return conv2d_nhwc_f32x2(x, self.w_lo[0], self.w_lo[1], bias, residual, self.stride[0], upsample, gn_sums, gn_groups, x2=x2,
                                      splitk_ws=shared_splitk_ws(x.device))
@@ -589,12 +596,13 @@ class FastUnet:
         B, Cc, H, W = x.shape
         T, ch = H * W, Cc // heads
         xt = x.permute(0, 2, 3, 1).reshape(B, T, Cc)                       # a view: channels_last storage is already [B][T][C]
-        xn = self._gn(xt, gn, None, False, stats=stats)                     # (B, T, C)
         own = qkv_conv.own and proj_conv.own and attention_supported(self.dtype, T, ch)
+        ps = own and qkv_conv.w_lo is not None and qkv_conv.takes_presplit(x)        # (fp32 executor: the qkv projection multiplies pre-split operands)
+        xn = self._gn(xt, gn, None, False, stats=stats, split=ps)           # (B, T, C)
         if own:
             # the whole block on the hand-written kernels: 1x1 projections on the implicit GEMM (bias, residual and the next norm's statistics in
             # its epilogue), softmax(QK^T)V on the MFMA flash-attention kernel
-            qkv = qkv_conv.igemm(xn.view(B, H, W, Cc).permute(0, 3, 1, 2), qkv_conv.bias)           # (B, 3C, H, W) channels_last
+            qkv = qkv_conv.igemm(xn.view(B, H, W, Cc).permute(0, 3, 1, 2), qkv_conv.bias, presplit=ps)   # (B, 3C, H, W) channels_last
             a = attention_qkv(qkv.permute(0, 2, 3, 1).reshape(B, T, 3 * Cc), heads)                  # (B, T, C)
             return self._conv_stats(proj_conv, a.view(B, H, W, Cc).permute(0, 3, 1, 2), proj_conv.bias, x)
         _lib_call(f"attention block C={Cc} T={T} (linear, sdpa, linear)")

@@ -771,7 +771,7 @@ def test_presplit_convolution_is_bit_identical_to_the_on_the_fly_split(B, cin, c
     gamma, beta = (torch.rand(cin, generator=g) + 0.5).cuda(), torch.randn(cin, generator=g).cuda()
     ss = (torch.randn(B, 2 * cin, generator=g) * 0.3).cuda()
     hi, lo = UF.split_bf16x2_adjacent(w)
-    assert UF.presplit_supported(x, cout, 3, True)
+    assert UF.presplit_supported(x, cout, 3, True) == 1                                  # the two-group row kernel
     outs = []
     for split in (False, True):
         ws = torch.zeros(B * 32 * 2, dtype=torch.float64, device="cuda")
@@ -791,9 +791,56 @@ def test_presplit_convolution_is_bit_identical_to_the_on_the_fly_split(B, cin, c
     assert float((outs[1][1] - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
-def test_presplit_is_not_offered_for_layers_the_row_kernel_does_not_take():
+@pytest.mark.parametrize("B,cin,cout,hw,k", [(8, 512, 512, 16, 3), (8, 256, 512, 16, 3), (8, 1024, 512, 8, 3), (8, 512, 1536, 16, 1), (8, 256, 256, 32, 3),
+                                             (1, 128, 128, 128, 3), (8, 384, 256, 32, 3), (3, 128, 192, 24, 3), (8, 128, 128, 128, 1)])
+def test_presplit_convolution_on_the_small_layers_matches_the_on_the_fly_kernel(B, cin, cout, hw, k):
+    """The generic DMA-ring kernel's PS form (csrc/conv_igemm.hip k_conv_igemm_bf16<..., PS>) on the layers the two-group kernel does not take: the same
+    hi / lo terms and the same three products per pair as k_conv_igemm_f32x2, summed in another order (and split along K the same way) -- equal to fp32
+    rounding of the sum, both against the on-the-fly kernel and against the library's fp32 convolution; GroupNorm sums from the epilogue / the
+    finishing pass; the shared split-K scratch is left all zero."""
     from ssdnerf_amd import unet_fast as UF
-    x = torch.empty(8, 512, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
-    assert not UF.presplit_supported(x, 512, 3)                                          # low resolution: the generic kernel (split once, in its loader)
-    assert not UF.presplit_supported(torch.empty(8, 128, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last), 128, 1)
-    assert not UF.presplit_supported(torch.empty(8, 24, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last), 128, 3)
+    g = torch.Generator().manual_seed(cin + cout + hw + k)
+    x = torch.randn(B, cin, hw, hw, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    res = torch.randn(B, cout, hw, hw, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    gamma, beta = (torch.rand(cin, generator=g) + 0.5).cuda(), torch.randn(cin, generator=g).cuda()
+    hi, lo = UF.split_bf16x2_adjacent(w)
+    with_stats = (hw * hw) % 64 == 0
+    assert UF.presplit_supported(x, cout, k, with_stats) == 2
+    scratch = UF.shared_splitk_ws(x.device)
+    outs = []
+    for split in (False, True):
+        ws = torch.zeros(B * 32 * 2, dtype=torch.float64, device="cuda")
+        gn = UF.group_norm_nhwc(x, 32, gamma, beta, None, 1e-5, True, ws, workspace_is_zero=True, split_out=split)
+        runs = torch.zeros(B * (cout // 4) * 2, dtype=torch.float64, device="cuda") if with_stats else None
+        if split:
+            y = UF.conv2d_nhwc_f32x2_presplit(gn, hi, lo, bias, res, runs, cout // 4 if with_stats else 0, splitk_ws=scratch)
+        else:
+            y = UF.conv2d_nhwc_f32x2(gn, hi, lo, bias, res, gn_sums=runs, gn_groups=cout // 4 if with_stats else 0, splitk_ws=scratch)
+        outs.append((gn, y, runs))
+    ref = F.conv2d(outs[0][0].double(), w.double(), bias.double(), padding=k // 2) + res.double()
+    scale = float(ref.abs().max())
+    assert float((outs[1][1] - outs[0][1]).abs().max()) <= 2e-6 * scale                    # fp32 rounding of sums in another order
+    e_ps, e_fly = float((outs[1][1] - ref).abs().max()), float((outs[0][1] - ref).abs().max())
+    assert e_ps <= 4e-5 * scale and e_ps <= 1.5 * e_fly + 1e-6 * scale, (e_ps, e_fly)     # as close to the fp64 answer as the on-the-fly kernel
+    if with_stats:
+        yd = outs[1][1].double().permute(0, 2, 3, 1).reshape(B, hw * hw, cout // 4, 4)
+        want = torch.stack([yd.sum(dim=(1, 3)), (yd ** 2).sum(dim=(1, 3))], dim=-1)
+        assert torch.allclose(outs[1][2].view(B, cout // 4, 2), want, rtol=1e-5, atol=1e-3)
+    assert float(scratch.abs().max()) == 0.0
+    # no scratch at hand: the partial sums go to the (zeroed) output instead
+    y2 = UF.conv2d_nhwc_f32x2_presplit(outs[1][0], hi, lo, bias, res)
+    assert float((y2 - outs[1][1]).abs().max()) <= 2e-6 * scale
+
+
+def test_presplit_is_not_offered_for_layers_no_kernel_takes():
+    from ssdnerf_amd import unet_fast as UF
+    cl = lambda *s: torch.empty(*s, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert UF.presplit_supported(cl(8, 512, 16, 16), 512, 3) == 2                        # low resolution: the generic kernel's PS form (r04)
+    assert UF.presplit_supported(cl(8, 128, 128, 128), 128, 3) == 1                      # the two-group row kernel
+    assert not UF.presplit_supported(cl(8, 24, 128, 128), 128, 3)                        # Cin % 32
+    assert not UF.presplit_supported(cl(8, 128, 32, 32), 6, 3)                           # Cout % 64 (the output layer)
+    assert not UF.presplit_supported(cl(8, 128, 32, 32), 128, 5)
+    assert not UF.presplit_supported(cl(8, 128, 32, 32).half(), 128, 3)
+    assert not UF.presplit_supported(torch.empty(8, 128, 32, 32), 128, 3)                # (CPU tensor)
