@@ -356,8 +356,10 @@ class TriPlaneDecoder(VolumeRenderer):
         return ok
 
     def packed_params(self) -> torch.Tensor:
-        ps = [self.base_net[0].weight, self.base_net[0].bias, self.density_net[0].weight, self.density_net[0].bias,
-              self.dir_net[0].weight, self.dir_net[0].bias, self.color_net[0].weight, self.color_net[0].bias]
+        cached = self.__dict__.get("_packed_ps")                         # (the four Linear modules, looked up once: Sequential.__getitem__ is slow)
+        if cached is None:
+            cached = self.__dict__["_packed_ps"] = (self.base_net[0], self.density_net[0], self.dir_net[0], self.color_net[0])
+        ps = [p for m in cached for p in (m._parameters["weight"], m._parameters["bias"])]
         key = tuple((p.data_ptr(), p._version, p.device.index, p.dtype) for p in ps)     # (writes through p.data bypass this: call invalidate_packed())
         if self._packed is None or key != self._packed_key:
             sd = {"base_net.0.weight": ps[0].detach(), "base_net.0.bias": ps[1].detach(), "density_net.0.weight": ps[2].detach(),
@@ -379,6 +381,7 @@ class TriPlaneDecoder(VolumeRenderer):
         """Forget the packed parameter block (re-packed on the next fused call).  Automatic after ``load_state_dict`` / ``.to()``; needed by hand
         only after writing weights through ``p.data``, which no version counter sees."""
         self._packed, self._packed_key = None, None
+        self.__dict__.pop("_packed_ps", None)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -521,10 +524,10 @@ class TriPlaneDecoder(VolumeRenderer):
         cams=(c2w (S,V,4,4), intrinsics (S,V,4), h, w) instead of ray arrays (rays_o = rays_d = None): the kernels generate ray n =
         pixel n % (h*w) of view n // (h*w) themselves (the arithmetic of ``nerf.get_cam_rays``), N = V*h*w.
         dt_gamma: per-scene list of floats, or a DEVICE tensor (S,) (no host sync)."""
-        params = self.packed_params()
         if cams is not None:
             assert rays_o is None and rays_d is None, "render_packed: give ray arrays or cameras, not both"
             return self._render_packed_cams(planes, cams, density_bitfield, grid_size, dt_gamma, T_thresh, bg_color, want_counts, check_overflow, want_u8)
+        params = self.packed_params()
         num_scenes = len(rays_o)
         dev = planes.device
         _, _, hp, wp, _ = planes.shape

@@ -62,7 +62,8 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
     the render kernels next to the float image on the camera-fed path, one ``quantize_u8`` pass otherwise."""
     cfg = cfg or {}
     was_training = decoder.training
-    decoder.train(False)
+    if was_training:                                                  # (nn.Module.train walks the module tree: ~20 us a call, exposed between two renders)
+        decoder.train(False)
     dt_gamma_scale = cfg.get("dt_gamma_scale", 0.0)
     s, v = poses.shape[:2]
     if dt_gamma_scale == 0:
@@ -106,7 +107,9 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
             depths.append(out["depth"] if isinstance(out["depth"], torch.Tensor) else torch.stack(out["depth"], dim=0))
         image = torch.cat(images, dim=1) if len(images) > 1 else images[0]
         depth = torch.cat(depths, dim=1) if len(depths) > 1 else depths[0]
-    if overflow and int(torch.stack([f.reshape(()) for f in overflow]).sum().item()) != 0:
+    # ONE host read per render call (the reference syncs once per loop iteration); a single launch's flag is read as it is -- no stack / sum kernels
+    # between the render and the read, which sits on the critical path of back-to-back renders (profiles/r04/l_host_gap_*.txt)
+    if overflow and int((overflow[0] if len(overflow) == 1 else torch.stack([f.reshape(()) for f in overflow]).sum()).item()) != 0:
         # a ray reached the reference loop's global step cap (max_steps occupied samples), where the reference's answer depends on its n_step
         # schedule: redo the batch through the reference-shaped stepwise path, which is exact by construction (same rule as
         # TriPlaneDecoder._forward_eval_fused).  One sync per render call; the reference syncs once per loop iteration.
@@ -120,7 +123,8 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
         image_u8 = None
     image = image.reshape(s, v, h, w, 3)
     depth = depth.reshape(s, v, h, w)
-    decoder.train(was_training)
+    if was_training:
+        decoder.train(True)
     if return_u8:
         return image, depth, (quantize_u8(image) if image_u8 is None else image_u8.reshape(s, v, h, w, 3))
     return image, depth
