@@ -324,10 +324,16 @@ class TimeEmbedding(nn.Module):
         self.dim = cfg["dim"]
         self.max_period = cfg.get("max_period", 10000)
 
+    _freqs: dict = {}                               # (half, max_period, device) -> the frequency table on that device
+
     @staticmethod
     def sinusodial_embedding(timesteps, dim, max_period=10000):
         half = dim // 2
-        freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+        key = (half, max_period, str(timesteps.device))
+        freqs = TimeEmbedding._freqs.get(key)
+        if freqs is None:                           # computed on the host as before (same values); the copy to the device once, not per call (a
+            # host-to-device copy per call also cannot be captured into a hipGraph)
+            freqs = TimeEmbedding._freqs[key] = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
         args = timesteps[:, None].float() * freqs[None]
         emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
         if dim % 2:
@@ -638,6 +644,7 @@ class DenoisingUnetMod(nn.Module):
             ex.invalidate()
         for m in self.modules():
             m.__dict__.pop("_f32x2_cache", None)
+        self.__dict__.pop("_grad_graphs", None)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -704,6 +711,58 @@ class DenoisingUnetMod(nn.Module):
     #: profiles/r04).  SSDNERF_UNET_GRAD_AUTOCAST=1 keeps the eager autocast modules (the reference's arithmetic for that config).
     grad_path_fp32_under_autocast = os.environ.get("SSDNERF_UNET_GRAD_AUTOCAST", "0") != "1"
 
+    #: r04: input-gradient calls with frozen weights (rendering-guided DDIM steps, the prior loss of fine-tuning) replay a CAPTURED forward and a captured
+    #: backward (two hipGraphs over static buffers, ``torch.cuda.make_graphed_callables``) once a signature has been seen ``grad_graph_after`` times: the
+    #: eager gradient path is ~600 launches and ~250 autograd nodes per call, ~25 ms of host time beside ~25 ms of kernels (profiles/r04).  Same kernels in
+    #: the same order.  SSDNERF_UNET_GRAD_GRAPH=0 keeps the eager path.
+    grad_graph = os.environ.get("SSDNERF_UNET_GRAD_GRAPH", "1") != "0"
+    grad_graph_after = int(os.environ.get("SSDNERF_UNET_GRAD_GRAPH_AFTER", "3"))
+    grad_graph_max = 2                                              # signatures kept (each holds the activations of one forward + backward)
+
+    def _grad_graph_call(self, x_t, t):
+        """The captured forward + backward for this call's signature, or None (not eligible, not yet seen often enough, capture failed)."""
+        if not (self.grad_graph and x_t.is_cuda and x_t.dtype == torch.float32 and x_t.requires_grad and torch.is_grad_enabled() and not self.training
+                and torch.is_tensor(t) and t.is_cuda and not t.requires_grad and not torch.is_autocast_enabled("cuda")
+                and not torch.cuda.is_current_stream_capturing()):
+            return None
+        versions = 0
+        for p in self.parameters():
+            if p.requires_grad:
+                return None                                          # (a weight gradient is asked for: the eager path)
+            versions += p._version
+        key = (tuple(x_t.shape), tuple(t.shape), t.dtype, x_t.device.index)
+        graphs = self.__dict__.setdefault("_grad_graphs", {})
+        entry = graphs.get(key)
+        if entry is None or entry["versions"] != versions:
+            if len(graphs) >= self.grad_graph_max and key not in graphs:
+                graphs.pop(next(iter(graphs)))
+            entry = graphs[key] = {"versions": versions, "calls": 0, "fn": None, "failed": False}
+        if entry["fn"] is not None:
+            return entry["fn"]
+        entry["calls"] += 1
+        if entry["failed"] or entry["calls"] <= self.grad_graph_after:
+            return None
+        try:
+            # (warm-up inside make_graphed_callables runs on a side stream; the eager calls before this one have filled every cache -- split weights,
+            # batched time-embedding projections, split-K scratch -- so nothing persistent is created inside the capture)
+            import time
+            t0 = time.perf_counter()
+            sx, st = x_t.detach().clone().requires_grad_(True), t.detach().clone()
+            entry["fn"] = torch.cuda.make_graphed_callables(lambda x, tt: self._forward_eager(x, tt), (sx, st), num_warmup_iters=1)
+            entry["capture_s"] = time.perf_counter() - t0
+        except Exception as e:                                       # noqa: BLE001  (e.g. a library call that cannot be captured: stay eager, say so once)
+            entry["failed"] = True
+            import traceback, warnings
+            warnings.warn(f"DenoisingUnetMod: capturing the gradient path failed ({e!r}); this signature stays on the eager path\n"
+                          + "".join(traceback.format_tb(e.__traceback__)[-8:]))
+            return None
+        return entry["fn"]
+
+    def grad_graph_info(self):
+        """[{signature, captured, capture_s, failed}] of the gradient path's captured graphs (bench / tests)"""
+        return [dict(x_shape=list(k[0]), captured=e["fn"] is not None, capture_s=e.get("capture_s"), failed=e["failed"])
+                for k, e in self.__dict__.get("_grad_graphs", {}).items()]
+
     def forward(self, x_t, t, label=None, concat_cond=None, return_noise=False):
         if self._fast_path_ok(x_t, label):
             dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
@@ -713,6 +772,13 @@ class DenoisingUnetMod(nn.Module):
                 and not self.out.conv.weight.requires_grad and not self.time_embedding.blocks[0].weight.requires_grad):
             with torch.autocast("cuda", enabled=False):
                 return self.forward(x_t.float(), t, label, None if concat_cond is None else concat_cond.float(), return_noise)
+        if label is None and concat_cond is None and not return_noise:
+            graphed = self._grad_graph_call(x_t, t)
+            if graphed is not None:
+                return graphed(x_t, t).clone()                       # (the graph's output buffer is overwritten by the next replay)
+        return self._forward_eager(x_t, t, label, concat_cond)
+
+    def _forward_eager(self, x_t, t, label=None, concat_cond=None):
         if self.use_rescale_timesteps:
             t = t.float() * (1000.0 / self.num_timesteps)
         embedding = self.time_embedding(t)

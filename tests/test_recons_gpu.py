@@ -247,3 +247,53 @@ def test_gradient_path_attention_library_fp32_is_reachable_and_agrees(monkeypatc
     monkeypatch.setattr(U, "GRAD_ATT_KERNEL", True)
     assert U.attention_kernel_ok(torch.empty(1, 64, 3 * 256, device="cuda"), heads=4)
     assert not U.attention_kernel_ok(torch.empty(20000, 4, 3 * 32, device="cuda"), heads=4)      # 80 000 (batch, head) pairs > 65 535 grid rows
+
+
+def test_captured_gradient_path_matches_the_eager_one():
+    """Input-gradient calls with frozen weights replay a captured forward + backward once a signature has been seen often enough
+    (``DenoisingUnetMod._grad_graph_call``): same kernels in the same order, so outputs and input gradients equal the eager path's to the rounding of
+    the kernels' atomics; new inputs go through the static buffers; a changed weight drops the graph (the result follows the new weights); a call that
+    asks for weight gradients stays eager."""
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.registry import MODULES
+    net = MODULES.build(dict(UNET, base_channels=64, channels_cfg=[1, 2, 2], attention_res=[32, 64])).cuda().eval()
+    _randomize(net, 5, scale=1.0)
+    net.requires_grad_(False)
+    net.grad_graph_after = 2
+    g = torch.Generator().manual_seed(1)
+
+    def call(x, t, graph):
+        net.grad_graph = graph
+        xi = x.clone().requires_grad_(True)
+        y = net(xi, t)
+        (gx,) = torch.autograd.grad((y * torch.sin(y.detach())).sum(), xi)
+        return y.detach().clone(), gx.detach().clone()
+
+    def captured():
+        return [e["fn"] is not None for e in net.__dict__.get("_grad_graphs", {}).values()]
+
+    xs = [torch.randn(2, 18, 128, 128, generator=g).cuda() for _ in range(6)]
+    ts = [torch.tensor([100 + 37 * i, 900 - 11 * i], device="cuda") for i in range(6)]
+    for i in range(6):
+        y_g, gx_g = call(xs[i], ts[i], True)
+        assert captured() == [i >= 2], (i, captured())                                  # calls 0, 1 eager; call 2 captures and replays
+        y_e, gx_e = call(xs[i], ts[i], False)
+        for a, b, what in ((y_g, y_e, "output"), (gx_g, gx_e, "input gradient")):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (i, what, float((a - b).abs().max()), float(b.abs().max()))
+    with torch.no_grad():
+        net.out.conv.weight.mul_(1.5); net.out.conv.bias.add_(0.25)                     # in place: the version counters move
+    y_g, gx_g = call(xs[0], ts[0], True)
+    assert captured() == [False]                                                        # dropped; counted from zero again
+    y_e, gx_e = call(xs[0], ts[0], False)
+    assert float((y_g - y_e).abs().max()) <= 2e-5 * float(y_e.abs().max()) and float((gx_g - gx_e).abs().max()) <= 2e-5 * float(gx_e.abs().max())
+    for i in range(1, 4):
+        y_g, gx_g = call(xs[i], ts[i], True)
+    assert captured() == [True]
+    y_e, gx_e = call(xs[3], ts[3], False)
+    assert float((y_g - y_e).abs().max()) <= 2e-5 * float(y_e.abs().max()) and float((gx_g - gx_e).abs().max()) <= 2e-5 * float(gx_e.abs().max())
+    net.out.conv.weight.requires_grad_(True)                                            # a weight gradient is wanted: eager, and it arrives
+    net.grad_graph = True
+    xi = xs[4].clone().requires_grad_(True)
+    y = net(xi, ts[4])
+    gx, gw = torch.autograd.grad(y.square().sum(), (xi, net.out.conv.weight))
+    assert gw is not None and float(gw.abs().max()) > 0

@@ -74,9 +74,11 @@ if a.profile:
 
 out = dict(scenes=ns, unet_dtype=a.dtype)
 # guidance: time k and 1 step runs, the difference is the per-step cost without the fixed setup
+unet = model.diffusion_ema.denoising
+model.test_cfg["num_timesteps"] = model.diffusion_ema.test_cfg["num_timesteps"] = 2 + int(getattr(unet, "grad_graph_after", 0))
+timed(lambda: model.val_guide(dict(data, noise=torch.randn(ns, 3, 6, 128, 128, generator=g).cuda())))      # warm-up (long enough for the gradient path's graph capture)
 model.test_cfg["num_timesteps"] = 1
 model.diffusion_ema.test_cfg["num_timesteps"] = 1
-timed(lambda: model.val_guide(dict(data, noise=torch.randn(ns, 3, 6, 128, 128, generator=g).cuda())))      # warm-up
 _, t1 = timed(lambda: model.val_guide(dict(data, noise=torch.randn(ns, 3, 6, 128, 128, generator=g).cuda())))
 model.test_cfg["num_timesteps"] = 1 + a.guide_steps
 model.diffusion_ema.test_cfg["num_timesteps"] = 1 + a.guide_steps
@@ -94,4 +96,5 @@ out["inner_render_iterations_per_outer"] = a.extra_scene_step + 1
 out["code_finite"] = bool(torch.isfinite(code).all())
 # the recons1v schedule: 75 guided steps + 25 outer iterations
 out["projected_s_per_batch_75_guided_25_outer"] = round((75 * out["ms_per_guided_ddim_step"] + 25 * out["ms_per_finetune_outer_iteration"]) / 1e3, 2)
+out["grad_graph"] = unet.grad_graph_info() if hasattr(unet, "grad_graph_info") else None
 print(json.dumps(out))
