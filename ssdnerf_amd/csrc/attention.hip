@@ -12,8 +12,9 @@
 //   * P = exp2((S - m) * scale*log2e) is rounded to bf16 in registers and is *already* the B operand of  O^T += V^T P : the
 //     C-layout's key order per lane half ({0-3, 8-11} / {4-7, 12-15} of every 16) is simply adopted as the k-slot order, and the
 //     V tile is written to LDS transposed in that same order, so no permute or LDS round trip of P is needed;
-//   * K fragments come straight from L2 into registers (each lane's 16 bytes are contiguous in the qkv row), V goes through LDS
-//     because it needs the transpose; one barrier per key block;
+//   * K and V of a key block go through LDS once per block of four waves, already as operand terms (r04; K used to be loaded -- and, fp32, split -- by
+//     every wave into its own registers): K row-major (its A fragments are one ds_read_b128 each), V transposed; global -> registers at the head of a
+//     key block, registers -> the other LDS buffer behind its products, one barrier per key block;
 //   * softmax statistics in fp32, O accumulated in fp32, divided by the row sum at the end.
 //
 // Two element types share the kernel (template F32):
@@ -66,22 +67,29 @@ SSD_DEV uint32_t at_key_pos(uint32_t kk) {
     return (kk & 16u) + ((w >> 2) & 1u) * 8u + (w & 3u) + 4u * (w >> 3);
 }
 
-template <int CHP, bool F32>
-__global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restrict__ qkv, unsigned char* __restrict__ out, uint32_t T, uint32_t heads,
+// WPB: waves (= 32-query tiles) per block; 4 is what at_launch uses (see there), 2 / 1 exist for A/B runs.
+template <int CHP, bool F32, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_attn_fwd(const unsigned char* __restrict__ qkv, unsigned char* __restrict__ out, uint32_t T, uint32_t heads,
                                                   uint32_t ch, float scale_log2e, float* __restrict__ lse2) {
     constexpr int KS = CHP / 16;           // k-steps of the QK^T product
     constexpr int CT = CHP / 32;           // 32-channel tiles of O
-    constexpr int VTOT = 32 * CHP / 8;     // 8-channel V chunks per key block
-    constexpr int VCH = (VTOT + 255) / 256; // ... per thread
+    constexpr int G = F32 ? 4 : 8;         // channels per staged V item and row (16 bytes)
+    constexpr int VTOT = 16 * CHP / G;     // V items per key block: (pair of adjacent keys, G-channel group)
+    constexpr int NTH = 64 * WPB;          // threads per block
+    constexpr int VCH = (VTOT + NTH - 1) / NTH; // ... per thread
     constexpr int ES = F32 ? 4 : 2;        // bytes per stored element
     constexpr int NT = F32 ? 2 : 1;        // operand terms (hi, lo)
+    constexpr int KROW = CHP * 2 + 16;     // bytes per LDS row of K (one key's CHP bf16 terms + 16 B pad: the 32 rows of a ds_read_b128 fall on different banks)
+    constexpr int KTOT = 32 * CHP / 8;     // K items per key block: (key, 8-channel chunk)
+    constexpr int KCH = (KTOT + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) unsigned char vt[2][NT][CHP * AT_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char kt[2][NT][32 * KROW];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
     const uint32_t b = blockIdx.y / heads, h = blockIdx.y % heads, C = heads * ch;
     const size_t row_bytes = (size_t)3 * C * ES;
     const unsigned char* base = qkv + (size_t)b * T * row_bytes + (size_t)h * 3 * ch * ES;      // q of this head; k at +ch, v at +2ch elements
-    const uint32_t q0 = blockIdx.x * 128 + wave * 32;
+    const uint32_t q0 = blockIdx.x * (32 * WPB) + wave * 32;
     const bool active = q0 < T;                          // wave-uniform
     const uint32_t nchunk = ch / 8;                      // valid 8-channel chunks per row
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -107,52 +115,82 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
         }
     }
 
-    // V staging: chunk id = tid + 256*i -> (key, 8-channel chunk)
-    bf16x8 vreg[NT][VCH];
+    // V staging (r04: as the backward kernels stage their operands -- the first form wrote eight 2-byte values per 8-channel chunk with every lane of a wave
+    // on the same two LDS banks, and THAT, not the products, was most of a key block's time: T = 256 / ch 128 ran 5.7 us per key block).  Item id ->
+    // (pair of adjacent keys 2 rp, 2 rp + 1 -- adjacent positions of a V^T row as well --, G channels): every LDS store is one dword {key 2 rp, key 2 rp + 1}
+    // of one channel, and the lanes of a wave half cover 16 key pairs x 2 channel groups = 32 different banks (a row is 80 bytes: 20 dwords).
+    uint4 va[VCH], vb[VCH];                              // the items' 16 bytes of the two rows, as loaded
+    auto v_item = [&](uint32_t id, uint32_t& rp, uint32_t& cg) { rp = (id >> 1) & 15u; cg = ((id >> 5) << 1) | (id & 1u); };
     auto v_load = [&](uint32_t kb) {
 #pragma unroll
         for (int i = 0; i < VCH; ++i) {
-            const uint32_t id = tid + 256 * i, key = id / (CHP / 8), cc = id % (CHP / 8);
-            bf16x8 hi, lo;
-            load8(id < VTOT ? kb * 32 + key : T, 2, cc, hi, lo);
-            vreg[0][i] = hi;
-            if constexpr (F32) vreg[1][i] = lo;
+            uint32_t rp, cg;
+            v_item(tid + NTH * i, rp, cg);
+            const uint32_t ra = kb * 32 + 2 * rp;
+            va[i] = make_uint4(0u, 0u, 0u, 0u); vb[i] = va[i];
+            if (tid + NTH * i < (uint32_t)VTOT && cg * G < ch) {
+                const unsigned char* p = base + (size_t)ra * row_bytes + ((size_t)2 * ch + cg * G) * ES;
+                if (ra < T) va[i] = *reinterpret_cast<const uint4*>(p);
+                if (ra + 1 < T) vb[i] = *reinterpret_cast<const uint4*>(p + row_bytes);
+            }
         }
     };
     auto v_store = [&](uint32_t buf) {
 #pragma unroll
-        for (int tm = 0; tm < NT; ++tm)
+        for (int i = 0; i < VCH; ++i) {
+            uint32_t rp, cg;
+            v_item(tid + NTH * i, rp, cg);
+            if (tid + NTH * i >= (uint32_t)VTOT) continue;
+            const uint32_t off = (cg * G) * AT_ROW + at_key_pos(2 * rp) * 2;
+            const uint32_t wa[4] = {va[i].x, va[i].y, va[i].z, va[i].w}, wb[4] = {vb[i].x, vb[i].y, vb[i].z, vb[i].w};
+            if constexpr (F32) {
 #pragma unroll
-            for (int i = 0; i < VCH; ++i) {
-                const uint32_t id = tid + 256 * i, key = id / (CHP / 8), cc = id % (CHP / 8);
-                if (id >= VTOT) continue;
-                const uint4 u = *reinterpret_cast<const uint4*>(&vreg[tm][i]);
-                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-                unsigned char* dst = vt[buf][tm] + (cc * 8) * AT_ROW + at_key_pos(key) * 2;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *reinterpret_cast<uint16_t*>(dst + e * AT_ROW) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
-            }
-    };
-    // K fragments are prefetched one key block ahead: bf16 16 B per lane and k-step; fp32 (r03) the RAW 32 B, split into the bf16 pair at their use
-    // -- r02 loaded them at their use, which left an L2 round trip exposed in every key block of a kernel that runs one wave per SIMD
-    // (T = 1024: 107 us per call against 43 us for the bf16 form; one wave per SIMD also means the registers are there)
-    bf16x8 kf[F32 ? 1 : KS];
-    float4 kraw[F32 ? KS : 1][2];
-    auto k_prefetch = [&](uint32_t kb) {
-        if constexpr (!F32) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { bf16x8 lo; load8(kb * 32 + l31, 1, 2 * s + hf, kf[s], lo); }
-        } else {
-            const uint32_t row = kb * 32 + l31;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const uint32_t c8 = 2 * s + hf;
-                kraw[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); kraw[s][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < T && c8 < nchunk) {
-                    const unsigned char* p = base + (size_t)row * row_bytes + ((size_t)ch + c8 * 8) * ES;
-                    kraw[s][0] = *reinterpret_cast<const float4*>(p); kraw[s][1] = *reinterpret_cast<const float4*>(p + 16);
+                for (int c = 0; c < 4; ++c) {
+                    const float fa = __uint_as_float(wa[c]), fb = __uint_as_float(wb[c]);
+                    const uint32_t wh = at_pack_bf16(fa, fb);
+                    *reinterpret_cast<uint32_t*>(vt[buf][0] + off + c * AT_ROW) = wh;
+                    *reinterpret_cast<uint32_t*>(vt[buf][1] + off + c * AT_ROW) = at_pack_bf16_rest(fa, fb, wh);
                 }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {                    // bf16 pairs as stored: channel c of the two keys -> one dword
+                    const uint32_t a = wa[c >> 1], b = wb[c >> 1];
+                    *reinterpret_cast<uint32_t*>(vt[buf][0] + off + c * AT_ROW) = (c & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                }
+            }
+        }
+    };
+    // K staging (r04): the block's waves share a key block, so its K goes through LDS ONCE, already as the operand terms -- the first forms had every wave
+    // load the 32 x ch tile into registers and (fp32) split it into the bf16 pair itself: four times the loads and splits, and 64-128 registers for the
+    // prefetched and the current raw fragments (the ch = 128 fp32 form moved 416 values per key block between VGPRs and AccVGPRs).  Item id -> (key, 8 channels),
+    // consecutive lanes = consecutive chunks of a row (coalesced); rows of KROW bytes, read back as the MFMA A fragments with one ds_read_b128 each.
+    uint4 ka[KCH], kb2[F32 ? KCH : 1];
+    auto k_load = [&](uint32_t kb) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const uint32_t id = tid + NTH * i, key = id / (CHP / 8), c8 = id % (CHP / 8), row = kb * 32 + key;
+            ka[i] = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (F32) kb2[i] = ka[i];
+            if (id < (uint32_t)KTOT && row < T && c8 < nchunk) {
+                const unsigned char* p = base + (size_t)row * row_bytes + ((size_t)ch + c8 * 8) * ES;
+                ka[i] = *reinterpret_cast<const uint4*>(p);
+                if constexpr (F32) kb2[i] = *reinterpret_cast<const uint4*>(p + 16);
+            }
+        }
+    };
+    auto k_store = [&](uint32_t buf) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const uint32_t id = tid + NTH * i, key = id / (CHP / 8), c8 = id % (CHP / 8);
+            if (id >= (uint32_t)KTOT) continue;
+            const uint32_t off = key * KROW + c8 * 16;
+            if constexpr (F32) {
+                bf16x8 hi, lo;
+                at_split8(*reinterpret_cast<const float4*>(&ka[i]), *reinterpret_cast<const float4*>(&kb2[i]), hi, lo);
+                *reinterpret_cast<bf16x8*>(kt[buf][0] + off) = hi;
+                *reinterpret_cast<bf16x8*>(kt[buf][1] + off) = lo;
+            } else {
+                *reinterpret_cast<uint4*>(kt[buf][0] + off) = ka[i];
             }
         }
     };
@@ -166,23 +204,15 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
 
     const uint32_t nkb = (T + 31) / 32;
     v_load(0);
+    k_load(0);
     v_store(0);
-    if (active) k_prefetch(0);
+    k_store(0);
     __syncthreads();
     for (uint32_t kb = 0; kb < nkb; ++kb) {
         const uint32_t buf = kb & 1;
-        bf16x8 kcur[F32 ? 1 : KS];
-        float4 kcur_raw[F32 ? KS : 1][2];
-        if constexpr (!F32) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) kcur[s] = kf[s];
-        } else {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { kcur_raw[s][0] = kraw[s][0]; kcur_raw[s][1] = kraw[s][1]; }
-        }
-        if (kb + 1 < nkb) {                                                  // prefetch the next key block (K -> registers, V -> registers)
+        if (kb + 1 < nkb) {                                                  // the next key block's K and V: global -> registers now, -> LDS after the products
             v_load(kb + 1);
-            if (active) k_prefetch(kb + 1);
+            k_load(kb + 1);
         }
         if (active) {
             f32x16 sacc;
@@ -190,15 +220,14 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
             for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {                                   // S^T[key][query]
+                const uint32_t koff = l31 * KROW + (2 * s + hf) * 16;
+                const bf16x8 khi = *reinterpret_cast<const bf16x8*>(kt[buf][0] + koff);
                 if constexpr (F32) {
-                    bf16x8 khi, klo;
-                    at_split8(kcur_raw[s][0], kcur_raw[s][1], khi, klo);
+                    const bf16x8 klo = *reinterpret_cast<const bf16x8*>(kt[buf][1] + koff);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qf[0][s], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[1][s], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[0][s], sacc, 0, 0, 0);
-                } else {
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[s], qf[0][s], sacc, 0, 0, 0);
                 }
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[0][s], sacc, 0, 0, 0);
             }
             if ((kb + 1) * 32 > T) {                                         // last, partial key block: keys past T never win the softmax
 #pragma unroll
@@ -252,7 +281,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const unsigned char* __restric
                     o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pb[0][s], o[c], 0, 0, 0);
                 }
         }
-        if (kb + 1 < nkb) v_store(buf ^ 1);
+        if (kb + 1 < nkb) { v_store(buf ^ 1); k_store(buf ^ 1); }
         __syncthreads();
     }
     if (!active || q0 + l31 >= T) return;
@@ -614,14 +643,20 @@ int at_launch(const char* who, const void* qkv, void* out, uint32_t B, uint32_t 
     SSD_REQUIRE(ch >= 8 && ch <= 128 && ch % 8 == 0, "%s: head width must be a multiple of 8 in [8, 128]", who);
     SSD_REQUIRE(heads > 0 && (uint64_t)B * heads <= 65535, "%s: B*heads <= 65535", who);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)ch);       // softmax(q.k / sqrt(ch)) == softmax((q s)(k s)), s = ch^-1/4
-    const dim3 grid((T + 127) / 128, B * heads), block(256);
+    // waves per block: four.  Fewer (so that the short sequences' 32-64 blocks become 128-256) measured SLOWER at every shape -- the block's K / V staging is
+    // shared work, and halving the waves that share it costs more than the idle CUs (profiles/r04/n_attention_*.txt); SSDNERF_ATTN_WPB=2|1 keeps the A/B.
+    static const int forced = getenv("SSDNERF_ATTN_WPB") ? atoi(getenv("SSDNERF_ATTN_WPB")) : 0;
+    const int wpb = (forced == 1 || forced == 2) ? forced : 4;
+    const dim3 grid((T + 32 * wpb - 1) / (32 * wpb), B * heads), block(64 * wpb);
     hipStream_t st = (hipStream_t)stream;
     const unsigned char* in = (const unsigned char*)qkv;
     unsigned char* o = (unsigned char*)out;
-    if (ch <= 32) hipLaunchKernelGGL((k_attn_fwd<32, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
-    else if (ch <= 64) hipLaunchKernelGGL((k_attn_fwd<64, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
-    else if (ch <= 96) hipLaunchKernelGGL((k_attn_fwd<96, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
-    else hipLaunchKernelGGL((k_attn_fwd<128, F32>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
+#define AT_FWD(CHP)                                                                                                                       \
+    if (wpb == 4) hipLaunchKernelGGL((k_attn_fwd<CHP, F32, 4>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);              \
+    else if (wpb == 2) hipLaunchKernelGGL((k_attn_fwd<CHP, F32, 2>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);         \
+    else hipLaunchKernelGGL((k_attn_fwd<CHP, F32, 1>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
+    if (ch <= 32) { AT_FWD(32) } else if (ch <= 64) { AT_FWD(64) } else if (ch <= 96) { AT_FWD(96) } else { AT_FWD(128) }
+#undef AT_FWD
     SSD_CHECK_LAUNCH(who);
     return SSDNERF_OK;
 }
