@@ -68,24 +68,32 @@ SSD_DEV uint32_t at_key_pos(uint32_t kk) {
 }
 
 // WPB: waves (= 32-query tiles) per block; 4 is what at_launch uses (see there), 2 / 1 exist for A/B runs.
-template <int CHP, bool F32, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) void k_attn_fwd(const unsigned char* __restrict__ qkv, unsigned char* __restrict__ out, uint32_t T, uint32_t heads,
+// KG (r04): key groups.  With KG = 2 a block has 2 x WPB waves: wave w and wave w + WPB own the SAME 32 queries and walk the even / the odd key blocks, each with
+// its own running max / sum / O, merged once at the end through LDS -- two waves per SIMD that stall independently instead of one that exposes every latency
+// (the cars shapes give 8 scenes x 4 heads x T / 32 query tiles = 1024 waves at T = 1024: ONE per SIMD; the loop was 5 k cycles per key block for 0.8 k of MFMA).
+template <int CHP, bool F32, int WPB = 4, int KG = 1>
+__global__ __launch_bounds__(64 * WPB * KG) void k_attn_fwd(const unsigned char* __restrict__ qkv, unsigned char* __restrict__ out, uint32_t T, uint32_t heads,
                                                   uint32_t ch, float scale_log2e, float* __restrict__ lse2) {
     constexpr int KS = CHP / 16;           // k-steps of the QK^T product
     constexpr int CT = CHP / 32;           // 32-channel tiles of O
     constexpr int G = F32 ? 4 : 8;         // channels per staged V item and row (16 bytes)
     constexpr int VTOT = 16 * CHP / G;     // V items per key block: (pair of adjacent keys, G-channel group)
-    constexpr int NTH = 64 * WPB;          // threads per block
+    constexpr int NTH = 64 * WPB;          // threads per key group (the staging of a key block is theirs)
     constexpr int VCH = (VTOT + NTH - 1) / NTH; // ... per thread
     constexpr int ES = F32 ? 4 : 2;        // bytes per stored element
     constexpr int NT = F32 ? 2 : 1;        // operand terms (hi, lo)
     constexpr int KROW = CHP * 2 + 16;     // bytes per LDS row of K (one key's CHP bf16 terms + 16 B pad: the 32 rows of a ds_read_b128 fall on different banks)
     constexpr int KTOT = 32 * CHP / 8;     // K items per key block: (key, 8-channel chunk)
     constexpr int KCH = (KTOT + NTH - 1) / NTH;
-    __shared__ __attribute__((aligned(16))) unsigned char vt[2][NT][CHP * AT_ROW];
-    __shared__ __attribute__((aligned(16))) unsigned char kt[2][NT][32 * KROW];
+    constexpr int VT_BYTES = 2 * KG * NT * CHP * AT_ROW, KT_BYTES = 2 * KG * NT * 32 * KROW;
+    constexpr int MERGE_BYTES = (KG - 1) * WPB * 64 * (CT * 16 + 2) * 4;              // the other key groups' (O, max, sum) per lane, after the loop
+    constexpr int LDS_BYTES = VT_BYTES + KT_BYTES > MERGE_BYTES ? VT_BYTES + KT_BYTES : MERGE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[LDS_BYTES];           // (ONE LDS object)
+    auto vt = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + ((buf * KG + g) * NT + tm) * (CHP * AT_ROW); };
+    auto kt = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + VT_BYTES + ((buf * KG + g) * NT + tm) * (32 * KROW); };
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const uint32_t lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6, kg = wave_all / WPB, wave = wave_all % WPB, tid = threadIdx.x - kg * NTH;   // tid: inside the key group
+    const uint32_t hf = lane >> 5, l31 = lane & 31;
     const uint32_t b = blockIdx.y / heads, h = blockIdx.y % heads, C = heads * ch;
     const size_t row_bytes = (size_t)3 * C * ES;
     const unsigned char* base = qkv + (size_t)b * T * row_bytes + (size_t)h * 3 * ch * ES;      // q of this head; k at +ch, v at +2ch elements
@@ -148,14 +156,14 @@ __global__ __launch_bounds__(64 * WPB) void k_attn_fwd(const unsigned char* __re
                 for (int c = 0; c < 4; ++c) {
                     const float fa = __uint_as_float(wa[c]), fb = __uint_as_float(wb[c]);
                     const uint32_t wh = at_pack_bf16(fa, fb);
-                    *reinterpret_cast<uint32_t*>(vt[buf][0] + off + c * AT_ROW) = wh;
-                    *reinterpret_cast<uint32_t*>(vt[buf][1] + off + c * AT_ROW) = at_pack_bf16_rest(fa, fb, wh);
+                    *reinterpret_cast<uint32_t*>(vt(buf, kg, 0) + off + c * AT_ROW) = wh;
+                    *reinterpret_cast<uint32_t*>(vt(buf, kg, 1) + off + c * AT_ROW) = at_pack_bf16_rest(fa, fb, wh);
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {                    // bf16 pairs as stored: channel c of the two keys -> one dword
                     const uint32_t a = wa[c >> 1], b = wb[c >> 1];
-                    *reinterpret_cast<uint32_t*>(vt[buf][0] + off + c * AT_ROW) = (c & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                    *reinterpret_cast<uint32_t*>(vt(buf, kg, 0) + off + c * AT_ROW) = (c & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
                 }
             }
         }
@@ -187,10 +195,10 @@ __global__ __launch_bounds__(64 * WPB) void k_attn_fwd(const unsigned char* __re
             if constexpr (F32) {
                 bf16x8 hi, lo;
                 at_split8(*reinterpret_cast<const float4*>(&ka[i]), *reinterpret_cast<const float4*>(&kb2[i]), hi, lo);
-                *reinterpret_cast<bf16x8*>(kt[buf][0] + off) = hi;
-                *reinterpret_cast<bf16x8*>(kt[buf][1] + off) = lo;
+                *reinterpret_cast<bf16x8*>(kt(buf, kg, 0) + off) = hi;
+                *reinterpret_cast<bf16x8*>(kt(buf, kg, 1) + off) = lo;
             } else {
-                *reinterpret_cast<uint4*>(kt[buf][0] + off) = ka[i];
+                *reinterpret_cast<uint4*>(kt(buf, kg, 0) + off) = ka[i];
             }
         }
     };
@@ -202,28 +210,28 @@ __global__ __launch_bounds__(64 * WPB) void k_attn_fwd(const unsigned char* __re
         for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    const uint32_t nkb = (T + 31) / 32;
-    v_load(0);
-    k_load(0);
+    const uint32_t nkb = (T + 31) / 32, nsb = (nkb + KG - 1) / KG;          // key blocks; rounds of KG key blocks (group kg takes block sb * KG + kg)
+    v_load(kg);
+    k_load(kg);
     v_store(0);
     k_store(0);
     __syncthreads();
-    for (uint32_t kb = 0; kb < nkb; ++kb) {
-        const uint32_t buf = kb & 1;
-        if (kb + 1 < nkb) {                                                  // the next key block's K and V: global -> registers now, -> LDS after the products
-            v_load(kb + 1);
-            k_load(kb + 1);
+    for (uint32_t sb = 0; sb < nsb; ++sb) {
+        const uint32_t buf = sb & 1, kb = sb * KG + kg;
+        if (sb + 1 < nsb) {                                                  // the next round's K and V: global -> registers now, -> LDS after the products
+            v_load(kb + KG);                                                 // (a block past the last one reads as zeros and is not multiplied)
+            k_load(kb + KG);
         }
-        if (active) {
+        if (active && kb < nkb) {
             f32x16 sacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {                                   // S^T[key][query]
                 const uint32_t koff = l31 * KROW + (2 * s + hf) * 16;
-                const bf16x8 khi = *reinterpret_cast<const bf16x8*>(kt[buf][0] + koff);
+                const bf16x8 khi = *reinterpret_cast<const bf16x8*>(kt(buf, kg, 0) + koff);
                 if constexpr (F32) {
-                    const bf16x8 klo = *reinterpret_cast<const bf16x8*>(kt[buf][1] + koff);
+                    const bf16x8 klo = *reinterpret_cast<const bf16x8*>(kt(buf, kg, 1) + koff);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qf[0][s], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qf[1][s], sacc, 0, 0, 0);
                 }
@@ -272,17 +280,47 @@ __global__ __launch_bounds__(64 * WPB) void k_attn_fwd(const unsigned char* __re
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {                                // O^T[channel][query] += V^T[channel][8 keys of this half] P
                     const size_t off = (size_t)(c * 32 + l31) * AT_ROW + s * 32 + hf * 16;
-                    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vt[buf][0] + off);
+                    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vt(buf, kg, 0) + off);
                     if constexpr (F32) {
-                        const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vt[buf][1] + off);
+                        const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vt(buf, kg, 1) + off);
                         o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, pb[0][s], o[c], 0, 0, 0);
                         o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pb[1][s], o[c], 0, 0, 0);
                     }
                     o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pb[0][s], o[c], 0, 0, 0);
                 }
         }
-        if (kb + 1 < nkb) { v_store(buf ^ 1); k_store(buf ^ 1); }
+        if (sb + 1 < nsb) { v_store(buf ^ 1); k_store(buf ^ 1); }
         __syncthreads();
+    }
+    if constexpr (KG > 1) {                                                  // merge the key groups' partial softmaxes: groups 1.. -> LDS -> group 0 (lane for lane: same query, same half)
+        constexpr int MS = CT * 16 + 2;
+        float* mg0 = reinterpret_cast<float*>(lds_all) + (wave * 64 + lane) * MS;
+        if (kg > 0) {
+            float* mg = mg0 + (kg - 1) * (WPB * 64 * MS);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(mg + c * 16 + e) = make_float4(o[c][e], o[c][e + 1], o[c][e + 2], o[c][e + 3]);
+            mg[CT * 16] = m_run; mg[CT * 16 + 1] = l_run;
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g) {
+            const float* mg = mg0 + (g - 1) * (WPB * 64 * MS);
+            const float m1 = mg[CT * 16], l1 = mg[CT * 16 + 1];
+            const float m_new = fmaxf(m_run, m1), a0 = __builtin_amdgcn_exp2f(m_run - m_new), a1 = __builtin_amdgcn_exp2f(m1 - m_new);
+            m_run = m_new;
+            l_run = __builtin_fmaf(l_run, a0, l1 * a1);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(mg + c * 16 + e);
+                    o[c][e] = __builtin_fmaf(o[c][e], a0, v.x * a1); o[c][e + 1] = __builtin_fmaf(o[c][e + 1], a0, v.y * a1);
+                    o[c][e + 2] = __builtin_fmaf(o[c][e + 2], a0, v.z * a1); o[c][e + 3] = __builtin_fmaf(o[c][e + 3], a0, v.w * a1);
+                }
+        }
     }
     if (!active || q0 + l31 >= T) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -651,8 +689,14 @@ int at_launch(const char* who, const void* qkv, void* out, uint32_t B, uint32_t 
     hipStream_t st = (hipStream_t)stream;
     const unsigned char* in = (const unsigned char*)qkv;
     unsigned char* o = (unsigned char*)out;
+    // key groups: two (8 waves per block, two per SIMD) when the grid alone leaves the chip at one wave per SIMD or less; SSDNERF_ATTN_KG=1|2 forces.
+    // r04, 8 scenes x 4 heads (profiles/r04/q_attention_key_groups.txt): T = 1024 fp32 73.5 -> 49.4 us, bf16 37.7 -> 25.0; T = 256 32.3 -> 25.5 / 15.5 -> 14.9;
+    // T = 64 unchanged (two key blocks: nothing to split); FOUR groups (16 waves, 128 registers each) 53.7 / 29.2 us at T = 1024: slower than two, removed.
+    static const int forced_kg = getenv("SSDNERF_ATTN_KG") ? atoi(getenv("SSDNERF_ATTN_KG")) : 0;
+    const bool kg2 = wpb == 4 && (forced_kg == 2 || (forced_kg != 1 && (uint64_t)grid.x * grid.y <= 512 && T >= 128));
 #define AT_FWD(CHP)                                                                                                                       \
-    if (wpb == 4) hipLaunchKernelGGL((k_attn_fwd<CHP, F32, 4>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);              \
+    if (kg2) hipLaunchKernelGGL((k_attn_fwd<CHP, F32, 4, 2>), grid, dim3(512), 0, st, in, o, T, heads, ch, scale_log2e, lse2);            \
+    else if (wpb == 4) hipLaunchKernelGGL((k_attn_fwd<CHP, F32, 4>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);         \
     else if (wpb == 2) hipLaunchKernelGGL((k_attn_fwd<CHP, F32, 2>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);         \
     else hipLaunchKernelGGL((k_attn_fwd<CHP, F32, 1>), grid, block, 0, st, in, o, T, heads, ch, scale_log2e, lse2);
     if (ch <= 32) { AT_FWD(32) } else if (ch <= 64) { AT_FWD(64) } else if (ch <= 96) { AT_FWD(96) } else { AT_FWD(128) }
