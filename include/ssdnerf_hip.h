@@ -304,6 +304,8 @@ int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint32_t C1, int
  * native_group_norm_backward, silu_backward and the scale/shift mul/add; modules.py:51-110).  x, dy, dx:
  * [B][HW][C] of `dtype`; fwd_sums: the forward's workspace (sum, sum of squares per sample and group); bwd_workspace: another
  * ssdnerf_group_norm_workspace(B, G) bytes, zero-filled by the call unless bwd_workspace_is_zero.  Two passes, nothing else saved.
+ * act: bit 0 = the forward applied SiLU; bit 1 (r04, fp32, C % 32 == 0): write dx PRE-SPLIT (the layout of ssdnerf_group_norm_nhwc's act | 2) for the
+ * backward-data convolution that consumes it (ssdnerf_conv2d_nhwc_f32x2_presplit on the transposed weights).
  * Arithmetic: csrc/gn_bwd_math.h (plain C, also built by gcc for tests/test_groupnorm_backward_cpu.py). */
 int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
                                      const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride,

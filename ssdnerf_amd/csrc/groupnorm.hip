@@ -338,7 +338,7 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_stats(const void* __restrict_
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float p, xh;
-                ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act, &p, &xh);
+                ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act & 1, &p, &xh);
                 s[i] += p;
                 q[i] = __builtin_fmaf(p, xh, q[i]);
             }
@@ -390,8 +390,11 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict_
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float p, xh;
-            ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act, &p, &xh);
+            ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act & 1, &p, &xh);
             f[i] = ssdg_dx(p, xh, R[i], m1[i], m2[i]);
+        }
+        if constexpr (DT == GN_F32) {
+            if (act & 2) { GnVec<DT>::store_split(dx, base + (size_t)r * tpr, f); continue; }       // (host: C % 32 == 0) dx PRE-SPLIT for the backward convolution
         }
         GnVec<DT>::store(dx, base + (size_t)r * tpr, f);
     }
@@ -477,6 +480,7 @@ extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, i
     SSD_REQUIRE(G > 0 && C % G == 0, "group_norm_nhwc_backward: channels must be divisible by groups");
     SSD_REQUIRE(!scale_shift || scale_shift_stride >= 2 * C, "group_norm_nhwc_backward: scale_shift_stride must be >= 2*C");
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc_backward: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
+    SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc_backward: the pre-split dx (act & 2) needs fp32 and C % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t rows_s = gn_rows_per_block(B, HW, 1024, 64), rows_a = gn_rows_per_block(B, HW, 2048, 16);
     const dim3 grid_s(HW / rows_s, B), grid_a(HW / rows_a, B), block(GN_TPB);

@@ -54,10 +54,14 @@ class _ConvF32x2Fn(torch.autograd.Function):
     then needs no statistics pass (``_GroupNormActFn``)."""
 
     @staticmethod
-    def forward(ctx, x, conv, residual=None, box=None, presplit=False):
+    def forward(ctx, x, conv, residual=None, box=None, presplit=False, gflag=None):
+        """``gflag`` (a dict shared with the ``_GroupNormActFn`` that reads this convolution's output, and with nobody else): if that norm's backward
+        writes its dx PRE-SPLIT it sets gflag['split'] in ITS forward, and this function's backward then multiplies the pre-split gradient
+        (``conv2d_nhwc_f32x2_presplit`` on the transposed weights) -- both sides read one decision, taken once."""
         from . import unet_fast as UF
         hi, lo = conv._split_pair(False)
         ctx.conv = conv
+        ctx.gflag = gflag
         ctx.has_residual = residual is not None
         xc = x.contiguous(memory_format=torch.channels_last)
         if presplit:                                                # x is what the norm in front wrote pre-split for the two-group kernel (see _GroupNormActFn)
@@ -84,8 +88,11 @@ class _ConvF32x2Fn(torch.autograd.Function):
         from . import unet_fast as UF
         hi, lo = ctx.conv._split_pair(True)
         gyc = gy.contiguous(memory_format=torch.channels_last)
+        if ctx.gflag is not None and ctx.gflag.get("split"):        # gy is the pre-split dx of the norm behind this convolution (no residual here: _Conv2d.forward)
+            gx = UF.conv2d_nhwc_f32x2_presplit(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
+            return gx, None, None, None, None, None
         gx = UF.conv2d_nhwc_f32x2(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
-        return gx, None, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None
+        return gx, None, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None, None
 
 
 class _Conv2d(nn.Conv2d):
@@ -126,14 +133,24 @@ class _Conv2d(nn.Conv2d):
     #: SSDNERF_UNET_GRAD_FUSE=0: residual adds and GroupNorm statistics as separate passes again (the r03 gradient path; A/B runs)
     fuse_epilogues = os.environ.get("SSDNERF_UNET_GRAD_FUSE", "1") != "0"
 
-    def forward(self, x, residual=None, box=None):
+    #: SSDNERF_UNET_GRAD_SPLIT_DY=0: the backward convolutions split their dy on the fly again (A/B runs)
+    grad_split_dy = os.environ.get("SSDNERF_UNET_GRAD_SPLIT_DY", "1") != "0"
+
+    def forward(self, x, residual=None, box=None, gflag=None):
         """``residual`` / ``box`` (extras of the input-gradient path, see ``_ConvF32x2Fn``): y + residual in the kernel's epilogue; box['runs'] = the
-        output's GroupNorm sums per run of 4 channels where the kernel can leave them."""
+        output's GroupNorm sums per run of 4 channels where the kernel can leave them.  ``gflag`` (extra): the caller promises that the output feeds ONE
+        ``_GroupNormActFn`` and nothing else, and hands the same dict to it; gflag['want'] says whether a pre-split dy would find a kernel here."""
         if self._eligible(x):
             if not self.fuse_epilogues:
                 y = _ConvF32x2Fn.apply(x, self, None, None)
                 return y if residual is None else y + residual
-            return _ConvF32x2Fn.apply(x, self, residual, box, bool(getattr(x, "_ssd_presplit", False)))
+            if gflag is not None:
+                from . import unet_fast as UF
+                gflag["want"] = bool(
+                    self.grad_split_dy and UF._Conv.PRESPLIT and residual is None and x.is_cuda
+                    and UF.C.lib().ssdnerf_conv2d_nhwc_f32x2_presplit_supported(UF.C.u32(x.size(0)), UF.C.u32(x.size(2)), UF.C.u32(x.size(3)), UF.C.u32(self.out_channels),
+                                                                                 UF.C.u32(self.in_channels), UF.C.u32(self.kernel_size[0]), 0))
+            return _ConvF32x2Fn.apply(x, self, residual, box, bool(getattr(x, "_ssd_presplit", False)), gflag)
         y = super().forward(x)
         return y if residual is None else y + residual
 
@@ -233,7 +250,7 @@ class _GroupNormActFn(torch.autograd.Function):
     inference executor."""
 
     @staticmethod
-    def forward(ctx, x, norm, scale_shift, act, runs=None, split_out=False):
+    def forward(ctx, x, norm, scale_shift, act, runs=None, split_out=False, gflag=None):
         """``split_out``: the result goes to a large 3 x 3 convolution of the fp32 gradient path and is written PRE-SPLIT for it (bf16 hi / lo pairs in
         the carrier tensor, ``unet_fast.group_norm_nhwc``); the caller tags the tensor ``_ssd_presplit`` and hands it to that convolution only."""
         from . import unet_fast as UF
@@ -251,6 +268,11 @@ class _GroupNormActFn(torch.autograd.Function):
             y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, sums, workspace_is_zero=True, split_out=split_out)
         ctx.save_for_backward(xc, sums)
         ctx.norm, ctx.ss, ctx.act = norm, ss, act
+        # ``gflag``: x is the output of a ``_ConvF32x2Fn`` that feeds only this norm, and whose backward would take a pre-split dy (gflag['want']): dx is
+        # then written pre-split, and the flag tells that convolution's backward so (see there)
+        ctx.grad_split = bool(gflag is not None and gflag.get("want") and Cc % 32 == 0)
+        if ctx.grad_split:
+            gflag["split"] = True
         return y
 
     @staticmethod
@@ -260,8 +282,8 @@ class _GroupNormActFn(torch.autograd.Function):
         norm = ctx.norm
         ws = ctx.arena.take(xc.size(0) * norm.num_groups * 2) if ctx.arena is not None else None
         dx = UF.group_norm_nhwc_backward(xc, dy.contiguous(memory_format=torch.channels_last), norm.num_groups, norm.weight.detach(), norm.bias.detach(),
-                                         ctx.ss, norm.eps, ctx.act, sums, workspace=ws)
-        return dx, None, None, None, None, None
+                                         ctx.ss, norm.eps, ctx.act, sums, workspace=ws, split_out=ctx.grad_split)
+        return dx, None, None, None, None, None, None
 
 
 def _tag_presplit(y, on: bool):
@@ -354,14 +376,14 @@ class NormWithEmbedding(nn.Module):
         out = in_channels * 2 if use_scale_shift else in_channels
         self.embedding_layer = nn.Sequential(_build_act(act_cfg), nn.Linear(embedding_channels, out))
 
-    def forward(self, x, y, fuse_silu=False, runs=None, split_for=None):
+    def forward(self, x, y, fuse_silu=False, runs=None, split_for=None, gflag=None):
         """``fuse_silu`` (extra): also apply the SiLU that follows in the residual block (only honoured on the fused path; returns
         (tensor, whether the activation was applied)).  ``runs`` (extra): x's statistics from the producing convolution's epilogue."""
         batched = getattr(y, "_ssd_projections", None)                 # DenoisingUnetMod.forward: every block's projection of the time embedding from ONE GEMM
         e = batched[id(self)] if batched is not None and id(self) in batched else self.embedding_layer(y)
         if self.use_scale_shift and fuse_silu and _gn_act_eligible(x, self.norm, e):
             ps = split_for is not None and split_for.wants_presplit(x)
-            return _tag_presplit(_GroupNormActFn.apply(x, self.norm, e, True, runs, ps), ps), True
+            return _tag_presplit(_GroupNormActFn.apply(x, self.norm, e, True, runs, ps, gflag), ps), True
         e = e[:, :, None, None]
         if self.use_scale_shift:
             scale, shift = torch.chunk(e, 2, dim=1)
@@ -402,10 +424,11 @@ class DenoisingResBlockMod(nn.Module):
                 and not (self.training and len(self.conv_2) > 2):
             # input-gradient path: GroupNorm + SiLU (and the scale/shift norm + SiLU) as one fused, channel-last op each; r04: the norms take their
             # statistics from the epilogue of the convolution that produced their input (no statistics pass), `+ s` rides in conv_2's epilogue
-            box1, box2 = {}, {}
+            box1, box2, gflag = {}, {}, {}
             ps1 = self.conv_1[-1].wants_presplit(x)                    # (r04: the norm writes the operand pair the large 3 x 3 layers multiply)
-            h = self.conv_1[-1](_tag_presplit(_GroupNormActFn.apply(x, self.conv_1[0], None, True, _runs_of(x), ps1), ps1), None, box1)
-            h, activated = self.norm_with_embedding(h, y, fuse_silu=True, runs=box1.get("runs"), split_for=self.conv_2[-1])
+            h = self.conv_1[-1](_tag_presplit(_GroupNormActFn.apply(x, self.conv_1[0], None, True, _runs_of(x), ps1), ps1), None, box1, gflag)
+            # conv_1's output feeds the second norm and nothing else: that norm's backward may hand its dx to conv_1's backward pre-split (gflag)
+            h, activated = self.norm_with_embedding(h, y, fuse_silu=True, runs=box1.get("runs"), split_for=self.conv_2[-1], gflag=gflag)
             out = self.conv_2[-1](h if activated else self.conv_2[0](h), s, box2)
             if box2.get("runs") is not None:
                 out._ssd_runs = box2["runs"]

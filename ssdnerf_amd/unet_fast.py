@@ -93,9 +93,10 @@ def group_norm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: tor
 
 
 def group_norm_nhwc_backward(x: torch.Tensor, dy: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, scale_shift: Optional[torch.Tensor],
-                             eps: float, act: bool, fwd_sums: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             eps: float, act: bool, fwd_sums: torch.Tensor, workspace: Optional[torch.Tensor] = None, split_out: bool = False) -> torch.Tensor:
     """d/dx of ``group_norm_nhwc`` (single source, no pre_bias) for frozen gamma / beta / scale_shift (csrc/groupnorm.hip, k_gn_bwd_*).
-    ``x``, ``dy``: (B, C, H, W) channels_last, same dtype; ``fwd_sums``: the forward's workspace (fp64, B * groups * 2)."""
+    ``x``, ``dy``: (B, C, H, W) channels_last, same dtype; ``fwd_sums``: the forward's workspace (fp64, B * groups * 2).  ``split_out`` (fp32,
+    C % 32 == 0): dx is written PRE-SPLIT for the backward-data convolution that consumes it (``conv2d_nhwc_f32x2_presplit``)."""
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or dy.shape != x.shape or dy.dtype != x.dtype \
             or not dy.is_contiguous(memory_format=torch.channels_last):
         raise RuntimeError("group_norm_nhwc_backward: x and dy must be channels_last 4-D tensors of the same shape and dtype")
@@ -107,7 +108,7 @@ def group_norm_nhwc_backward(x: torch.Tensor, dy: torch.Tensor, groups: int, gam
     dx = torch.empty_like(x)
     ws = workspace if workspace is not None else torch.zeros(B * groups * 2, dtype=torch.float64, device=x.device)   # (all zero on entry)
     C.check(C.lib().ssdnerf_group_norm_nhwc_backward(C.ptr(x), C.ptr(dy), _GN_DTYPE[x.dtype], C.u32(B), C.u32(H * W), C.u32(Cc), C.u32(groups), C.ptr(gamma),
-                                                      C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)), C.ptr(fwd_sums), C.ptr(ws), 1,
+                                                      C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)) | (2 if split_out else 0), C.ptr(fwd_sums), C.ptr(ws), 1,
                                                       C.ptr(dx), C.stream()), "group_norm_nhwc_backward")
     return dx
 

@@ -297,3 +297,38 @@ def test_captured_gradient_path_matches_the_eager_one():
     y = net(xi, ts[4])
     gx, gw = torch.autograd.grad(y.square().sum(), (xi, net.out.conv.weight))
     assert gw is not None and float(gw.abs().max()) > 0
+
+
+def test_gradient_path_with_pre_split_dy_matches_the_on_the_fly_split(monkeypatch):
+    """r04: the second norm of a residual block writes its dx PRE-SPLIT for the first convolution's backward-data kernel (one decision shared by the two
+    autograd functions through a flag dict; ``SSDNERF_UNET_GRAD_SPLIT_DY=0`` / ``_Conv2d.grad_split_dy`` restores the on-the-fly split).  Same hi / lo
+    terms and the same products: the UNet's input gradient agrees to fp32 rounding (relative L2 error <= 1e-5), on a net with large (two-group kernel) and small (generic kernel) layers,
+    and the pre-split form is really taken."""
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd import unet as U, unet_fast as UF
+    from ssdnerf_amd.registry import MODULES
+    net = MODULES.build(dict(UNET, base_channels=128, channels_cfg=[1, 2, 2], attention_res=[32])).cuda().eval()
+    _randomize(net, 7, scale=1.0)
+    net.requires_grad_(False)
+    net.grad_graph = False
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 18, 128, 128, generator=g).cuda()
+    t = torch.tensor([700, 40], device="cuda")
+    calls = {"split": 0}
+    real = UF.group_norm_nhwc_backward
+    monkeypatch.setattr(UF, "group_norm_nhwc_backward", lambda *a, **k: (calls.__setitem__("split", calls["split"] + int(bool(k.get("split_out")))), real(*a, **k))[1])
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(U._Conv2d, "grad_split_dy", on)
+        calls["split"] = 0
+        xi = x.clone().requires_grad_(True)
+        y = net(xi, t)
+        (gx,) = torch.autograd.grad((y * torch.cos(y.detach())).sum(), xi)
+        res[on] = (y.detach(), gx, calls["split"])
+    assert res[True][2] >= 6 and res[False][2] == 0, (res[True][2], res[False][2])      # every residual block whose conv_1 a pre-split kernel takes
+    fscale = float(res[False][0].abs().max())                                            # (the forward is untouched: equal up to the order of its kernels' atomics)
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5 * fscale
+    err, scale = float((res[True][1] - res[False][1]).abs().max()), float(res[False][1].abs().max())
+    # fp32 rounding through ~40 layers of backward: the small layers' pre-split kernel sums in another order, and the kernels' atomics differ run to run
+    rel_l2 = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
+    assert err <= 5e-5 * scale and rel_l2 <= 1e-5, (err, scale, rel_l2)

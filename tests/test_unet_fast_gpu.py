@@ -655,8 +655,9 @@ def test_input_gradient_convs_on_the_matrix_cores_match_the_library_path():
         return y.detach(), torch.autograd.grad((y * probe).sum(), x)[0]
 
     calls = []
-    orig = unet_fast.conv2d_nhwc_f32x2
+    orig, orig_ps = unet_fast.conv2d_nhwc_f32x2, unet_fast.conv2d_nhwc_f32x2_presplit     # (r04: layers behind a norm take the pre-split form, either direction)
     unet_fast.conv2d_nhwc_f32x2 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    unet_fast.conv2d_nhwc_f32x2_presplit = lambda *a, **k: (calls.append(1), orig_ps(*a, **k))[1]
     try:
         y, gx = grad_of()
         n = len(calls)
@@ -665,7 +666,7 @@ def test_input_gradient_convs_on_the_matrix_cores_match_the_library_path():
         assert len(calls) == n
     finally:
         unet._Conv2d.grad_conv = True
-        unet_fast.conv2d_nhwc_f32x2 = orig
+        unet_fast.conv2d_nhwc_f32x2, unet_fast.conv2d_nhwc_f32x2_presplit = orig, orig_ps
     assert n >= 20 and n % 2 == 0
     assert float((y - y_ref).abs().max()) <= 1e-4 * float(y_ref.abs().max())
     assert float((gx - g_ref).abs().max()) <= 1e-4 * float(g_ref.abs().max())
