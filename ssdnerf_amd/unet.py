@@ -748,11 +748,11 @@ class DenoisingUnetMod(nn.Module):
                 and torch.is_tensor(t) and t.is_cuda and not t.requires_grad and not torch.is_autocast_enabled("cuda")
                 and not torch.cuda.is_current_stream_capturing()):
             return None
-        versions = 0
+        versions = 0                                                 # (version counters only grow: any in-place update moves the sum; the storage pointers catch `p.data = ...`)
         for p in self.parameters():
             if p.requires_grad:
                 return None                                          # (a weight gradient is asked for: the eager path)
-            versions += p._version
+            versions += p._version + (p.data_ptr() & 0xffffffff)
         key = (tuple(x_t.shape), tuple(t.shape), t.dtype, x_t.device.index)
         graphs = self.__dict__.setdefault("_grad_graphs", {})
         entry = graphs.get(key)
