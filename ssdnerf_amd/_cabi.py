@@ -16,7 +16,7 @@ import torch
 _LIB_PATH = os.environ.get("SSDNERF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssdnerf_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, F16 = 0, 1
 
 EXPORTS = [

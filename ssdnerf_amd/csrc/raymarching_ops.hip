@@ -7,7 +7,8 @@
 thread_local char g_ssdnerf_err[512] = {0};
 
 extern "C" const char* ssdnerf_last_error(void) { return g_ssdnerf_err; }
-extern "C" int ssdnerf_abi_version(void) { return 2; }   // 2 (r03): conv2d_nhwc_f32x2 takes a split-K scratch; group_norm_nhwc_runs; render workspace holds 8-byte survivor entries
+extern "C" int ssdnerf_abi_version(void) { return 3; }   // 2 (r03): conv2d_nhwc_f32x2 takes a split-K scratch; group_norm_nhwc_runs; render workspace holds 8-byte survivor entries
+                                                           // 3 (r04): conv2d_nhwc_f32x2_presplit(_supported) (ksize, hints, scratch), marching cubes, act bit 1 of the GroupNorm calls
 
 static constexpr unsigned TPB = 256;
 
