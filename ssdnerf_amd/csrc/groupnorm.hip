@@ -400,6 +400,16 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict_
     }
 }
 
+// fp32 [pixel][C] -> the PRE-SPLIT layout (store_split) and nothing else: for a convolution operand that does not come out of a norm (the gradient path's
+// accumulated dy in front of a residual block's second convolution).  One 4-channel vector per thread, grid-stride.
+__global__ __launch_bounds__(256) void k_split_f32(const float4* __restrict__ x, void* __restrict__ y, size_t n_vec) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * 256) {
+        const float4 v = x[i];
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        GnVec<GN_F32>::store_split(y, i, f);
+    }
+}
+
 uint32_t gn_rows_per_block(uint32_t B, uint32_t HW, uint32_t min_blocks, uint32_t min_rows) {
     uint32_t rows = HW;                                 // largest power-of-two split of HW that still leaves >= min_blocks blocks
     while (rows > min_rows && (rows % 2 == 0) && (uint64_t)B * (HW / rows) < min_blocks) rows /= 2;
@@ -512,5 +522,19 @@ extern "C" int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint32_t B, 
     if (dtype == GN_F32) { SSD_BR_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_BR_LAUNCH(GN_F16) } else { SSD_BR_LAUNCH(GN_BF16) }
 #undef SSD_BR_LAUNCH
     SSD_CHECK_LAUNCH("bias_residual_nhwc");
+    return SSDNERF_OK;
+}
+
+// y = x in the pre-split layout of ssdnerf_group_norm_nhwc's act | 2 (fp32 [pixels][C], C % 32 == 0; y: the same number of bytes): an operand for
+// ssdnerf_conv2d_nhwc_f32x2_presplit that no norm produced.  Two passes over the tensor (17 us at 128 x 128 x 128 x 8) against the 60 us the two-group
+// kernel's on-the-fly split costs per large layer.
+extern "C" int ssdnerf_split_f32_nhwc(const void* x, void* y, uint64_t pixels, uint32_t C, void* stream) {
+    if (pixels == 0 || C == 0) return SSDNERF_OK;
+    SSD_REQUIRE(x && y && x != y, "split_f32_nhwc: null pointer / in place");
+    SSD_REQUIRE(C % 32 == 0, "split_f32_nhwc: C %% 32 == 0");
+    const size_t n_vec = (size_t)pixels * (C / 4);
+    const size_t blocks = (n_vec + 255) / 256;
+    hipLaunchKernelGGL(k_split_f32, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, y, n_vec);
+    SSD_CHECK_LAUNCH("split_f32_nhwc");
     return SSDNERF_OK;
 }

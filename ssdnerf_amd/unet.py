@@ -91,7 +91,15 @@ class _ConvF32x2Fn(torch.autograd.Function):
         if ctx.gflag is not None and ctx.gflag.get("split"):        # gy is the pre-split dx of the norm behind this convolution (no residual here: _Conv2d.forward)
             gx = UF.conv2d_nhwc_f32x2_presplit(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
             return gx, None, None, None, None, None
-        gx = UF.conv2d_nhwc_f32x2(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            conv = ctx.conv
+            # a LARGE layer (the two-group row kernel's) whose dy no norm produced -- the accumulated gradient in front of a block's second convolution --:
+            # one split pass (two passes over dy) + the pre-split kernel beat that kernel's on-the-fly split (211 vs 17 + 150 us at 128 x 128 x 128 x 8)
+            if getattr(conv, "grad_split_dy", False) and gyc.size(1) % 32 == 0 and UF.presplit_supported(gyc, conv.in_channels, conv.kernel_size[0]) == 1:
+                gx = UF.conv2d_nhwc_f32x2_presplit(UF.split_f32_nhwc(gyc), hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device))
+            else:
+                gx = UF.conv2d_nhwc_f32x2(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device))
         return gx, None, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None, None
 
 

@@ -192,6 +192,16 @@ def presplit_supported(x: torch.Tensor, cout: int, k: int, with_stats: bool = Fa
         C.u32(x.size(0)), C.u32(x.size(2)), C.u32(x.size(3)), C.u32(x.size(1)), C.u32(cout), C.u32(k), int(with_stats)))
 
 
+def split_f32_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """channels_last fp32 (B, C, H, W), C % 32 == 0 -> the carrier tensor of its PRE-SPLIT form (what ``group_norm_nhwc(..., split_out=True)`` writes), for a
+    convolution operand that does not come out of a norm (csrc/groupnorm.hip, k_split_f32)."""
+    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last) or x.size(1) % 32 != 0:
+        raise RuntimeError("split_f32_nhwc: channels_last fp32 (B, C, H, W) with C % 32 == 0")
+    y = torch.empty_like(x)
+    C.check(C.lib().ssdnerf_split_f32_nhwc(C.ptr(x), C.ptr(y), ctypes.c_uint64(x.size(0) * x.size(2) * x.size(3)), C.u32(x.size(1)), C.stream()), "split_f32_nhwc")
+    return y
+
+
 def conv2d_nhwc_f32x2_presplit(x_split: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor, bias: Optional[torch.Tensor] = None,
                                residual: Optional[torch.Tensor] = None, gn_sums: Optional[torch.Tensor] = None, gn_groups: int = 0,
                                splitk_ws: Optional[torch.Tensor] = None, tile_hint: int = 0, splits_hint: int = 0) -> torch.Tensor:

@@ -314,18 +314,20 @@ def test_gradient_path_with_pre_split_dy_matches_the_on_the_fly_split(monkeypatc
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 18, 128, 128, generator=g).cuda()
     t = torch.tensor([700, 40], device="cuda")
-    calls = {"split": 0}
-    real = UF.group_norm_nhwc_backward
+    calls = {"split": 0, "pass": 0}
+    real, real_pass = UF.group_norm_nhwc_backward, UF.split_f32_nhwc
     monkeypatch.setattr(UF, "group_norm_nhwc_backward", lambda *a, **k: (calls.__setitem__("split", calls["split"] + int(bool(k.get("split_out")))), real(*a, **k))[1])
+    monkeypatch.setattr(UF, "split_f32_nhwc", lambda *a, **k: (calls.__setitem__("pass", calls["pass"] + 1), real_pass(*a, **k))[1])
     res = {}
     for on in (True, False):
         monkeypatch.setattr(U._Conv2d, "grad_split_dy", on)
-        calls["split"] = 0
+        calls["split"] = calls["pass"] = 0
         xi = x.clone().requires_grad_(True)
         y = net(xi, t)
         (gx,) = torch.autograd.grad((y * torch.cos(y.detach())).sum(), xi)
-        res[on] = (y.detach(), gx, calls["split"])
+        res[on] = (y.detach(), gx, calls["split"], calls["pass"])
     assert res[True][2] >= 6 and res[False][2] == 0, (res[True][2], res[False][2])      # every residual block whose conv_1 a pre-split kernel takes
+    assert res[True][3] >= 2 and res[False][3] == 0, (res[True][3], res[False][3])      # the large second convolutions: one split pass in front of the pre-split kernel
     fscale = float(res[False][0].abs().max())                                            # (the forward is untouched: equal up to the order of its kernels' atomics)
     assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5 * fscale
     err, scale = float((res[True][1] - res[False][1]).abs().max()), float(res[False][1].abs().max())

@@ -845,3 +845,21 @@ def test_presplit_is_not_offered_for_layers_no_kernel_takes():
     assert not UF.presplit_supported(cl(8, 128, 32, 32), 128, 5)
     assert not UF.presplit_supported(cl(8, 128, 32, 32).half(), 128, 3)
     assert not UF.presplit_supported(torch.empty(8, 128, 32, 32), 128, 3)                # (CPU tensor)
+
+
+def test_split_pass_feeds_the_pre_split_kernel_bit_identically():
+    """``split_f32_nhwc``: an fp32 operand that no norm produced, written in the pre-split layout by one elementwise pass (the gradient path's accumulated dy
+    in front of a block's second convolution): the two-group kernel's PS form on it equals its F32 form (split on the fly) on the original, bit for bit."""
+    from ssdnerf_amd import unet_fast as UF
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 128, 128, 128, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(256, 128, 3, 3, generator=g) * 0.05).cuda()
+    hi, lo = UF.split_bf16x2_adjacent(w)
+    xs = UF.split_f32_nhwc(x)
+    assert xs.shape == x.shape and not torch.equal(xs, x)
+    assert UF.presplit_supported(x, 256, 3) == 1
+    y_ps = UF.conv2d_nhwc_f32x2_presplit(xs, hi, lo)
+    y_fly = UF.conv2d_nhwc_f32x2(x, hi, lo, tile_hint=6)
+    assert torch.equal(y_ps, y_fly)
+    with pytest.raises(RuntimeError):
+        UF.split_f32_nhwc(x[:, :24].contiguous(memory_format=torch.channels_last))
