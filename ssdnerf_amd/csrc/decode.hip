@@ -112,10 +112,16 @@ extern "C" int ssdnerf_point_decode(const void* planes, int planes_dtype, uint32
 //
 // The order of the additions inside a tile is not fixed, so the gradient is reproducible to rounding only, as before (and as with
 // ATen's grid_sampler_2d_backward, which this replaces).
-static constexpr uint32_t DB_TILE = 32;                       // texels per tile edge
+#ifndef DB_TILE_EDGE
+#define DB_TILE_EDGE 32
+#endif
+static constexpr uint32_t DB_TILE = DB_TILE_EDGE;             // texels per tile edge
 static constexpr uint32_t DB_TILE_FLOATS = DB_TILE * DB_TILE * 6;
 static constexpr uint32_t DB_LIST = 512;                      // per-wave ring of collected sample slots (a 256-key scan step adds at most 256 to < 64 waiting)
-static constexpr uint32_t DB_MAX_SPLIT = 32;                  // sample splits per (scene, plane, tile): many short blocks, so that the tiles most samples
+#ifndef DB_MAX_SPLIT_N
+#define DB_MAX_SPLIT_N 32
+#endif
+static constexpr uint32_t DB_MAX_SPLIT = DB_MAX_SPLIT_N;                  // sample splits per (scene, plane, tile): many short blocks, so that the tiles most samples
                                                               // fall in (the object's, or where a view's rays enter the box) do not end the launch with a few long ones
 static constexpr size_t DB_PARTIAL_BUDGET = (size_t)256 << 20;  // bytes of per-split tile images (r02 advisor: K was chosen from the sample count alone)
 static constexpr uint32_t DB_COUNTER_STRIDE = 32;             // one 128-byte line per scene counter (same-line device atomics serialise)

@@ -334,3 +334,43 @@ def test_gradient_path_with_pre_split_dy_matches_the_on_the_fly_split(monkeypatc
     # fp32 rounding through ~40 layers of backward: the small layers' pre-split kernel sums in another order, and the kernels' atomics differ run to run
     rel_l2 = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
     assert err <= 5e-5 * scale and rel_l2 <= 1e-5, (err, scale, rel_l2)
+
+
+def test_host_noise_keeps_the_seeded_sequence_and_val_optim_its_draw_order():
+    """The prior loss's noise (and the Langevin / ancestral noise) is a HOST draw, as in the reference (mmgen ``_get_noise_batch``): a seeded CPU generator
+    reproduces a trajectory on any device.  r04 moved the draws to where the device has work queued (pinned buffer + asynchronous upload; the next
+    fine-tuning iteration's draw behind this iteration's UNet launches): the VALUES and their ORDER must be those of plain ``torch.randn`` calls --
+    checked on the helper itself and end to end: ``val_optim`` with implicit draws equals ``val_optim`` with the same seeded draws injected."""
+    from ssdnerf_amd import diffusion as D, synthetic as S
+    like = torch.empty(2, 18, 128, 128, device="cuda")
+    torch.manual_seed(11)
+    want = [torch.randn(2, 18, 128, 128) for _ in range(4)]
+    torch.manual_seed(11)
+    got = [D._host_noise(like) for _ in range(4)]                                # four draws: both pinned buffers are reused once
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b.cpu()) for a, b in zip(want, got))
+
+    hw, S_, n_outer = 64, 2, 3
+    cfg = dict(img_size=(hw, hw), num_timesteps=n_outer, clip_range=[-3, 3], density_thresh=0.1, dt_gamma_scale=0.5, n_inverse_rays=2 ** 12, loss_coef=0.1 / (128 * 128),
+               cond_mode="optim", n_inverse_steps=n_outer, extra_scene_step=1, optimizer=dict(type="Adam", lr=0.005, weight_decay=0.0),
+               lr_scheduler=dict(type="ExponentialLR", gamma=0.998))
+    m = _model(cfg)
+    g = torch.Generator().manual_seed(5)
+    data = dict(cond_imgs=torch.rand(S_, 1, hw, hw, 3, generator=g).cuda(), cond_intrinsics=S.cars_intrinsics(hw, hw).cuda()[None, None].expand(S_, 1, -1),
+                cond_poses=S.spiral_poses()[[64]].cuda()[None].expand(S_, -1, -1, -1))
+    code0 = torch.stack([S.make_triplane(41 + i) for i in range(S_)]).cuda()
+
+    def run(inject):
+        torch.manual_seed(23); np.random.seed(23)
+        noises = None
+        if inject:
+            noises = [torch.randn(S_, 18, 128, 128).cuda() for _ in range(n_outer)]      # the draws val_optim would make, in its order, from the same seed
+            torch.manual_seed(23)                                                        # (the DEVICE generator back to the state the other run starts from)
+        code_ = m.code_activation.inverse(code0).clone().requires_grad_(True)
+        out, _, _ = m.val_optim(data, code_=code_, prior_noises=noises)
+        return out
+
+    a, b = run(False), run(True)
+    moved = float((a - code0).abs().max())
+    assert moved > 1e-3                                                                  # the optimisation did something
+    assert float((a - b).abs().max()) <= 2e-4 * moved + 1e-6, (float((a - b).abs().max()), moved)

@@ -14,6 +14,7 @@ from ssdnerf_amd import synthetic as S
 ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--guide-steps", type=int, default=3); ap.add_argument("--outer", type=int, default=3)
 ap.add_argument("--extra-scene-step", type=int, default=3); ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+ap.add_argument("--cprofile", action="store_true", help="cProfile of the timed fine-tuning call (host side: top functions by own time)")
 ap.add_argument("--profile", action="store_true", help="instead of timing: torch.profiler tables (top kernels by device time) of one guided step and one outer iteration")
 a = ap.parse_args()
 cfg = dict(type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64,
@@ -90,7 +91,12 @@ model.test_cfg["n_inverse_steps"] = 1
 timed(lambda: model.val_optim(data, code_=code_.clone().requires_grad_(True), density_grid=grid.clone(), density_bitfield=bits.clone()))   # warm-up
 _, t1 = timed(lambda: model.val_optim(data, code_=code_.clone().requires_grad_(True), density_grid=grid.clone(), density_bitfield=bits.clone()))
 model.test_cfg["n_inverse_steps"] = 1 + a.outer
+if a.cprofile:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
 (code, _, _), tk = timed(lambda: model.val_optim(data, code_=code_.clone().requires_grad_(True), density_grid=grid.clone(), density_bitfield=bits.clone()))
+if a.cprofile:
+    pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 out["ms_per_finetune_outer_iteration"] = round((tk - t1) / a.outer * 1e3, 2)
 out["inner_render_iterations_per_outer"] = a.extra_scene_step + 1
 out["code_finite"] = bool(torch.isfinite(code).all())
