@@ -676,6 +676,7 @@ class DenoisingUnetMod(nn.Module):
         for m in self.modules():
             m.__dict__.pop("_f32x2_cache", None)
         self.__dict__.pop("_grad_graphs", None)
+        self.__dict__.pop("_grad_graph_params", None)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -756,8 +757,11 @@ class DenoisingUnetMod(nn.Module):
                 and torch.is_tensor(t) and t.is_cuda and not t.requires_grad and not torch.is_autocast_enabled("cuda")
                 and not torch.cuda.is_current_stream_capturing()):
             return None
+        params = self.__dict__.get("_grad_graph_params")             # (walking the module tree costs 1.5 ms per call: the list is kept until invalidate_fast_cache(),
+        if params is None:                                           #  which load_state_dict / .to() call; a Parameter OBJECT swapped by hand needs that call too)
+            params = self.__dict__["_grad_graph_params"] = tuple(self.parameters())
         versions = 0                                                 # (version counters only grow: any in-place update moves the sum; the storage pointers catch `p.data = ...`)
-        for p in self.parameters():
+        for p in params:
             if p.requires_grad:
                 return None                                          # (a weight gradient is asked for: the eager path)
             versions += p._version + (p.data_ptr() & 0xffffffff)

@@ -14,6 +14,7 @@ from ssdnerf_amd import synthetic as S
 ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--guide-steps", type=int, default=3); ap.add_argument("--outer", type=int, default=3)
 ap.add_argument("--extra-scene-step", type=int, default=3); ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+ap.add_argument("--full-batch", action="store_true", help="also time (and with --cprofile: profile the host side of) ONE whole val_step: 75 guided steps + 25 x (1 + 4) + 250 views")
 ap.add_argument("--cprofile", action="store_true", help="cProfile of the timed fine-tuning call (host side: top functions by own time)")
 ap.add_argument("--profile", action="store_true", help="instead of timing: torch.profiler tables (top kernels by device time) of one guided step and one outer iteration")
 a = ap.parse_args()
@@ -83,7 +84,12 @@ model.diffusion_ema.test_cfg["num_timesteps"] = 1
 _, t1 = timed(lambda: model.val_guide(dict(data, noise=torch.randn(ns, 3, 6, 128, 128, generator=g).cuda())))
 model.test_cfg["num_timesteps"] = 1 + a.guide_steps
 model.diffusion_ema.test_cfg["num_timesteps"] = 1 + a.guide_steps
+if a.cprofile:
+    import cProfile, pstats
+    prg = cProfile.Profile(); prg.enable()
 _, tk = timed(lambda: model.val_guide(dict(data, noise=torch.randn(ns, 3, 6, 128, 128, generator=g).cuda())))
+if a.cprofile:
+    prg.disable(); print("==== guided steps (host side)"); pstats.Stats(prg).sort_stats("tottime").print_stats(22)
 out["ms_per_guided_ddim_step"] = round((tk - t1) / a.guide_steps * 1e3, 2)
 
 code_ = model.code_activation.inverse(codes)
@@ -103,4 +109,17 @@ out["code_finite"] = bool(torch.isfinite(code).all())
 # the recons1v schedule: 75 guided steps + 25 outer iterations
 out["projected_s_per_batch_75_guided_25_outer"] = round((75 * out["ms_per_guided_ddim_step"] + 25 * out["ms_per_finetune_outer_iteration"]) / 1e3, 2)
 out["grad_graph"] = unet.grad_graph_info() if hasattr(unet, "grad_graph_info") else None
+if a.full_batch:
+    tp = S.spiral_poses(251)[:250].cuda()[None].expand(ns, -1, -1, -1).contiguous()
+    ti = S.cars_intrinsics(128, 128).cuda()[None, None].expand(ns, 250, -1).contiguous()
+    model.test_cfg.update(num_timesteps=75, n_inverse_steps=25, extra_scene_step=3, cond_mode="guide_optim")
+    model.diffusion_ema.test_cfg.update(num_timesteps=75)
+    run = lambda: model.val_step(dict(data, noise=torch.randn(ns, 3, 6, 128, 128, generator=g).cuda(), test_poses=tp, test_intrinsics=ti))
+    if a.cprofile:
+        import cProfile, pstats
+        prf = cProfile.Profile(); prf.enable()
+    _, tb = timed(run)
+    if a.cprofile:
+        prf.disable(); print("==== whole batch (host side)"); st_ = pstats.Stats(prf).sort_stats("tottime"); st_.print_stats(30); st_.print_callers("item"); st_.print_callers("method .to. of"); st_.print_callers("run_backward")
+    out["full_batch_s"] = round(tb, 3)
 print(json.dumps(out))
