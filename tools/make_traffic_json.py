@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """tools/make_traffic_json.py <dir> <tag> -- profiles/traffic_latest.json from ONE tools/prof_render.sh session: the PMC passes (<tag>_pmc.txt), the
 rocprofv3 launch averages (<tag>_launch_avg.txt) and the bench line printed under the profiler (<tag>_bench_under_rocprof.json) of the same session;
-written to <dir>/traffic_latest.json (copy it to profiles/).  bench.py copies it into `roofline.traffic` / `roofline.traffic_source`.
+written to <dir>/traffic_latest.json AND to <repo>/profiles/traffic_latest.json.  bench.py copies it into `roofline.traffic` / `roofline.traffic_source`.
 SSDNERF_PROFILED_COMMIT: the commit that was profiled (.git does not travel to the GPU box: the caller passes `git rev-parse --short HEAD`)."""
 import json
 import os
@@ -43,4 +43,9 @@ tj = {"workload": {"scenes": cfg["scenes_per_gpu"], "views": cfg["views_per_scen
       "profiled_commit": os.environ.get("SSDNERF_PROFILED_COMMIT"),
       "source": f"profiles/r04/{tag}_pmc.txt, {tag}_launch_avg.txt, {tag}_bench_under_rocprof.json"}
 json.dump(tj, open(f"{out}/traffic_latest.json", "w"), indent=1)
+# ... and installed where bench.py reads it (on the GPU box that copy is scratch: run this tool again on the merged gpurun_out/prof_<tag>/ and commit)
+import os
+_prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+if os.path.isdir(_prof):
+    json.dump(tj, open(os.path.join(_prof, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(tj, indent=1))
