@@ -1572,6 +1572,10 @@ __global__ __launch_bounds__(512) void k_conv_pp_bf16(const ConvArgs a) {
   }
 }
 
+#ifndef CV_NS_SMALL
+#define CV_NS_SMALL 4                              // DMA ring depth of the 64 x 64 tile (66 KB of LDS: two blocks per CU).  r04 A/B, UNet step fp32 / bf16: 4: 8.23 / 4.29 ms,
+                                                   // 3 (three blocks per CU): 8.22 / 4.31, 2 (four): 8.40 / 4.69 -- occupancy is not what these layers lack
+#endif
 template <int TM, int TN, int WM, int WN, int NS>
 int cv_launch(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -1806,7 +1810,7 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const voi
         const dim3 grid(a.m_tiles * a.n_tiles * a.splits);
         if (choice == 1) hipLaunchKernelGGL((k_conv_igemm_bf16<2, 2, 2, 2, 2, false, true>), grid, dim3(256), 0, st, a);
         else if (choice == 2) hipLaunchKernelGGL((k_conv_igemm_bf16<1, 2, 2, 2, 3, false, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_conv_igemm_bf16<1, 1, 2, 2, 4, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_igemm_bf16<1, 1, 2, 2, CV_NS_SMALL, false, true>), grid, dim3(256), 0, st, a);
         if (a.splits > 1) {
             const uint32_t HWo = H * W, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
             uint32_t rows = HWo;
@@ -1904,7 +1908,7 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     if (rows) {
         a.m_tiles = (a.M + 127) / 128; a.n_tiles = Cout / 128;
         hipLaunchKernelGGL(k_conv3x3_bf16_rows, dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
-    } else if (choice == 4) cv_launch<2, 2, 4, 2, 3>(a, st); else if (choice == 1) cv_launch<2, 2, 2, 2, 2>(a, st); else if (choice == 2) cv_launch<1, 2, 2, 2, 3>(a, st); else cv_launch<1, 1, 2, 2, 4>(a, st);
+    } else if (choice == 4) cv_launch<2, 2, 4, 2, 3>(a, st); else if (choice == 1) cv_launch<2, 2, 2, 2, 2>(a, st); else if (choice == 2) cv_launch<1, 2, 2, 2, 3>(a, st); else cv_launch<1, 1, 2, 2, CV_NS_SMALL>(a, st);
     if (splits > 1) {
         const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
         uint32_t rows = HWo;                                                 // rows per block: >= one pass of the rows in flight, ~1024 blocks
