@@ -410,6 +410,18 @@ __global__ __launch_bounds__(256) void k_split_f32(const float4* __restrict__ x,
     }
 }
 
+// least blocks / rows per block of the backward's passes.  r04 A/B, one guided step (71 norms, profiles/r04/w_gn_bwd_grid_ab.txt): statistics pass with
+// (1024 blocks, >= 64 rows) 1.94 ms, (2048, 32) 1.52, (4096, 16) 1.67 -- the rows of a block are walked serially by eight row groups, two 16-byte loads in flight
+// each: more, shorter blocks hide the load latency better until the fp64 atomics per block take over; the normalisation pass does not care (1.24 ms either way).
+#ifndef GN_BWD_STATS_BLOCKS
+#define GN_BWD_STATS_BLOCKS 2048
+#endif
+#ifndef GN_BWD_STATS_ROWS
+#define GN_BWD_STATS_ROWS 32
+#endif
+#ifndef GN_BWD_APPLY_BLOCKS
+#define GN_BWD_APPLY_BLOCKS 2048
+#endif
 uint32_t gn_rows_per_block(uint32_t B, uint32_t HW, uint32_t min_blocks, uint32_t min_rows) {
     uint32_t rows = HW;                                 // largest power-of-two split of HW that still leaves >= min_blocks blocks
     while (rows > min_rows && (rows % 2 == 0) && (uint64_t)B * (HW / rows) < min_blocks) rows /= 2;
@@ -492,7 +504,7 @@ extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, i
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc_backward: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
     SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc_backward: the pre-split dx (act & 2) needs fp32 and C % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t rows_s = gn_rows_per_block(B, HW, 1024, 64), rows_a = gn_rows_per_block(B, HW, 2048, 16);
+    const uint32_t rows_s = gn_rows_per_block(B, HW, GN_BWD_STATS_BLOCKS, GN_BWD_STATS_ROWS), rows_a = gn_rows_per_block(B, HW, GN_BWD_APPLY_BLOCKS, 16);
     const dim3 grid_s(HW / rows_s, B), grid_a(HW / rows_a, B), block(GN_TPB);
     if (!bwd_workspace_is_zero && hipMemsetAsync(bwd_workspace, 0, ssdnerf_group_norm_workspace(B, G), st) != hipSuccess)
         return ssdnerf_fail(SSDNERF_E_LAUNCH, "group_norm_nhwc_backward: memset failed");
