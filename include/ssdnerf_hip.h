@@ -367,8 +367,9 @@ int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t Cin1, cons
  * does (any other stride-1 layer with Cin % 32 == 0, Cout % 64 == 0; same products, another summation order), 0 = neither: ask the producing norm for the
  * split output only when it is non-zero.  tile_hint 1 / 2 / 3 (128 x 128, 64 x 128, 64 x 64) and splits_hint > 0 force the generic form's plan (sweeps); 0 = auto. */
 int ssdnerf_conv2d_nhwc_f32x2_presplit_supported(uint32_t B, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, int with_gn_sums);
-/* x fp32 [pixels][C] (C % 32 == 0) -> y, the same bytes in the pre-split layout: for an operand no norm produced (unet._ConvF32x2Fn.backward). */
-int ssdnerf_split_f32_nhwc(const void* x, void* y, uint64_t pixels, uint32_t C, void* stream);
+/* x fp32 [pixels][C] (C % 32 == 0) -> y, the same bytes in the pre-split layout: for an operand no norm produced (unet._ConvF32x2Fn.backward).
+ * x_stride: floats from pixel to pixel in the source (0 = C: dense; > C: a channel slice of a wider channel-last tensor, read in place). */
+int ssdnerf_split_f32_nhwc(const void* x, void* y, uint64_t pixels, uint32_t C, uint64_t x_stride, void* stream);
 int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const void* w_hi, const void* w_lo, const float* bias, const void* residual, void* y, uint32_t B,
                                        uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t ksize, void* gn_sums, uint32_t gn_groups,
                                        int tile_hint, int splits_hint, void* splitk_ws, size_t splitk_ws_bytes, void* stream);

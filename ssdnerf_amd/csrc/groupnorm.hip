@@ -401,10 +401,13 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict_
 }
 
 // fp32 [pixel][C] -> the PRE-SPLIT layout (store_split) and nothing else: for a convolution operand that does not come out of a norm (the gradient path's
-// accumulated dy in front of a residual block's second convolution).  One 4-channel vector per thread, grid-stride.
-__global__ __launch_bounds__(256) void k_split_f32(const float4* __restrict__ x, void* __restrict__ y, size_t n_vec) {
+// accumulated dy in front of a residual block's second convolution).  One 4-channel vector per thread, grid-stride.  The source may be a CHANNEL SLICE of a wider
+// channel-last tensor (x_stride floats from pixel to pixel: what autograd hands back for one input of a concatenation) -- the dense copy a consumer would
+// otherwise make first (125 us for 8 x 256 x 128 x 128) is folded into this pass.
+__global__ __launch_bounds__(256) void k_split_f32(const float* __restrict__ x, void* __restrict__ y, size_t n_vec, uint32_t vpp, size_t x_stride) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * 256) {
-        const float4 v = x[i];
+        const size_t pix = i / vpp;
+        const float4 v = *reinterpret_cast<const float4*>(x + pix * x_stride + (i - pix * vpp) * 4);
         const float f[4] = {v.x, v.y, v.z, v.w};
         GnVec<GN_F32>::store_split(y, i, f);
     }
@@ -540,13 +543,15 @@ extern "C" int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint32_t B, 
 // y = x in the pre-split layout of ssdnerf_group_norm_nhwc's act | 2 (fp32 [pixels][C], C % 32 == 0; y: the same number of bytes): an operand for
 // ssdnerf_conv2d_nhwc_f32x2_presplit that no norm produced.  Two passes over the tensor (17 us at 128 x 128 x 128 x 8) against the 60 us the two-group
 // kernel's on-the-fly split costs per large layer.
-extern "C" int ssdnerf_split_f32_nhwc(const void* x, void* y, uint64_t pixels, uint32_t C, void* stream) {
+extern "C" int ssdnerf_split_f32_nhwc(const void* x, void* y, uint64_t pixels, uint32_t C, uint64_t x_stride, void* stream) {
     if (pixels == 0 || C == 0) return SSDNERF_OK;
     SSD_REQUIRE(x && y && x != y, "split_f32_nhwc: null pointer / in place");
     SSD_REQUIRE(C % 32 == 0, "split_f32_nhwc: C %% 32 == 0");
+    if (x_stride == 0) x_stride = C;
+    SSD_REQUIRE(x_stride >= C && x_stride % 4 == 0 && ((uintptr_t)x & 15) == 0, "split_f32_nhwc: the source's pixel stride must be >= C and, like its base, a multiple of 16 bytes");
     const size_t n_vec = (size_t)pixels * (C / 4);
     const size_t blocks = (n_vec + 255) / 256;
-    hipLaunchKernelGGL(k_split_f32, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, y, n_vec);
+    hipLaunchKernelGGL(k_split_f32, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, (const float*)x, y, n_vec, C / 4, (size_t)x_stride);
     SSD_CHECK_LAUNCH("split_f32_nhwc");
     return SSDNERF_OK;
 }

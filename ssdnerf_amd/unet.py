@@ -87,19 +87,20 @@ class _ConvF32x2Fn(torch.autograd.Function):
     def backward(ctx, gy):
         from . import unet_fast as UF
         hi, lo = ctx.conv._split_pair(True)
-        gyc = gy.contiguous(memory_format=torch.channels_last)
         if ctx.gflag is not None and ctx.gflag.get("split"):        # gy is the pre-split dx of the norm behind this convolution (no residual here: _Conv2d.forward)
+            gyc = gy.contiguous(memory_format=torch.channels_last)
             gx = UF.conv2d_nhwc_f32x2_presplit(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
             return gx, None, None, None, None, None
-        gx = None
-        if ctx.needs_input_grad[0]:
-            conv = ctx.conv
-            # a LARGE layer (the two-group row kernel's) whose dy no norm produced -- the accumulated gradient in front of a block's second convolution --:
-            # one split pass (two passes over dy) + the pre-split kernel beat that kernel's on-the-fly split (211 vs 17 + 150 us at 128 x 128 x 128 x 8)
-            if getattr(conv, "grad_split_dy", False) and gyc.size(1) % 32 == 0 and UF.presplit_supported(gyc, conv.in_channels, conv.kernel_size[0]) == 1:
-                gx = UF.conv2d_nhwc_f32x2_presplit(UF.split_f32_nhwc(gyc), hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device))
-            else:
-                gx = UF.conv2d_nhwc_f32x2(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device))
+        conv = ctx.conv
+        # a LARGE layer (the two-group row kernel's) whose dy no norm produced -- the accumulated gradient in front of a block's second convolution, or the
+        # channel slice autograd returns for one input of a concatenation --: one split pass (two passes over dy, reading a slice IN PLACE) + the pre-split
+        # kernel beat that kernel's on-the-fly split (211 vs 17 + 150 us at 128 x 128 x 128 x 8) and the dense copy a slice would need first
+        if (getattr(conv, "grad_split_dy", False) and gy.dtype == torch.float32 and gy.size(1) % 32 == 0 and UF.nhwc_pixel_stride(gy) % 4 == 0
+                and UF.nhwc_pixel_stride(gy) > 0 and gy.data_ptr() % 16 == 0 and UF.presplit_supported(gy, conv.in_channels, conv.kernel_size[0]) == 1):
+            gx = UF.conv2d_nhwc_f32x2_presplit(UF.split_f32_nhwc(gy), hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
+            return gx, None, (gy if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None, None
+        gyc = gy.contiguous(memory_format=torch.channels_last)
+        gx = UF.conv2d_nhwc_f32x2(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
         return gx, None, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None, None
 
 

@@ -192,13 +192,28 @@ def presplit_supported(x: torch.Tensor, cout: int, k: int, with_stats: bool = Fa
         C.u32(x.size(0)), C.u32(x.size(2)), C.u32(x.size(3)), C.u32(x.size(1)), C.u32(cout), C.u32(k), int(with_stats)))
 
 
+def nhwc_pixel_stride(x: torch.Tensor) -> int:
+    """floats from pixel to pixel if the (B, C, H, W) tensor is channel-last over a possibly WIDER channel axis (a dense channels_last tensor, or the
+    channel slice autograd returns for one input of a concatenation), else 0"""
+    if x.dim() != 4:
+        return 0
+    B, Cc, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    if sc != 1 or sw < Cc or sh != W * sw or (B > 1 and sb != H * W * sw):
+        return 0
+    return int(sw)
+
+
 def split_f32_nhwc(x: torch.Tensor) -> torch.Tensor:
-    """channels_last fp32 (B, C, H, W), C % 32 == 0 -> the carrier tensor of its PRE-SPLIT form (what ``group_norm_nhwc(..., split_out=True)`` writes), for a
-    convolution operand that does not come out of a norm (csrc/groupnorm.hip, k_split_f32)."""
-    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last) or x.size(1) % 32 != 0:
-        raise RuntimeError("split_f32_nhwc: channels_last fp32 (B, C, H, W) with C % 32 == 0")
-    y = torch.empty_like(x)
-    C.check(C.lib().ssdnerf_split_f32_nhwc(C.ptr(x), C.ptr(y), ctypes.c_uint64(x.size(0) * x.size(2) * x.size(3)), C.u32(x.size(1)), C.stream()), "split_f32_nhwc")
+    """channel-last fp32 (B, C, H, W), C % 32 == 0 -> the carrier tensor of its PRE-SPLIT form (what ``group_norm_nhwc(..., split_out=True)`` writes), for a
+    convolution operand that does not come out of a norm (csrc/groupnorm.hip, k_split_f32).  ``x`` may be a channel slice of a wider channel-last tensor
+    (``nhwc_pixel_stride``): it is read in place, the dense copy is never made."""
+    stride = nhwc_pixel_stride(x)
+    if x.dtype != torch.float32 or stride == 0 or x.size(1) % 32 != 0 or stride % 4 != 0 or x.data_ptr() % 16 != 0:
+        raise RuntimeError("split_f32_nhwc: channel-last fp32 (B, C, H, W) with C % 32 == 0 (dense, or a 16-byte aligned channel slice)")
+    y = torch.empty((x.size(0), x.size(1), x.size(2), x.size(3)), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    C.check(C.lib().ssdnerf_split_f32_nhwc(C.ptr(x), C.ptr(y), ctypes.c_uint64(x.size(0) * x.size(2) * x.size(3)), C.u32(x.size(1)), ctypes.c_uint64(stride),
+                                           C.stream()), "split_f32_nhwc")
     return y
 
 

@@ -863,3 +863,9 @@ def test_split_pass_feeds_the_pre_split_kernel_bit_identically():
     assert torch.equal(y_ps, y_fly)
     with pytest.raises(RuntimeError):
         UF.split_f32_nhwc(x[:, :24].contiguous(memory_format=torch.channels_last))
+    # a channel slice of a wider channel-last tensor (what autograd returns for one input of a concatenation) is read in place
+    wide = torch.randn(2, 384, 64, 128, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    for sl in (wide[:, :256], wide[:, 256:]):
+        assert not sl.is_contiguous(memory_format=torch.channels_last) and UF.nhwc_pixel_stride(sl) == 384
+        assert torch.equal(UF.split_f32_nhwc(sl), UF.split_f32_nhwc(sl.contiguous(memory_format=torch.channels_last)))
+    assert UF.nhwc_pixel_stride(wide) == 384 and UF.nhwc_pixel_stride(wide.contiguous()) == 0        # (NCHW-contiguous: not channel-last)
