@@ -416,6 +416,16 @@ __global__ __launch_bounds__(256) void k_split_f32(const float* __restrict__ x, 
 // least blocks / rows per block of the backward's passes.  r04 A/B, one guided step (71 norms, profiles/r04/w_gn_bwd_grid_ab.txt): statistics pass with
 // (1024 blocks, >= 64 rows) 1.94 ms, (2048, 32) 1.52, (4096, 16) 1.67 -- the rows of a block are walked serially by eight row groups, two 16-byte loads in flight
 // each: more, shorter blocks hide the load latency better until the fp64 atomics per block take over; the normalisation pass does not care (1.24 ms either way).
+// (forward grids: r04 A/B of (4096 blocks, 8 rows) / (8192, 4) for the normalisation pass and (2048, 32) for the statistics pass: UNet step 8.16 -> 8.12 / 8.19 ms fp32,
+//  4.25 -> 4.27 / 4.36 ms bf16 -- nothing to gain, unlike the backward's statistics pass below)
+#ifndef GN_FWD_STATS_BLOCKS
+#define GN_FWD_STATS_BLOCKS 1024
+#define GN_FWD_STATS_ROWS 64
+#endif
+#ifndef GN_FWD_APPLY_BLOCKS
+#define GN_FWD_APPLY_BLOCKS 2048
+#define GN_FWD_APPLY_ROWS 16
+#endif
 #ifndef GN_BWD_STATS_BLOCKS
 #define GN_BWD_STATS_BLOCKS 2048
 #endif
@@ -449,7 +459,7 @@ extern "C" int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C
     SSD_REQUIRE(C1 <= C && C1 % V == 0 && (x2 || C1 == C), "group_norm_nhwc: the first tensor's channel count must be a multiple of the 16-byte vector and <= C");
     SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc: the pre-split output (act & 2) needs fp32 and C % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t rows_s = gn_rows_per_block(B, HW, 1024, 64), rows_a = gn_rows_per_block(B, HW, 2048, 16);
+    const uint32_t rows_s = gn_rows_per_block(B, HW, GN_FWD_STATS_BLOCKS, GN_FWD_STATS_ROWS), rows_a = gn_rows_per_block(B, HW, GN_FWD_APPLY_BLOCKS, GN_FWD_APPLY_ROWS);
     const dim3 grid_s(HW / rows_s, B), grid_a(HW / rows_a, B), block(GN_TPB);
     SSD_REQUIRE(workspace_state >= 0 && workspace_state <= 2 && !(workspace_state == 2 && pre_bias), "group_norm_nhwc: bad workspace_state");
     const bool stats_ready = workspace_state == 2;
@@ -481,7 +491,7 @@ extern "C" int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint3
     SSD_REQUIRE(C1 <= C && C1 % V == 0 && (x2 || C1 == C), "group_norm_nhwc_runs: the first tensor's channel count must be a multiple of the 16-byte vector and <= C");
     SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc_runs: the pre-split output (act & 2) needs fp32 and C % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t rows_a = gn_rows_per_block(B, HW, 2048, 16);
+    const uint32_t rows_a = gn_rows_per_block(B, HW, GN_FWD_APPLY_BLOCKS, GN_FWD_APPLY_ROWS);
     const dim3 grid_a(HW / rows_a, B), block(GN_TPB);
 #define SSD_GN_LAUNCH(DT)                                                                                                                    \
     hipLaunchKernelGGL((k_gn_apply<DT, true>), grid_a, block, 0, st, x, x2, C1, (const float*)nullptr, HW, C, G, rows_a, (const double*)runs1, gamma, beta, scale_shift,    \
@@ -530,7 +540,7 @@ extern "C" int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint32_t B, 
     const uint32_t V = dtype == GN_F32 ? 4 : 8;
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "bias_residual_nhwc: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
     SSD_REQUIRE(!gn_sums || (gn_groups > 0 && C % gn_groups == 0), "bias_residual_nhwc: channels must be divisible by groups");
-    const uint32_t rows = gn_rows_per_block(B, HW, 2048, 16);
+    const uint32_t rows = gn_rows_per_block(B, HW, GN_FWD_APPLY_BLOCKS, GN_FWD_APPLY_ROWS);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(HW / rows, B), block(GN_TPB);
 #define SSD_BR_LAUNCH(DT) hipLaunchKernelGGL(k_bias_residual<DT>, grid, block, 0, st, x, bias, residual, HW, C, rows, y, (double*)gn_sums, gn_groups ? gn_groups : 1u);
