@@ -793,7 +793,8 @@ def test_presplit_convolution_is_bit_identical_to_the_on_the_fly_split(B, cin, c
 
 
 @pytest.mark.parametrize("B,cin,cout,hw,k", [(8, 512, 512, 16, 3), (8, 256, 512, 16, 3), (8, 1024, 512, 8, 3), (8, 512, 1536, 16, 1), (8, 256, 256, 32, 3),
-                                             (1, 128, 128, 128, 3), (8, 384, 256, 32, 3), (3, 128, 192, 24, 3), (8, 128, 128, 128, 1)])
+                                             (1, 128, 128, 128, 3), (8, 384, 256, 32, 3), (3, 128, 192, 24, 3), (8, 128, 128, 128, 1),
+                                             (1, 64, 64, 20, 3), (5, 32, 64, 10, 1), (2, 96, 320, 12, 3)])        # (pixel counts that are no multiple of the 64-row tile)
 def test_presplit_convolution_on_the_small_layers_matches_the_on_the_fly_kernel(B, cin, cout, hw, k):
     """The generic DMA-ring kernel's PS form (csrc/conv_igemm.hip k_conv_igemm_bf16<..., PS>) on the layers the two-group kernel does not take: the same
     hi / lo terms and the same three products per pair as k_conv_igemm_f32x2, summed in another order (and split along K the same way) -- equal to fp32
