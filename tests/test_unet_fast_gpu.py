@@ -408,7 +408,7 @@ def test_attention_kernel_peaked_softmax():
 
 
 @pytest.mark.parametrize("B,T,heads,ch", [(2, 1024, 4, 64), (2, 256, 4, 128), (1, 64, 4, 128), (2, 768, 4, 40), (1, 192, 4, 80), (2, 48, 4, 80),
-                                           (1, 12, 4, 24), (1, 3, 2, 48), (1, 33, 1, 8)])
+                                           (1, 12, 4, 24), (1, 3, 2, 48), (1, 33, 1, 8), (1, 200, 2, 64), (1, 129, 1, 32), (2, 352, 3, 96)])   # (the last three: two key groups, ragged / odd key-block counts)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_kernel_general_shapes_and_fp32(B, T, heads, ch, dtype):
     """Every shape of the cars and tiled layouts (T = 768 / 192 / 48 with head widths 40 / 80: ragged key blocks, widths that are not a power of
