@@ -440,13 +440,57 @@ __global__ __launch_bounds__(256) void k_attn_bwd_D(const float* __restrict__ ou
     Dv[((size_t)b * heads + h) * T + t] = acc;
 }
 
-template <int CHP>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse2,
-                                                     const float* __restrict__ Dv, float* __restrict__ dqkv, uint32_t T, uint32_t heads, uint32_t ch,
-                                                     float scale, float scale_log2e) {
-    constexpr int KS = CHP / 16, CT = CHP / 32;
-    __shared__ __attribute__((aligned(16))) unsigned char kt[2][2][CHP * AT_ROW];       // K^T of a key block, [buffer][hi | lo]
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+// rows [r0, r0 + 32) x ch channels of an fp32 tensor -> LDS ROW-MAJOR as the bf16 pair (hi | lo buffers, rows of CHP * 2 + 16 bytes: an MFMA A fragment = one
+// ds_read_b128, the 32 rows on different banks): the block's waves share the tile, so it is loaded and split ONCE (r04; the backward kernels used to fetch these rows
+// into every wave's registers -- raw fp32, one block ahead, 128 registers at 64-wide heads, and at 128-wide heads not ahead at all).  NTH threads; load / store halves
+// as at_stage_load / at_stage_store.
+template <int CHP, int NTH> struct AtRowStage {
+    static constexpr int TOT = 32 * CHP / 8, N = (TOT + NTH - 1) / NTH;            // (row, 8-channel chunk) items; per thread
+    float4 a[N], b[N];
+};
+template <int CHP, int NTH>
+SSD_DEV void at_row_load(AtRowStage<CHP, NTH>& st, const float* __restrict__ src, size_t rstride, uint32_t r0, uint32_t T, uint32_t ch, uint32_t tid) {
+#pragma unroll
+    for (int i = 0; i < AtRowStage<CHP, NTH>::N; ++i) {
+        const uint32_t id = tid + NTH * i, row = id / (CHP / 8), c8 = id % (CHP / 8);
+        st.a[i] = make_float4(0.f, 0.f, 0.f, 0.f); st.b[i] = st.a[i];
+        if (id < (uint32_t)AtRowStage<CHP, NTH>::TOT && r0 + row < T && c8 * 8 < ch) {
+            const float* p = src + (size_t)(r0 + row) * rstride + c8 * 8;
+            st.a[i] = *reinterpret_cast<const float4*>(p); st.b[i] = *reinterpret_cast<const float4*>(p + 4);
+        }
+    }
+}
+template <int CHP, int NTH>
+SSD_DEV void at_row_store(const AtRowStage<CHP, NTH>& st, unsigned char* dst_hi, unsigned char* dst_lo, uint32_t tid) {
+    constexpr int KROW = CHP * 2 + 16;
+#pragma unroll
+    for (int i = 0; i < AtRowStage<CHP, NTH>::N; ++i) {
+        const uint32_t id = tid + NTH * i, row = id / (CHP / 8), c8 = id % (CHP / 8);
+        if (id >= (uint32_t)AtRowStage<CHP, NTH>::TOT) break;
+        bf16x8 hi, lo;
+        at_split8(st.a[i], st.b[i], hi, lo);
+        *reinterpret_cast<bf16x8*>(dst_hi + row * KROW + c8 * 16) = hi;
+        *reinterpret_cast<bf16x8*>(dst_lo + row * KROW + c8 * 16) = lo;
+    }
+}
+
+// KG (r04, as in the forward): with KG = 2 a block has eight waves: wave w and wave w + 4 own the SAME 32 queries (dq) / keys (dkv) and walk the even / the odd blocks
+// of the other axis; their partial gradients are plain sums, merged through LDS at the end.  Two waves per SIMD instead of one; 64-wide heads only (the 128-wide
+// forms need more than 256 registers).
+template <int CHP, int KG>
+__global__ __launch_bounds__(256 * KG) void k_attn_bwd_dq(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse2,
+                                                          const float* __restrict__ Dv, float* __restrict__ dqkv, uint32_t T, uint32_t heads, uint32_t ch,
+                                                          float scale, float scale_log2e) {
+    constexpr int KS = CHP / 16, CT = CHP / 32, KROW = CHP * 2 + 16;
+    constexpr int TR_BYTES = 2 * KG * 2 * CHP * AT_ROW, ROW_BYTES = 2 * KG * 2 * 32 * KROW;          // K^T; K and V row-major
+    constexpr int MERGE_BYTES = (KG - 1) * 4 * 64 * CT * 16 * 4;
+    constexpr int LDS_BYTES = TR_BYTES + 2 * ROW_BYTES > MERGE_BYTES ? TR_BYTES + 2 * ROW_BYTES : MERGE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[LDS_BYTES];                         // (ONE LDS object)
+    auto kt = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + ((buf * KG + g) * 2 + tm) * (CHP * AT_ROW); };            // K^T of a key block, hi | lo
+    auto kr = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + TR_BYTES + ((buf * KG + g) * 2 + tm) * (32 * KROW); };    // K rows
+    auto vr = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + TR_BYTES + ROW_BYTES + ((buf * KG + g) * 2 + tm) * (32 * KROW); };
+    const uint32_t lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6, kg = wave_all / 4, wave = wave_all % 4, tid = threadIdx.x - kg * 256;   // tid: inside the key group
+    const uint32_t hf = lane >> 5, l31 = lane & 31;
     const uint32_t b = blockIdx.y / heads, h = blockIdx.y % heads, C = heads * ch, nchunk = ch / 8;
     const size_t rs = (size_t)3 * C;
     const float* base = qkv + (size_t)b * T * rs + (size_t)h * 3 * ch;             // q of this head; k at + ch, v at + 2 ch
@@ -467,50 +511,36 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ q
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[c][e] = 0.f;
-    const uint32_t nkb = (T + 31) / 32;
-    // the A-operand rows of K and V (row = key kb * 32 + l31) are fetched ONE KEY BLOCK AHEAD as raw fp32 (one wave per SIMD: nothing else hides the L2
-    // round trip) -- up to 64-wide heads; wider ones (T <= 256 in the UNet) would spill
-    constexpr bool PF = CHP <= 64;
-    AtRaw8 kraw[PF ? KS : 1], vraw[PF ? KS : 1];
-    auto prefetch = [&](uint32_t kb) {
-        if constexpr (PF) {
-            const uint32_t key = kb * 32 + l31;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const uint32_t c8 = 2 * s + hf;
-                const bool ok = active && key < T && c8 < nchunk;
-                kraw[s] = at_load_raw(base + (size_t)key * rs + ch + c8 * 8, ok);
-                vraw[s] = at_load_raw(base + (size_t)key * rs + 2 * ch + c8 * 8, ok);
-            }
-        }
-    };
+    const uint32_t nkb = (T + 31) / 32, nsb = (nkb + KG - 1) / KG;                 // key blocks; rounds of KG key blocks (group kg takes block sb * KG + kg)
     AtStage<CHP> st;
-    prefetch(0);
-    at_stage_load<CHP>(st, base + ch, rs, 0, T, ch, tid);
-    at_stage_store<CHP>(st, kt[0][0], kt[0][1], tid);
+    AtRowStage<CHP, 256> sk, sv;
+    auto stage_load = [&](uint32_t kb) {                                           // (a block past the last one reads as zeros and is not multiplied)
+        at_stage_load<CHP>(st, base + ch, rs, kb * 32, T, ch, tid);
+        at_row_load<CHP, 256>(sk, base + ch, rs, kb * 32, T, ch, tid);
+        at_row_load<CHP, 256>(sv, base + 2 * ch, rs, kb * 32, T, ch, tid);
+    };
+    auto stage_store = [&](uint32_t buf) {
+        at_stage_store<CHP>(st, kt(buf, kg, 0), kt(buf, kg, 1), tid);
+        at_row_store<CHP, 256>(sk, kr(buf, kg, 0), kr(buf, kg, 1), tid);
+        at_row_store<CHP, 256>(sv, vr(buf, kg, 0), vr(buf, kg, 1), tid);
+    };
+    stage_load(kg);
+    stage_store(0);
     __syncthreads();
-    for (uint32_t kb = 0; kb < nkb; ++kb) {
-        const uint32_t buf = kb & 1;
-        AtRaw8 kcur[PF ? KS : 1], vcur[PF ? KS : 1];
-        if constexpr (PF) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { kcur[s] = kraw[s]; vcur[s] = vraw[s]; }
-        }
-        if (kb + 1 < nkb) { prefetch(kb + 1); at_stage_load<CHP>(st, base + ch, rs, (kb + 1) * 32, T, ch, tid); }
-        if (active) {
+    for (uint32_t sb = 0; sb < nsb; ++sb) {
+        const uint32_t buf = sb & 1, kb = sb * KG + kg;
+        if (sb + 1 < nsb) stage_load(kb + KG);
+        if (active && kb < nkb) {
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const uint32_t key = kb * 32 + l31, c8 = 2 * s + hf;                  // the row this lane supplies to the A operands
-                bf16x8 ah, al;
-                if constexpr (PF) at_split8(kcur[s].a, kcur[s].b, ah, al);
-                else at_load_split(base + (size_t)key * rs + ch + c8 * 8, key < T && c8 < nchunk, ah, al);        // K: S^T[key][query]
-                sacc = at_mfma3(ah, al, qh[s], ql[s], sacc);
-                if constexpr (PF) at_split8(vcur[s].a, vcur[s].b, ah, al);
-                else at_load_split(base + (size_t)key * rs + 2 * ch + c8 * 8, key < T && c8 < nchunk, ah, al);    // V: dP^T[key][query]
-                dpacc = at_mfma3(ah, al, gh[s], gl[s], dpacc);
+                const uint32_t roff = l31 * KROW + (2 * s + hf) * 16;               // the row this lane supplies to the A operands: key kb * 32 + l31
+                const bf16x8 k_h = *reinterpret_cast<const bf16x8*>(kr(buf, kg, 0) + roff), k_l = *reinterpret_cast<const bf16x8*>(kr(buf, kg, 1) + roff);
+                sacc = at_mfma3(k_h, k_l, qh[s], ql[s], sacc);                      // K: S^T[key][query]
+                const bf16x8 v_h = *reinterpret_cast<const bf16x8*>(vr(buf, kg, 0) + roff), v_l = *reinterpret_cast<const bf16x8*>(vr(buf, kg, 1) + roff);
+                dpacc = at_mfma3(v_h, v_l, gh[s], gl[s], dpacc);                    // V: dP^T[key][query]
             }
             float ds[16];
 #pragma unroll
@@ -526,12 +556,33 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ q
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {                                       // dQ^T[channel][query] += K^T[channel][8 keys of this half] dS^T
                     const size_t off = (size_t)(c * 32 + l31) * AT_ROW + s * 32 + hf * 16;
-                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kt[buf][0] + off), kl = *reinterpret_cast<const bf16x8*>(kt[buf][1] + off);
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kt(buf, kg, 0) + off), kl = *reinterpret_cast<const bf16x8*>(kt(buf, kg, 1) + off);
                     dq[c] = at_mfma3(kh, kl, dsh[s], dsl[s], dq[c]);
                 }
         }
-        if (kb + 1 < nkb) at_stage_store<CHP>(st, kt[buf ^ 1][0], kt[buf ^ 1][1], tid);
+        if (sb + 1 < nsb) stage_store(buf ^ 1);
         __syncthreads();
+    }
+    if constexpr (KG > 1) {                                                         // the key groups' partial dQ: groups 1.. -> LDS -> group 0 (lane for lane)
+        float* mg0 = reinterpret_cast<float*>(lds_all) + (wave * 64 + lane) * (CT * 16);
+        if (kg > 0) {
+            float* mg = mg0 + (kg - 1) * (4 * 64 * CT * 16);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(mg + c * 16 + e) = make_float4(dq[c][e], dq[c][e + 1], dq[c][e + 2], dq[c][e + 3]);
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(mg0 + (g - 1) * (4 * 64 * CT * 16) + c * 16 + e);
+                    dq[c][e] += v.x; dq[c][e + 1] += v.y; dq[c][e + 2] += v.z; dq[c][e + 3] += v.w;
+                }
     }
     if (!active || !q_ok) return;
     float* op = dqkv + (size_t)(b * T + q) * rs + (size_t)h * 3 * ch;
@@ -545,15 +596,24 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ q
         }
 }
 
-template <int CHP>
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse2,
-                                                      const float* __restrict__ Dv, float* __restrict__ dqkv, uint32_t T, uint32_t heads, uint32_t ch,
-                                                      float scale, float scale_log2e) {
-    constexpr int KS = CHP / 16, CT = CHP / 32;
-    __shared__ __attribute__((aligned(16))) unsigned char qt[2][2][CHP * AT_ROW];       // Q^T of a query block, [buffer][hi | lo]
-    __shared__ __attribute__((aligned(16))) unsigned char gt[2][2][CHP * AT_ROW];       // dO^T
-    __shared__ __attribute__((aligned(16))) float lse_s[2][32], d_s[2][32];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+template <int CHP, int KG>
+__global__ __launch_bounds__(256 * KG) void k_attn_bwd_dkv(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse2,
+                                                           const float* __restrict__ Dv, float* __restrict__ dqkv, uint32_t T, uint32_t heads, uint32_t ch,
+                                                           float scale, float scale_log2e) {
+    constexpr int KS = CHP / 16, CT = CHP / 32, KROW = CHP * 2 + 16;
+    constexpr int TR_BYTES = 2 * KG * 2 * CHP * AT_ROW, ROW_BYTES = 2 * KG * 2 * 32 * KROW, SC_BYTES = 2 * KG * 32 * 4;      // Q^T, dO^T; Q, dO rows; lse, D
+    constexpr int MERGE_BYTES = (KG - 1) * 4 * 64 * 2 * CT * 16 * 4;
+    constexpr int STAGE_BYTES = 2 * TR_BYTES + 2 * ROW_BYTES + 2 * SC_BYTES;
+    constexpr int LDS_BYTES = STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[LDS_BYTES];                         // (ONE LDS object)
+    auto qt = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + ((buf * KG + g) * 2 + tm) * (CHP * AT_ROW); };                          // Q^T of a query block
+    auto gt = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + TR_BYTES + ((buf * KG + g) * 2 + tm) * (CHP * AT_ROW); };               // dO^T
+    auto qr = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + 2 * TR_BYTES + ((buf * KG + g) * 2 + tm) * (32 * KROW); };              // Q rows
+    auto gr = [&](uint32_t buf, uint32_t g, uint32_t tm) { return lds_all + 2 * TR_BYTES + ROW_BYTES + ((buf * KG + g) * 2 + tm) * (32 * KROW); };  // dO rows
+    auto lse_s = [&](uint32_t buf, uint32_t g) { return reinterpret_cast<float*>(lds_all + 2 * TR_BYTES + 2 * ROW_BYTES) + (buf * KG + g) * 32; };
+    auto d_s = [&](uint32_t buf, uint32_t g) { return reinterpret_cast<float*>(lds_all + 2 * TR_BYTES + 2 * ROW_BYTES + SC_BYTES) + (buf * KG + g) * 32; };
+    const uint32_t lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6, kg = wave_all / 4, wave = wave_all % 4, tid = threadIdx.x - kg * 256;   // tid: inside the query group
+    const uint32_t hf = lane >> 5, l31 = lane & 31;
     const uint32_t b = blockIdx.y / heads, h = blockIdx.y % heads, C = heads * ch, nchunk = ch / 8;
     const size_t rs = (size_t)3 * C;
     const float* base = qkv + (size_t)b * T * rs + (size_t)h * 3 * ch;
@@ -572,12 +632,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[c][e] = 0.f; dv[c][e] = 0.f; }
-    const uint32_t nqb = (T + 31) / 32;
+    const uint32_t nqb = (T + 31) / 32, nsb = (nqb + KG - 1) / KG;                 // query blocks; rounds of KG of them (group kg takes block sb * KG + kg)
     AtStage<CHP> sq, sg;
+    AtRowStage<CHP, 256> rq, rg;
     float s_lse = 0.f, s_d = 0.f;
-    auto stage_load = [&](uint32_t qb) {
+    auto stage_load = [&](uint32_t qb) {                                           // (a block past the last one: zeros, lse = +huge -> P = 0; it is not multiplied anyway)
         at_stage_load<CHP>(sq, base, rs, qb * 32, T, ch, tid);
         at_stage_load<CHP>(sg, dbase, (size_t)C, qb * 32, T, ch, tid);
+        at_row_load<CHP, 256>(rq, base, rs, qb * 32, T, ch, tid);
+        at_row_load<CHP, 256>(rg, dbase, (size_t)C, qb * 32, T, ch, tid);
         if (tid < 32) {
             const uint32_t qi = qb * 32 + tid;
             s_lse = qi < T ? lse2[(size_t)blockIdx.y * T + qi] : 1e30f;             // rows past T: P = exp2(-huge) = 0
@@ -585,57 +648,34 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
         }
     };
     auto stage_store = [&](uint32_t buf) {
-        at_stage_store<CHP>(sq, qt[buf][0], qt[buf][1], tid);
-        at_stage_store<CHP>(sg, gt[buf][0], gt[buf][1], tid);
-        if (tid < 32) { lse_s[buf][tid] = s_lse; d_s[buf][tid] = s_d; }
+        at_stage_store<CHP>(sq, qt(buf, kg, 0), qt(buf, kg, 1), tid);
+        at_stage_store<CHP>(sg, gt(buf, kg, 0), gt(buf, kg, 1), tid);
+        at_row_store<CHP, 256>(rq, qr(buf, kg, 0), qr(buf, kg, 1), tid);
+        at_row_store<CHP, 256>(rg, gr(buf, kg, 0), gr(buf, kg, 1), tid);
+        if (tid < 32) { lse_s(buf, kg)[tid] = s_lse; d_s(buf, kg)[tid] = s_d; }
     };
-    // the A-operand rows of Q and dO (row = query qb * 32 + l31) one query block ahead as raw fp32, up to 64-wide heads (see k_attn_bwd_dq)
-    constexpr bool PF = CHP <= 64;
-    AtRaw8 qraw[PF ? KS : 1], graw[PF ? KS : 1];
-    auto prefetch = [&](uint32_t qb) {
-        if constexpr (PF) {
-            const uint32_t qrow = qb * 32 + l31;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const uint32_t c8 = 2 * s + hf;
-                const bool ok = active && qrow < T && c8 < nchunk;
-                qraw[s] = at_load_raw(base + (size_t)qrow * rs + c8 * 8, ok);
-                graw[s] = at_load_raw(dbase + (size_t)qrow * C + c8 * 8, ok);
-            }
-        }
-    };
-    prefetch(0);
-    stage_load(0);
+    stage_load(kg);
     stage_store(0);
     __syncthreads();
-    for (uint32_t qb = 0; qb < nqb; ++qb) {
-        const uint32_t buf = qb & 1;
-        AtRaw8 qcur[PF ? KS : 1], gcur[PF ? KS : 1];
-        if constexpr (PF) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { qcur[s] = qraw[s]; gcur[s] = graw[s]; }
-        }
-        if (qb + 1 < nqb) { prefetch(qb + 1); stage_load(qb + 1); }
-        if (active) {
-            const uint32_t qrow = qb * 32 + l31;                                    // the row this lane supplies to the A operands
+    for (uint32_t sb = 0; sb < nsb; ++sb) {
+        const uint32_t buf = sb & 1, qb = sb * KG + kg;
+        if (sb + 1 < nsb) stage_load(qb + KG);
+        if (active && qb < nqb) {
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const uint32_t c8 = 2 * s + hf;
-                bf16x8 ah, al;
-                if constexpr (PF) at_split8(qcur[s].a, qcur[s].b, ah, al);
-                else at_load_split(base + (size_t)qrow * rs + c8 * 8, qrow < T && c8 < nchunk, ah, al);          // Q: S[query][key]
-                sacc = at_mfma3(ah, al, kh[s], kl[s], sacc);
-                if constexpr (PF) at_split8(gcur[s].a, gcur[s].b, ah, al);
-                else at_load_split(dbase + (size_t)qrow * C + c8 * 8, qrow < T && c8 < nchunk, ah, al);          // dO: dP[query][key]
-                dpacc = at_mfma3(ah, al, vh[s], vl[s], dpacc);
+                const uint32_t roff = l31 * KROW + (2 * s + hf) * 16;               // the row this lane supplies to the A operands: query qb * 32 + l31
+                const bf16x8 q_h = *reinterpret_cast<const bf16x8*>(qr(buf, kg, 0) + roff), q_l = *reinterpret_cast<const bf16x8*>(qr(buf, kg, 1) + roff);
+                sacc = at_mfma3(q_h, q_l, kh[s], kl[s], sacc);                      // Q: S[query][key]
+                const bf16x8 g_h = *reinterpret_cast<const bf16x8*>(gr(buf, kg, 0) + roff), g_l = *reinterpret_cast<const bf16x8*>(gr(buf, kg, 1) + roff);
+                dpacc = at_mfma3(g_h, g_l, vh[s], vl[s], dpacc);                    // dO: dP[query][key]
             }
             float p[16], ds[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                                           // registers 4 g .. 4 g + 3 = queries 8 g + 4 hf + {0 .. 3} of the block
-                const float4 lq = *reinterpret_cast<const float4*>(&lse_s[buf][8 * g + 4 * hf]), dq4 = *reinterpret_cast<const float4*>(&d_s[buf][8 * g + 4 * hf]);
+                const float4 lq = *reinterpret_cast<const float4*>(lse_s(buf, kg) + 8 * g + 4 * hf), dq4 = *reinterpret_cast<const float4*>(d_s(buf, kg) + 8 * g + 4 * hf);
                 const float lv[4] = {lq.x, lq.y, lq.z, lq.w}, dvv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -652,14 +692,41 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const size_t off = (size_t)(c * 32 + l31) * AT_ROW + s * 32 + hf * 16;
-                    const bf16x8 g_h = *reinterpret_cast<const bf16x8*>(gt[buf][0] + off), g_l = *reinterpret_cast<const bf16x8*>(gt[buf][1] + off);
+                    const bf16x8 g_h = *reinterpret_cast<const bf16x8*>(gt(buf, kg, 0) + off), g_l = *reinterpret_cast<const bf16x8*>(gt(buf, kg, 1) + off);
                     dv[c] = at_mfma3(g_h, g_l, ph[s], pl[s], dv[c]);                 // dV^T[channel][key] += dO^T[channel][8 queries of this half] P
-                    const bf16x8 q_h = *reinterpret_cast<const bf16x8*>(qt[buf][0] + off), q_l = *reinterpret_cast<const bf16x8*>(qt[buf][1] + off);
+                    const bf16x8 q_h = *reinterpret_cast<const bf16x8*>(qt(buf, kg, 0) + off), q_l = *reinterpret_cast<const bf16x8*>(qt(buf, kg, 1) + off);
                     dk[c] = at_mfma3(q_h, q_l, dsh[s], dsl[s], dk[c]);               // dK^T[channel][key] += Q^T[channel][8 queries of this half] dS
                 }
         }
-        if (qb + 1 < nqb) stage_store(buf ^ 1);
+        if (sb + 1 < nsb) stage_store(buf ^ 1);
         __syncthreads();
+    }
+    if constexpr (KG > 1) {                                                         // the query groups' partial dK, dV: groups 1.. -> LDS -> group 0 (lane for lane)
+        constexpr int MS = 2 * CT * 16;
+        float* mg0 = reinterpret_cast<float*>(lds_all) + (wave * 64 + lane) * MS;
+        if (kg > 0) {
+            float* mg = mg0 + (kg - 1) * (4 * 64 * MS);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    *reinterpret_cast<float4*>(mg + c * 16 + e) = make_float4(dk[c][e], dk[c][e + 1], dk[c][e + 2], dk[c][e + 3]);
+                    *reinterpret_cast<float4*>(mg + CT * 16 + c * 16 + e) = make_float4(dv[c][e], dv[c][e + 1], dv[c][e + 2], dv[c][e + 3]);
+                }
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const float* mg = mg0 + (g - 1) * (4 * 64 * MS);
+                    const float4 a = *reinterpret_cast<const float4*>(mg + c * 16 + e), v = *reinterpret_cast<const float4*>(mg + CT * 16 + c * 16 + e);
+                    dk[c][e] += a.x; dk[c][e + 1] += a.y; dk[c][e + 2] += a.z; dk[c][e + 3] += a.w;
+                    dv[c][e] += v.x; dv[c][e + 1] += v.y; dv[c][e + 2] += v.z; dv[c][e + 3] += v.w;
+                }
     }
     if (!active || !k_ok) return;
     float* op = dqkv + (size_t)(b * T + key) * rs + (size_t)h * 3 * ch;
@@ -735,12 +802,18 @@ extern "C" int ssdnerf_attention_qkv_f32_backward(const void* qkv, const void* o
     float* Dv = (float*)workspace;                                            // B * heads * T floats
     float* d = (float*)dqkv;
     hipLaunchKernelGGL(k_attn_bwd_D, dim3((B * T * heads + 255) / 256), dim3(256), 0, st, (const float*)out, g, Dv, B, T, heads, ch);
-    const dim3 grid((T + 127) / 128, B * heads), block(256);
-#define AT_BWD(CHP)                                                                                                                     \
-    hipLaunchKernelGGL((k_attn_bwd_dq<CHP>), grid, block, 0, st, q, g, l, (const float*)Dv, d, T, heads, ch, scale, scale_log2e);        \
-    hipLaunchKernelGGL((k_attn_bwd_dkv<CHP>), grid, block, 0, st, q, g, l, (const float*)Dv, d, T, heads, ch, scale, scale_log2e);
-    if (ch <= 32) { AT_BWD(32) } else if (ch <= 64) { AT_BWD(64) } else if (ch <= 96) { AT_BWD(96) } else { AT_BWD(128) }
-#undef AT_BWD
+    const dim3 grid((T + 127) / 128, B * heads);
+    // two key / query groups (eight waves per block, two per SIMD) for the 64-wide-or-narrower heads when the grid leaves the chip at <= one wave per SIMD;
+    // SSDNERF_ATTN_BWD_KG=1|2 forces (A/B runs)
+    static const int forced_kg = getenv("SSDNERF_ATTN_BWD_KG") ? atoi(getenv("SSDNERF_ATTN_BWD_KG")) : 0;
+    const bool kg2 = ch <= 64 && (forced_kg == 2 || (forced_kg != 1 && (uint64_t)grid.x * grid.y <= 512 && T >= 128));
+#define AT_BWD_KG(CHP, KG)                                                                                                                    \
+    hipLaunchKernelGGL((k_attn_bwd_dq<CHP, KG>), grid, dim3(256 * KG), 0, st, q, g, l, (const float*)Dv, d, T, heads, ch, scale, scale_log2e);  \
+    hipLaunchKernelGGL((k_attn_bwd_dkv<CHP, KG>), grid, dim3(256 * KG), 0, st, q, g, l, (const float*)Dv, d, T, heads, ch, scale, scale_log2e);
+    if (ch <= 32) { if (kg2) { AT_BWD_KG(32, 2) } else { AT_BWD_KG(32, 1) } }
+    else if (ch <= 64) { if (kg2) { AT_BWD_KG(64, 2) } else { AT_BWD_KG(64, 1) } }
+    else if (ch <= 96) { AT_BWD_KG(96, 1) } else { AT_BWD_KG(128, 1) }
+#undef AT_BWD_KG
     SSD_CHECK_LAUNCH("attention_qkv_f32_backward");
     return SSDNERF_OK;
 }

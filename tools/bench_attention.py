@@ -13,4 +13,13 @@ for T, ch in ((1024, 64), (256, 128), (64, 128)):
         s.record()
         for _ in range(50): UF.attention_qkv(qkv, heads)
         e.record(); torch.cuda.synchronize()
-        print(f"T={T:5d} ch={ch:4d} {str(dt)[6:]:9s} {s.elapsed_time(e) / 50 * 1e3:7.1f} us")
+        line = f"T={T:5d} ch={ch:4d} {str(dt)[6:]:9s} forward {s.elapsed_time(e) / 50 * 1e3:7.1f} us"
+        if dt == torch.float32:                               # the gradient path's backward (k_attn_bwd_D + dq + dkv), fp32 only
+            out, lse = UF.attention_qkv_f32_with_lse(qkv, heads)
+            dout = torch.randn_like(out)
+            for _ in range(3): UF.attention_qkv_f32_backward(qkv, out, dout, lse, heads)
+            s.record()
+            for _ in range(30): UF.attention_qkv_f32_backward(qkv, out, dout, lse, heads)
+            e.record(); torch.cuda.synchronize()
+            line += f"   backward {s.elapsed_time(e) / 30 * 1e3:7.1f} us"
+        print(line)
