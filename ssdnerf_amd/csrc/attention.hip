@@ -354,6 +354,8 @@ __global__ __launch_bounds__(64 * WPB * KG) void k_attn_fwd(const unsigned char*
 //                   LDS in the C-layout key order, as the forward's V^T)
 //   k_attn_bwd_dkv  a wave owns 32 keys and walks the query blocks: S = Q K^T and dP = dO V^T (a lane = one key, 16 queries in its registers; their lse
 //                   and D come from LDS), P and dS are the B operands of  dV^T += dO^T P  and  dK^T += Q^T dS  (Q^T and dO^T through LDS).
+// r04: the A-operand ROWS of the walked axis (K, V for dQ; Q, dO for dK / dV) also go through LDS, once per block and already split (AtRowStage), and the 64-wide
+// heads run two key / query groups per block (template KG): profiles/r04/z_attention_backward_lds_key_groups.txt.
 SSD_DEV void at_load_split(const float* p, bool ok, bf16x8& hi, bf16x8& lo) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (ok) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
