@@ -38,6 +38,11 @@ class _PinnedRing:
         key = (tuple(shape), str(device))
         ring = cls.rings.get(key)
         if ring is None:
+            if len(cls.rings) >= 8:                             # (pinned memory is a scarce resource: keep the rings of the last few shapes only)
+                old = cls.rings.pop(next(iter(cls.rings)))
+                for ev in old["events"]:
+                    if ev is not None:
+                        ev.synchronize()
             ring = cls.rings[key] = {"bufs": [torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(2)], "events": [None, None], "i": 0}
         i = ring["i"]
         ring["i"] = i ^ 1

@@ -95,8 +95,8 @@ class _ConvF32x2Fn(torch.autograd.Function):
         # a LARGE layer (the two-group row kernel's) whose dy no norm produced -- the accumulated gradient in front of a block's second convolution, or the
         # channel slice autograd returns for one input of a concatenation --: one split pass (two passes over dy, reading a slice IN PLACE) + the pre-split
         # kernel beat that kernel's on-the-fly split (211 vs 17 + 150 us at 128 x 128 x 128 x 8) and the dense copy a slice would need first
-        if (getattr(conv, "grad_split_dy", False) and gy.dtype == torch.float32 and gy.size(1) % 32 == 0 and UF.nhwc_pixel_stride(gy) % 4 == 0
-                and UF.nhwc_pixel_stride(gy) > 0 and gy.data_ptr() % 16 == 0 and UF.presplit_supported(gy, conv.in_channels, conv.kernel_size[0]) == 1):
+        pstride = UF.nhwc_pixel_stride(gy) if getattr(conv, "grad_split_dy", False) and gy.dtype == torch.float32 and gy.size(1) % 32 == 0 else 0
+        if pstride > 0 and pstride % 4 == 0 and gy.data_ptr() % 16 == 0 and UF.presplit_supported(gy, conv.in_channels, conv.kernel_size[0]) == 1:
             gx = UF.conv2d_nhwc_f32x2_presplit(UF.split_f32_nhwc(gy), hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
             return gx, None, (gy if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None, None
         gyc = gy.contiguous(memory_format=torch.channels_last)

@@ -279,3 +279,20 @@ def test_input_gradient_norms_fused_channel_last(monkeypatch):
     net(x0.clone().requires_grad_(True), t)
     net.eval()
     assert len(fwd) == 1 + n_att                                               # the output head and the attention blocks (no dropout there)
+
+
+def test_nhwc_pixel_stride_recognises_dense_tensors_and_channel_slices():
+    """``unet_fast.nhwc_pixel_stride``: floats from pixel to pixel of a channel-last tensor over a possibly wider channel axis (the slices autograd returns for the
+    inputs of a concatenation), 0 for anything else -- what decides whether the split pass may read a gradient in place."""
+    wide = torch.randn(2, 48, 5, 7).contiguous(memory_format=torch.channels_last)
+    assert unet_fast.nhwc_pixel_stride(wide) == 48
+    assert unet_fast.nhwc_pixel_stride(wide[:, :32]) == 48 and unet_fast.nhwc_pixel_stride(wide[:, 32:]) == 48
+    assert unet_fast.nhwc_pixel_stride(wide[:1, 16:]) == 48                      # (one sample: the batch stride does not matter)
+    assert unet_fast.nhwc_pixel_stride(wide.contiguous()) == 0                   # NCHW
+    assert unet_fast.nhwc_pixel_stride(wide[:, :, ::2]) == 0                     # rows skipped
+    assert unet_fast.nhwc_pixel_stride(wide[:, ::2]) == 0                        # channels skipped
+    assert unet_fast.nhwc_pixel_stride(wide[0]) == 0                             # not 4-D
+    a, b = wide[:, :32].clone(memory_format=torch.contiguous_format).requires_grad_(True), torch.randn(2, 16, 5, 7, requires_grad=True)
+    cat = torch.cat([a.contiguous(memory_format=torch.channels_last), b.contiguous(memory_format=torch.channels_last)], dim=1)
+    ga, gb = torch.autograd.grad(cat, (a, b), wide)                              # the case it exists for
+    assert cat.is_contiguous(memory_format=torch.channels_last)
