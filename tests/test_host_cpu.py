@@ -313,3 +313,27 @@ def test_density_volume_for_mesh_extraction_matches_oracle_decode():
     # reference's backend, stays an optional one and is not installed here
     with pytest.raises(ImportError):
         nerf.extract_geometry(dec, code, resolution=res, backend="mcubes")
+
+
+def test_pre_split_convolution_planning_is_host_logic():
+    """``ssdnerf_conv2d_nhwc_f32x2_presplit_supported`` and the tile / split-K plans are pure host functions (no device call): which layers a norm may hand
+    over pre-split -- 1: the two-group row kernel, 2: the generic kernel's PS form, 0: neither --, and that refusals come back as error codes with a message."""
+    from ssdnerf_amd import build
+    lib = ctypes.CDLL(build.build())
+    u32 = ctypes.c_uint32
+    sup = lambda B, H, W, Cin, Cout, k, stats=0: lib.ssdnerf_conv2d_nhwc_f32x2_presplit_supported(u32(B), u32(H), u32(W), u32(Cin), u32(Cout), u32(k), stats)
+    assert sup(8, 128, 128, 128, 128, 3) == 1 and sup(8, 64, 64, 256, 256, 3, 1) == 1            # the large 3 x 3 layers of the cars UNet
+    assert sup(8, 16, 16, 512, 512, 3, 1) == 2 and sup(8, 32, 32, 256, 768, 1) == 2              # low resolution, 1 x 1 projections
+    assert sup(1, 128, 128, 128, 128, 3) == 2                                                    # one scene: too few pixels for the row kernel
+    assert sup(8, 128, 128, 24, 128, 3) == 0 and sup(8, 32, 32, 128, 6, 3) == 0 and sup(8, 32, 32, 128, 128, 5) == 0 and sup(0, 32, 32, 128, 128, 3) == 0
+    assert sup(1, 20, 20, 64, 64, 3, 0) == 2 and sup(1, 20, 20, 64, 64, 3, 1) == 0               # 400 pixels: no fused statistics on an unsplit 64-row tile
+    plan = lib.ssdnerf_conv2d_nhwc_f32x2_plan(u32(2048), u32(512), u32(512), u32(3), 0, 0)
+    assert plan & 0xff in (1, 3) and (plan >> 8) >= 1
+    lib.ssdnerf_last_error.restype = ctypes.c_char_p
+    rc = lib.ssdnerf_conv2d_nhwc_f32x2_presplit(None, None, None, None, None, None, u32(8), u32(16), u32(16), u32(512), u32(512), u32(3), None, u32(0), 0, 0, None,
+                                                ctypes.c_size_t(0), None)
+    assert rc == -1 and b"null pointer" in lib.ssdnerf_last_error()
+    buf = (ctypes.c_float * 16)()
+    rc = lib.ssdnerf_split_f32_nhwc(buf, buf, ctypes.c_uint64(4), u32(32), ctypes.c_uint64(0), None)                       # in place
+    assert rc == -1 and b"split_f32_nhwc" in lib.ssdnerf_last_error()
+    assert lib.ssdnerf_split_f32_nhwc(None, None, ctypes.c_uint64(0), u32(32), ctypes.c_uint64(0), None) == 0                # empty: a no-op
