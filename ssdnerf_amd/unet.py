@@ -567,6 +567,55 @@ class _NormActConv(nn.Module):
         return self.conv(self.activate(self.gn(x)))
 
 
+class _GraphedGrad:
+    """fn(x, t) -> y with its gradient w.r.t. x, as two captured hipGraphs over static buffers (what ``torch.cuda.make_graphed_callables`` builds, with the
+    capture mode of ``unet_fast.CAPTURE_MODE``: in an N > 1 job other threads -- the collective library's watchdog -- make calls that a global-mode capture
+    does not tolerate).  One warm-up iteration on a side stream, forward capture, backward capture into the same pool; calls copy (x, t) into the static
+    inputs and replay; the backward copies the incoming gradient and replays.  The returned tensors are the STATIC buffers (overwritten by the next replay)."""
+
+    def __init__(self, fn, x, t):
+        from .unet_fast import CAPTURE_MODE
+        self.x, self.t = x, t                                       # x: a leaf that requires grad
+        cur = torch.cuda.current_stream(x.device)
+        side = torch.cuda.Stream(x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            y = fn(self.x, self.t)
+            (g,) = torch.autograd.grad(y, self.x, torch.ones_like(y))
+            del y, g
+        cur.wait_stream(side)
+        self.fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd, capture_error_mode=CAPTURE_MODE):
+            self.y = fn(self.x, self.t)
+        self.gy = torch.zeros_like(self.y)
+        self.bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd, pool=self.fwd.pool(), capture_error_mode=CAPTURE_MODE):
+            (self.gx,) = torch.autograd.grad(self.y, self.x, self.gy)
+        outer = self
+
+        class _Replay(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x_in, t_in):
+                if x_in.data_ptr() != outer.x.data_ptr():
+                    outer.x.copy_(x_in)
+                outer.t.copy_(t_in)
+                outer.fwd.replay()
+                return outer.y.detach()
+
+            @staticmethod
+            @torch.autograd.function.once_differentiable
+            def backward(ctx, g_in):
+                if g_in.data_ptr() != outer.gy.data_ptr():
+                    outer.gy.copy_(g_in)
+                outer.bwd.replay()
+                return outer.gx.detach(), None
+
+        self._replay = _Replay
+
+    def __call__(self, x, t):
+        return self._replay.apply(x, t)
+
+
 @MODULES.register_module()
 class DenoisingUnetMod(nn.Module):
     """Same constructor keywords and topology as the reference (denoising.py:15-187)."""
@@ -745,7 +794,7 @@ class DenoisingUnetMod(nn.Module):
     grad_path_fp32_under_autocast = os.environ.get("SSDNERF_UNET_GRAD_AUTOCAST", "0") != "1"
 
     #: r04: input-gradient calls with frozen weights (rendering-guided DDIM steps, the prior loss of fine-tuning) replay a CAPTURED forward and a captured
-    #: backward (two hipGraphs over static buffers, ``torch.cuda.make_graphed_callables``) once a signature has been seen ``grad_graph_after`` times: the
+    #: backward (two hipGraphs over static buffers, ``_GraphedGrad``) once a signature has been seen ``grad_graph_after`` times: the
     #: eager gradient path is ~600 launches and ~250 autograd nodes per call, ~25 ms of host time beside ~25 ms of kernels (profiles/r04).  Same kernels in
     #: the same order.  SSDNERF_UNET_GRAD_GRAPH=0 keeps the eager path.
     grad_graph = os.environ.get("SSDNERF_UNET_GRAD_GRAPH", "1") != "0"
@@ -779,12 +828,12 @@ class DenoisingUnetMod(nn.Module):
         if entry["failed"] or entry["calls"] <= self.grad_graph_after:
             return None
         try:
-            # (warm-up inside make_graphed_callables runs on a side stream; the eager calls before this one have filled every cache -- split weights,
+            # (_GraphedGrad's warm-up runs on a side stream; the eager calls before this one have filled every cache -- split weights,
             # batched time-embedding projections, split-K scratch -- so nothing persistent is created inside the capture)
             import time
             t0 = time.perf_counter()
             sx, st = x_t.detach().clone().requires_grad_(True), t.detach().clone()
-            entry["fn"] = torch.cuda.make_graphed_callables(lambda x, tt: self._forward_eager(x, tt), (sx, st), num_warmup_iters=1)
+            entry["fn"] = _GraphedGrad(lambda x, tt: self._forward_eager(x, tt), sx, st)
             entry["capture_s"] = time.perf_counter() - t0
         except Exception as e:                                       # noqa: BLE001  (e.g. a library call that cannot be captured: stay eager, say so once)
             entry["failed"] = True

@@ -332,6 +332,10 @@ def attention_qkv(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     return attention_qkv_bf16(qkv, heads) if qkv.dtype == torch.bfloat16 else attention_qkv_f32(qkv, heads)
 
 
+#: hipGraph capture mode of the executor and of the gradient path (unet._GraphedGrad)
+CAPTURE_MODE = os.environ.get("SSDNERF_GRAPH_CAPTURE_MODE", "thread_local")
+
+
 class _Conv:
     """A convolution split into its bias-less GEMM part (``mm``) and an fp32 bias that the *consumer* folds in: the following
     GroupNorm (``pre_bias``) or the residual epilogue -- the library convolution would spend a pass of its own on it.
@@ -747,7 +751,9 @@ class FastUnet:
                     self._forward(sx, st)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (thread-local capture mode: what OTHER threads do -- the collective library's watchdog polling its events in an N > 1 job -- must not invalidate
+            #  a capture of this thread's stream; this thread issues only capturable calls, as the warm-up above has just shown)
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 sy = self._forward(sx, st)
             entry = self._graphs[key] = (g, sx, st, sy)
         g, sx, st, sy = entry
