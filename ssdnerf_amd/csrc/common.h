@@ -237,7 +237,9 @@ __host__ __device__ static inline uint32_t ssd_counter(uint32_t kind, uint32_t S
 //   view_masks [S][<= N/64 views][8] u32: per view, a 16 x 16-tile mask of the image tiles that a set coarse block projects into (k_view_masks)
 //   view_zr [S][<= N/256 views][256] u32: per image tile, the camera-depth range of the set coarse blocks that project into it, as two bf16
 //              (low half: lower end rounded down, high half: upper end rounded up): k_ray_cull scans a ray's test points inside that range only
-struct RenderWs { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; uint2* survivors; uint32_t* view_masks; uint32_t* view_zr; uint64_t* blocks64; size_t counter_bytes, bytes; };
+//   qkey [S][key_stride] u8: per queue entry, an upper bound of the ray's remaining march steps (<= 255); order [S][order_stride] u32: the queue's 64-entry
+//              slices in the order the shading kernel's tickets take them (k_ticket_order: longest slice first, r05)
+struct RenderWs { uint32_t* counters; uint8_t* lin_bits; uint8_t* coarse; uint2* queue; uint2* survivors; uint32_t* view_masks; uint32_t* view_zr; uint64_t* blocks64; uint8_t* qkey; uint32_t* order; uint32_t key_stride, order_stride; size_t counter_bytes, bytes; };
 static inline RenderWs ssd_render_ws(void* base, uint32_t S, uint32_t N, uint32_t grid_size) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t counters = up((size_t)SSD_CNT_KINDS * S * SSD_COUNTER_STRIDE * 4), bits = up((size_t)S * grid_size * grid_size * grid_size / 8);
@@ -255,8 +257,13 @@ static inline RenderWs ssd_render_ws(void* base, uint32_t S, uint32_t N, uint32_
     w.view_zr = (uint32_t*)(b + counters + bits + coarse + queue + surv + masks);
     const size_t zr = up((size_t)S * (N / 256 + 1) * 1024);
     w.blocks64 = (uint64_t*)(b + counters + bits + coarse + queue + surv + masks + zr);      // [S][(H/4)^3] u64: the 64 cells of a 4^3 block in one word (k_survivor_march)
+    w.key_stride = (uint32_t)(((size_t)N + 63) / 64 * 64);
+    w.order_stride = (uint32_t)(((size_t)N + 63) / 64);
+    const size_t keys = up((size_t)S * w.key_stride), order = up((size_t)S * w.order_stride * 4);
+    w.qkey = b + counters + bits + coarse + queue + surv + masks + zr + bits;
+    w.order = (uint32_t*)(b + counters + bits + coarse + queue + surv + masks + zr + bits + keys);
     w.counter_bytes = counters;
-    w.bytes = counters + bits + coarse + queue + surv + masks + zr + bits;
+    w.bytes = counters + bits + coarse + queue + surv + masks + zr + bits + keys + order;
     return w;
 }
 

@@ -436,11 +436,12 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
                                                             const uint2* __restrict__ survivors, float* __restrict__ image,
                                                             float* __restrict__ depth, float* __restrict__ weights_sum,
                                                             int32_t* __restrict__ sample_counts, uint2* __restrict__ queue,
-                                                            uint32_t* __restrict__ counters) {
+                                                            uint32_t* __restrict__ counters, uint8_t* __restrict__ qkey /* or null */, uint32_t key_stride) {
     const uint32_t scene = blockIdx.y;
     const uint32_t count = counters[ssd_counter(SSD_CNT_SURVIVORS, c.S, scene)];
     if (blockIdx.x * (RQ_CHUNKS * RQ_TPB) >= count) return;                  // the grid covers the worst case (every ray survives)
     __shared__ uint2 list[RQ_CHUNKS * RQ_TPB];                                // long rays from the front, short rays from the back
+    __shared__ uint8_t keys[RQ_CHUNKS * RQ_TPB];                              // (ticket order) per list entry: upper bound of the remaining march steps
     __shared__ uint32_t list_count, short_count, slot, slot_short;
     if (threadIdx.x == 0) { list_count = 0; short_count = 0; }
     __syncthreads();
@@ -524,8 +525,24 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
                 if (sample_counts) sample_counts[gi] = 0;
             }
         }
-        const bool is_long = hit && (far_b - t) > (float)RQ_LONG_STEPS * c.m.dt_min;
-        rq_lds_append(is_long, make_uint2(e, __float_as_uint(t)), list, &list_count);
+        // ticket order (r05, qkey != null): every hit goes to the front part IN ARRIVAL ORDER -- a wave of this kernel is an 8 x 8 pixel block of a
+        // view (k_ray_cull), so 64 consecutive entries are neighbouring rays -- with its bound on the steps it can still take; k_ticket_order then
+        // sorts the queue's 64-entry SLICES, not the rays.  Otherwise two classes, long rays first (the r02 - r04 form).
+        const float steps_left = (far_b - t) / c.m.dt_min;
+        const bool is_long = hit && (qkey != nullptr || (far_b - t) > (float)RQ_LONG_STEPS * c.m.dt_min);
+        {
+            const uint64_t m = __ballot(is_long);
+            if (m != 0) {
+                uint32_t base = 0;
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) base = atomicAdd(&list_count, (uint32_t)__popcll(m));
+                base = __shfl(base, __builtin_ctzll(m), 64);
+                if (is_long) {
+                    const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    list[at] = make_uint2(e, __float_as_uint(t));
+                    keys[at] = (uint8_t)fminf(255.0f, fmaxf(steps_left, 0.0f));
+                }
+            }
+        }
         {   // short rays: the same append, growing down from the end of the list
             const uint64_t m = __ballot(hit && !is_long);
             if (m != 0) {
@@ -551,6 +568,8 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
     __syncthreads();
     uint2* q = queue + (uint64_t)scene * c.N;
     for (uint32_t i = threadIdx.x; i < n_long; i += blockDim.x) q[slot + i] = list[i];
+    if (qkey != nullptr)
+        for (uint32_t i = threadIdx.x; i < n_long; i += blockDim.x) qkey[(uint64_t)scene * key_stride + slot + i] = keys[i];
     for (uint32_t i = threadIdx.x; i < n_short; i += blockDim.x) q[c.N - 1u - (slot_short + i)] = list[RQ_CHUNKS * RQ_TPB - 1u - i];
 }
 
@@ -568,6 +587,50 @@ __global__ void __launch_bounds__(RQ_TPB) k_queue_close(uint32_t S, uint32_t N, 
 __global__ void k_queue_total(uint32_t S, uint32_t* __restrict__ counters) {
     const uint32_t scene = blockIdx.x * blockDim.x + threadIdx.x;
     if (scene < S) counters[ssd_counter(SSD_CNT_HITS, S, scene)] += counters[ssd_counter(SSD_CNT_HITS_SHORT, S, scene)];
+}
+
+// Ticket order (r05).  The persistent shading kernel ends when its last wave has drained the rays it still holds after the last ticket; a ray's
+// samples are sequential, so that drain lasts as long as the longest ray that was STARTED late.  Two classes (long / short at 48 steps) do not help on
+// object scenes -- 98.8 % of the bench's hitting rays take at most 48 samples (tools/ray_length_hist.py), the launch ended 0.3 ms (6 %) after its
+// mean wave with or without them -- and a finer sort of RAYS would scatter neighbouring pixels over the queue.  So the queue stays in arrival order
+// and its 64-entry slices (= tickets = stage fills) are handed out longest first: key = the largest step bound of the slice's rays, 64 buckets
+// of 4 steps, one block per scene (a few thousand slices), counting sort.  order[pos] = slice index; the position inside a bucket is whatever the
+// atomics give -- the order of tickets never changes a ray's result.  Also folds the short-class count into the total like k_queue_total.
+__global__ void __launch_bounds__(1024) k_ticket_order(uint32_t S, const uint8_t* __restrict__ qkey, uint32_t key_stride, uint32_t* __restrict__ counters,
+                                                        uint32_t* __restrict__ order, uint32_t order_stride) {
+    const uint32_t scene = blockIdx.x;
+    __shared__ uint32_t hist[64], cursor[64];
+    const uint32_t count = counters[ssd_counter(SSD_CNT_HITS, S, scene)] + counters[ssd_counter(SSD_CNT_HITS_SHORT, S, scene)];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n_slices = (count + 63u) / 64u;
+    const uint8_t* k = qkey + (uint64_t)scene * key_stride;
+    auto bucket_of = [&](uint32_t sl) -> uint32_t {
+        uint32_t mx = 0;
+        const uint32_t n = min(64u, count - sl * 64u);
+        if (n == 64u) {
+            const uint4* p4 = reinterpret_cast<const uint4*>(k + (uint64_t)sl * 64u);            // 64-byte aligned: key_stride is a multiple of 64
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 v = p4[j];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mx = max(mx, max(max(w[q] & 0xffu, (w[q] >> 8) & 0xffu), max((w[q] >> 16) & 0xffu, w[q] >> 24)));
+            }
+        } else {
+            for (uint32_t j = 0; j < n; ++j) mx = max(mx, (uint32_t)k[(uint64_t)sl * 64u + j]);
+        }
+        return 63u - (mx >> 2);                                                                  // bucket 0 = the longest rays
+    };
+    for (uint32_t sl = threadIdx.x; sl < n_slices; sl += blockDim.x) atomicAdd(&hist[bucket_of(sl)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 64; ++b) { cursor[b] = run; run += hist[b]; }
+        counters[ssd_counter(SSD_CNT_HITS, S, scene)] = count;
+    }
+    __syncthreads();
+    for (uint32_t sl = threadIdx.x; sl < n_slices; sl += blockDim.x) order[(uint64_t)scene * order_stride + atomicAdd(&cursor[bucket_of(sl)], 1u)] = sl;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -798,14 +861,21 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
         hipLaunchKernelGGL(k_view_masks, dim3(src.V, S), dim3(RQ_TPB), 0, s, c.m, src, cg.views_cap, cg.zr_cap, w.coarse, w.view_masks, w.view_zr);
     hipLaunchKernelGGL(k_ray_cull, grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
                        w.survivors, w.counters, view_cull ? w.view_masks : (const uint32_t*)nullptr, w.view_zr);
+    const char* to_env = getenv("SSDNERF_TICKET_ORDER");            // =0: the two-class queue of r02 - r04 (A/B runs, the bit-identity test); read per call,
+    const bool ticket_order = !(to_env && to_env[0] == '0');        // and the same way by the shading launch (shade_mfma.hip, sm_shade)
+    uint8_t* qkey = ticket_order ? w.qkey : nullptr;
     if (dt_gammas == nullptr && dt_gamma == 0.0f)
         hipLaunchKernelGGL(k_survivor_march<true>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, blocks64, w.survivors, image, depth, weights_sum,
-                           sample_counts, w.queue, w.counters);
+                           sample_counts, w.queue, w.counters, qkey, w.key_stride);
     else
         hipLaunchKernelGGL(k_survivor_march<false>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, blocks64, w.survivors, image, depth, weights_sum,
-                           sample_counts, w.queue, w.counters);
-    hipLaunchKernelGGL(k_queue_close, dim3(ssd_blocks(N / 2 + 1, RQ_TPB), S), dim3(RQ_TPB), 0, s, S, N, (uint2*)w.queue, w.counters);   // moves <= N/2 entries
-    hipLaunchKernelGGL(k_queue_total, dim3(ssd_blocks(S, 64)), dim3(64), 0, s, S, w.counters);
+                           sample_counts, w.queue, w.counters, qkey, w.key_stride);
+    if (ticket_order) {
+        hipLaunchKernelGGL(k_ticket_order, dim3(S), dim3(1024), 0, s, S, (const uint8_t*)w.qkey, w.key_stride, w.counters, w.order, w.order_stride);
+    } else {
+        hipLaunchKernelGGL(k_queue_close, dim3(ssd_blocks(N / 2 + 1, RQ_TPB), S), dim3(RQ_TPB), 0, s, S, N, (uint2*)w.queue, w.counters);   // moves <= N/2 entries
+        hipLaunchKernelGGL(k_queue_total, dim3(ssd_blocks(S, 64)), dim3(64), 0, s, S, w.counters);
+    }
     SSD_CHECK_LAUNCH("render_first_hit");
     return SSDNERF_OK;
 }

@@ -106,7 +106,17 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 #define SM_HEAD_GROUP 4                            // SiLU pairs per stage-ordered group of the colour head that runs without MFMAs beside it (16 % SM_HEAD_GROUP == 0)
 #endif
 #ifndef SM_GATHER_BY_PLANE
-#define SM_GATHER_BY_PLANE 1                       // gather one plane at a time (24 texel registers in flight instead of 72)
+#define SM_GATHER_BY_PLANE 0                       // 1: gather one plane at a time (24 texel registers in flight instead of 72; three dependent rounds, the r01-r04 form);
+                                                   // 0 (r05): all twelve texels in ONE round -- 5.05 -> 4.94 ms with two waves per SIMD, 6.72 -> 6.53 with one
+#endif
+// SM_EVENT_MIN (r05): lane bookkeeping -- the stores of a finished ray, the pool entry of a parked one, the refill of an idle lane and the SH
+// operands of a fresh ray -- is ~300 VALU instructions plus ~200 scalar / branch instructions that the WHOLE wave issues whenever ONE lane needs
+// them, and with 24 samples per hitting ray 2.6 lanes of 64 need them in every iteration (r04 census: 844 of the 1 219 VALU instructions per
+// iteration are gather + split + MLP, the rest is this).  A lane that finishes or must park now just raises a flag and sits out; the wave runs
+// the bookkeeping as ONE event when SM_EVENT_MIN lanes are waiting (or nothing is left to shade).  Per-ray arithmetic and its order are
+// untouched -- every output is bit-identical for any value; 1 = an event in every iteration (the r01-r04 behaviour).
+#ifndef SM_EVENT_MIN
+#define SM_EVENT_MIN 4                             // r05 A/B (bench scene, shade kernel, with SM_SEARCH_AHEAD and the one-round gather): 1: 5.06, 3: 4.94-4.97, 4: 4.94-4.96, 5: 4.97, 6: 5.01 ms
 #endif
 
 // Run-to-run reproducibility (r02 symptom, r03 cause).  r02: with two waves per SIMD a render repeated on the same inputs differed on groups of
@@ -118,6 +128,81 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 // the failure, a 64-byte shift did not; lengthening only the compiler's own `s_nop 0` behind transcendentals to `s_nop 1` IN PLACE (identical code
 // layout) gave 0 differing renders of 200 at every placement, 40 of 40 without.  The fix is therefore not here but in the build: asm_postpass.py
 // gives every transcendental -> use pair of the library four wait states, and the r02 barriers are gone.
+
+// SM_ADDR32 (r05): the gather of decode_core.h with the texel address as ONE 32-bit byte offset from the scene's (wave-uniform) plane base, so that
+// the loads take the base from SGPRs (saddr form) instead of a 64-bit add per corner; element-wise the same arithmetic, bit-identical features.
+// The host refuses plane sets of 4 GiB and more per scene (sm_shade).
+#ifndef SM_ADDR32
+#define SM_ADDR32 1
+#endif
+template <typename PT> struct SmTexel;
+template <> struct SmTexel<float> {
+    static SSD_DEV void load6(const float* __restrict__ base, uint32_t byte_off, float v[6]) {
+        const char* q = reinterpret_cast<const char*>(base) + byte_off;
+        const float4 a = *reinterpret_cast<const float4*>(q);
+        const float2 b = *reinterpret_cast<const float2*>(q + 16);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y;
+    }
+};
+template <> struct SmTexel<__half> {
+    static SSD_DEV void load6(const __half* __restrict__ base, uint32_t byte_off, float v[6]) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + byte_off);
+        const __half2* h = reinterpret_cast<const __half2*>(&raw);
+        const float2 a = __half22float2(h[0]), b = __half22float2(h[1]), c = __half22float2(h[2]);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+    }
+};
+// one plane: the four texels of the bilinear footprint (issue) and their blend (consume), separately, so that a caller can put work between them
+template <typename PT> struct SmPlaneTap {
+    float t00[6], t01[6], t10[6], t11[6];
+    float w00, w01, w10, w11;
+    SSD_DEV void issue(const PT* __restrict__ planes, const PlaneGeom& g, int p, float u, float v) {
+        uint32_t x0, x1, y0, y1;
+        float wx0, wx1, wy0, wy1;
+        ssd_grid_coord(u, g.Wf, g.Wp, x0, x1, wx0, wx1);
+        ssd_grid_coord(v, g.Hf, g.Hp, y0, y1, wy0, wy1);
+        constexpr uint32_t TEXEL = 8u * (uint32_t)sizeof(PT);
+        const uint32_t row0 = ((uint32_t)p * g.Hp + y0) * g.Wp, row1 = ((uint32_t)p * g.Hp + y1) * g.Wp;
+        SmTexel<PT>::load6(planes, (row0 + x0) * TEXEL, t00);
+        SmTexel<PT>::load6(planes, (row0 + x1) * TEXEL, t01);
+        SmTexel<PT>::load6(planes, (row1 + x0) * TEXEL, t10);
+        SmTexel<PT>::load6(planes, (row1 + x1) * TEXEL, t11);
+        w00 = wx0 * wy0; w01 = wx1 * wy0; w10 = wx0 * wy1; w11 = wx1 * wy1;
+    }
+    SSD_DEV void blend(int p, float f[18]) const {             // decode_core.h ssd_gather18's chain, on channel pairs
+        typedef float ssd_f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+            const ssd_f2 a00 = {t00[c], t00[c + 1]}, a01 = {t01[c], t01[c + 1]}, a10 = {t10[c], t10[c + 1]}, a11 = {t11[c], t11[c + 1]};
+            ssd_f2 r = a00 * ssd_f2{w00, w00};
+            r = __builtin_elementwise_fma(a01, ssd_f2{w01, w01}, r);
+            r = __builtin_elementwise_fma(a10, ssd_f2{w10, w10}, r);
+            r = __builtin_elementwise_fma(a11, ssd_f2{w11, w11}, r);
+            f[c * 3 + p] = r.x;
+            f[(c + 1) * 3 + p] = r.y;
+        }
+    }
+};
+template <typename PT, bool PLANE_BY_PLANE>
+SSD_DEV void sm_gather18(const PT* __restrict__ planes, const PlaneGeom& g, float x, float y, float z, float f[18]) {
+    const float us[3] = {x, x, y};
+    const float vs[3] = {y, z, z};
+    if (PLANE_BY_PLANE) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            SmPlaneTap<PT> tap;
+            tap.issue(planes, g, p, us[p], vs[p]);
+            tap.blend(p, f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        SmPlaneTap<PT> tap[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) tap[p].issue(planes, g, p, us[p], vs[p]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) tap[p].blend(p, f);
+    }
+}
 
 struct FastMarchB {
     float bound, dt_gamma, dt_min, dt_max, mip_bound, rb, half_H, two_rH, Hm1f;
@@ -133,6 +218,9 @@ struct ShadeCfg {
     uint32_t bitfield_stride;
     const float* dt_gammas;
     uint8_t* image_u8;          // [S][N][3] or null: quantised copy of the image (k_quantize_u8's rounding), written with it
+    const uint64_t* blocks64;   // [S][(H/4)^3] or null: the bitfield block-major, one u64 per 4^3 cells (k_bitfield_blocks64): the march pass skips empty blocks
+    const uint32_t* order;      // [S][order_stride] or null: ticket i of a scene is slice order[i] of its queue (k_ticket_order, render_queue.hip)
+    uint32_t order_stride;
 };
 
 struct ProbeB { float x, y, z, dt; int nx, ny, nz; bool occ; };
@@ -166,6 +254,54 @@ SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, fl
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     do { t += sm_dt<DTG0>(m, t); } while (t < tt);
     return t;
+}
+
+// SM_SEARCH_AHEAD (r05).  The successor of a sample does not depend on the sample's MLP -- only on the march: t1 = t + dt is probed; if that cell is
+// empty the DDA skip gives t2 (a function of the empty cell's INDEX, not of the loaded bit), then t3.  So both probe addresses and both skips are
+// straight-line arithmetic on t, and both occupancy bytes can be requested BEFORE the sample's gather and MLP; after compositing, the lane only
+// selects: the same far / cap / probe-budget tests in the same order on the same values as the loop they replace (bit-identical sample
+// sequences), without its two dependent load rounds and its divergent control flow (r05 section timing: composite + search was 2.8 k of a lone
+// wave's 14.3 k cycles per iteration).
+#ifndef SM_SEARCH_AHEAD
+#define SM_SEARCH_AHEAD 1
+#endif
+#ifndef SM_MARCH_BLOCKS
+#define SM_MARCH_BLOCKS 1                          // the march pass skips empty 4^3 / 2^3 blocks (r05 A/B below)
+#endif
+#ifndef SM_DRAIN_MARCH
+#define SM_DRAIN_MARCH 0                           // r05, measured and off: march parked rays as soon as a quarter of the lanes idle once the queue is used up -- 46 k -> 77 k
+#endif                                             // march passes per launch, 4.78 -> 4.93 ms: a pass costs ~18 k cycles whatever its size
+// sm_probe without the load: position, step, cell, and the cell's bit index
+template <bool DTG0>
+SSD_DEV ProbeB sm_probe_addr(const FastMarchB& m, const RayGeom& r, float t, uint32_t& idx) {
+    ProbeB p;
+    p.x = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dx, r.ox), -m.bound, m.bound);
+    p.y = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dy, r.oy), -m.bound, m.bound);
+    p.z = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dz, r.oz), -m.bound, m.bound);
+    p.dt = sm_dt<DTG0>(m, t);
+    p.nx = (int)fminf(ssd_fma(p.x, m.rb, 1.0f) * m.half_H, m.Hm1f);
+    p.ny = (int)fminf(ssd_fma(p.y, m.rb, 1.0f) * m.half_H, m.Hm1f);
+    p.nz = (int)fminf(ssd_fma(p.z, m.rb, 1.0f) * m.half_H, m.Hm1f);
+    idx = ((((uint32_t)p.nz << m.log2H) + (uint32_t)p.ny) << m.log2H) + (uint32_t)p.nx;
+    p.occ = false;
+    return p;
+}
+// the position / step part only (what a sample's gather and composite need): the same expressions as sm_probe's
+template <bool DTG0>
+SSD_DEV void sm_sample_at(const FastMarchB& m, const RayGeom& r, float t, float& x, float& y, float& z, float& dt) {
+    x = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dx, r.ox), -m.bound, m.bound);
+    y = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dy, r.oy), -m.bound, m.bound);
+    z = __builtin_amdgcn_fmed3f(ssd_fma(t, r.dz, r.oz), -m.bound, m.bound);
+    dt = sm_dt<DTG0>(m, t);
+}
+
+// exit parameter of the SZ^3-cell block around probe p, `e` inside the exit face (render_queue.hip rq_block_exit, k_survivor_march's block skip)
+template <int SZ>
+SSD_DEV float sm_block_exit(const FastMarchB& m, const RayGeom& r, const ProbeB& p, float sgx, float sgy, float sgz, float ex, float ey, float ez, float t) {
+    const float tx = (ssd_fma(ssd_fma((float)(p.nx & ~(SZ - 1)) + (float)SZ * sgx, m.two_rH, -1.0f), m.mip_bound, -p.x) - ex) * r.rdx;
+    const float ty = (ssd_fma(ssd_fma((float)(p.ny & ~(SZ - 1)) + (float)SZ * sgy, m.two_rH, -1.0f), m.mip_bound, -p.y) - ey) * r.rdy;
+    const float tz = (ssd_fma(ssd_fma((float)(p.nz & ~(SZ - 1)) + (float)SZ * sgz, m.two_rH, -1.0f), m.mip_bound, -p.z) - ez) * r.rdz;
+    return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
 }
 
 // v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.
@@ -298,6 +434,17 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
   uint32_t dbg_iters = 0, dbg_live = 0;
   const uint64_t dbg_t0 = wall_clock64();
 #endif
+  // SM_DEBUG_SECTIONS (tools/shade_sections.py): shader cycles a wave spends in each section of the loop body (its own stalls and the other wave's
+  // turns included), summed over waves into spare words of scene 0's boundary-counter line: 0 event, 1 gather, 2 split + MLP, 3 composite + search
+#ifdef SM_DEBUG_SECTIONS
+  uint64_t dbg_sec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t dbg_marches = 0, dbg_stages = 0, dbg_poolrefills = 0;
+  uint32_t dbg_events = 0, dbg_loops = 0;
+  uint64_t dbg_last = clock64();
+#define SM_SEC(i) do { __builtin_amdgcn_sched_barrier(0); const uint64_t n_ = clock64(); dbg_sec[i] += n_ - dbg_last; dbg_last = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SM_SEC(i) do { } while (0)
+#endif
   for (uint32_t sk = 0; sk < c.S; ++sk) {
     const uint32_t scene = (start_scene + sk) % c.S;
     const uint32_t count = queue_count[ssd_counter(SSD_CNT_HITS, c.S, scene)];
@@ -305,6 +452,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
     const uint64_t ray0 = (uint64_t)scene * c.N;
     planes = planes_base + scene * c.plane_stride;
     lin_bits = bits_base + (uint64_t)scene * c.bitfield_stride;
+    const uint64_t* blocks64 = c.blocks64 ? c.blocks64 + (uint64_t)scene * (c.bitfield_stride >> 3) : nullptr;
     queue = queue_base + ray0;
     c.m.dt_gamma = DTG0 ? 0.0f : (c.dt_gammas ? c.dt_gammas[scene] : dt_gamma_default);
     uint32_t next = 0, end = 0;
@@ -353,8 +501,51 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         }
     };
 
+    uint32_t wait = 0;                                                 // 0: shading; 1: finished, outputs not stored yet; 2: must park (SM_EVENT_MIN)
     for (;;) {
-        // ================= refill idle lanes: parked-and-found rays first, then the global hit queue =================
+      // ================= event: store finished rays, park, refill, march pass (every iteration when SM_EVENT_MIN == 1) =================
+      bool event = true;
+      if (SM_EVENT_MIN > 1) {
+          const uint64_t actv = __ballot(ray >= 0 && wait == 0);
+          const bool sources = rp_count != 0 || st_count != 0 || next < end || !scene_done;
+          const uint32_t waiting = (uint32_t)__popcll(__ballot(wait != 0)) + (sources ? (uint32_t)__popcll(__ballot(ray < 0)) : 0u);
+          event = actv == 0 || waiting >= (uint32_t)SM_EVENT_MIN ||
+                  (SM_DRAIN_MARCH && !sources && sp_count != 0 && (uint32_t)__popcll(actv) <= 48u);       // draining with parked rays: see the march-pass trigger below
+      }
+      if (event) {
+        SM_SEC(0);
+        if (wait == 1) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; wait = 0; }      // the ONE store sequence of the loop body
+        SM_SEC(4);
+        // ---- park rays that need a long search (state -> LDS search pool) ----
+        {
+            const uint64_t pm = __ballot(wait == 2);
+            if (pm != 0) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                const uint32_t room = SM_POOL - sp_count;
+                if (wait == 2 && rank < room) {
+                    uint32_t* e = pool_search + ((sp_head + sp_count + rank) % SM_POOL) * 8;
+                    *reinterpret_cast<uint4*>(e) = make_uint4((uint32_t)ray, __float_as_uint(t), __float_as_uint(ws), __float_as_uint(dep));
+                    *reinterpret_cast<uint4*>(e + 4) = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cb), cnt);
+                    ray = -1;
+                    wait = 0;
+                }
+                sp_count += min((uint32_t)__popcll(pm), room);
+                if (wait == 2) {   // pool full (cannot happen with the march-pass trigger below, kept as a guard): finish the search in the lane
+                    for (;;) {
+                        if (!(t < far_)) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break; }
+                        const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, r, t);
+                        if (p.occ) { sx = p.x; sy = p.y; sz = p.z; sdt = p.dt; break; }
+                        t = sm_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
+                    }
+                    wait = 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        SM_SEC(5);
+        // ---- refill idle lanes: parked-and-found rays first, then the global hit queue ----
         {
             const uint64_t idle = __ballot(ray < 0);
             if (idle != 0 && rp_count != 0) {
@@ -370,14 +561,17 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                     ssd_near_far(c.aabb, r, c.min_near, near_, far_);
                     far_ = ssd_tail_far(r, cell_world, near_, far_, e0.x, packing);
                     set_signs();
+#if !SM_SEARCH_AHEAD                                                               // (SM_SEARCH_AHEAD: position and step are recomputed from t where they are used)
                     const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, r, t);      // t points at an occupied probe
                     sx = p.x; sy = p.y; sz = p.z; sdt = p.dt;
+#endif
                     fresh = true;
                 }
                 rp_head = (rp_head + take) % SM_POOL;
                 rp_count -= take;
             }
         }
+        SM_SEC(6);
         // ---- from the staged rays (LDS); when the stage runs dry the whole wave prepares the next 64 queue entries ----
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
@@ -388,7 +582,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                     uint32_t sl = 0;
                     if (lane == 0) sl = atomicAdd(queue_count + ssd_counter(SSD_CNT_TICKETS, c.S, scene), 1u);
                     sl = __builtin_amdgcn_readfirstlane(sl);
-                    if (sl < n_slices) { next = sl * SM_SLICE; end = min(next + SM_SLICE, count); }
+                    if (sl < n_slices) {
+                        if (c.order != nullptr) sl = c.order[(uint64_t)scene * c.order_stride + sl];
+                        next = sl * SM_SLICE; end = min(next + SM_SLICE, count);
+                    }
                     else scene_done = true;
                 }
                 if (next >= end) break;
@@ -400,7 +597,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                     ssd_near_far(c.aabb, q, c.min_near, qn, qf);
                     qf = ssd_tail_far(q, cell_world, qn, qf, e.x, packing);
                     const float qt = __uint_as_float(e.y);
+#if SM_SEARCH_AHEAD
+                    ProbeB p; p.x = p.y = p.z = p.dt = 0.f;                     // (unused: recomputed from t at the top of the shading section)
+#else
                     const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, q, qt);      // the queued t is an occupied probe by construction
+#endif
                     float4* dst = stage + lane * 4;
                     dst[0] = make_float4(__uint_as_float(e.x), qt, qf, p.dt);
                     dst[1] = make_float4(q.ox, q.oy, q.oz, q.dx);
@@ -409,6 +610,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                 }
                 next = __builtin_amdgcn_readfirstlane(next + n);
                 st_head = 0; st_count = n;
+#ifdef SM_DEBUG_SECTIONS
+                ++dbg_stages;
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -427,11 +631,16 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             }
             st_head += take; st_count -= take;
         }
+        SM_SEC(7);
         if (fresh) { store_sh(); fresh = false; }               // (one copy of the SH evaluation + operand split for both refill sources)
         const uint64_t live = __ballot(ray >= 0);
+        SM_SEC(8);
 
         // ================= march pass: every lane takes one parked ray to its next hit or to the end of the box =================
-        if ((sp_count >= SM_MARCH_W || (live == 0 && sp_count != 0)) && rp_count <= SM_POOL - SM_MARCH_W) {
+        // (r05) ... or, once the scene's queue is used up, as soon as a quarter of the lanes idle: parked rays that wait for `live == 0` would start their
+        // remaining samples only after everything else has drained, one drain after the other at the very end of the launch
+        const bool draining = SM_DRAIN_MARCH && scene_done && next >= end && st_count == 0 && rp_count == 0 && sp_count != 0 && (uint32_t)__popcll(live) <= 48u;
+        if ((sp_count >= SM_MARCH_W || draining || (live == 0 && sp_count != 0)) && rp_count <= SM_POOL - SM_MARCH_W) {
             const uint32_t n = min(sp_count, SM_MARCH_W);
             bool found = false, mine = (uint32_t)lane < n;
             uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
@@ -444,6 +653,33 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                 qf = ssd_tail_far(q, cell_world, qn, qf, e0.x, packing);
                 const float qx = ssd_fma(0.5f, ssd_sign1(q.dx), 0.5f), qy = ssd_fma(0.5f, ssd_sign1(q.dy), 0.5f), qz = ssd_fma(0.5f, ssd_sign1(q.dz), 0.5f);
                 float qt = __uint_as_float(e0.y);
+                if (SM_MARCH_BLOCKS && blocks64 != nullptr) {
+                    // BLOCK SKIP (k_survivor_march's, r03; here since r05): the march's parameter sequence does not depend on the cells, and the next sample is the
+                    // first member whose cell is occupied.  While the 4^3 block (or its 2^3 sub-block) around the position holds no occupied cell, the members
+                    // whose positions are still inside it -- monotone per axis, `blk_eps` inside the exit face covers rounding -- are run through without
+                    // probes: one 8-byte load per block instead of one byte load per cell (a parked ray crosses ~30 empty cells to leave the box).
+                    const float blk_eps = c.m.two_rH * c.m.mip_bound * (1.0f / 4096.0f);
+                    const float ex = blk_eps * ssd_sign1(q.dx), ey = blk_eps * ssd_sign1(q.dy), ez = blk_eps * ssd_sign1(q.dz);
+                    const uint32_t lb = c.m.log2H - 2;
+                    while (qt < qf) {
+                        uint32_t idx;
+                        const ProbeB p = sm_probe_addr<DTG0>(c.m, q, qt, idx);
+                        const uint32_t bi = (((((uint32_t)p.nz >> 2) << lb) + ((uint32_t)p.ny >> 2)) << lb) + ((uint32_t)p.nx >> 2);
+                        const uint64_t w = blocks64[bi];
+                        float tt;
+                        if (w == 0) tt = sm_block_exit<4>(c.m, q, p, qx, qy, qz, ex, ey, ez, qt);
+                        else {
+                            const uint64_t sub = w >> ((((uint32_t)p.nz & 2u) << 4) | (((uint32_t)p.ny & 2u) << 2) | ((uint32_t)p.nx & 2u));
+                            if ((sub & 0x00330033ull) == 0) tt = sm_block_exit<2>(c.m, q, p, qx, qy, qz, ex, ey, ez, qt);
+                            else {
+                                if ((sub >> ((((uint32_t)p.nz & 1u) << 4) | (((uint32_t)p.ny & 1u) << 2) | ((uint32_t)p.nx & 1u))) & 1ull) { found = true; break; }
+                                qt = sm_skip<DTG0>(c.m, q, p, qx, qy, qz, qt);
+                                continue;
+                            }
+                        }
+                        do { qt += sm_dt<DTG0>(c.m, qt); } while (qt < tt);
+                    }
+                } else
                 while (qt < qf) {
                     const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, q, qt);
                     if (p.occ) { found = true; break; }
@@ -464,23 +700,85 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef SM_DEBUG_SECTIONS
+            ++dbg_marches;
+#endif
+            SM_SEC(9);
             continue;   // refill from the ready pool before shading
         }
         if (live == 0) {
             if (scene_done && next >= end && st_count == 0 && sp_count == 0 && rp_count == 0) break;      // this scene is finished for this wave: go steal from the next one
             continue;
         }
-
-#ifdef SM_DEBUG_ITERS
-        ++dbg_iters; dbg_live += (uint32_t)__popcll(live);
+#ifdef SM_DEBUG_SECTIONS
+        ++dbg_events;
 #endif
+      }   // event
+      const bool on = ray >= 0 && wait == 0;                          // this lane shades a sample in this iteration
+#ifdef SM_DEBUG_ITERS
+        ++dbg_iters; dbg_live += (uint32_t)__popcll(__ballot(on));
+#endif
+#ifdef SM_DEBUG_SECTIONS
+      ++dbg_loops;
+#endif
+      SM_SEC(0);
+
         // ================= shade: gather -> MFMA layers -> output layer -> composite =================
         float f[18];
-        if (ray >= 0) ssd_gather18<PT, SM_GATHER_BY_PLANE != 0>(planes, c.g, sx, sy, sz, f);
+#if SM_SEARCH_AHEAD
+        // the successor search of this sample, as far as it can go without the MLP: t1, t2, t3 and the two occupancy bytes (requested here, read after compositing)
+        float sa_t2 = 0.f, sa_t3 = 0.f;
+        uint32_t sa_b1 = 0, sa_b2 = 0, sa_sh = 0;
+        if (on) {
+            sm_sample_at<DTG0>(c.m, r, t, sx, sy, sz, sdt);
+            uint32_t i1, i2;
+            const float t1 = t + sdt;
+            const ProbeB q1 = sm_probe_addr<DTG0>(c.m, r, t1, i1);
+            sa_t2 = sm_skip<DTG0>(c.m, r, q1, sgx, sgy, sgz, t1);
+            const ProbeB q2 = sm_probe_addr<DTG0>(c.m, r, sa_t2, i2);
+            sa_t3 = sm_skip<DTG0>(c.m, r, q2, sgx, sgy, sgz, sa_t2);
+            sa_b1 = lin_bits[i1 >> 3];
+            sa_b2 = lin_bits[i2 >> 3];
+            sa_sh = (i1 & 7u) | ((i2 & 7u) << 3);
+        }
+#endif
+#if SM_ADDR32
+        if (on) sm_gather18<PT, SM_GATHER_BY_PLANE != 0>(planes, c.g, sx, sy, sz, f);
+#else
+        if (on) ssd_gather18<PT, SM_GATHER_BY_PLANE != 0>(planes, c.g, sx, sy, sz, f);
+#endif
         else {
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
         }
+        SM_SEC(1);
+#if defined(SM_X_VALU) || defined(SM_X_TRANS) || defined(SM_X_SLEEP) || defined(SM_X_LDS)
+        // sensitivity probes (tools/ab_shade.sh, profiles/r05): extra work of ONE kind per iteration, results unchanged
+        {
+            float xd = f[0];
+#ifdef SM_X_VALU
+#pragma unroll
+            for (int i = 0; i < SM_X_VALU; ++i) asm volatile("v_add_f32 %0, %1, %1" : "=v"(xd) : "v"(f[1]));
+#endif
+#ifdef SM_X_TRANS
+            {
+                float xe[8];
+#pragma unroll
+                for (int i = 0; i < SM_X_TRANS; ++i) asm volatile("v_exp_f32 %0, %1" : "=v"(xe[i & 7]) : "v"(f[1 + (i & 7)]));
+                asm volatile("" :: "v"(xe[0]), "v"(xe[1]), "v"(xe[2]), "v"(xe[3]), "v"(xe[4]), "v"(xe[5]), "v"(xe[6]), "v"(xe[7]));
+            }
+#endif
+#ifdef SM_X_SLEEP
+            __builtin_amdgcn_s_sleep(SM_X_SLEEP);
+#endif
+#ifdef SM_X_LDS
+            uint32_t xa = (uint32_t)lane * 16u;
+#pragma unroll
+            for (int i = 0; i < SM_X_LDS; ++i) { uint32_t xv; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(xv) : "v"(xa) : "memory"); xa = (xa + (xv & 0u)) ; }
+#endif
+            asm volatile("" :: "v"(xd));
+        }
+#endif
         // Split every feature into three bf16 terms, pack feature pairs, and trade halves so that T[t][0..3] is tile 0's k-step-0 operand
         // (features 0-15 of the samples of lanes 0-31) and T[t][4..7] tile 1's; T[t][8] / Z[t] carry features 16, 17 for k-step 1 (their other
         // k slots are the bias row and zeros).
@@ -634,6 +932,19 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             heads(I0{}, std::true_type{}, std::integral_constant<int, QB[g]>{}, std::integral_constant<int, QB[g + 1] - QB[g]>{});
             __builtin_amdgcn_sched_barrier(0);
         });
+#ifdef SM_X_MFMA
+        {   // sensitivity probe: SM_X_MFMA extra matrix instructions on their own accumulators, beside the last head (which has none of its own)
+            floatx16 xa0, xa1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xa0[i] = 0.f; xa1[i] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < SM_X_MFMA / 2; ++i) {
+                xa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[0][0], sb[0], xa0, 0, 0, 0);
+                xa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2[1][0], sb[1], xa1, 0, 0, 0);
+            }
+            asm volatile("" :: "v"(xa0), "v"(xa1));
+        }
+#endif
         // ---- E: colour head of tile 1, SM_HEAD_GROUP pairs at a time
         sm_static_for<16 / SM_HEAD_GROUP>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -649,8 +960,8 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         const float sg = ssd_fma(ssd_sigmoid(pg0 + pg1 + bc1), sat_k, -c.sat);
         const float sb_ = ssd_fma(ssd_sigmoid(pb0 + pb1 + bc2), sat_k, -c.sat);
 
-        bool park = false, finish = false;
-        if (ray >= 0) {
+        SM_SEC(2);
+        if (on) {
             const float alpha = 1.0f - __expf(-sigma * sdt);
             const float Tr = 1.0f - ws;
             const float w = alpha * Tr;
@@ -662,53 +973,49 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             cr = ssd_fma(w, sr, cr);
             cg = ssd_fma(w, sg, cg);
             cb = ssd_fma(w, sb_, cb);
-            t += sdt;
             ++cnt;
-            finish = Tr < c.T_thresh;
-            if (!finish) {
+#if SM_SEARCH_AHEAD
+            const float t1 = t + sdt;
+            if (Tr < c.T_thresh || !(t1 < far_)) wait = 1;
+            else if (cnt >= c.cap) {
+                if (overflow_flag) atomicAdd(overflow_flag, 1);
+                wait = 1;
+            }
+            else if ((sa_b1 >> (sa_sh & 7u)) & 1u) t = t1;
+            else if (!(sa_t2 < far_)) wait = 1;
+            else if ((sa_b2 >> (sa_sh >> 3)) & 1u) t = sa_t2;
+            else { t = sa_t3; wait = (sa_t3 < far_) ? 2u : 1u; }          // two empty probes: park at t3 (SM_SEARCH_PROBES == 2 in this form)
+#else
+            t += sdt;
+            if (Tr < c.T_thresh) wait = 1;
+            else {
                 uint32_t probes = 0;
                 for (;;) {
-                    if (!(t < far_)) { finish = true; break; }
+                    if (!(t < far_)) { wait = 1; break; }
                     if (cnt >= c.cap) {
                         if (overflow_flag) atomicAdd(overflow_flag, 1);
-                        finish = true; break;
+                        wait = 1; break;
                     }
-                    if (probes == SM_SEARCH_PROBES) { park = true; break; }
+                    if (probes == SM_SEARCH_PROBES) { wait = 2; break; }
                     const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, r, t);
                     if (p.occ) { sx = p.x; sy = p.y; sz = p.z; sdt = p.dt; break; }
                     t = sm_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
                     ++probes;
                 }
             }
+#endif
         }
-        if (finish) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; }      // the ONE store sequence of the loop body
-        // ---- park rays that need a long search (state -> LDS search pool) ----
-        const uint64_t pm = __ballot(park);
-        if (pm != 0) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-            const uint32_t room = SM_POOL - sp_count;
-            if (park && rank < room) {
-                uint32_t* e = pool_search + ((sp_head + sp_count + rank) % SM_POOL) * 8;
-                *reinterpret_cast<uint4*>(e) = make_uint4((uint32_t)ray, __float_as_uint(t), __float_as_uint(ws), __float_as_uint(dep));
-                *reinterpret_cast<uint4*>(e + 4) = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cb), cnt);
-                ray = -1;
-                park = false;
-            }
-            sp_count += min((uint32_t)__popcll(pm), room);
-            if (park) {   // pool full (cannot happen with the trigger above, kept as a guard): finish the search in the lane
-                for (;;) {
-                    if (!(t < far_)) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break; }
-                    const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, r, t);
-                    if (p.occ) { sx = p.x; sy = p.y; sz = p.z; sdt = p.dt; break; }
-                    t = sm_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+        SM_SEC(3);
     }
   }   // scene loop
+#ifdef SM_DEBUG_SECTIONS
+  if (lane == 0) {   // words 10..29: cycles / 16 per section (u64 x 10); 4: events, 5: loop iterations, 6: waves, 7: march passes, 8: stage fills
+      uint32_t* d = queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 0);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(d + 10 + 2 * i), (unsigned long long)(dbg_sec[i] >> 4));   // (units of 16 cycles)
+      atomicAdd(d + 4, dbg_events); atomicAdd(d + 5, dbg_loops); atomicAdd(d + 6, 1u); atomicAdd(d + 7, dbg_marches); atomicAdd(d + 8, dbg_stages);
+  }
+#endif
 #ifdef SM_DEBUG_ITERS
   if (lane == 0) {   // words 1..3 of scene 0's boundary-counter line: sum of wave iterations, max over waves, sum of live lanes
       uint32_t* d = queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 0);
@@ -733,6 +1040,7 @@ static int sm_shade(const void* planes, int planes_dtype, uint32_t Hp, uint32_t 
     planes_dtype &= 0xff;
     SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "render_shade_queue_mfma: unsupported plane dtype");
     SSD_REQUIRE(grid_size >= 8 && grid_size <= 512 && (grid_size & (grid_size - 1)) == 0, "render_shade_queue_mfma: grid_size must be a power of two in [8, 512]");
+    SSD_REQUIRE((uint64_t)3 * Hp * Wp * 8 * (planes_dtype == 0 ? 4 : 2) < (1ull << 32), "render_shade_queue_mfma: a scene's planes must stay below 4 GiB (32-bit texel offsets)");
     if (workspace_bytes < ssdnerf_render_queue_workspace(S, N, grid_size))
         return ssdnerf_fail(SSDNERF_E_WORKSPACE, "render_shade_queue_mfma: workspace too small");
     ShadeCfg c;
@@ -750,6 +1058,12 @@ static int sm_shade(const void* planes, int planes_dtype, uint32_t Hp, uint32_t 
     c.dt_gammas = dt_gammas;
     c.image_u8 = image_u8;
     const RenderWs w = ssd_render_ws(workspace, S, N, grid_size);
+    const char* to_env = getenv("SSDNERF_TICKET_ORDER");            // must say what render_first_hit said for this render (render_queue.hip, rq_first_hit)
+    const bool ticket_order = !(to_env && to_env[0] == '0');
+    static_assert(SM_SLICE == 64, "k_ticket_order sorts 64-entry slices");
+    c.blocks64 = (grid_size >= 16 && getenv("SSDNERF_NO_COARSE") == nullptr) ? w.blocks64 : nullptr;      // (what rq_first_hit built: same condition)
+    c.order = ticket_order ? w.order : nullptr;
+    c.order_stride = w.order_stride;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""tools/repro_check.py [renders] -- bench-scale reproducibility of the fused renderer (GPU box): renders the bench workload (8 scenes x 251 views
+x 128^2) `renders` times and compares every image, depth and per-ray sample count with the first render, bit for bit.  Prints the number of
+differing rays per render (all zeros expected; the r02 / r03 transcendental -> use hazard showed here as groups of 16 neighbouring rays)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ssdnerf_amd import synthetic as S
+from ssdnerf_amd.decoders import TriPlaneDecoder, pack_triplanes
+from ssdnerf_amd.density import get_density
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device("cuda")
+dec = TriPlaneDecoder(base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], dir_layers=[16, 64], max_steps=256)
+dec.load_state_dict(S.make_decoder_params(2021), strict=False); dec = dec.to(dev).eval()
+g = torch.Generator().manual_seed(7); jit = [torch.rand(64 ** 3, 3, generator=g).to(dev) for _ in range(8)]
+ns, nv, hw = 8, 251, 128
+poses = S.spiral_poses(nv).to(dev)[None].expand(ns, -1, -1, -1).contiguous(); intr = S.cars_intrinsics(hw, hw).to(dev)[None, None].expand(ns, nv, -1).contiguous()
+code = torch.stack([S.make_triplane(2021 + s, "object") for s in range(ns)]).to(dev)
+_, bits = get_density(dec, code, 64, density_thresh=0.1, density_step=8, jitters=jit)
+planes = pack_triplanes(code, dec.plane_dtype)
+ref, bad = None, []
+for it in range(n):
+    out = dec.render_packed(planes, None, None, bits, 64, [0.0] * ns, 1e-4, bg_color=1.0, want_counts=True, cams=(poses, intr, hw, hw))
+    cur = (out["image"].clone(), out["depth"].clone(), dec.last_render_stats["sample_counts"].clone())
+    if ref is None:
+        ref = cur
+        continue
+    diff = (cur[0] != ref[0]).any(-1) | (cur[1] != ref[1]) | (cur[2] != ref[2])
+    bad.append(int(diff.sum()))
+    if bad[-1]:
+        idx = diff.flatten().nonzero().flatten()[:8].tolist()
+        print(f"render {it}: {bad[-1]} rays differ, first at {idx}, counts {cur[2].flatten()[idx[:4]].tolist()} vs {ref[2].flatten()[idx[:4]].tolist()}")
+print(f"{n} renders, rays differing from render 0: {bad}")
+print("samples", int(ref[2].sum()))
