@@ -115,6 +115,12 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 // iteration are gather + split + MLP, the rest is this).  A lane that finishes or must park now just raises a flag and sits out; the wave runs
 // the bookkeeping as ONE event when SM_EVENT_MIN lanes are waiting (or nothing is left to shade).  Per-ray arithmetic and its order are
 // untouched -- every output is bit-identical for any value; 1 = an event in every iteration (the r01-r04 behaviour).
+#ifndef SM_GATHER_FIRST
+#define SM_GATHER_FIRST 1                          // (r05) texel requests in front of the search arithmetic, blend behind it
+#endif
+#ifndef SM_SKIP_UNROLL
+#define SM_SKIP_UNROLL 0                           // (r05) sm_skip: this many predicated steps before the loop (0: the plain do-while)
+#endif
 #ifndef SM_EVENT_MIN
 #define SM_EVENT_MIN 4                             // r05 A/B (bench scene, shade kernel, with SM_SEARCH_AHEAD and the one-round gather): 1: 5.06, 3: 4.94-4.97, 4: 4.94-4.96, 5: 4.97, 6: 5.01 ms
 #endif
@@ -252,7 +258,12 @@ SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, fl
     const float ty = ssd_fma(ssd_fma((float)p.ny + sgy, m.two_rH, -1.0f), m.mip_bound, -p.y) * r.rdy;
     const float tz = ssd_fma(ssd_fma((float)p.nz + sgz, m.two_rH, -1.0f), m.mip_bound, -p.z) * r.rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-    do { t += sm_dt<DTG0>(m, t); } while (t < tt);
+    // `do t += dt(t); while (t < tt)` -- the same additions on the same values in the same order, but the first steps as selects (a cell is 2.3 minimum
+    // steps wide, its diagonal 4: a divergent loop paid a branch round trip per step per wave); the loop itself stays for whatever is left
+    t += sm_dt<DTG0>(m, t);
+#pragma unroll
+    for (int i = 0; i < SM_SKIP_UNROLL; ++i) t = t < tt ? t + sm_dt<DTG0>(m, t) : t;
+    while (t < tt) t += sm_dt<DTG0>(m, t);
     return t;
 }
 
@@ -267,6 +278,10 @@ SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, fl
 #endif
 #ifndef SM_MARCH_BLOCKS
 #define SM_MARCH_BLOCKS 1                          // the march pass skips empty 4^3 / 2^3 blocks (r05 A/B below)
+#endif
+#ifndef SM_MARCH_TRIPS
+#define SM_MARCH_TRIPS 0                           // probes per lane and march pass (0: unbounded).  r05 A/B: 3: 4.82, 4: 4.79, 6: 4.80, 8: 4.81, 12: 4.80, unbounded: 4.80 ms --
+                                                   // a pass costs ~18 k cycles whatever its probe count (53 k passes of 6 trips against 47 k unbounded): off
 #endif
 #ifndef SM_DRAIN_MARCH
 #define SM_DRAIN_MARCH 0                           // r05, measured and off: march parked rays as soon as a quarter of the lanes idle once the queue is used up -- 46 k -> 77 k
@@ -437,13 +452,18 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
   // SM_DEBUG_SECTIONS (tools/shade_sections.py): shader cycles a wave spends in each section of the loop body (its own stalls and the other wave's
   // turns included), summed over waves into spare words of scene 0's boundary-counter line: 0 event, 1 gather, 2 split + MLP, 3 composite + search
 #ifdef SM_DEBUG_SECTIONS
-  uint64_t dbg_sec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t dbg_sec[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t dbg_marches = 0, dbg_stages = 0, dbg_poolrefills = 0;
   uint32_t dbg_events = 0, dbg_loops = 0;
   uint64_t dbg_last = clock64();
 #define SM_SEC(i) do { __builtin_amdgcn_sched_barrier(0); const uint64_t n_ = clock64(); dbg_sec[i] += n_ - dbg_last; dbg_last = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SM_SEC(i) do { } while (0)
+#endif
+#if defined(SM_DEBUG_SECTIONS) && defined(SM_DEBUG_MLP_PHASES)
+#define SM_SEC_MLP(i) SM_SEC(i)
+#else
+#define SM_SEC_MLP(i) do { } while (0)
 #endif
   for (uint32_t sk = 0; sk < c.S; ++sk) {
     const uint32_t scene = (start_scene + sk) % c.S;
@@ -642,7 +662,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         const bool draining = SM_DRAIN_MARCH && scene_done && next >= end && st_count == 0 && rp_count == 0 && sp_count != 0 && (uint32_t)__popcll(live) <= 48u;
         if ((sp_count >= SM_MARCH_W || draining || (live == 0 && sp_count != 0)) && rp_count <= SM_POOL - SM_MARCH_W) {
             const uint32_t n = min(sp_count, SM_MARCH_W);
-            bool found = false, mine = (uint32_t)lane < n;
+            bool found = false, again = false, mine = (uint32_t)lane < n;
             uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
             if (mine) {
                 const uint32_t* e = pool_search + ((sp_head + lane) % SM_POOL) * 8;
@@ -653,6 +673,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                 qf = ssd_tail_far(q, cell_world, qn, qf, e0.x, packing);
                 const float qx = ssd_fma(0.5f, ssd_sign1(q.dx), 0.5f), qy = ssd_fma(0.5f, ssd_sign1(q.dy), 0.5f), qz = ssd_fma(0.5f, ssd_sign1(q.dz), 0.5f);
                 float qt = __uint_as_float(e0.y);
+                // SM_MARCH_TRIPS (r05): a pass lasts as long as its slowest lane, and a few rays (no tail bound: a gap between two parts of the object, the whole
+                // box behind it) need dozens of dependent probes where the others need three -- a lane gives up after this many and its ray goes back to
+                // the search pool with the parameter it reached (0: no limit, the r01 - r04 form; the sequence of parameters does not depend on where
+                // a pass stops, so nothing a ray computes changes)
+                uint32_t trips = 0;
                 if (SM_MARCH_BLOCKS && blocks64 != nullptr) {
                     // BLOCK SKIP (k_survivor_march's, r03; here since r05): the march's parameter sequence does not depend on the cells, and the next sample is the
                     // first member whose cell is occupied.  While the 4^3 block (or its 2^3 sub-block) around the position holds no occupied cell, the members
@@ -662,6 +687,8 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                     const float ex = blk_eps * ssd_sign1(q.dx), ey = blk_eps * ssd_sign1(q.dy), ez = blk_eps * ssd_sign1(q.dz);
                     const uint32_t lb = c.m.log2H - 2;
                     while (qt < qf) {
+                        if (SM_MARCH_TRIPS != 0 && trips == (uint32_t)SM_MARCH_TRIPS) { again = true; break; }
+                        ++trips;
                         uint32_t idx;
                         const ProbeB p = sm_probe_addr<DTG0>(c.m, q, qt, idx);
                         const uint32_t bi = (((((uint32_t)p.nz >> 2) << lb) + ((uint32_t)p.ny >> 2)) << lb) + ((uint32_t)p.nx >> 2);
@@ -681,11 +708,13 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                     }
                 } else
                 while (qt < qf) {
+                    if (SM_MARCH_TRIPS != 0 && trips == (uint32_t)SM_MARCH_TRIPS) { again = true; break; }
+                    ++trips;
                     const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, q, qt);
                     if (p.occ) { found = true; break; }
                     qt = sm_skip<DTG0>(c.m, q, p, qx, qy, qz, qt);
                 }
-                if (found) e0.y = __float_as_uint(qt);
+                if (found || again) e0.y = __float_as_uint(qt);
                 else write_out(e0.x, __uint_as_float(e0.z), __uint_as_float(e0.w), __uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z), e1.w);
             }
             const uint64_t fm = __ballot(found);
@@ -697,6 +726,13 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             rp_count += (uint32_t)__popcll(fm);
             sp_head = (sp_head + n) % SM_POOL;
             sp_count -= n;
+            const uint64_t am = __ballot(again);                           // back to the search pool, behind what is already parked (n slots were just freed)
+            if (again) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                uint32_t* e = pool_search + ((sp_head + sp_count + rank) % SM_POOL) * 8;
+                *reinterpret_cast<uint4*>(e) = e0; *reinterpret_cast<uint4*>(e + 4) = e1;
+            }
+            sp_count += (uint32_t)__popcll(am);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -729,6 +765,33 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         // the successor search of this sample, as far as it can go without the MLP: t1, t2, t3 and the two occupancy bytes (requested here, read after compositing)
         float sa_t2 = 0.f, sa_t3 = 0.f;
         uint32_t sa_b1 = 0, sa_b2 = 0, sa_sh = 0;
+#if SM_GATHER_FIRST && SM_ADDR32
+        // (r05) one block, in this order: the twelve texel requests, THEN the search arithmetic (two probe addresses, two DDA skips: ~100 VALU
+        // instructions that need nothing from memory) under their latency, then the blend
+        if (on) {
+            sm_sample_at<DTG0>(c.m, r, t, sx, sy, sz, sdt);
+            SmPlaneTap<PT> tap[3];
+            tap[0].issue(planes, c.g, 0, sx, sy);
+            tap[1].issue(planes, c.g, 1, sx, sz);
+            tap[2].issue(planes, c.g, 2, sy, sz);
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t i1, i2;
+            const float t1 = t + sdt;
+            const ProbeB q1 = sm_probe_addr<DTG0>(c.m, r, t1, i1);
+            sa_t2 = sm_skip<DTG0>(c.m, r, q1, sgx, sgy, sgz, t1);
+            const ProbeB q2 = sm_probe_addr<DTG0>(c.m, r, sa_t2, i2);
+            sa_t3 = sm_skip<DTG0>(c.m, r, q2, sgx, sgy, sgz, sa_t2);
+            sa_b1 = lin_bits[i1 >> 3];
+            sa_b2 = lin_bits[i2 >> 3];
+            sa_sh = (i1 & 7u) | ((i2 & 7u) << 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) tap[pl].blend(pl, f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) f[i] = 0.f;
+        }
+#else
         if (on) {
             sm_sample_at<DTG0>(c.m, r, t, sx, sy, sz, sdt);
             uint32_t i1, i2;
@@ -742,6 +805,8 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             sa_sh = (i1 & 7u) | ((i2 & 7u) << 3);
         }
 #endif
+#endif
+#if !(SM_SEARCH_AHEAD && SM_GATHER_FIRST && SM_ADDR32)
 #if SM_ADDR32
         if (on) sm_gather18<PT, SM_GATHER_BY_PLANE != 0>(planes, c.g, sx, sy, sz, f);
 #else
@@ -751,6 +816,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
         }
+#endif
         SM_SEC(1);
 #if defined(SM_X_VALU) || defined(SM_X_TRANS) || defined(SM_X_SLEEP) || defined(SM_X_LDS)
         // sensitivity probes (tools/ab_shade.sh, profiles/r05): extra work of ONE kind per iteration, results unchanged
@@ -896,12 +962,17 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                 }
             }
         };
-        constexpr int QB[7] = {0, 3, 6, 9, 12, 14, 16};                 // 16 SiLU pairs spread over the 6 MFMA groups of a phase
+#ifndef SM_QB
+#define SM_QB {0, 3, 6, 9, 12, 14, 16}
+#endif
+        constexpr int QB[7] = SM_QB;                                     // 16 SiLU pairs spread over the 6 MFMA groups of a phase
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
+        SM_SEC_MLP(10);
         // ---- A
 #pragma unroll
         for (int g = 0; g < 6; ++g) layer1(0, g);
+        SM_SEC_MLP(11);
         // ---- B: layer 1 of tile 1 || density head of tile 0;  C: direction term of tile 0 || density head of tile 1;  D: direction term of tile 1 || colour head of tile 0
         sm_static_for<6>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -918,6 +989,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             if (DIRP == 6) dir_term(nt, g);
             else if (g & 1) dir_term(nt, 3 + g / 2);                         // products (1,0), (0,1), (0,0) behind the groups 1, 3, 5
         };
+        SM_SEC_MLP(12);
         load_sh(0);
         sm_static_for<6>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -925,6 +997,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             heads(I1{}, std::false_type{}, std::integral_constant<int, QB[g]>{}, std::integral_constant<int, QB[g + 1] - QB[g]>{});
             __builtin_amdgcn_sched_barrier(0);
         });
+        SM_SEC_MLP(13);
         load_sh(1);
         sm_static_for<6>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -932,6 +1005,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             heads(I0{}, std::true_type{}, std::integral_constant<int, QB[g]>{}, std::integral_constant<int, QB[g + 1] - QB[g]>{});
             __builtin_amdgcn_sched_barrier(0);
         });
+        SM_SEC_MLP(14);
 #ifdef SM_X_MFMA
         {   // sensitivity probe: SM_X_MFMA extra matrix instructions on their own accumulators, beside the last head (which has none of its own)
             floatx16 xa0, xa1;
@@ -951,6 +1025,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             heads(I1{}, std::true_type{}, std::integral_constant<int, g * SM_HEAD_GROUP>{}, std::integral_constant<int, SM_HEAD_GROUP>{});
             __builtin_amdgcn_sched_barrier(0);
         });
+        SM_SEC_MLP(15);
         ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y; pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y;
         pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
@@ -975,16 +1050,20 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             cb = ssd_fma(w, sb_, cb);
             ++cnt;
 #if SM_SEARCH_AHEAD
+            // the loop's tests in the loop's order -- far, cap, probe 1, far, probe 2, far, park -- as predicates and selects (the if / else-if chain
+            // compiled to nine branches; r05 section timing: ~1 k cycles for ~50 VALU instructions)
             const float t1 = t + sdt;
-            if (Tr < c.T_thresh || !(t1 < far_)) wait = 1;
-            else if (cnt >= c.cap) {
-                if (overflow_flag) atomicAdd(overflow_flag, 1);
-                wait = 1;
-            }
-            else if ((sa_b1 >> (sa_sh & 7u)) & 1u) t = t1;
-            else if (!(sa_t2 < far_)) wait = 1;
-            else if ((sa_b2 >> (sa_sh >> 3)) & 1u) t = sa_t2;
-            else { t = sa_t3; wait = (sa_t3 < far_) ? 2u : 1u; }          // two empty probes: park at t3 (SM_SEARCH_PROBES == 2 in this form)
+            const bool go = !(Tr < c.T_thresh) & (t1 < far_);                      // still marching after this sample
+            const bool capped = cnt >= c.cap;
+            const bool o1 = ((sa_b1 >> (sa_sh & 7u)) & 1u) != 0, o2 = ((sa_b2 >> (sa_sh >> 3)) & 1u) != 0;
+            const bool look = go & !capped;
+            const bool take1 = look & o1;
+            const bool look2 = look & !o1 & (sa_t2 < far_);
+            const bool take2 = look2 & o2;
+            const bool park = look2 & !o2 & (sa_t3 < far_);                        // two empty probes: park at t3 (SM_SEARCH_PROBES == 2 in this form)
+            if (go & capped) { if (overflow_flag) atomicAdd(overflow_flag, 1); }
+            t = take1 ? t1 : take2 ? sa_t2 : sa_t3;
+            wait = (take1 | take2) ? 0u : park ? 2u : 1u;
 #else
             t += sdt;
             if (Tr < c.T_thresh) wait = 1;
@@ -1013,6 +1092,10 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
       uint32_t* d = queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 0);
 #pragma unroll
       for (int i = 0; i < 10; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(d + 10 + 2 * i), (unsigned long long)(dbg_sec[i] >> 4));   // (units of 16 cycles)
+      // MLP phases (SM_DEBUG_MLP_PHASES): 10 split, 11 A, 12 B, 13 C, 14 D, 15 E -> the ticket line of scene 0, words 2..13 (the tickets are taken: word 0 only)
+      uint32_t* d2 = queue_count + ssd_counter(SSD_CNT_TICKETS, c.S, 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(d2 + 2 + 2 * i), (unsigned long long)(dbg_sec[10 + i] >> 4));
       atomicAdd(d + 4, dbg_events); atomicAdd(d + 5, dbg_loops); atomicAdd(d + 6, 1u); atomicAdd(d + 7, dbg_marches); atomicAdd(d + 8, dbg_stages);
   }
 #endif
