@@ -172,7 +172,9 @@ def marching_cubes(volume, iso: float):
     vol = volume.detach().to(torch.float32).contiguous()
     nx, ny, nz = (int(v) for v in vol.shape)
     n = nx * ny * nz
-    assert n < 2 ** 31
+    # the prefix sums of triangles (<= 5 per cell) and vertices (<= 3 per lattice point) and the emit kernel's offsets are int32
+    if 5 * n >= 2 ** 31:
+        raise ValueError(f"marching_cubes: a {nx} x {ny} x {nz} lattice can hold more than 2^31 triangle slots (int32 offsets); extract it in chunks")
     dev = vol.device
     counts, table = triangle_table()
     key = str(dev)

@@ -592,6 +592,11 @@ class _GraphedGrad:
         with torch.cuda.graph(self.bwd, pool=self.fwd.pool(), capture_error_mode=CAPTURE_MODE):
             (self.gx,) = torch.autograd.grad(self.y, self.x, self.gy)
         outer = self
+        # Re-entrancy (r04 advisor): the saved activations and the norms' backward workspaces live in the graphs' static memory; only a forward replay
+        # refills / re-zeroes them.  `serial` counts forward replays, `pending` is the serial whose backward has not run yet (0: none): a second
+        # forward before that backward (`busy()`: the caller takes the eager path instead), or a second backward through one forward, would
+        # return gradients of the wrong activations without any error -- the former is refused up front, the latter raises.
+        self.serial, self.pending = 0, 0
 
         class _Replay(torch.autograd.Function):
             @staticmethod
@@ -600,17 +605,31 @@ class _GraphedGrad:
                     outer.x.copy_(x_in)
                 outer.t.copy_(t_in)
                 outer.fwd.replay()
+                outer.serial += 1
+                ctx.serial = outer.pending = outer.serial
                 return outer.y.detach()
 
             @staticmethod
             @torch.autograd.function.once_differentiable
             def backward(ctx, g_in):
+                if ctx.serial != outer.serial or outer.pending != ctx.serial:
+                    raise RuntimeError("DenoisingUnetMod: the captured gradient path keeps the activations of ONE forward; this backward belongs to a forward "
+                                       "that was replayed over, or runs a second time (retain_graph).  Set SSDNERF_UNET_GRAD_GRAPH=0 for such call patterns.")
+                outer.pending = 0
                 if g_in.data_ptr() != outer.gy.data_ptr():
                     outer.gy.copy_(g_in)
                 outer.bwd.replay()
-                return outer.gx.detach(), None
+                return outer.gx.clone(), None                     # (a copy: AccumulateGrad may keep the tensor it is handed; latent-sized)
 
         self._replay = _Replay
+
+    def busy(self) -> bool:
+        """a forward has been replayed whose backward has not run: another forward now would overwrite its activations"""
+        return self.pending != 0
+
+    def release(self) -> None:
+        """forget a pending backward (its autograd graph was dropped without being run)"""
+        self.pending = 0
 
     def __call__(self, x, t):
         return self._replay.apply(x, t)
@@ -843,6 +862,13 @@ class DenoisingUnetMod(nn.Module):
             return None
         return entry["fn"]
 
+    def _all_weights_frozen(self) -> bool:
+        """no parameter asks for a gradient (the cached parameter tuple of ``_grad_graph_call``: a partially frozen UNet is NOT forced out of autocast)"""
+        params = self.__dict__.get("_grad_graph_params")
+        if params is None:
+            params = self.__dict__["_grad_graph_params"] = tuple(self.parameters())
+        return not any(p.requires_grad for p in params)
+
     def grad_graph_info(self):
         """[{signature, captured, capture_s, failed}] of the gradient path's captured graphs (bench / tests)"""
         return [dict(x_shape=list(k[0]), captured=e["fn"] is not None, capture_s=e.get("capture_s"), failed=e["failed"])
@@ -854,13 +880,24 @@ class DenoisingUnetMod(nn.Module):
             with torch.autocast("cuda", enabled=False):
                 return self._fast_executor(dtype)(x_t.float(), t)
         if (self.grad_path_fp32_under_autocast and x_t.is_cuda and torch.is_grad_enabled() and x_t.requires_grad and torch.is_autocast_enabled("cuda")
-                and not self.out.conv.weight.requires_grad and not self.time_embedding.blocks[0].weight.requires_grad):
+                and self._all_weights_frozen()):
             with torch.autocast("cuda", enabled=False):
                 return self.forward(x_t.float(), t, label, None if concat_cond is None else concat_cond.float(), return_noise)
         if label is None and concat_cond is None and not return_noise:
             graphed = self._grad_graph_call(x_t, t)
+            if graphed is not None and graphed.busy():
+                # a forward whose backward is still outstanding (two forwards before their backwards; or the caller dropped the last graph without
+                # running it): the eager path keeps its own activations per call.  A dropped graph is recognised by its output having died.
+                ref = self.__dict__.get("_grad_graph_last_out")
+                if ref is not None and ref() is None:
+                    graphed.release()
+                else:
+                    graphed = None
             if graphed is not None:
-                return graphed(x_t, t).clone()                       # (the graph's output buffer is overwritten by the next replay)
+                out = graphed(x_t, t).clone()                        # (the graph's output buffer is overwritten by the next replay)
+                import weakref
+                self.__dict__["_grad_graph_last_out"] = weakref.ref(out)
+                return out
         return self._forward_eager(x_t, t, label, concat_cond)
 
     def _forward_eager(self, x_t, t, label=None, concat_cond=None):

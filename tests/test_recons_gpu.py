@@ -299,6 +299,64 @@ def test_captured_gradient_path_matches_the_eager_one():
     assert gw is not None and float(gw.abs().max()) > 0
 
 
+def test_captured_gradient_path_is_guarded_against_re_entry():
+    """r04 advisor: the captured gradient path keeps the activations of ONE forward in static graph memory.  (1) Two forwards of one signature before
+    their backwards -- loss(unet(x1)) + loss(unet(x2)) -- must still give the right gradients: the second forward takes the eager path while the
+    first one's backward is outstanding.  (2) A second backward through one replayed forward (retain_graph) raises instead of accumulating onto
+    stale norm workspaces.  (3) A forward whose graph the caller dropped without running it does not block the captured path for ever.
+    (4) The returned input gradient is a copy, not the graph's static buffer."""
+    import ssdnerf_amd  # noqa: F401
+    from ssdnerf_amd.registry import MODULES
+    net = MODULES.build(dict(UNET, base_channels=64, channels_cfg=[1, 2, 2], attention_res=[32, 64])).cuda().eval()
+    _randomize(net, 5, scale=1.0)
+    net.requires_grad_(False)
+    net.grad_graph_after = 1
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, 18, 128, 128, generator=g).cuda() for _ in range(4)]
+    t = torch.tensor([500, 20], device="cuda")
+
+    def eager(x):
+        net.grad_graph = False
+        xi = x.clone().requires_grad_(True)
+        (gx,) = torch.autograd.grad(net(xi, t).square().sum(), xi)
+        net.grad_graph = True
+        return gx
+    net.grad_graph = True
+    for x in xs[:2]:                                                                   # call 0 eager, call 1 captures
+        xi = x.clone().requires_grad_(True)
+        torch.autograd.grad(net(xi, t).square().sum(), xi)
+    fn = next(iter(net.__dict__["_grad_graphs"].values()))["fn"]
+    assert fn is not None and not fn.busy()
+    # (1) interleaved forwards
+    x1, x2 = xs[2].clone().requires_grad_(True), xs[3].clone().requires_grad_(True)
+    y1 = net(x1, t)
+    assert fn.busy()
+    y2 = net(x2, t)                                                                    # must not replay over y1's activations
+    g1, g2 = torch.autograd.grad(y1.square().sum() + y2.square().sum(), (x1, x2))
+    for got, x in ((g1, xs[2]), (g2, xs[3])):
+        ref = eager(x)
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert not fn.busy()
+    # (4) the gradient handed out is not the static buffer
+    assert g1.data_ptr() != fn.gx.data_ptr() and g2.data_ptr() != fn.gx.data_ptr()
+    # (2) double backward through one replay
+    x3 = xs[0].clone().requires_grad_(True)
+    loss = net(x3, t).square().sum()
+    torch.autograd.grad(loss, x3, retain_graph=True)
+    with pytest.raises(RuntimeError, match="ONE forward"):
+        torch.autograd.grad(loss, x3)
+    # (3) a dropped graph releases the path
+    x4 = xs[1].clone().requires_grad_(True)
+    y4 = net(x4, t)
+    assert fn.busy()
+    del y4
+    x5 = xs[2].clone().requires_grad_(True)
+    (g5,) = torch.autograd.grad(net(x5, t).square().sum(), x5)                         # replays (the pending forward's output is gone)
+    assert fn.serial >= 4 and not fn.busy()
+    ref = eager(xs[2])
+    assert float((g5 - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 def test_gradient_path_with_pre_split_dy_matches_the_on_the_fly_split(monkeypatch):
     """r04: the second norm of a residual block writes its dx PRE-SPLIT for the first convolution's backward-data kernel (one decision shared by the two
     autograd functions through a flag dict; ``SSDNERF_UNET_GRAD_SPLIT_DY=0`` / ``_Conv2d.grad_split_dy`` restores the on-the-fly split).  Same hi / lo
