@@ -141,7 +141,7 @@ def test_reference_configs_load_and_build_unchanged():
 def test_render_queue_workspace_size_host_side():
     """``ssdnerf_render_queue_workspace`` (common.h: ssd_render_ws) is host arithmetic: every region of the two-stage renderer's scratch is in it
     -- counters, the bitfield in linear and in block-major order, coarse bits, 8-byte survivor and hit-queue entries, per-view tile masks and
-    tile depth ranges -- regions are 256-byte aligned, and the size grows with the scene and ray counts."""
+    tile depth ranges, the ticket order's keys and slice list -- regions are 256-byte aligned, and the size grows with the scene and ray counts."""
     import ctypes
     from ssdnerf_amd import _cabi as C
     lib = C.lib()
@@ -154,8 +154,9 @@ def test_render_queue_workspace_size_host_side():
     lists = 2 * S * N * 8                                   # survivors + hit queue
     bitfields = 2 * S * H ** 3 // 8                         # linear + block-major (one u64 per 4^3 cells)
     tiles = S * (N // 64 + 1) * 32 + S * (N // 256 + 1) * 1024
+    tickets = S * ((N + 63) // 64 * 64) + S * ((N + 63) // 64) * 4          # r05: one key byte per queue entry + the order of the 64-entry slices
     assert got % 256 == 0
-    assert lists + bitfields + tiles <= got <= lists + bitfields + tiles + S * (H // 2) ** 3 // 8 + 5 * S * 128 + 16 * 256
+    assert lists + bitfields + tiles + tickets <= got <= lists + bitfields + tiles + tickets + S * (H // 2) ** 3 // 8 + 5 * S * 128 + 16 * 256
     assert size(S + 1, N, H) > got and size(S, N + 4096, H) > got and size(S, N, 128) > got
     assert size(1, 1, 8) >= 256 and size(1, 1, 8) % 256 == 0
 
