@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--packed-loop", action="store_true", help="time TriPlaneDecoder.render_packed(check_overflow=False) instead of nerf.render (the r01-r03 "
                     "timed region: no overflow-flag read per batch); A/B only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-nccl", action="store_true", help="with --gpus 1: take the N > 1 code path with a ONE-rank RCCL process group (backend 'nccl', "
+                    "world_size 1) -- RCCL initialisation, the asynchronous all-gather on RCCL's stream, graph captures beside RCCL's watchdog thread -- a "
+                    "self-check of the multi-GPU path on a one-GPU box, not a measurement of scaling")
     ap.add_argument("--no-extras", action="store_true", help="skip gpu_baseline / ddim / uniform_variant (profiling runs)")
     ap.add_argument("--cpu-views", type=int, default=251, help="views of scene 0 rendered by the CPU oracle (251 = the whole scene, ~10 s on 32 host threads)")
     ap.add_argument("--b1-views", type=int, default=251, help="views of scene 0 rendered by the reference-shaped eager GPU path (the reference batches all views of a scene)")
@@ -103,8 +106,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.dry_nccl                      # the N > 1 code path (collectives, per-rank breakdown, every rank runs the legs)
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if share_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -165,7 +170,7 @@ def main():
 
     # N > 1: every rank ends up with every rank's quantised views (RCCL all-gather over xGMI).  The collective of step i runs on RCCL's
     # stream while step i+1 renders (two landing buffers); the compute stream only waits for it before issuing the next collective.
-    gathered = [torch.empty(world * ns, nv, hw, hw, 3, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty(world * ns, nv, hw, hw, 3, dtype=torch.uint8, device=dev) for _ in range(2)] if multi else None
     pending = {"work": None, "i": 0, "keep": None, "waits": []}   # waits: HIP event pairs around every wait of the compute stream for a collective
 
     def step(planes_, bits_, events=None, code_=None):
@@ -176,7 +181,7 @@ def main():
             dec.stage_events = None
         # the uint8 views that are gathered / written: stored by the render kernels next to the float image (camera-fed path), else one more pass
         img_u8 = (out["image_u8"] if "image_u8" in out else nerf.quantize_u8(out["image"])).reshape(ns, nv, hw, hw, 3)
-        if world > 1:
+        if multi:
             if pending["work"] is not None:
                 wait_collective()
             pending["keep"] = img_u8                     # the source must stay alive until the collective has run
@@ -213,7 +218,7 @@ def main():
         drain()
         torch.cuda.synchronize()
         del pending["waits"][:]
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -221,11 +226,11 @@ def main():
             out = step(planes_, bits_, events, code_)
         drain()                                              # the last step's collective is inside the timed region
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             # per-rank breakdown (r04): this rank's own wall time, its render launches and how long its compute stream stood waiting for collectives
             mine = torch.tensor([elapsed / steps * 1e3, float(np.mean([e[0].elapsed_time(e[2]) for e in events])),
                                  sum(a.elapsed_time(b) for a, b in pending["waits"]) / steps], dtype=torch.float64, device=dev)
@@ -243,7 +248,7 @@ def main():
     elapsed, kernel_events, out = timed(planes, bits, args.warmup, args.steps, code_dev)
     per_rank = pending.get("per_rank")
     n_samples = stats["n_samples"]
-    if world > 1:
+    if multi:
         tot = torch.tensor([n_samples], dtype=torch.float64, device=dev)
         dist.all_reduce(tot)
         n_samples_all = int(tot.item())
@@ -293,7 +298,7 @@ def main():
                                      "see dir3_variant)",
                    "timed_call": "TriPlaneDecoder.render_packed(check_overflow=False) [--packed-loop]" if args.packed_loop else
                                  "nerf.render (BaseNeRF.render on cached planes: two launches + the overflow-flag read per batch + uint8 views)",
-                   "collective": "all_gather(uint8 views), overlapped with the next step's render" if world > 1 else "none"},
+                   "collective": "all_gather(uint8 views), overlapped with the next step's render" if multi else "none"},
         "views_per_s": rays_per_s / (hw * hw), "samples_per_s": n_samples_all / (elapsed / args.steps),
         "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": stats["overflow"],
         "roofline": {"bound": "hbm", "kernel": "k_shade_mfma", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -313,14 +318,14 @@ def main():
         "boundary_rays": {"termination_tests_within_2e-6_of_T_thresh": stats["boundary"], "samples_per_step_per_gpu": n_samples},
     }
 
-    extras = rank == 0 and world == 1 and not args.no_extras
+    extras = rank == 0 and not multi and not args.no_extras
     if extras:
         try:
             result["gpu_baseline"] = gpu_baseline_b1(dec, code_cpu[0].to(dev), bits[0], min(args.b1_views, nv), hw, out, nv, rays_per_s)
             log(f"gpu_baseline done: {result['gpu_baseline']['value']:.3g} rays/s")
         except Exception as e:                               # an extra must never cost the headline line
             result["gpu_baseline"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(params, code_cpu[0], bits[0].cpu().numpy(), min(args.cpu_views, nv), hw, out, nv)
         log("cpu_baseline done")
     del out
@@ -364,7 +369,7 @@ def main():
             model = build_model(dev, rank)
         except Exception as e:
             result["sampling"] = {"error": repr(e)}
-        if world > 1:                                        # a rank that could not build the model must not leave the others in a collective
+        if multi:                                        # a rank that could not build the model must not leave the others in a collective
             ok = torch.tensor([0 if model is None else 1], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
@@ -381,9 +386,13 @@ def main():
         # --diff_seed does), renders them and takes part in the all-gather of the uint8 views; the time is the max over ranks.
         try:
             samp = {}
-            for name in (("fp32", "bf16") if world == 1 else ("fp32",)):
-                samp[name] = sampling_leg(model, dev, ns, nv, hw, args.ddim_steps, name, rank, world, dist if world > 1 else None, log)
-            if world == 1:
+            for name in (("fp32", "bf16") if not multi else ("fp32",)):
+                samp[name] = sampling_leg(model, dev, ns, nv, hw, args.ddim_steps, name, rank, world, dist if multi else None, log)
+            if multi:
+                # (r05) the N > 1 line carries the other two legs as well, on every rank: configs[3]'s 10-view form of the sampler, and -- below -- a
+                # SHORTENED reconstruction (configs[2] / [4] shard their scenes over the ranks exactly like the sampler: lib/apis/test.py:12-73)
+                samp["abo_10_views_fp32"] = sampling_leg(model, dev, ns, 10, hw, args.ddim_steps, "fp32", rank, world, dist, log)
+            if not multi:
                 # BASELINE.json configs[3] (ssdnerf_abotables_uncond.py:103-111): the same sampler, but val_uncond renders 10 views per scene, so the
                 # leg is UNet-bound (the N > 1 form of this config is the `sampling` leg itself: every rank samples, renders and all-gathers)
                 samp["abo_10_views_fp32"] = sampling_leg(model, dev, ns, 10, hw, args.ddim_steps, "fp32", rank, world, None, log)
@@ -399,7 +408,7 @@ def main():
             # space: ~12 ms per scene against 0.77 ms for the object-like scenes of the headline step).  Derived, not measured: what each leg would
             # read with the headline step's render time per scene in place of the fog render -- the figure to expect from a trained prior.
             for leg in samp.values():
-                if isinstance(leg, dict) and "ddim_ms" in leg and world == 1:
+                if isinstance(leg, dict) and "ddim_ms" in leg and not multi:
                     t = (leg["ddim_ms"] + leg["density_ms"]) * 1e-3 + (ms_per_step * 1e-3 / ns) * leg["scenes_per_rank"] * leg["views_per_scene"] / nv
                     leg["derived_scenes_per_s_with_object_like_render"] = leg["scenes_per_rank"] / t
             result["sampling"] = samp
@@ -411,9 +420,30 @@ def main():
             result["recons"] = recons_leg(model, dev, ns, log, full=not args.no_full_recons)
         except Exception as e:
             result["recons"] = {"error": repr(e)}
+    if multi and model is not None:
+        # every rank reconstructs its own 8 scenes (no collective inside: scenes are independent); shortened -- 8 guided steps and 2 fine-tuning
+        # iterations measured as differences, the 75 + 25 schedule projected -- so that the N = 1, 2, 4, 8 sweep stays within minutes
+        try:
+            rec = recons_leg(model, dev, ns, log, guide_steps=8, outer=2, full=False, seed=rank)
+            mine = torch.tensor([rec["ms_per_guided_ddim_step"], rec["ms_per_finetune_iteration"], rec["projected_s_per_batch_75_guided_25_finetune"]],
+                                dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rec["per_rank"] = [dict(rank=r, ms_per_guided_ddim_step=float(v[0]), ms_per_finetune_iteration=float(v[1]), projected_s_per_batch=float(v[2]))
+                               for r, v in enumerate(every)]
+            slow = max(rec["per_rank"], key=lambda r: r["projected_s_per_batch"])
+            rec.update(n_gpus=world, slowest_rank=slow["rank"], projected_scenes_per_s_all_ranks=world * ns / slow["projected_s_per_batch"],
+                       note="shortened: 8 guided steps + 2 fine-tuning iterations per rank, schedule of configs[2] projected from the slowest rank")
+            result["recons"] = rec
+        except Exception as e:
+            result["recons"] = {"error": repr(e)}
+        if args.dry_nccl:
+            result["dry_nccl"] = {"backend": dist.get_backend(), "world_size": world,
+                                  "note": "N > 1 code path on ONE rank over RCCL: a self-check of initialisation, stream ordering and graph capture beside the "
+                                          "collective library's threads -- not a scaling measurement"}
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
@@ -543,7 +573,7 @@ def sampling_leg(model, dev, ns, nv, hw, n_steps, dtype_name, rank, world, dist,
     intr = S.cars_intrinsics(hw, hw).to(dev)[None, None].expand(ns, nv, -1).contiguous()
     g = torch.Generator().manual_seed(2021 + rank)           # mirrors --diff_seed: distinct scenes per rank
     jit = [torch.rand(64 ** 3, 3, generator=g).to(dev) for _ in range(8)]
-    gathered = torch.empty(world * ns, nv, hw, hw, 3, dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * ns, nv, hw, hw, 3, dtype=torch.uint8, device=dev) if dist is not None else None
 
     def ev():
         e = torch.cuda.Event(enable_timing=True)
@@ -555,7 +585,7 @@ def sampling_leg(model, dev, ns, nv, hw, n_steps, dtype_name, rank, world, dist,
         for rep in range(3):                                 # rep 0: graph capture, allocator warm-up
             noise = torch.randn(ns, 3, 6, 128, 128, generator=g).to(dev)
             torch.cuda.synchronize()
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -570,16 +600,16 @@ def sampling_leg(model, dev, ns, nv, hw, n_steps, dtype_name, rank, world, dist,
                 image, _ = model.render(model.decoder_ema, code, bits, hw, hw, intr, poses, cfg=model.test_cfg)
                 img_u8 = nerf.quantize_u8(image).reshape(ns, nv, hw, hw, 3)
                 e3 = ev()
-                if world > 1:
+                if dist is not None:
                     dist.all_gather_into_tensor(gathered, img_u8)
             torch.cuda.synchronize()
             own = time.perf_counter() - t0                   # this rank's own time (the all-gather included), before it waits for the others
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             ranks = None
-            if world > 1:
+            if dist is not None:
                 mine = torch.tensor([own * 1e3, e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)], dtype=torch.float64, device=dev)
                 every = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(every, mine)
@@ -599,7 +629,7 @@ def sampling_leg(model, dev, ns, nv, hw, n_steps, dtype_name, rank, world, dist,
     return out
 
 
-def recons_leg(model, dev, ns, log, guide_steps=3, outer=3, full=True):
+def recons_leg(model, dev, ns, log, guide_steps=3, outer=3, full=True, seed=0):
     """Config 3 (ssdnerf_cars_recons1v, cond_mode 'guide_optim'; lib/models/autodecoders/diffusion_nerf.py:241-311, 313-404): ms per rendering-guided
     DDIM step and ms per fine-tuning outer iteration (UNet forward + backward, then extra_scene_step + 1 train-branch render iterations) for `ns`
     scenes with one 128x128 conditioning view each, measured as (k + 1 iterations) - (1 iteration) so that fixed setup cancels; fp32 as the
@@ -609,8 +639,8 @@ def recons_leg(model, dev, ns, log, guide_steps=3, outer=3, full=True):
     from ssdnerf_amd import synthetic as S
     cfg = model.test_cfg
     saved = dict(cfg)
-    g = torch.Generator().manual_seed(0)
-    codes = torch.stack([S.make_triplane(100 + i) for i in range(ns)]).to(dev)
+    g = torch.Generator().manual_seed(seed)
+    codes = torch.stack([S.make_triplane(100 + seed * ns + i) for i in range(ns)]).to(dev)          # (distinct scenes per rank at N > 1)
     poses = S.spiral_poses()[[64]].to(dev)[None].expand(ns, -1, -1, -1).contiguous()
     intr = S.cars_intrinsics(128, 128).to(dev)[None, None].expand(ns, 1, -1).contiguous()
     with torch.no_grad():
