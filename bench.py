@@ -30,6 +30,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -61,6 +62,8 @@ def parse_args():
     ap.add_argument("--ray-arrays", action="store_true", help="feed materialised (S,N,3) ray arrays instead of cameras")
     ap.add_argument("--packed-loop", action="store_true", help="time TriPlaneDecoder.render_packed(check_overflow=False) instead of nerf.render (the r01-r03 "
                     "timed region: no overflow-flag read per batch); A/B only")
+    ap.add_argument("--sync-overflow-check", action="store_true", help="read every render's overflow flag before the next render is queued (the r04 timed "
+                    "step) instead of nerf.render's deferred check (flag copied asynchronously, examined behind the next render's launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-nccl", action="store_true", help="with --gpus 1: take the N > 1 code path with a ONE-rank RCCL process group (backend 'nccl', "
                     "world_size 1) -- RCCL initialisation, the asynchronous all-gather on RCCL's stream, graph captures beside RCCL's watchdog thread -- a "
@@ -165,7 +168,7 @@ def main():
         ``render_packed`` plus what the product path does around them: the ONE overflow-flag read per batch (a host sync) that decides whether the batch
         has to be redone through the stepwise path, and the uint8 views"""
         image, depth, image_u8 = nerf.render(dec, code_, bits_, hw, hw, intr, poses, grid_size=64, bg_color=1.0, cfg={}, planes=planes_,
-                                              rays=rays, return_u8=True)
+                                              rays=rays, return_u8=True, defer_overflow_check=not args.sync_overflow_check)
         return {"image": image.reshape(ns, nv * hw * hw, 3), "depth": depth.reshape(ns, nv * hw * hw), "image_u8": image_u8}
 
     # N > 1: every rank ends up with every rank's quantised views (RCCL all-gather over xGMI).  The collective of step i runs on RCCL's
@@ -200,6 +203,7 @@ def main():
         if pending["work"] is not None:
             wait_collective()
             pending["work"] = None
+        nerf.finish_render(dec)                          # the last step's overflow flag (deferred check: nerf.render's docstring); inside the timed region
 
     def stat_pass(planes_, bits_):
         """one untimed pass for the integer statistics (exact sample count of this workload, hitting rays, boundary tests)"""
@@ -297,7 +301,10 @@ def main():
                                      "(6 = the default since r04, fp32 class throughout; 3 = opt-in SSDNERF_SHADE_DIR_PRODUCTS=3, 2^-16 class on that additive term: "
                                      "see dir3_variant)",
                    "timed_call": "TriPlaneDecoder.render_packed(check_overflow=False) [--packed-loop]" if args.packed_loop else
-                                 "nerf.render (BaseNeRF.render on cached planes: two launches + the overflow-flag read per batch + uint8 views)",
+                                 ("nerf.render (BaseNeRF.render on cached planes: two launches + the overflow-flag read per batch + uint8 views)" if args.sync_overflow_check else
+                                  "nerf.render(defer_overflow_check=True) + nerf.finish_render after the last step (BaseNeRF.render on cached planes: two launches + uint8 "
+                                  "views per batch; every batch's overflow flag is copied to pinned host memory asynchronously and examined behind the NEXT batch's "
+                                  "launches -- a raised flag redoes that batch into its own output tensors; --sync-overflow-check restores the r04 read before the next launch)"),
                    "collective": "all_gather(uint8 views), overlapped with the next step's render" if multi else "none"},
         "views_per_s": rays_per_s / (hw * hw), "samples_per_s": n_samples_all / (elapsed / args.steps),
         "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": stats["overflow"],
@@ -730,20 +737,75 @@ def recons_full_batch(model, dev, ns, data, g, log, timed, config5=False, n_test
             model.decoder_ema.plane_dtype = torch.float16
         n_eval = len(model.diffusion_ema.sampling_plan("ddim"))
 
+        import numpy as np
+        noise = torch.randn(ns, 3, 6, 128, 128, generator=g).to(dev)
+
         def run():
-            return model.val_step(dict(data, noise=torch.randn(ns, 3, 6, 128, 128, generator=g).to(dev), test_poses=poses, test_intrinsics=intr))
+            # every draw of the batch is seeded the same way for the timed run and for the reference run below: the initial noise is shared, the
+            # host-side draws (prior-loss noise and Langevin noise: torch's CPU generator; timesteps: numpy) and the device draws (march jitter,
+            # density-grid jitter: torch's device generator) restart from fixed seeds
+            torch.manual_seed(1234); np.random.seed(1234)
+            return model.val_step(dict(data, noise=noise, test_poses=poses, test_intrinsics=intr))
+
+        def psnr(a, b):                                          # lib/core/evaluation/metrics.py:52-55 (eval_psnr), per image, then the mean
+            mse = (a.float() - b.float()).square().flatten(-3).mean(dim=-1)
+            return 10.0 * (-torch.log10(mse + 1e-6))
 
         res, wall = timed(run)
         ok = bool(torch.isfinite(res["code"]).all()) and bool(torch.isfinite(res["pred_imgs"]).all())
+        pred = res["pred_imgs"]                                  # (ns, views, 3, h, w), quantised to k / 255 like the reference's eval_and_viz
+        # (a) against the conditioning view: test view 64 IS the conditioning pose, its image should reproduce the target the guidance was given
+        cond = data["cond_imgs"][:, 0].permute(0, 3, 1, 2) if data["cond_imgs"].dim() == 5 else None
+        psnr_cond = psnr(pred[:, 64], cond) if cond is not None and n_test_views > 64 else None
+        # (b) the same batch, same seeds, through the REFERENCE-SHAPED arithmetic once, untimed: fp32, no autocast, fp32 planes, the eager modules
+        # (no captured graphs, no inference executor) -- what the fast path has to agree with.  `parity` is false below 35 dB.
+        unet = model.diffusion_ema.denoising
+        saved_fast = (getattr(unet, "fast_inference", None), getattr(unet, "grad_graph", None), model.autocast_dtype, model.decoder_ema.plane_dtype)
+        try:
+            if saved_fast[0] is not None:
+                unet.fast_inference = False
+            if saved_fast[1] is not None:
+                unet.grad_graph = False
+            model.autocast_dtype = None
+            model.decoder_ema.plane_dtype = torch.float32
+            ref, ref_wall = timed(run)
+        finally:
+            if saved_fast[0] is not None:
+                unet.fast_inference = saved_fast[0]
+            if saved_fast[1] is not None:
+                unet.grad_graph = saved_fast[1]
+            model.autocast_dtype, model.decoder_ema.plane_dtype = saved_fast[2], saved_fast[3]
+        psnr_ref = psnr(pred, ref["pred_imgs"])                  # (ns, views)
+        # how much of the views is not background (bg 1.0): a reconstruction that came out empty would make both PSNR figures meaningless
+        foreground = float((pred < 0.995).any(dim=2).float().mean())
+        identical = float((pred == ref["pred_imgs"]).all(dim=2).float().mean())
+        code_err = float((res["code"].float() - ref["code"].float()).abs().max())
+        # the same comparison on the CODES (what the guided steps and the fine-tuning produce; the views are a function of them): PSNR with the reference
+        # code's own range as peak.  With random UNet weights the fine-tuning of this synthetic batch ends in EMPTY scenes (see foreground_pixel_fraction:
+        # white views on both sides, image PSNR at its cap), so the code figure is the one that can move
+        code_scale = float(ref["code"].float().abs().max())
+        code_mse = float((res["code"].float() - ref["code"].float()).square().mean())
+        code_psnr = 10.0 * math.log10(code_scale ** 2 / max(code_mse, 1e-20))
+        parity = bool(psnr_ref.mean() >= 35.0) and code_psnr >= 35.0
         out = dict(wall_s=wall, scenes_per_s=ns / wall, guided_unet_evaluations=n_eval, finetune_outer_iterations=25, inner_render_iterations=4,
                    test_views_per_scene=n_test_views, finite=ok,
+                   psnr_conditioning_view_db=None if psnr_cond is None else dict(mean=float(psnr_cond.mean()), min=float(psnr_cond.min())),
+                   psnr_vs_fp32_eager_reference_db=dict(mean=float(psnr_ref.mean()), min=float(psnr_ref.min()), views=int(psnr_ref.numel())),
+                   max_abs_code_diff_vs_reference=code_err, code_abs_max=code_scale, code_psnr_vs_reference_db=code_psnr, reference_wall_s=ref_wall, parity=parity,
+                   foreground_pixel_fraction=foreground, pixels_identical_to_reference_fraction=identical,
                    precision="bf16 autocast (UNet) + fp16 planes" if config5 else "fp32",
-                   note="one timed val_step (guide_optim) after the warm-up the per-step measurements above provide")
+                   note="one timed val_step (guide_optim) after the warm-up the per-step measurements above provide; then the SAME batch (same noise, same "
+                        "seeds) once through the fp32 eager modules, untimed: PSNR of the 250 views per scene between the two (lib/core/evaluation/metrics.py:52-55), "
+                        "and of the codes; psnr_conditioning_view_db: test view 64 (the conditioning pose) against the target.  Random UNet weights: this synthetic "
+                        "batch fine-tunes into empty scenes (foreground_pixel_fraction), so the image figures sit at the 60 dB cap and the conditioning-view figure "
+                        "is the target's distance from white -- the code figures are the sensitive ones")
     finally:
         cfg.clear(); cfg.update(saved)
         model.diffusion_ema.test_cfg.clear(); model.diffusion_ema.test_cfg.update(saved_d)
         model.autocast_dtype, model.decoder_ema.plane_dtype = saved_ac, saved_pd
-    log(f"recons {'config 5' if config5 else 'config 3'} full batch: {wall:.2f} s for {ns} scenes ({n_eval} guided evaluations + 25 x 5 fine-tune)")
+    log(f"recons {'config 5' if config5 else 'config 3'} full batch: {wall:.2f} s for {ns} scenes ({n_eval} guided evaluations + 25 x 5 fine-tune); "
+        f"PSNR vs fp32 eager {out['psnr_vs_fp32_eager_reference_db']['mean']:.1f} dB (min {out['psnr_vs_fp32_eager_reference_db']['min']:.1f}), "
+        f"conditioning view {out['psnr_conditioning_view_db']}")
     return out
 
 

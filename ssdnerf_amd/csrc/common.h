@@ -157,6 +157,29 @@ SSD_DEV float ssd_skip_empty(const MarchCfg& c, const RayGeom& r, const Probe& p
 }
 
 // ------------------------------------------------------------------------------------------------
+// `do { t += dt; } while (t < tt);` with a CONSTANT step, without the loop (r05).  The march's parameters are a chain of fp32 additions, so the kernels
+// may not replace k steps by t + k * dt -- but inside one binade the chain IS an exact arithmetic progression: t is a multiple of u = ulp(t), so
+// fl(t + dt) = t + D with D = dt rounded to a multiple of u, the same D at every step (a tie -- dt's residue exactly u / 2 -- would alternate with the
+// parity of t: excluded by comparing the first two differences), and t + k D is a multiple of u below the binade's end, hence representable: the chain's
+// k-th member is fma(k, D, t), exactly.  The count k comes from a reciprocal estimate and is corrected by one step either way; anything that leaves the
+// binade (or a tie) takes the loop.  tests/test_march_closed_form_cpu.py replays the identity in numpy; the GPU parity tests pin the kernels.
+SSD_DEV float ssd_run_to_const(float dt, float t, float tt) {
+    const float t1 = t + dt;
+    if (!(t1 < tt)) return t1;                                           // one step is enough (the loop takes at least one)
+    const float t2 = t1 + dt;
+    const float D = t1 - t, D2 = t2 - t1;                                // exact differences of neighbours in one binade
+    float k = ceilf((tt - t) * __builtin_amdgcn_rcpf(D));
+    float c = ssd_fma(k, D, t);
+    c = c < tt ? c + D : c;                                              // the estimate may be one short ...
+    c = (c - D < tt) ? c : c - D;                                        // ... or one long
+    const bool ok = D == D2 && ((__float_as_uint(t) ^ __float_as_uint(c)) >> 23) == 0 && !(c < tt) && (c - D < tt);
+    if (ok) return c;
+    t = t2;                                                              // (two steps are already known to be needed ... t1 < tt; t2 is the chain's second member)
+    while (t < tt) t += dt;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Camera rays (reference: get_ray_directions / get_rays / get_cam_rays, lib/core/utils/nerf_utils.py:17-61).  ONE statement of the arithmetic,
 // shared by k_cam_rays (raygen.hip, materialises the arrays the reference API hands around) and by the render kernels when they are given
 // cameras instead of ray arrays -- so a ray generated in a kernel is bit-identical to the one k_cam_rays would have stored.

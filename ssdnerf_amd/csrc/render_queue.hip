@@ -57,6 +57,10 @@ SSD_DEV int rq_cell(const FastMarch& m, float v) { return (int)fminf(v * m.half_
 struct FastProbe { float x, y, z, dt; int nx, ny, nz; bool occ; };
 
 // DTG0: dt_gamma == 0 (the uncond render), where clamp(t * 0, dt_min, dt_max) == dt_min: the march step is a constant
+#ifndef RQ_RUN_TO_CLOSED
+#define RQ_RUN_TO_CLOSED 0                     // (r05) 1: `do t += dt while (t < tt)` with the constant step as ssd_run_to_const (common.h): bit-identical, and no
+                                               // faster here (stage A 0.80 ms either way: profiles/r05) -- off
+#endif
 template <bool DTG0>
 SSD_DEV float rq_dt(const FastMarch& m, float t) { return DTG0 ? m.dt_min : ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max); }
 
@@ -82,6 +86,7 @@ SSD_DEV float rq_skip(const FastMarch& m, const RayGeom& r, const FastProbe& p, 
     const float ty = ssd_fma(ssd_fma((float)p.ny + sgy, m.two_rH, -1.0f), m.mip_bound, -p.y) * r.rdy;
     const float tz = ssd_fma(ssd_fma((float)p.nz + sgz, m.two_rH, -1.0f), m.mip_bound, -p.z) * r.rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    if (DTG0 && RQ_RUN_TO_CLOSED) return ssd_run_to_const(m.dt_min, t, tt);      // (r05) the same chain of additions in closed form: common.h
     do {
         t += rq_dt<DTG0>(m, t);
     } while (t < tt);
@@ -509,7 +514,8 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
                             continue;
                         }
                     }
-                    do { t += rq_dt<DTG0>(c.m, t); } while (t < tt);
+                    if (DTG0 && RQ_RUN_TO_CLOSED) t = ssd_run_to_const(c.m.dt_min, t, tt);
+                    else do { t += rq_dt<DTG0>(c.m, t); } while (t < tt);
                 }
             } else {
                 while (t < far_) {

@@ -238,6 +238,18 @@ struct ProbeB { float x, y, z, dt; int nx, ny, nz; bool occ; };
 template <bool DTG0>
 SSD_DEV float sm_dt(const FastMarchB& m, float t) { return DTG0 ? m.dt_min : ssd_clamp(t * m.dt_gamma, m.dt_min, m.dt_max); }
 
+// `do { t += dt(t); } while (t < tt);` -- SM_RUN_TO_CLOSED (r05): for the constant step the closed form of common.h (ssd_run_to_const), bit-identical
+#ifndef SM_RUN_TO_CLOSED
+#define SM_RUN_TO_CLOSED 0                         // 0: loops (default); 1: closed form in the march pass's block exits (up to ~16 steps): no measurable change (4.78 ms either
+                                                   // way); 2: in the cell skips too: +1.2 % (a cell is 1 - 4 steps).  Bit-identical in all three (profiles/r05/q_*)
+#endif
+template <bool DTG0>
+SSD_DEV float sm_run_to(const FastMarchB& m, float t, float tt) {
+    if (DTG0 && SM_RUN_TO_CLOSED) return ssd_run_to_const(m.dt_min, t, tt);
+    do { t += sm_dt<DTG0>(m, t); } while (t < tt);
+    return t;
+}
+
 template <bool DTG0>
 SSD_DEV ProbeB sm_probe(const FastMarchB& m, const uint8_t* __restrict__ lin_bits, const RayGeom& r, float t) {
     ProbeB p;
@@ -260,6 +272,7 @@ SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, fl
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     // `do t += dt(t); while (t < tt)` -- the same additions on the same values in the same order, but the first steps as selects (a cell is 2.3 minimum
     // steps wide, its diagonal 4: a divergent loop paid a branch round trip per step per wave); the loop itself stays for whatever is left
+    if (DTG0 && SM_RUN_TO_CLOSED > 1) return ssd_run_to_const(m.dt_min, t, tt);      // (a cell is 1 - 4 steps: the loop is cheaper here, r05 A/B)
     t += sm_dt<DTG0>(m, t);
 #pragma unroll
     for (int i = 0; i < SM_SKIP_UNROLL; ++i) t = t < tt ? t + sm_dt<DTG0>(m, t) : t;
@@ -465,6 +478,11 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #else
 #define SM_SEC_MLP(i) do { } while (0)
 #endif
+#if defined(SM_DEBUG_SECTIONS) && defined(SM_DEBUG_MARCH) && !defined(SM_DEBUG_MLP_PHASES)
+#define SM_SEC_MARCH(i) SM_SEC(i)          // 10: everything since the last mark up to the pass, 11: pool read + ray + bounds, 12: the probe loop, 13: stores + pool writes
+#else
+#define SM_SEC_MARCH(i) do { } while (0)
+#endif
   for (uint32_t sk = 0; sk < c.S; ++sk) {
     const uint32_t scene = (start_scene + sk) % c.S;
     const uint32_t count = queue_count[ssd_counter(SSD_CNT_HITS, c.S, scene)];
@@ -661,6 +679,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         // remaining samples only after everything else has drained, one drain after the other at the very end of the launch
         const bool draining = SM_DRAIN_MARCH && scene_done && next >= end && st_count == 0 && rp_count == 0 && sp_count != 0 && (uint32_t)__popcll(live) <= 48u;
         if ((sp_count >= SM_MARCH_W || draining || (live == 0 && sp_count != 0)) && rp_count <= SM_POOL - SM_MARCH_W) {
+            SM_SEC_MARCH(10);
             const uint32_t n = min(sp_count, SM_MARCH_W);
             bool found = false, again = false, mine = (uint32_t)lane < n;
             uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
@@ -673,6 +692,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                 qf = ssd_tail_far(q, cell_world, qn, qf, e0.x, packing);
                 const float qx = ssd_fma(0.5f, ssd_sign1(q.dx), 0.5f), qy = ssd_fma(0.5f, ssd_sign1(q.dy), 0.5f), qz = ssd_fma(0.5f, ssd_sign1(q.dz), 0.5f);
                 float qt = __uint_as_float(e0.y);
+                SM_SEC_MARCH(11);
                 // SM_MARCH_TRIPS (r05): a pass lasts as long as its slowest lane, and a few rays (no tail bound: a gap between two parts of the object, the whole
                 // box behind it) need dozens of dependent probes where the others need three -- a lane gives up after this many and its ray goes back to
                 // the search pool with the parameter it reached (0: no limit, the r01 - r04 form; the sequence of parameters does not depend on where
@@ -704,7 +724,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                                 continue;
                             }
                         }
-                        do { qt += sm_dt<DTG0>(c.m, qt); } while (qt < tt);
+                        qt = sm_run_to<DTG0>(c.m, qt, tt);
                     }
                 } else
                 while (qt < qf) {
@@ -714,6 +734,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                     if (p.occ) { found = true; break; }
                     qt = sm_skip<DTG0>(c.m, q, p, qx, qy, qz, qt);
                 }
+                SM_SEC_MARCH(12);
                 if (found || again) e0.y = __float_as_uint(qt);
                 else write_out(e0.x, __uint_as_float(e0.z), __uint_as_float(e0.w), __uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z), e1.w);
             }
@@ -736,6 +757,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            SM_SEC_MARCH(13);
 #ifdef SM_DEBUG_SECTIONS
             ++dbg_marches;
 #endif

@@ -53,8 +53,16 @@ def get_cam_rays(c2w: torch.Tensor, intrinsics: torch.Tensor, h: int, w: int) ->
 @torch.no_grad()
 def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch.Tensor, h: int, w: int, intrinsics: torch.Tensor,
            poses: torch.Tensor, grid_size: int = 64, bg_color: float = 1.0, cfg: Optional[Dict] = None,
-           planes: Optional[torch.Tensor] = None, rays: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, return_u8: bool = False):
+           planes: Optional[torch.Tensor] = None, rays: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, return_u8: bool = False,
+           defer_overflow_check: bool = False):
     """``BaseNeRF.render``: (S,V) views of S scenes -> image (S,V,h,w,3) blended with ``bg_color``, depth (S,V,h,w).
+
+    ``defer_overflow_check`` (extra, r05): the one host read per call -- did a ray reach the ``max_steps`` cap, so that the batch has to be redone through the
+    stepwise path? -- normally sits between this call's launches and the next call's (a host sync: ~0.12 ms per 6 ms render, and the GPU idles while the
+    next call's Python runs).  With the flag set, the device flag is copied to pinned host memory asynchronously and examined when the NEXT ``render`` on this
+    decoder has queued its own launches (or in ``finish_render(decoder)``): by then the copy has long landed, nothing waits.  If the flag was raised, the
+    batch is redone THEN, into the SAME output tensors.  Contract: the tensors returned by a deferred call are final once the next ``render`` /
+    ``finish_render`` on the decoder has returned -- a caller that streams batches (evaluation loops, bench.py) calls ``finish_render`` after the last one.
 
     ``planes`` / ``rays`` let callers that render the same scenes or cameras repeatedly keep the packed planes /
     ray arrays resident instead of rebuilding them (they are pure functions of ``code`` / ``poses, intrinsics``).
@@ -107,19 +115,28 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
             depths.append(out["depth"] if isinstance(out["depth"], torch.Tensor) else torch.stack(out["depth"], dim=0))
         image = torch.cat(images, dim=1) if len(images) > 1 else images[0]
         depth = torch.cat(depths, dim=1) if len(depths) > 1 else depths[0]
+    deferred = defer_overflow_check and len(overflow) == 1 and (not return_u8 or image_u8 is not None)
+    # an earlier deferred call's flag: its copy was queued a whole render ago
+    _settle_deferred(decoder)
+    if deferred:
+        st = decoder.__dict__.setdefault("_deferred_overflow", {"ring": [], "i": 0, "pending": None})
+        if len(st["ring"]) < 2:
+            st["ring"].append(torch.empty((), dtype=torch.int32, pin_memory=True))
+        host = st["ring"][st["i"] & 1]
+        st["i"] += 1
+        host.copy_(overflow[0].reshape(()), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["pending"] = dict(host=host, event=ev, image=image, depth=depth, image_u8=image_u8 if return_u8 else None,
+                             args=(code, density_bitfield, h, w, intrinsics, poses, grid_size, bg_color, rays, dt_gamma, s))
+        overflow = []
     # ONE host read per render call (the reference syncs once per loop iteration); a single launch's flag is read as it is -- no stack / sum kernels
     # between the render and the read, which sits on the critical path of back-to-back renders (profiles/r04/l_host_gap_*.txt)
     if overflow and int((overflow[0] if len(overflow) == 1 else torch.stack([f.reshape(()) for f in overflow]).sum()).item()) != 0:
         # a ray reached the reference loop's global step cap (max_steps occupied samples), where the reference's answer depends on its n_step
         # schedule: redo the batch through the reference-shaped stepwise path, which is exact by construction (same rule as
         # TriPlaneDecoder._forward_eval_fused).  One sync per render call; the reference syncs once per loop iteration.
-        rays_o, rays_d = get_cam_rays(poses, intrinsics, h, w) if rays is None else rays
-        gammas = [float(g) for g in (dt_gamma if isinstance(dt_gamma, list) else dt_gamma.tolist())]
-        out = decoder._forward_eval_stepwise(list(rays_o.reshape(s, -1, 3)), list(rays_d.reshape(s, -1, 3)), code, density_bitfield,
-                                             [grid_size] * s if isinstance(grid_size, int) else grid_size, gammas, False, 1e-4)
-        ws = torch.stack(out["weights_sum"], dim=0)
-        image = torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1))
-        depth = torch.stack(out["depth"], dim=0)
+        image, depth = _stepwise_redo(decoder, code, density_bitfield, h, w, intrinsics, poses, grid_size, bg_color, rays, dt_gamma, s)
         image_u8 = None
     image = image.reshape(s, v, h, w, 3)
     depth = depth.reshape(s, v, h, w)
@@ -128,6 +145,39 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
     if return_u8:
         return image, depth, (quantize_u8(image) if image_u8 is None else image_u8.reshape(s, v, h, w, 3))
     return image, depth
+
+
+def _stepwise_redo(decoder, code, density_bitfield, h, w, intrinsics, poses, grid_size, bg_color, rays, dt_gamma, s):
+    """the batch through the reference-shaped stepwise path (exact at the global step cap by construction): image (S, N, 3) with background, depth (S, N)"""
+    rays_o, rays_d = get_cam_rays(poses, intrinsics, h, w) if rays is None else rays
+    gammas = [float(g) for g in (dt_gamma if isinstance(dt_gamma, list) else dt_gamma.tolist())]
+    out = decoder._forward_eval_stepwise(list(rays_o.reshape(s, -1, 3)), list(rays_d.reshape(s, -1, 3)), code, density_bitfield,
+                                         [grid_size] * s if isinstance(grid_size, int) else grid_size, gammas, False, 1e-4)
+    ws = torch.stack(out["weights_sum"], dim=0)
+    return torch.stack(out["image"], dim=0) + bg_color * (1 - ws.unsqueeze(-1)), torch.stack(out["depth"], dim=0)
+
+
+@torch.no_grad()
+def _settle_deferred(decoder) -> bool:
+    """examine the flag of the decoder's last deferred render; redo that batch into its own output tensors if it was raised.  True if a batch was redone."""
+    st = decoder.__dict__.get("_deferred_overflow")
+    if not st or st["pending"] is None:
+        return False
+    p, st["pending"] = st["pending"], None
+    p["event"].synchronize()                                          # (recorded a render ago: no wait in a streaming loop)
+    if int(p["host"].item()) == 0:
+        return False
+    image, depth = _stepwise_redo(decoder, *p["args"])
+    p["image"].copy_(image.reshape(p["image"].shape))
+    p["depth"].copy_(depth.reshape(p["depth"].shape))
+    if p["image_u8"] is not None:
+        p["image_u8"].copy_(quantize_u8(p["image"]).reshape(p["image_u8"].shape))
+    return True
+
+
+def finish_render(decoder) -> bool:
+    """settle the last ``render(..., defer_overflow_check=True)`` on this decoder (see there).  Returns True if that batch had to be redone."""
+    return _settle_deferred(decoder)
 
 
 def quantize_u8(image: torch.Tensor) -> torch.Tensor:

@@ -112,6 +112,60 @@ def test_full_scene_sample_counts_match_the_oracle(variant, n_views):
     assert near_thresh > 0 or mismatched == 0                                  # (the kernel's own diagnostic count of tests within 2e-6)
 
 
+# ---------------------------------------------------------------------------------------------- a11: the deferred overflow check of nerf.render
+def test_deferred_overflow_check_redoes_the_batch_in_place():
+    """``nerf.render(..., defer_overflow_check=True)`` (r05) returns without the host read of the overflow flag; the flag is examined behind the next render's
+    launches, or in ``finish_render``.  (1) On a batch that stays below the step cap the outputs equal the synchronous call's, bit for bit, and nothing is
+    redone.  (2) A fog scene with a full bitfield and ``T_thresh`` 0 reaches the cap: the synchronous call redoes it through the stepwise path; the deferred
+    call hands out the fused kernels' images first and, once settled, the SAME tensors hold the stepwise result -- settled by ``finish_render`` and, equally,
+    by the next ``render`` on the decoder."""
+    from ssdnerf_amd import nerf, synthetic as S
+    dec = _decoder()
+    nv = 3
+    poses = S.spiral_poses()[::90][:nv][None].cuda().contiguous()
+    intr = S.cars_intrinsics(128, 128)[None, None].expand(1, nv, -1).cuda().contiguous()
+    g = torch.Generator().manual_seed(7)
+    jit = [torch.rand(64 ** 3, 3, generator=g).cuda() for _ in range(8)]
+    from ssdnerf_amd.density import get_density
+    code = S.make_triplane(2021, "object").cuda()[None]
+    _, bits = get_density(dec, code, 64, density_thresh=0.1, density_step=8, jitters=jit)
+    # (1) no overflow
+    a = nerf.render(dec, code, bits, 128, 128, intr, poses, return_u8=True)
+    b = nerf.render(dec, code, bits, 128, 128, intr, poses, return_u8=True, defer_overflow_check=True)
+    assert nerf.finish_render(dec) is False
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # (2) a raised flag.  With bound 1 a ray cannot really collect max_steps occupied samples (the box diagonal is exactly max_steps minimum steps), so the
+    # flag is raised by hand behind the fused launch: the synchronous call then redoes the batch through the stepwise path at once, the deferred one later
+    real = dec.render_packed
+
+    def flagged(*a, **k):
+        out = real(*a, **k)
+        dec.last_render_stats["overflow"] = torch.ones(1, dtype=torch.int32, device="cuda")
+        return out
+    dec.render_packed = flagged
+    try:
+        sync = nerf.render(dec, code, bits, 128, 128, intr, poses, return_u8=True)                 # stepwise result (redone at once)
+        d1 = nerf.render(dec, code, bits, 128, 128, intr, poses, return_u8=True, defer_overflow_check=True)
+        first = [t.clone() for t in d1]
+        for x, y in zip(a, first):
+            assert torch.equal(x, y)                                       # what the caller holds first is the fused kernels' batch
+        assert nerf.finish_render(dec) is True                             # redone now ...
+        for x, y in zip(sync, d1):
+            assert torch.equal(x, y)                                       # ... into the tensors the caller already holds
+        assert float((sync[0] - a[0]).abs().max()) <= 2e-5                 # (stepwise and fused agree to rounding when nothing really overflowed)
+        d2 = nerf.render(dec, code, bits, 128, 128, intr, poses, return_u8=True, defer_overflow_check=True)
+        dec.render_packed = real
+        ok = nerf.render(dec, code, bits, 128, 128, intr, poses, return_u8=True, defer_overflow_check=True)      # settles d2 behind its own launches
+        for x, y in zip(sync, d2):
+            assert torch.equal(x, y)
+    finally:
+        dec.__dict__.pop("render_packed", None)
+    assert nerf.finish_render(dec) is False
+    for x, y in zip(a, ok):
+        assert torch.equal(x, y)
+
+
 # ---------------------------------------------------------------------------------------------- (f)3: 16-bit scene cache -> fused render
 def test_sixteen_bit_cached_scene_renders_through_the_fused_path(tmp_path):
     """``MultiSceneNeRF.save_cache`` with ``cache_16bit`` writes fp16 pre-activation codes (+ bf16 optimizer moments); the files are read back

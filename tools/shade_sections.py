@@ -39,7 +39,11 @@ print(f"waves {waves}  loop iterations {loops}  events {events} ({loops / max(ev
 print(f"render {ms_per_render:.3f} ms (both stages); wave cycles / render time = {tot / max(waves, 1) / (ms_per_render * 1e-3) / 1e9:.3f} GHz x (shade share of the render)")
 tl = ws[:nk * ns * 128].view(torch.int32).view(nk, ns, 32)[1, 0]
 mlp = [16 * v for v in tl[2:14].contiguous().view(torch.int64).tolist()]
-if sum(mlp):                                  # -DSM_DEBUG_MLP_PHASES: the MLP section in phases (their sum replaces "split+MLP" above, whose mark then only holds the tail)
+if os.environ.get("SHADE_SECTIONS_MARCH") and sum(mlp):      # -DSM_DEBUG_MARCH: inside the march pass (per PASS)
+    for n, v in zip(["(up to the pass)", "march: pool read + ray + bounds", "march: probe loop", "march: stores + pool writes"], mlp):
+        print(f"  {n:36s} {v / max(marches, 1):8.0f} cycles per pass")
+    tot += sum(mlp)
+elif sum(mlp):                                  # -DSM_DEBUG_MLP_PHASES: the MLP section in phases (their sum replaces "split+MLP" above, whose mark then only holds the tail)
     for n, v in zip(["MLP: split", "MLP: A (layer 1, tile 0)", "MLP: B (layer 1 tile 1 | density 0)", "MLP: C (dir 0 | density 1)", "MLP: D (dir 1 | colour 0)", "MLP: E (colour 1)"], mlp):
         print(f"  {n:36s} {v / max(loops, 1):8.0f} cycles per iteration")
     tot += sum(mlp)
