@@ -115,6 +115,9 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 // iteration are gather + split + MLP, the rest is this).  A lane that finishes or must park now just raises a flag and sits out; the wave runs
 // the bookkeeping as ONE event when SM_EVENT_MIN lanes are waiting (or nothing is left to shade).  Per-ray arithmetic and its order are
 // untouched -- every output is bit-identical for any value; 1 = an event in every iteration (the r01-r04 behaviour).
+#ifndef SM_W_EARLY
+#define SM_W_EARLY 0                               // heads: the group's output-weight reads in front of its transcendentals instead of behind them
+#endif
 #ifndef SM_GATHER_FIRST
 #define SM_GATHER_FIRST 1                          // (r05) texel requests in front of the search arithmetic, blend behind it
 #endif
@@ -953,6 +956,16 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             constexpr int nt = decltype(ntc)::value, Q0 = decltype(q0c)::value, N = decltype(nc)::value;
             constexpr bool COLOUR = decltype(colour_c)::value;
             floatx2 h[N], u[N], v[N];
+            float4 w0[N], w1[N];
+#if SM_W_EARLY
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int q = Q0 + i, mt = q >> 3, p2 = q & 7;
+                w0[i] = wout2[((mt * 8 + p2) * 2 + half) * 2];
+                if (COLOUR) w1[i] = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const int q = Q0 + i, mt = q >> 3, p2 = q & 7;
@@ -960,13 +973,14 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) { v[i].x = __builtin_amdgcn_exp2f(h[i].x); v[i].y = __builtin_amdgcn_exp2f(h[i].y); }
-            float4 w0[N], w1[N];
+#if !SM_W_EARLY
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const int q = Q0 + i, mt = q >> 3, p2 = q & 7;
                 w0[i] = wout2[((mt * 8 + p2) * 2 + half) * 2];
                 if (COLOUR) w1[i] = wout2[((mt * 8 + p2) * 2 + half) * 2 + 1];
             }
+#endif
 #pragma unroll
             for (int i = 0; i < N; ++i) u[i] = v[i] + floatx2{1.0f, 1.0f};
 #pragma unroll
