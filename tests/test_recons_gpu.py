@@ -253,7 +253,8 @@ def test_captured_gradient_path_matches_the_eager_one():
     """Input-gradient calls with frozen weights replay a captured forward + backward once a signature has been seen often enough
     (``DenoisingUnetMod._grad_graph_call``): same kernels in the same order, so outputs and input gradients equal the eager path's to the rounding of
     the kernels' atomics; new inputs go through the static buffers; a changed weight drops the graph (the result follows the new weights); a call that
-    asks for weight gradients stays eager."""
+    asks for weight gradients stays eager.  (Tolerance 3e-5 of the largest entry since r05: the stem, the head and the stride-2 layers run the fp32-class
+    kernels in both arms, six more layers whose split-K atomics order differently between two runs: 2.8e-6 observed on a 0.127 gradient.)"""
     import ssdnerf_amd  # noqa: F401
     from ssdnerf_amd.registry import MODULES
     net = MODULES.build(dict(UNET, base_channels=64, channels_cfg=[1, 2, 2], attention_res=[32, 64])).cuda().eval()
@@ -279,18 +280,18 @@ def test_captured_gradient_path_matches_the_eager_one():
         assert captured() == [i >= 2], (i, captured())                                  # calls 0, 1 eager; call 2 captures and replays
         y_e, gx_e = call(xs[i], ts[i], False)
         for a, b, what in ((y_g, y_e, "output"), (gx_g, gx_e, "input gradient")):
-            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (i, what, float((a - b).abs().max()), float(b.abs().max()))
+            assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()), (i, what, float((a - b).abs().max()), float(b.abs().max()))
     with torch.no_grad():
         net.out.conv.weight.mul_(1.5); net.out.conv.bias.add_(0.25)                     # in place: the version counters move
     y_g, gx_g = call(xs[0], ts[0], True)
     assert captured() == [False]                                                        # dropped; counted from zero again
     y_e, gx_e = call(xs[0], ts[0], False)
-    assert float((y_g - y_e).abs().max()) <= 2e-5 * float(y_e.abs().max()) and float((gx_g - gx_e).abs().max()) <= 2e-5 * float(gx_e.abs().max())
+    assert float((y_g - y_e).abs().max()) <= 3e-5 * float(y_e.abs().max()) and float((gx_g - gx_e).abs().max()) <= 3e-5 * float(gx_e.abs().max())
     for i in range(1, 4):
         y_g, gx_g = call(xs[i], ts[i], True)
     assert captured() == [True]
     y_e, gx_e = call(xs[3], ts[3], False)
-    assert float((y_g - y_e).abs().max()) <= 2e-5 * float(y_e.abs().max()) and float((gx_g - gx_e).abs().max()) <= 2e-5 * float(gx_e.abs().max())
+    assert float((y_g - y_e).abs().max()) <= 3e-5 * float(y_e.abs().max()) and float((gx_g - gx_e).abs().max()) <= 3e-5 * float(gx_e.abs().max())
     net.out.conv.weight.requires_grad_(True)                                            # a weight gradient is wanted: eager, and it arrives
     net.grad_graph = True
     xi = xs[4].clone().requires_grad_(True)
@@ -391,7 +392,9 @@ def test_gradient_path_with_pre_split_dy_matches_the_on_the_fly_split(monkeypatc
     err, scale = float((res[True][1] - res[False][1]).abs().max()), float(res[False][1].abs().max())
     # fp32 rounding through ~40 layers of backward: the small layers' pre-split kernel sums in another order, and the kernels' atomics differ run to run
     rel_l2 = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
-    assert err <= 5e-5 * scale and rel_l2 <= 1e-5, (err, scale, rel_l2)
+    # (r05: 2e-5 -- the stem, the head and the four stride-2 layers run the fp32-class kernels in both arms now, six more layers whose split-K atomics
+    # order differently from run to run; measured 1.3e-5 between the arms, 1.0e-5 before)
+    assert err <= 5e-5 * scale and rel_l2 <= 2e-5, (err, scale, rel_l2)
 
 
 def test_host_noise_keeps_the_seeded_sequence_and_val_optim_its_draw_order():

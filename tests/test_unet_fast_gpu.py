@@ -182,6 +182,65 @@ def test_guided_path_stays_on_autograd():
     assert x.grad is not None and torch.isfinite(x.grad).all()
 
 
+def test_guided_step_of_the_cars_unet_runs_no_library_convolution():
+    """r05 (r03 / r04 verdicts, missing #3): ONE input-gradient call of the full cars UNet with frozen weights -- what a guided DDIM step and the prior
+    loss of fine-tuning run -- puts no convolution on the library: the four stride-2 downsampling layers, the 18 -> 128 stem and the 128 -> 18 head go
+    through ``unet._ConvGeneralFn`` (zero-padded channels, the kernel's stride-2 index map forward, a zero-inserted dy backward).  Checked two ways: the
+    module's own fall-back counter, and the profiler's kernel names (no MIOpen / convolution_backward); output and input gradient against the same net with
+    the library convolutions (SSDNERF_UNET_GRAD_CONV=0's path) to the fp32-class tolerance."""
+    from ssdnerf_amd import unet as U
+    net = _bench_unet()
+    net.requires_grad_(False)
+    net.grad_graph = False
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(2, 18, 128, 128, generator=g).cuda()
+    t = torch.tensor([600, 40]).cuda()
+
+    def call():
+        x = x0.clone().requires_grad_(True)
+        y = net(x, t)
+        (gx,) = torch.autograd.grad((y * torch.sin(y.detach())).sum(), x)
+        return y.detach(), gx
+    U._Conv2d.library_calls = 0
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        y, gx = call()
+    names = {e.key for e in prof.key_averages()}
+    assert U._Conv2d.library_calls == 0
+    assert not any(("miopen" in n.lower() or "convolution_backward" in n or n == "aten::conv2d") for n in names), sorted(n for n in names if "conv" in n.lower())
+    saved = U._Conv2d.grad_conv
+    U._Conv2d.grad_conv = False
+    try:
+        y_ref, gx_ref = call()
+    finally:
+        U._Conv2d.grad_conv = saved
+    assert U._Conv2d.library_calls > 0                                      # the reference run did go to the library
+    assert float((y - y_ref).abs().max()) <= 1e-4 * float(y_ref.abs().max())
+    assert float((gx - gx_ref).abs().max()) <= 2e-4 * float(gx_ref.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,stride,hw", [(18, 128, 1, 32), (128, 18, 1, 32), (128, 128, 2, 32), (256, 256, 2, 16), (20, 44, 2, 12)])
+def test_general_gradient_path_convolution_matches_the_library(cin, cout, stride, hw):
+    """``unet._ConvGeneralFn`` alone: forward and input gradient of stride-2 / odd-channel-count layers against torch's convolution in fp64."""
+    from ssdnerf_amd import unet as U
+    g = torch.Generator().manual_seed(cin * 7 + cout + stride)
+    conv = U._Conv2d(cin, cout, 3, stride, 1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (cin * 9) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+    conv.requires_grad_(False)
+    x = torch.randn(2, cin, hw, hw, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(2, cout, hw // stride, hw // stride, generator=g).cuda()
+    assert conv._eligible_general(x) and not conv._eligible(x)
+    y = conv(x)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    xd = x.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, conv.weight.double(), conv.bias.double(), stride, 1)
+    (gxd,) = torch.autograd.grad(yd, xd, gy.double())
+    assert y.shape == yd.shape and gx.shape == gxd.shape
+    assert float((y.double() - yd).abs().max()) <= 3e-5 * float(yd.abs().max())
+    assert float((gx.double() - gxd).abs().max()) <= 3e-5 * float(gxd.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------ implicit-GEMM convolution
 def _conv_ref(x, w, bias, residual, stride, upsample):
     xf = x.float()
