@@ -194,7 +194,10 @@ int ssdnerf_render_rays_fused_batch(const void* planes, int planes_dtype, uint32
  *                 are finished too, the others are appended to a per-scene hit queue inside `workspace`;
  *   shade_queue : persistent waves shade the queued rays (gather + MLP + composite + onward march).
  * Both take the SAME workspace (ssdnerf_render_queue_workspace(S, N, grid_size) bytes, caller-owned) and must be issued
- * in this order on one stream.  Results are bit-identical to ssdnerf_render_rays_fused_batch. */
+ * in this order on one stream.  Results are bit-identical to ssdnerf_render_rays_fused_batch.
+ * r05: first_hit also leaves, per hit-queue entry, a bound of the ray's remaining march steps and -- k_ticket_order -- the order in which the
+ * MFMA shading kernel takes the queue's 64-entry slices (longest first; + 1.06 B per ray of workspace).  The order never enters a ray's result.
+ * Environment SSDNERF_TICKET_ORDER=0 (read per call, by both stages) restores the two-class queue of earlier rounds. */
 size_t ssdnerf_render_queue_workspace(uint32_t S, uint32_t N, uint32_t grid_size);
 int ssdnerf_render_first_hit(const uint8_t* bitfield, uint32_t grid_size, const float* rays_o, const float* rays_d, uint32_t S,
                              uint32_t N, float bound, float min_near, float dt_gamma, const float* dt_gammas, uint32_t max_steps,
