@@ -1170,6 +1170,12 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
       atomicMax(reinterpret_cast<unsigned long long*>(d + 4), ~(unsigned long long)dbg_t0);     // (counters start at zero: keep the complement)
       atomicMax(reinterpret_cast<unsigned long long*>(d + 6), (unsigned long long)t1);
       atomicAdd(reinterpret_cast<unsigned long long*>(d + 8), (unsigned long long)(t1 & 0xffffffffull));
+      // histogram of the waves' own durations in bins of 0.1 ms (words 1..31 of the boundary lines of scenes 1 and 2: 62 bins) and, beside it, of their iteration counts per bin
+      if (c.S >= 5) {
+          const uint32_t bin = min((uint32_t)((t1 - dbg_t0) / 10000ull), 61u);
+          atomicAdd(queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 1 + bin / 31) + 1 + bin % 31, 1u);
+          atomicAdd(queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 3 + bin / 31) + 1 + bin % 31, dbg_iters);
+      }
   }
 #endif
 }

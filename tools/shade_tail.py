@@ -26,3 +26,10 @@ c64 = ws[:4 * ns * 128].view(torch.int64).view(4, ns, 16)[3, 0, :6].tolist()
 t0, tmax, tsum = (~c64[2]) & (2 ** 64 - 1), c64[3], c64[4]
 print("start", t0, "max_end-start (ms)", (tmax - t0) / 1e5, "mean_end-start (ms)", ((tsum / 2048) - (t0 & 0xffffffff)) / 1e5)
 print("boundary", c[0], "sum_iters", c[1], "max_iters", c[2], "mean_iters", c[1] / 2048, "max/mean", c[2] / (c[1] / 2048), "live_lane_frac", c[3] / c[1])
+
+nk = 5
+lines = ws[:nk * ns * 128].view(torch.int32).view(nk, ns, 32)[3]
+hist = lines[1, 1:32].tolist() + lines[2, 1:32].tolist()
+its = lines[3, 1:32].tolist() + lines[4, 1:32].tolist()
+print("waves per 0.1 ms bin of their own duration (mean iterations per wave in the bin):")
+print("  " + "  ".join(f"{0.1 * b:.1f}ms:{n}({its[b] // max(n, 1)})" for b, n in enumerate(hist) if n))
