@@ -130,8 +130,8 @@ def test_executor_refuses_conditioning():
 
 def _conv_f32x2_standin(x, w_hi, w_lo, bias=None, residual=None, stride=1, upsample=False, gn_sums=None, gn_groups=0, tile_hint=0, x2=None, splits_hint=0, splitk_ws=None):
     assert x.is_contiguous(memory_format=torch.channels_last) and w_hi.dtype == torch.bfloat16 and w_hi.is_contiguous(memory_format=torch.channels_last)
-    assert stride == 1 and not upsample and x2 is None
-    y = F.conv2d(x, w_hi.float() + w_lo.float(), bias, padding=w_hi.shape[-1] // 2)
+    assert stride in (1, 2) and not upsample and x2 is None and x.size(1) % 8 == 0 and w_hi.size(0) % 8 == 0      # (r05: stride 2 and zero-padded channel counts reach the kernel too)
+    y = F.conv2d(x, w_hi.float() + w_lo.float(), bias, stride=stride, padding=w_hi.shape[-1] // 2)
     if residual is not None:
         assert residual.is_contiguous(memory_format=torch.channels_last)
         y = y + residual
@@ -166,13 +166,16 @@ def test_input_gradient_convs_use_the_same_kernel_forward_and_backward(monkeypat
     net.requires_grad_(False)
     y_ref, g_ref = grad_of(x0)                                            # CPU tensors: every conv is nn.Conv2d's own forward
     calls = []
+    unet._Conv2d.library_calls = 0
     monkeypatch.setattr(unet, "_device_ok", lambda x: True)
     monkeypatch.setattr(unet, "GRAD_GN", False)                     # this test is about the convolutions only (the fused norms have their own below)
     monkeypatch.setattr(unet, "GRAD_ATT", False)
     monkeypatch.setattr(unet_fast, "conv2d_nhwc_f32x2", lambda *a, **k: (calls.append(a[1].shape), _conv_f32x2_standin(*a, **k))[1])
     y, gx = grad_of(x0)
-    n_fwd = sum(1 for m in net.modules() if isinstance(m, unet._Conv2d) and m.in_channels % 8 == 0 and m.out_channels % 8 == 0)
-    assert n_fwd >= 8 and len(calls) == 2 * n_fwd                         # each eligible conv: one forward launch + one backward-data launch
+    n_fwd = sum(1 for m in net.modules() if isinstance(m, unet._Conv2d))    # r05: EVERY convolution -- the 6 -> 64 stem, the 64 -> 6 head and the stride-2 layer through
+    n_general = sum(1 for m in net.modules() if isinstance(m, unet._Conv2d) and (m.stride != (1, 1) or m.in_channels % 8 or m.out_channels % 8))
+    assert n_general == 3 and unet._Conv2d.library_calls == 0               # `_ConvGeneralFn` (zero-padded channels, zero-inserted dy), the others through `_ConvF32x2Fn`
+    assert n_fwd >= 11 and len(calls) == 2 * n_fwd                        # each convolution: one forward launch + one backward-data launch
     assert torch.allclose(y, y_ref, atol=1e-4, rtol=1e-4), (y - y_ref).abs().max()
     assert float((gx - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
     # weights that need their own gradient, autocast, and no-grad inputs all stay on the library path
