@@ -55,6 +55,20 @@ class _PinnedRing:
         ring["events"][i] = ev
         return out
 
+    @classmethod
+    def release(cls) -> None:
+        """give the pinned buffers back (r04 advisor: up to 8 shapes x 2 buffers stayed pinned for the life of the process); in-flight uploads are waited for"""
+        for ring in cls.rings.values():
+            for ev in ring["events"]:
+                if ev is not None:
+                    ev.synchronize()
+        cls.rings.clear()
+
+
+def release_pinned_buffers() -> None:
+    """free the pinned host staging buffers of the seeded host draws (``_host_noise``); they are re-created on demand"""
+    _PinnedRing.release()
+
 
 def _host_noise(like: torch.Tensor) -> torch.Tensor:
     """Fresh N(0, 1) drawn with the CPU generator and moved to the latent's device: seeding the host generator reproduces a trajectory on

@@ -554,9 +554,18 @@ class DiffusionNeRF(MultiSceneNeRF):
                 sch = self.build_scheduler(opt, cfg)
                 inner_cfg = dict(cfg, n_inverse_steps=extra + 1)
                 from .diffusion import _host_noise
-                next_noise = None
+                next_noise, rng_after_prefetch, prefetch_ok = None, None, True
                 for k in range(n_outer):
                     opt.zero_grad()
+                    # (r04 advisor) the prefetch keeps the reference's order of host draws only while nothing else draws from torch's CPU generator between the
+                    # prefetch and this point -- true of this library (march jitter: device draws; timesteps: numpy), not of an arbitrary hook or decoder: the
+                    # generator's state is compared, and a foreign draw switches the prefetch off for the rest of the loop, with a warning
+                    if rng_after_prefetch is not None and not torch.equal(torch.get_rng_state(), rng_after_prefetch):
+                        import warnings
+                        warnings.warn("val_optim: something drew from torch's CPU generator between the prior-loss noise of this iteration (drawn one iteration "
+                                      "early, under queued device work) and its use: the seeded sequence differs from drawing it here.  Prefetch switched off.")
+                        prefetch_ok = False
+                    rng_after_prefetch = None
                     # the prior loss's noise is a HOST draw (the reference's, seed-reproducible on any device; 4.8 ms for 8 cars latents): iteration k + 1's
                     # is drawn right behind iteration k's UNet launches, while the device works through them -- same generator, same order of draws (nothing
                     # else in this loop draws on the host)
@@ -566,8 +575,9 @@ class DiffusionNeRF(MultiSceneNeRF):
                         prior, _ = diffusion(x0_in, return_loss=True, concat_cond=None, x_t_detach=cfg.get("x_t_detach", False), cfg=cfg,
                                              timesteps=None if prior_timesteps is None else prior_timesteps[k], noise=noise_k, **kwargs)
                     prior.backward()
-                    if prior_noises is None and k + 1 < n_outer:
+                    if prior_noises is None and k + 1 < n_outer and prefetch_ok:
                         next_noise = _host_noise(x0_in.detach())
+                        rng_after_prefetch = torch.get_rng_state()
                     if extra > 0:
                         self.inverse_code(decoder, cond.images, cond.rays_o, cond.rays_d, dt_gamma=cond.dt_gamma, cfg=inner_cfg, code_=code_,
                                           density_grid=density_grid, density_bitfield=density_bitfield, code_optimizer=opt, code_scheduler=sch,
