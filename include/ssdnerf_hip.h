@@ -76,7 +76,8 @@ int ssdnerf_march_rays_train(const float* rays_o, const float* rays_d, const uin
 
 /* replaces composite_rays_train_forward / _backward (raymarching.h:14-15; raymarching.cu:502-698).
  * forward writes weights_sum/depth [N], image [N,3] at index rays[n,0]; backward writes grad_sigmas [M],
- * grad_rgbs [M,3] (caller zero-initialises, as the reference's Python does); grad wrt depth is not propagated. */
+ * grad_rgbs [M,3] (caller zero-initialises, as the reference's Python does); grad wrt depth is not propagated.
+ * M == 0 (no ray of the batch took a sample): the sample arrays may be null; forward still writes the N per-ray zeros, backward is a no-op. */
 int ssdnerf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                          uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth,
                                          float* image, void* stream);

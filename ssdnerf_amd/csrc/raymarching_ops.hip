@@ -438,7 +438,9 @@ extern "C" int ssdnerf_composite_rays_train_forward(const float* sigmas, const f
                                                     uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth, float* image,
                                                     void* stream) {
     if (N == 0) return SSDNERF_OK;  // empty input: nothing to do (pointers may be null)
-    SSD_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
+    // M == 0 (no ray of the batch found an occupied cell: an empty scene, e.g. the first fitting iterations from a blank code): the sample arrays are
+    // empty -- null -- and never dereferenced (every ray record says zero steps); the per-ray outputs are still written (zeros), as the reference's launch does
+    SSD_REQUIRE((M == 0 || (sigmas && rgbs && deltas)) && rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
     hipLaunchKernelGGL(k_composite_train_fwd, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, M, N, T_thresh,
                        weights_sum, depth, image);
     SSD_CHECK_LAUNCH("composite_rays_train_forward");
@@ -447,9 +449,9 @@ extern "C" int ssdnerf_composite_rays_train_forward(const float* sigmas, const f
 extern "C" int ssdnerf_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas, const float* rgbs,
                                                      const float* deltas, const int32_t* rays, const float* weights_sum, const float* image,
                                                      uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas, float* grad_rgbs, void* stream) {
+    if (N == 0 || M == 0) return SSDNERF_OK;          // no samples: no gradient to write (empty arrays may be null)
     SSD_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs,
                 "composite_rays_train_backward: null pointer");
-    if (N == 0) return SSDNERF_OK;
     hipLaunchKernelGGL(k_composite_train_bwd, dim3(ssd_blocks(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, grad_weights_sum, grad_image, sigmas, rgbs,
                        deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
     SSD_CHECK_LAUNCH("composite_rays_train_backward");

@@ -150,6 +150,21 @@ def test_composite_train_fwd_bwd(orc, rm):
         np.testing.assert_allclose(bw[i].cpu().numpy(), ref[i][0], rtol=0, atol=2e-6)
 
 
+def test_composite_train_on_an_empty_scene(rm):
+    """r05: a batch in which no ray found an occupied cell -- an empty scene, e.g. the first fitting iterations from a blank code -- has M == 0 samples: the sample
+    arrays are empty (null data pointers).  The reference's launch writes zeros for every ray and its backward writes nothing; the C ABI refused the null
+    pointers (``val_optim`` from a blank code on the synthetic decoder died in ``composite_rays_train_forward``)."""
+    n = 1000
+    rays = torch.zeros(n, 3, dtype=torch.int32, device="cuda")
+    rays[:, 0] = torch.arange(n, device="cuda")                            # (index, offset 0, 0 steps) records
+    sig = torch.zeros(0, device="cuda", requires_grad=True)
+    rgb = torch.zeros(0, 3, device="cuda", requires_grad=True)
+    ws, dep, img = rm.composite_rays_train(sig, rgb, torch.zeros(0, 2, device="cuda"), rays, 1e-4)
+    assert ws.shape == (n,) and img.shape == (n, 3) and float(ws.abs().max()) == 0 and float(img.abs().max()) == 0 and float(dep.abs().max()) == 0
+    (ws.sum() + img.sum()).backward()
+    assert sig.grad is not None and sig.grad.shape == (0,) and rgb.grad.shape == (0, 3)
+
+
 @pytest.mark.parametrize("n_step,dt_gamma", [(1, 0.0), (4, 0.0038095), (8, 0.0)])
 def test_march_and_composite_inference(orc, rm, n_step, dt_gamma):
     rng = np.random.default_rng(5)
