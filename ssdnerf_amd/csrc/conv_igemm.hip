@@ -53,7 +53,60 @@ struct ConvArgs {
     uint32_t ksize, stride, pad, upsample;
     uint32_t G;                  // GroupNorm groups of the output (for gn_sums)
     uint32_t m_tiles, n_tiles;
+    uint32_t* tickets;           // r05, split-K fold: one arrival counter per output tile (all zero on entry, left all zero), or null: the finishing pass is a kernel of its own
 };
+
+// Split-K fold (r05).  A split layer's blocks add their partial sums to the fp32 scratch; until r04 a second kernel (k_conv_splitk_finish / k_conv_f32_finish: 45 launches
+// per UNet forward, 0.2 - 0.3 ms of a 4.3 / 8.3 ms step) read the sums back, added bias / residual, took the GroupNorm statistics and wrote the output.  With
+// `tickets`, the block that ARRIVES LAST at a tile does that itself: every block fences its atomics and takes a ticket; the holder of the last one reads the tile's sums
+// back into its accumulators with agent-scope loads (the other blocks' atomics were performed at the memory side; a plain load could hit a stale line of this XCD's L2),
+// zeroes scratch and ticket, and runs the kernel's ordinary epilogue.  Same sums (the order of the fp32 atomics was already arbitrary), one launch less per layer.
+// Host side: cv_fold_tickets() -- needs the scratch (not the output) as accumulator, room for the tickets behind it, and, for the epilogue's statistics, tiles inside one sample.
+constexpr size_t CV_TICKET_BYTES = 16384;
+static uint32_t* cv_fold_tickets(const ConvArgs& a, void* splitk_ws, size_t splitk_ws_bytes, uint32_t bm, bool want_stats) {
+    // OFF unless SSDNERF_CONV_FOLD=1 (r05, measured on the cars UNet at 8 scenes: fp32 step 8.13 -> 8.87 ms, bf16 4.24 -> 4.50 ms WITH the fold): the finishing
+    // kernel spreads a layer's epilogue over the whole chip, the fold leaves it to the one block per tile that arrives last -- 64 uncached loads per lane in series
+    // with that tile's tail -- and these layers are latency-bound already.  Kept as an opt-in; results equal the finishing pass's (tests/test_unet_fast_gpu.py run with it).
+    static const bool on = getenv("SSDNERF_CONV_FOLD") != nullptr;
+    if (!on || a.splits <= 1 || splitk_ws == nullptr || (void*)a.splitk_ws != splitk_ws) return nullptr;
+    if (splitk_ws_bytes < (size_t)a.M * a.Cout * 4 + CV_TICKET_BYTES || (size_t)a.m_tiles * a.n_tiles * 4 > CV_TICKET_BYTES) return nullptr;
+    if (want_stats && (a.Ho * a.Wo) % bm != 0) return nullptr;
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(splitk_ws) + splitk_ws_bytes - CV_TICKET_BYTES);
+}
+// device side, behind a block's atomics: true for the block that arrived last -- its accumulators then hold the tile's complete sums and scratch / ticket are zero again
+template <int TM, int TN>
+SSD_DEV bool cv_fold_last(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* ws, uint32_t* flag_lds, uint32_t tile, uint32_t m0, uint32_t n0, uint32_t row_off, uint32_t col_off, bool PT) {
+    // this block's atomics are acknowledged before its ticket is taken: `s_waitcnt vmcnt(0)` per wave (a workgroup-scope release), then the barrier.  NOT
+    // __threadfence(): an agent-scope release writes the L2's dirty lines back (buffer_wbl2) -- measured: the UNet step 8.1 -> 11.5 ms with it.  The float atomics
+    // and the ticket are device-scope read-modify-writes resolved at one coherence point; the sums are read back with agent-scope loads that bypass this XCD's L2.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) *flag_lds = atomicAdd(a.tickets + tile, 1u);
+    __syncthreads();
+    const bool last = *flag_lds == a.splits - 1;
+    __syncthreads();                                                         // (the flag's word belongs to the epilogue's scratch)
+    if (!last) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t m = m0 + row_off + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const uint32_t col = n0 + col_off + j * 32 + (lane & 31);
+                float v = 0.f;
+                if (m < a.M && (!PT || col < a.Cout)) {
+                    float* p = ws + (size_t)m * a.Cout + col;
+                    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *p = 0.f;
+                }
+                acc[i][j][e] = v;
+            }
+    if (threadIdx.x == 0) a.tickets[tile] = 0u;
+    return true;
+}
 
 constexpr int CV_BK = 64;                  // bf16 elements per K-tile = 128 bytes per tile row
 constexpr int CV_ROWB = CV_BK * 2;
@@ -484,7 +537,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_bf16(const ConvArgs
                     const uint32_t col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
                     if (m < a.M && (!PT || col < a.Cout)) unsafeAtomicAdd(a.splitk_ws + (size_t)m * a.Cout + col, acc[i][j][e]);
                 }
-        return;
+        if (a.tickets == nullptr) return;
+        if (!cv_fold_last<TM, TN>(a, acc, a.splitk_ws, reinterpret_cast<uint32_t*>(lds + LDS_BYTES - 4), tile, m0, n0, wm * 32 * TM, wn * 32 * TN, PT)) return;
     }
 
     if constexpr (PS) cv_epilogue_f32<TM, TN, false>(a, acc, lds, m0, n0);
@@ -884,7 +938,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm_f32x2(const ConvArgs a, cons
                     const uint32_t col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
                     if (m < a.M && (!PT || col < a.Cout)) unsafeAtomicAdd(yo + (size_t)m * a.Cout + col, acc[i][j][e]);
                 }
-        return;
+        if (a.tickets == nullptr) return;
+        if (!cv_fold_last<TM, TN>(a, acc, yo, reinterpret_cast<uint32_t*>(lds + LDS_BYTES - 4), tile, m0, n0, wm * 32 * TM, wn * 32 * TN, PT)) return;
     }
 
     cv_epilogue_f32<TM, TN, PT>(a, acc, lds, m0, n0);
@@ -1657,6 +1712,7 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
     SSD_REQUIRE((uint64_t)Cout * ksize * ksize * Cin * 2 < (1ull << 31), "conv2d_nhwc_f32x2: weight tensor too large");
     SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0), "conv2d_nhwc_f32x2: fused GroupNorm statistics need groups of a multiple of 4 channels");
     ConvArgs a;
+    a.tickets = nullptr;
     a.x2 = (const unsigned char*)x2; a.Cin1 = Cin1;
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w_hi; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
     a.gn_sums = (double*)gn_sums; a.G = gn_groups ? gn_groups : 1;
@@ -1676,8 +1732,11 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
     SSD_REQUIRE(!gn_sums || splits > 1 || (a.Ho * a.Wo) % bm == 0, "conv2d_nhwc_f32x2: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
     hipStream_t st = (hipStream_t)stream;
     double* stats = a.gn_sums;
+    a.tickets = nullptr;
+    a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = (Cout + bm - 1) / bm;
     if (splits > 1) {
-        a.gn_sums = nullptr;
+        a.tickets = cv_fold_tickets(a, splitk_ws, splitk_ws_bytes, bm, stats != nullptr);
+        if (!a.tickets) a.gn_sums = nullptr;                                 // (folded: the last block's epilogue takes the statistics)
         if (!a.splitk_ws && !y_is_zero && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2: memset failed");
     } else {
         a.splitk_ws = nullptr;
@@ -1723,7 +1782,7 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2(const void* x, const void* x2, uint32_t
         else if (partial) hipLaunchKernelGGL((k_conv_igemm_f32x2<1, 1, true>), grid, dim3(256), 0, st, a, (const unsigned char*)w_lo);
         else hipLaunchKernelGGL((k_conv_igemm_f32x2<1, 1, false>), grid, dim3(256), 0, st, a, (const unsigned char*)w_lo);
     }
-    if (splits > 1) {
+    if (splits > 1 && !a.tickets) {
         const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
         uint32_t rows = HWo;
         while (rows > rstep && rows % 2 == 0 && (uint64_t)B * (HWo / rows) < 1024) rows /= 2;
@@ -1786,13 +1845,14 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const voi
     SSD_REQUIRE(!gn_sums || (gn_groups > 0 && Cout % gn_groups == 0 && (Cout / gn_groups) % 4 == 0), "conv2d_nhwc_f32x2_presplit: fused GroupNorm statistics need groups of a multiple of 4 channels");
     hipStream_t st = (hipStream_t)stream;
     ConvArgs a;
+    a.tickets = nullptr;
     a.x2 = nullptr; a.Cin1 = Cin;
     a.x = (const unsigned char*)x_split; a.w = (const unsigned char*)w_hi; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
     a.gn_sums = (double*)gn_sums; a.G = gn_groups ? gn_groups : 1;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.ksize = ksize; a.stride = 1; a.pad = ksize / 2; a.upsample = 0;
     a.Ho = H; a.Wo = W; a.M = B * H * W;
-    a.splits = 1; a.splitk_ws = nullptr;
+    a.splits = 1; a.splitk_ws = nullptr; a.tickets = nullptr;
     if (kind == 2) {
         const int plan = cv_ps_plan(a.M, Cin, Cout, ksize, tile_hint, splits_hint);
         const int choice = plan & 0xff;
@@ -1803,15 +1863,16 @@ extern "C" int ssdnerf_conv2d_nhwc_f32x2_presplit(const void* x_split, const voi
         float* ws = (splitk_ws && splitk_ws_bytes >= (size_t)a.M * Cout * 4) ? (float*)splitk_ws : nullptr;
         double* stats = a.gn_sums;
         if (a.splits > 1) {
-            a.gn_sums = nullptr;
             if (!ws && hipMemsetAsync(y, 0, (size_t)a.M * Cout * 4, st) != hipSuccess) return ssdnerf_fail(SSDNERF_E_LAUNCH, "conv2d_nhwc_f32x2_presplit: memset failed");
             a.splitk_ws = ws ? ws : (float*)y;
+            a.tickets = cv_fold_tickets(a, splitk_ws, splitk_ws_bytes, bm, stats != nullptr);
+            if (!a.tickets) a.gn_sums = nullptr;
         }
         const dim3 grid(a.m_tiles * a.n_tiles * a.splits);
         if (choice == 1) hipLaunchKernelGGL((k_conv_igemm_bf16<2, 2, 2, 2, 2, false, true>), grid, dim3(256), 0, st, a);
         else if (choice == 2) hipLaunchKernelGGL((k_conv_igemm_bf16<1, 2, 2, 2, 3, false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_conv_igemm_bf16<1, 1, 2, 2, CV_NS_SMALL, false, true>), grid, dim3(256), 0, st, a);
-        if (a.splits > 1) {
+        if (a.splits > 1 && !a.tickets) {
             const uint32_t HWo = H * W, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
             uint32_t rows = HWo;
             while (rows > rstep && rows % 2 == 0 && (uint64_t)B * (HWo / rows) < 1024) rows /= 2;
@@ -1854,6 +1915,7 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     SSD_REQUIRE((uint64_t)Cout * ksize * ksize * Cin * 2 < (1ull << 31), "conv2d_nhwc_bf16: weight tensor too large");
     const bool c64 = Cin % 64 == 0 && Cin1 % 64 == 0;                         // what the row-reuse and two-group kernels take
     ConvArgs a;
+    a.tickets = nullptr;
     a.x2 = (const unsigned char*)x2; a.Cin1 = Cin1;
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w; a.bias = bias; a.res = (const unsigned char*)residual; a.y = (unsigned char*)y;
     a.gn_sums = (double*)gn_sums; a.G = gn_groups ? gn_groups : 1;
@@ -1902,14 +1964,20 @@ extern "C" int ssdnerf_conv2d_nhwc_bf16(const void* x, const void* x2, uint32_t 
     SSD_REQUIRE(!gn_sums || splits > 1 || (a.Ho * a.Wo) % (choice == 4 ? 256 : choice == 1 ? 128 : 64) == 0, "conv2d_nhwc_bf16: fused GroupNorm statistics need Ho*Wo to be a multiple of the M tile");
     a.splits = splits; a.splitk_ws = (float*)splitk_ws;
     double* stats = a.gn_sums;
-    if (splits > 1) a.gn_sums = nullptr;                                     // a split layer's statistics are taken by the finishing pass
+    a.tickets = nullptr;
+    if (splits > 1) {
+        const uint32_t bm = choice == 4 ? 256 : choice == 1 ? 128 : 64, bn = choice == 3 ? 64 : 128;
+        a.m_tiles = (a.M + bm - 1) / bm; a.n_tiles = (Cout + bn - 1) / bn;     // (what cv_launch sets; the fold needs the tile count now)
+        a.tickets = cv_fold_tickets(a, splitk_ws, splitk_ws_bytes, bm, stats != nullptr);
+        if (!a.tickets) a.gn_sums = nullptr;                                 // a split layer's statistics are taken by the finishing pass, or -- folded -- by the last block's epilogue
+    }
     static const bool rows_ok = getenv("SSDNERF_CONV_NO_ROW_REUSE") == nullptr;
     const bool rows = rows_ok && c64 && choice == 1 && splits == 1 && ksize == 3 && stride == 1 && !upsample && (W == 128 || W == 64 || W == 32) && (H * W) % 128 == 0;
     if (rows) {
         a.m_tiles = (a.M + 127) / 128; a.n_tiles = Cout / 128;
         hipLaunchKernelGGL(k_conv3x3_bf16_rows, dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
     } else if (choice == 4) cv_launch<2, 2, 4, 2, 3>(a, st); else if (choice == 1) cv_launch<2, 2, 2, 2, 2>(a, st); else if (choice == 2) cv_launch<1, 2, 2, 2, 3>(a, st); else cv_launch<1, 1, 2, 2, CV_NS_SMALL>(a, st);
-    if (splits > 1) {
+    if (splits > 1 && !a.tickets) {
         const uint32_t HWo = a.Ho * a.Wo, cpr = Cout / 8, rstep = 256 / cpr ? 256 / cpr : 1;
         uint32_t rows = HWo;                                                 // rows per block: >= one pass of the rows in flight, ~1024 blocks
         while (rows > rstep && rows % 2 == 0 && (uint64_t)B * (HWo / rows) < 1024) rows /= 2;
