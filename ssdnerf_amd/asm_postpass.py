@@ -140,6 +140,13 @@ def _history(pendings: List[Dict[int, int]]) -> List[list]:
     return run
 
 
+#: Bisect aid (tools/hazard_bisect.py, r05): (kernel name substring, first site, last site + 1, wait states inside the range).  A "site" is a reader that the
+#: pass would pad at `inside` wait states, counted in listing order inside the named kernel; sites in the range get `inside`, every other pair the build's own
+#: distance.  None in product builds.
+SITE_FILTER = None
+SITE_COUNT: Dict[str, int] = {}                 # sites seen per kernel by the last filtered walk (the bisect's upper bound)
+
+
 def _walk(listing: str, wait_states: int, edit: bool):
     """one walk over the kernels of a listing, control flow included: a block that is entered by a branch (loop back-edges too) or by fall-through
     starts with the transcendental results its predecessors may have left in flight.  edit=False: only measure (returns the closest pair)."""
@@ -193,12 +200,14 @@ def _walk(listing: str, wait_states: int, edit: bool):
     stats = dict(trans_instructions=0, pairs_closer_than_required=0, lengthened_in_place=0, inserted=0)
     closest = 1 << 30
     in_kernel = False
+    site, kernel_name = 0, ""
     for raw in lines:
         t = raw.strip()
         if t.startswith((".amdhsa_kernel", ".end_amdhsa_kernel")):
             in_kernel = False
         elif re.match(r"^[\w$.]+:\s*(;.*)?$", t) and not t.startswith(".L"):
             in_kernel, run = True, entry_state(t)               # a device FUNCTION's caller may have left anything in flight; a kernel starts clean
+            kernel_name, site = t.split(":")[0], 0
             out.append(raw)
             continue
         if not in_kernel:
@@ -225,6 +234,7 @@ def _walk(listing: str, wait_states: int, edit: bool):
         if reads and op.startswith("v_"):
             d = 0
             pending = set(reads)
+            need_inside = 0
             for prev in reversed(run):
                 if d >= max(wait_states, 16) or not pending:
                     break
@@ -233,8 +243,15 @@ def _walk(listing: str, wait_states: int, edit: bool):
                     if prev[0].startswith(TRANS):
                         closest = min(closest, d)
                         need = max(need, wait_states - d)
+                        if SITE_FILTER is not None:
+                            need_inside = max(need_inside, SITE_FILTER[3] - d)
                     pending -= hit                              # the nearest writer decides
                 d += prev[3]
+            if SITE_FILTER is not None and edit and SITE_FILTER[0] in kernel_name and need_inside > 0:
+                if SITE_FILTER[1] <= site < SITE_FILTER[2]:
+                    need = max(need, need_inside)
+                site += 1
+                SITE_COUNT[kernel_name] = site
         if need > 0 and edit:
             stats["pairs_closer_than_required"] += 1
             if run and run[-1][0] == "s_nop" and run[-1][4] >= 0 and run[-1][3] + need <= 8:
