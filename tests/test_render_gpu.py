@@ -277,6 +277,31 @@ def test_ticket_order_changes_nothing(scene, decoder, dt_gamma, monkeypatch):
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
 
 
+@pytest.mark.parametrize("n_rays", [1, 63, 64, 65, 5001])
+def test_ticket_order_on_ragged_ray_counts(scene, decoder, n_rays, monkeypatch):
+    """The ticket order's bookkeeping on ray counts that are not multiples of its 64-entry slices (key stride rounded up, a partial last slice, fewer hits than one
+    slice, a single ray): ray-array renders of the first ``n_rays`` rays of a view that looks at the object, bit-identical with the order switched off."""
+    ro, rd = _view(64)
+    centre = 128 * 64 + 40                                                     # start inside the object's silhouette so that small counts hit something
+    o = torch.from_numpy(ro[centre:centre + n_rays] if n_rays < 5000 else ro[:n_rays]).cuda()[None].contiguous()
+    d = torch.from_numpy(rd[centre:centre + n_rays] if n_rays < 5000 else rd[:n_rays]).cuda()[None].contiguous()
+    from ssdnerf_amd.decoders import pack_triplanes
+    planes = pack_triplanes(scene["code"].cuda()[None])
+    bits = torch.from_numpy(scene["bits"]).cuda()[None]
+
+    def render():
+        with torch.no_grad():
+            out = decoder.render_packed(planes, o, d, bits, [64], [0.0], 1e-4, bg_color=1.0, want_counts=True)
+        return [out["image"][0].cpu().numpy(), out["depth"][0].cpu().numpy(), decoder.last_render_stats["sample_counts"][0].cpu().numpy()]
+    a = render()
+    monkeypatch.setenv("SSDNERF_TICKET_ORDER", "0")
+    b = render()
+    monkeypatch.delenv("SSDNERF_TICKET_ORDER")
+    assert a[2].shape == (n_rays,) and (n_rays < 64 or int(a[2].sum()) > 0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+
+
 @pytest.mark.parametrize("view,dt_gamma", [(64, 0.0), (17, 0.0038095), (230, 0.0)])
 def test_coarse_empty_space_pretest_changes_nothing(scene, decoder, view, dt_gamma, monkeypatch):
     """k_ray_cull's conservative coarse-occupancy pre-test (and the view-level tile masks) only removes marches that cannot find a sample: every output, including the
