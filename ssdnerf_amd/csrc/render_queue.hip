@@ -274,7 +274,18 @@ struct CullGrid { uint32_t group; uint32_t views_cap; uint32_t zr_cap; int32_t t
                                                // per ray.  Bit-identical, 3 store instructions instead of 8 -- and NOT faster: stage A 0.799 / 0.807 ms without, 0.812 / 0.817
                                                // with (two interleaved pairs on one box, profiles/r05/y_cull_wave_fill_ab.txt): the L2 merges the 4-byte pieces already
 #endif
-static constexpr unsigned RQ_CHUNKS = 8;       // 256-ray chunks per block: the block stages its list in LDS and reserves global slots ONCE
+#ifndef RQ_CULL_CHUNKS
+#define RQ_CULL_CHUNKS 8
+#endif
+#ifndef RQ_MARCH_CHUNKS
+#define RQ_MARCH_CHUNKS 1
+#endif
+static constexpr unsigned RQ_CHUNKS = RQ_CULL_CHUNKS;        // 256-ray chunks per block of k_ray_cull: the block stages its list in LDS and reserves global slots ONCE
+static constexpr unsigned RQ_MCHUNKS = RQ_MARCH_CHUNKS;      // ... and of k_survivor_march
+#ifndef RQ_MARCH_TPB
+#define RQ_MARCH_TPB 256
+#endif
+static constexpr unsigned RQ_MTPB = RQ_MARCH_TPB;            // threads per block of k_survivor_march
 
 // Appends `item` of every lane with `take` to the block's LDS list (one LDS atomic per wave).
 template <typename T>
@@ -476,7 +487,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
 // step 0.17 ms SLOWER, 6.62 against 6.45 ms on one box: the probes are L1 / L2 hits and eight waves per SIMD hide them better than three with
 // LDS-latency probes.)
 template <bool DTG0>
-__global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc src, const uint8_t* __restrict__ lin_bits,
+__global__ void __launch_bounds__(RQ_MTPB) k_survivor_march(QueueCfg c, RaySrc src, const uint8_t* __restrict__ lin_bits,
                                                             const uint64_t* __restrict__ blocks64 /* k_bitfield_blocks64 or null */,
                                                             const uint2* __restrict__ survivors, float* __restrict__ image,
                                                             float* __restrict__ depth, float* __restrict__ weights_sum,
@@ -484,9 +495,9 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
                                                             uint32_t* __restrict__ counters, uint8_t* __restrict__ qkey /* or null */, uint32_t key_stride) {
     const uint32_t scene = blockIdx.y;
     const uint32_t count = counters[ssd_counter(SSD_CNT_SURVIVORS, c.S, scene)];
-    if (blockIdx.x * (RQ_CHUNKS * RQ_TPB) >= count) return;                  // the grid covers the worst case (every ray survives)
-    __shared__ uint2 list[RQ_CHUNKS * RQ_TPB];                                // long rays from the front, short rays from the back
-    __shared__ uint8_t keys[RQ_CHUNKS * RQ_TPB];                              // (ticket order) per list entry: upper bound of the remaining march steps
+    if (blockIdx.x * (RQ_MCHUNKS * RQ_MTPB) >= count) return;                  // the grid covers the worst case (every ray survives)
+    __shared__ uint2 list[RQ_MCHUNKS * RQ_MTPB];                                // long rays from the front, short rays from the back
+    __shared__ uint8_t keys[RQ_MCHUNKS * RQ_MTPB];                              // (ticket order) per list entry: upper bound of the remaining march steps
     __shared__ uint32_t list_count, short_count, slot, slot_short;
     if (threadIdx.x == 0) { list_count = 0; short_count = 0; }
     __syncthreads();
@@ -497,8 +508,8 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
     if (c.dt_gammas) c.m.dt_gamma = c.dt_gammas[scene];
     const bool packing = c.N <= SSD_RAY_ID_MASK + 1u;
 #pragma unroll 1
-    for (uint32_t chunk = 0; chunk < RQ_CHUNKS; ++chunk) {
-        const uint32_t i = (blockIdx.x * RQ_CHUNKS + chunk) * RQ_TPB + threadIdx.x;
+    for (uint32_t chunk = 0; chunk < RQ_MCHUNKS; ++chunk) {
+        const uint32_t i = (blockIdx.x * RQ_MCHUNKS + chunk) * RQ_MTPB + threadIdx.x;
         bool hit = false;
         uint32_t e = 0;
         float t = 0.f, far_b = 0.f;
@@ -596,7 +607,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
                 if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) base = atomicAdd(&short_count, (uint32_t)__popcll(m));
                 base = __shfl(base, __builtin_ctzll(m), 64);
                 if (hit && !is_long)
-                    list[RQ_CHUNKS * RQ_TPB - 1u - (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))] =
+                    list[RQ_MCHUNKS * RQ_MTPB - 1u - (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))] =
                         make_uint2(e, __float_as_uint(t));
             }
         }
@@ -616,7 +627,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_survivor_march(QueueCfg c, RaySrc sr
     for (uint32_t i = threadIdx.x; i < n_long; i += blockDim.x) q[slot + i] = list[i];
     if (qkey != nullptr)
         for (uint32_t i = threadIdx.x; i < n_long; i += blockDim.x) qkey[(uint64_t)scene * key_stride + slot + i] = keys[i];
-    for (uint32_t i = threadIdx.x; i < n_short; i += blockDim.x) q[c.N - 1u - (slot_short + i)] = list[RQ_CHUNKS * RQ_TPB - 1u - i];
+    for (uint32_t i = threadIdx.x; i < n_short; i += blockDim.x) q[c.N - 1u - (slot_short + i)] = list[RQ_MCHUNKS * RQ_MTPB - 1u - i];
 }
 
 // The short-ray entries sit at [N - n_short, N); the final queue is [0, n_long + n_short).  Entries beyond that range move into the holes
@@ -911,10 +922,10 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     const bool ticket_order = !(to_env && to_env[0] == '0');        // and the same way by the shading launch (shade_mfma.hip, sm_shade)
     uint8_t* qkey = ticket_order ? w.qkey : nullptr;
     if (dt_gammas == nullptr && dt_gamma == 0.0f)
-        hipLaunchKernelGGL(k_survivor_march<true>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, blocks64, w.survivors, image, depth, weights_sum,
+        hipLaunchKernelGGL(k_survivor_march<true>, dim3(ssd_blocks(N, RQ_MTPB * RQ_MCHUNKS), S), dim3(RQ_MTPB), 0, s, c, src, w.lin_bits, blocks64, w.survivors, image, depth, weights_sum,
                            sample_counts, w.queue, w.counters, qkey, w.key_stride);
     else
-        hipLaunchKernelGGL(k_survivor_march<false>, dim3(ssd_blocks(N, RQ_TPB * RQ_CHUNKS), S), dim3(RQ_TPB), 0, s, c, src, w.lin_bits, blocks64, w.survivors, image, depth, weights_sum,
+        hipLaunchKernelGGL(k_survivor_march<false>, dim3(ssd_blocks(N, RQ_MTPB * RQ_MCHUNKS), S), dim3(RQ_MTPB), 0, s, c, src, w.lin_bits, blocks64, w.survivors, image, depth, weights_sum,
                            sample_counts, w.queue, w.counters, qkey, w.key_stride);
     if (ticket_order) {
         hipLaunchKernelGGL(k_ticket_order, dim3(S), dim3(1024), 0, s, S, (const uint8_t*)w.qkey, w.key_stride, w.counters, w.order, w.order_stride);
