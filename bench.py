@@ -759,22 +759,41 @@ def recons_full_batch(model, dev, ns, data, g, log, timed, config5=False, n_test
         psnr_cond = psnr(pred[:, 64], cond) if cond is not None and n_test_views > 64 else None
         # (b) the same batch, same seeds, through the REFERENCE-SHAPED arithmetic once, untimed: fp32, no autocast, fp32 planes, the eager modules
         # (no captured graphs, no inference executor) -- what the fast path has to agree with.  `parity` is false below 35 dB.
+        # r05 (last): the reference run also leaves this repository's UNet / decode-gradient KERNELS -- its convolutions, GroupNorm and attention go through
+        # PyTorch's library operators in IEEE fp32 (MIOpen / native kernels, forward and backward by autograd), the triplane decode's gradient through autograd
+        # over the reference-shaped decode -- so the two runs share the ray march / compositing operators (pinned bit for bit elsewhere) and nothing else.
         unet = model.diffusion_ema.denoising
+        from ssdnerf_amd import unet as U
+        dec_cls = type(model.decoder_ema)
         saved_fast = (getattr(unet, "fast_inference", None), getattr(unet, "grad_graph", None), model.autocast_dtype, model.decoder_ema.plane_dtype)
+        saved_lib = (U._Conv2d.grad_conv, U.GRAD_ATT_KERNEL, U.GRAD_ATT_POINTWISE, U.GRAD_GN, U.GRAD_ATT, dec_cls.fused_code_grad)
+        lib_before = U._Conv2d.library_calls
         try:
             if saved_fast[0] is not None:
                 unet.fast_inference = False
             if saved_fast[1] is not None:
                 unet.grad_graph = False
+            U._Conv2d.grad_conv = False
+            U.GRAD_ATT_KERNEL = U.GRAD_ATT_POINTWISE = U.GRAD_GN = U.GRAD_ATT = False
+            dec_cls.fused_code_grad = False
             model.autocast_dtype = None
             model.decoder_ema.plane_dtype = torch.float32
-            ref, ref_wall = timed(run)
+            ref_error = None
+            try:
+                ref, ref_wall = timed(run)
+            except Exception as e:                                   # (the untimed checker must not take the bench line down: fall back to the eager modules on this
+                ref_error = f"{type(e).__name__}: {e}"[:300]         # repository's gradient-path kernels, the r05 form of this comparison, and say so)
+                log(f"library-arithmetic reference run failed ({ref_error}); repeating it on the eager modules with the gradient-path kernels")
+                U._Conv2d.grad_conv, U.GRAD_ATT_KERNEL, U.GRAD_ATT_POINTWISE, U.GRAD_GN, U.GRAD_ATT, dec_cls.fused_code_grad = saved_lib
+                ref, ref_wall = timed(run)
         finally:
             if saved_fast[0] is not None:
                 unet.fast_inference = saved_fast[0]
             if saved_fast[1] is not None:
                 unet.grad_graph = saved_fast[1]
+            U._Conv2d.grad_conv, U.GRAD_ATT_KERNEL, U.GRAD_ATT_POINTWISE, U.GRAD_GN, U.GRAD_ATT, dec_cls.fused_code_grad = saved_lib
             model.autocast_dtype, model.decoder_ema.plane_dtype = saved_fast[2], saved_fast[3]
+        ref_library_convs = U._Conv2d.library_calls - lib_before      # > 0: the reference's gradient calls really went to the library convolution
         psnr_ref = psnr(pred, ref["pred_imgs"])                  # (ns, views)
         # how much of the views is not background (bg 1.0): a reconstruction that came out empty would make both PSNR figures meaningless
         foreground = float((pred < 0.995).any(dim=2).float().mean())
@@ -794,8 +813,12 @@ def recons_full_batch(model, dev, ns, data, g, log, timed, config5=False, n_test
                    max_abs_code_diff_vs_reference=code_err, code_abs_max=code_scale, code_psnr_vs_reference_db=code_psnr, reference_wall_s=ref_wall, parity=parity,
                    foreground_pixel_fraction=foreground, pixels_identical_to_reference_fraction=identical,
                    precision="bf16 autocast (UNet) + fp16 planes" if config5 else "fp32",
+                   reference_arithmetic="PyTorch library operators in fp32 for the UNet (MIOpen convolutions, native GroupNorm / attention, autograd backward), autograd over the "
+                                        "reference-shaped triplane decode, fp32 planes, no autocast, no executor, no captured graphs; shared with the timed run: the ray "
+                                        "march / compositing operators and the fused render of the test views",
+                   reference_library_convolution_calls=ref_library_convs, reference_error=ref_error,
                    note="one timed val_step (guide_optim) after the warm-up the per-step measurements above provide; then the SAME batch (same noise, same "
-                        "seeds) once through the fp32 eager modules, untimed: PSNR of the 250 views per scene between the two (lib/core/evaluation/metrics.py:52-55), "
+                        "seeds) once through the library-arithmetic reference (reference_arithmetic), untimed: PSNR of the 250 views per scene between the two (lib/core/evaluation/metrics.py:52-55), "
                         "and of the codes; psnr_conditioning_view_db: test view 64 (the conditioning pose) against the target.  Random UNet weights: this synthetic "
                         "batch fine-tunes into empty scenes (foreground_pixel_fraction), so the image figures sit at the 60 dB cap and the conditioning-view figure "
                         "is the target's distance from white -- the code figures are the sensitive ones")
