@@ -278,8 +278,9 @@ struct CullGrid { uint32_t group; uint32_t views_cap; uint32_t zr_cap; int32_t t
 #define RQ_CULL_CHUNKS 8
 #endif
 #ifndef RQ_MARCH_CHUNKS
-#define RQ_MARCH_CHUNKS 1
-#endif
+#define RQ_MARCH_CHUNKS 1                      // (r05; 8 = k_ray_cull's until then) a block walks its chunks one after the other and a chunk lasts as long as its slowest ray: 2048-ray
+#endif                                         // blocks were 2 441 blocks on 2 048 slots, a second mostly empty round.  Stage A 0.797 -> 0.711 ms; 16 / 4 / 2 chunks 0.93 / 0.76 / 0.76;
+                                               // blocks of 128 / 64 threads 0.85 / 1.11 (profiles/r05/z_march_block_granularity_ab.txt)
 static constexpr unsigned RQ_CHUNKS = RQ_CULL_CHUNKS;        // 256-ray chunks per block of k_ray_cull: the block stages its list in LDS and reserves global slots ONCE
 static constexpr unsigned RQ_MCHUNKS = RQ_MARCH_CHUNKS;      // ... and of k_survivor_march
 #ifndef RQ_MARCH_TPB
