@@ -269,11 +269,10 @@ struct CullGrid { uint32_t group; uint32_t views_cap; uint32_t zr_cap; int32_t t
 #ifndef RQ_LONG_STEPS
 #define RQ_LONG_STEPS 48                       // a hitting ray whose remaining segment (first hit .. tail bound) is longer than this many minimum steps goes to the FRONT of the queue
 #endif
-#ifndef RQ_WAVE_FILL
-#define RQ_WAVE_FILL 0                         // (r05) 1: waves that lie entirely in unmarked tiles write their background as 16-byte pieces (k_ray_cull) instead of one lane
-                                               // per ray.  Bit-identical, 3 store instructions instead of 8 -- and NOT faster: stage A 0.799 / 0.807 ms without, 0.812 / 0.817
-                                               // with (two interleaved pairs on one box, profiles/r05/y_cull_wave_fill_ab.txt): the L2 merges the 4-byte pieces already
-#endif
+// (r05, measured and removed: writing the background of culled pixels as dense 16-byte stores -- per wave for 8 x 8-pixel waves that lie entirely in unmarked
+// tiles, or per block for whole bands of 8 image rows whose tile row has no marked tile -- instead of 8 stores of 4-byte / 1-byte pieces per lane.  Bit-identical and
+// no faster, stage A 0.812 / 0.817 against 0.799 / 0.807 ms and 0.722 - 0.725 against 0.716 - 0.721: k_ray_cull is not bound by its stores but by the rays of the MARKED
+// tiles (ray generation, slab test, coarse scan).  profiles/r05/y_cull_wave_fill_ab.txt.)
 #ifndef RQ_CULL_CHUNKS
 #define RQ_CULL_CHUNKS 8
 #endif
@@ -323,10 +322,6 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
     const uint32_t tile_w = view_cull ? (src.w + 15u) / 16u : 1u, tile_h = view_cull ? (src.hw / src.w + 15u) / 16u : 1u;
     const bool tiled = view_cull && (src.w & 7u) == 0 && ((src.hw / src.w) & 7u) == 0;
     const bool pow2 = src.w_shift >= 3 && cg.tile_w_shift >= 0 && cg.tile_h_shift >= 0;          // power-of-two view and tile sizes: shifts instead of divisions
-    // (wave_fill: see the chunk loop; the 16-byte / 8-byte pieces need aligned arrays and pixel blocks that start at multiples of 8)
-    const bool wave_fill = RQ_WAVE_FILL && tiled && src.c2w != nullptr && (c.N & 7u) == 0 && (src.hw & 7u) == 0 &&
-                           ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(depth) | reinterpret_cast<uintptr_t>(weights_sum) |
-                             reinterpret_cast<uintptr_t>(sample_counts)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(c.image_u8) & 7u) == 0;
     // this scene's coarse bitfield -> LDS ((H/4)^3 bits; 512 B for H = 64)
     __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
     __shared__ uint2 list[RQ_CHUNKS * RQ_TPB];
@@ -355,37 +350,6 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
         bool alive = false;
         uint32_t tail = SSD_TAIL_NONE;
         float t_start = 0.f;
-        // WHOLE WAVE IN UNMARKED TILES (r05; 88 % of the bench's rays are culled, most of them here): the wave's 8 x 8 pixels are eight row segments of
-        // 96 B (float image), 32 B (depth, weights_sum, counts) and 24 B (uint8 image).  One lane per ray made 8 - 9 store instructions of 4-byte / 1-byte
-        // pieces at 12-byte / 3-byte strides out of them; the wave writes them as 16-byte (8-byte: uint8) pieces instead -- three store instructions,
-        // every row segment contiguous.  Same bytes, same values (the background is a constant).
-        if (wave_fill) {
-            bool out = false;
-            if (in_group < cg.group && n < c.N) {
-                const uint32_t tile = pow2 ? ((py >> cg.tile_h_shift) << 4) + (px >> cg.tile_w_shift) : (py / tile_h) * 16u + px / tile_w;
-                out = !((tile_mask[tile >> 5] >> (tile & 31u)) & 1u);
-            }
-            if (__ballot(out) == ~0ull) {
-                const uint32_t l = threadIdx.x & 63u;
-                const uint64_t p0 = gi - ((uint64_t)(l >> 3) * src.w + (l & 7u));             // the block's first pixel (a multiple of 8)
-                {
-                    float* ptr; float v;
-                    if (l < 48u) { const uint32_t r = l / 6u, q = l - 6u * r; ptr = image + 3 * (p0 + (uint64_t)r * src.w) + 4u * q; v = c.bg; }
-                    else { const uint32_t k = l - 48u; ptr = depth + (p0 + (uint64_t)(k >> 1) * src.w) + 4u * (k & 1u); v = 0.f; }
-                    *reinterpret_cast<float4*>(ptr) = make_float4(v, v, v, v);
-                }
-                if (l < 16u || (l < 32u && sample_counts != nullptr)) {
-                    const uint32_t k = l & 15u;
-                    float* ptr = (l < 16u ? weights_sum : reinterpret_cast<float*>(sample_counts)) + (p0 + (uint64_t)(k >> 1) * src.w) + 4u * (k & 1u);
-                    *reinterpret_cast<float4*>(ptr) = make_float4(0.f, 0.f, 0.f, 0.f);         // (int32 0 == float 0.0f bit for bit)
-                }
-                if (c.image_u8 != nullptr && l < 24u) {
-                    const uint32_t r = l / 3u, q = l - 3u * r, q4 = (uint32_t)ssd_quant_u8(c.bg) * 0x01010101u;
-                    *reinterpret_cast<uint2*>(c.image_u8 + 3 * (p0 + (uint64_t)r * src.w) + 8u * q) = make_uint2(q4, q4);
-                }
-                continue;                                                                      // (nothing to append: rq_lds_append of an all-false wave is a no-op)
-            }
-        }
         if (in_group < cg.group && n < c.N) {
             RayGeom r = {};
             bool outside = false;
