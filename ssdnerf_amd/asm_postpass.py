@@ -1,5 +1,6 @@
 """Assembly post-pass of the library build: at least N issue slots (build.TRANS_USE_WAIT_STATES, 4) between a transcendental VALU instruction and the
-instruction that reads its result.
+instruction that reads its result -- and (r05, ``SWAP_MFMA_WAIT_STATES`` below) at least 8 between a `v_permlane32_swap` and a matrix instruction that
+reads one of the swapped registers as an operand.
 
 Why (round 3, profiles/r03/hazard.txt): on gfx950 the quarter-rate instructions (v_exp / v_rcp / v_rsq / v_sqrt / v_log / v_sin / v_cos: 16 lanes per
 pass) hand their result to a following VALU instruction through a software-managed hazard; ROCm 7.2's hazard recogniser (VALUTransUseHazard) pads it
@@ -146,6 +147,14 @@ def _history(pendings: List[Dict[int, int]]) -> List[list]:
 SITE_FILTER = None
 SITE_COUNT: Dict[str, int] = {}                 # sites seen per kernel by the last filtered walk (the bisect's upper bound)
 
+#: Second rule (r05, last hours; build.SWAP_MFMA_WAIT_STATES): issue slots between a `v_permlane32_swap` / `v_permlane16_swap` and a matrix instruction that reads one
+#: of the swapped registers as its A or B operand.  The toolchain pads that pair like any VALU write -> MFMA operand read (2 wait states); the 12 000-render soaks of
+#: the shading kernel (profiles/r05/zz_soak_reproducibility.txt) show one quarter-wave with a stale low-order operand term about once in 3 000 renders, whatever the
+#: transcendental rule's distance, and the swaps that put the features' split terms into B-operand order are the only VALU producers within 24 slots of a matrix
+#: instruction's operand read in that kernel (one of them at 2).  0 = rule off.  Straight-line code only (a label clears the swap history).
+SWAP_MFMA_WAIT_STATES = 0
+_SWAPS = ("v_permlane32_swap", "v_permlane16_swap")
+
 
 def _walk(listing: str, wait_states: int, edit: bool):
     """one walk over the kernels of a listing, control flow included: a block that is entered by a branch (loop back-edges too) or by fall-through
@@ -252,6 +261,20 @@ def _walk(listing: str, wait_states: int, edit: bool):
                     need = max(need, need_inside)
                 site += 1
                 SITE_COUNT[kernel_name] = site
+        if SWAP_MFMA_WAIT_STATES > 0 and op.startswith("v_mfma"):
+            ops_ = _split(t.split(";")[0].split(None, 1)[1])
+            pending = (_vregs(ops_[1]) | _vregs(ops_[2])) if len(ops_) >= 3 else set()
+            d = 0
+            for prev in reversed(run):
+                if d >= SWAP_MFMA_WAIT_STATES or not pending:
+                    break
+                hit = prev[1] & pending
+                if hit:
+                    if prev[0].startswith(_SWAPS):
+                        need = max(need, SWAP_MFMA_WAIT_STATES - d)
+                        stats["swap_mfma_pairs_padded"] = stats.get("swap_mfma_pairs_padded", 0) + 1
+                    pending -= hit
+                d += prev[3]
         if need > 0 and edit:
             stats["pairs_closer_than_required"] += 1
             if run and run[-1][0] == "s_nop" and run[-1][4] >= 0 and run[-1][3] + need <= 8:

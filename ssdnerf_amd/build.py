@@ -6,7 +6,8 @@ reproducible bit for bit against the CPU oracle.
 
 Every source goes  hipcc -S (device listing) -> ``asm_postpass.pad_trans_use`` (FOUR issue slots, ``TRANS_USE_WAIT_STATES``, behind every
 transcendental instruction before its result is read: the toolchain pads that hazard to one, which is not always enough on gfx950 with two waves
-on a SIMD -- see asm_postpass.py and profiles/r03/hazard.txt) -> assembler -> lld -> ``asm_postpass.verify_code_object`` (the rule re-checked on
+on a SIMD -- see asm_postpass.py and profiles/r03/hazard.txt; r05: and EIGHT, ``SWAP_MFMA_WAIT_STATES``, between a `v_permlane32_swap` and a matrix
+instruction that reads a swapped register as its A / B operand -- profiles/r05/zz_soak_reproducibility.txt) -> assembler -> lld -> ``asm_postpass.verify_code_object`` (the rule re-checked on
 the LINKED code object with an independent scanner) -> offload bundle -> host object that embeds it.  ``SSDNERF_NO_POSTPASS=1`` builds the
 compiler's own code (A/B runs only).  ``lib/postpass_report.json`` records what the pass did per source, the settings, and the toolchain.
 
@@ -29,6 +30,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libssdnerf_hip.so")
 SOURCES = ["raymarching_ops.hip", "shencoder.hip", "decode.hip", "render_fused.hip", "render_queue.hip", "shade_mfma.hip", "ddim.hip", "groupnorm.hip", "conv_igemm.hip", "attention.hip", "raygen.hip", "marching_cubes.hip"]
 LLVM_BIN = os.environ.get("SSDNERF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 TRANS_USE_WAIT_STATES = int(os.environ.get("SSDNERF_TRANS_USE_WAIT_STATES", "4"))
+SWAP_MFMA_WAIT_STATES = int(os.environ.get("SSDNERF_SWAP_MFMA_WAIT_STATES", "8"))    # asm_postpass.SWAP_MFMA_WAIT_STATES (0 = rule off)
 HEADERS = ["common.h", "sh_basis.h", "decode_core.h", "decode_bwd_math.h", "gn_bwd_math.h", os.path.join("..", "..", "include", "ssdnerf_hip.h")]
 VALIDATED_HIP_VERSIONS = ("7.2.",)              # prefixes of `hipcc --version`'s "HIP version:" the post-pass + hazard analysis were validated on (r03 / r04)
 FLAGS = os.environ.get("SSDNERF_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-result"]
@@ -44,7 +46,7 @@ def _hipcc() -> str:
 def _settings() -> dict:
     """what, besides the sources, decides the bytes of the library: compared with the shipped report by needs_build()"""
     return {"wait_states": TRANS_USE_WAIT_STATES if os.environ.get("SSDNERF_NO_POSTPASS", "0") != "1" else None,
-            "extra_flags": os.environ.get("SSDNERF_EXTRA_FLAGS", "")}
+            "extra_flags": os.environ.get("SSDNERF_EXTRA_FLAGS", ""), "swap_mfma_wait_states": SWAP_MFMA_WAIT_STATES}
 
 
 def toolchain() -> dict:
@@ -93,6 +95,8 @@ def _compile_with_postpass(src: str, obj: str, verbose: bool) -> dict:
     _run([_hipcc()] + FLAGS + ["-S", "--cuda-device-only", src, "-o", dev_s], verbose)
     with open(dev_s) as f:
         listing = f.read()
+    from . import asm_postpass
+    asm_postpass.SWAP_MFMA_WAIT_STATES = SWAP_MFMA_WAIT_STATES
     patched, stats = pad_trans_use(listing, TRANS_USE_WAIT_STATES)
     closest = closest_trans_use(patched)
     if closest < TRANS_USE_WAIT_STATES:                              # (an explicit raise: `python -O` drops asserts)

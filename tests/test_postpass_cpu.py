@@ -56,6 +56,58 @@ def test_pairs_are_padded_in_place_where_possible_and_the_pass_is_idempotent():
     assert [l for l in out.split("\n") if "s_nop" not in l] == [l for l in LISTING.split("\n") if "s_nop" not in l]
 
 
+SWAP_LISTING = """
+	.text
+_Z1sPf:                                 ; @_Z1sPf
+	v_perm_b32 v4, v1, v0, s2
+	v_perm_b32 v5, v3, v2, s2
+	s_nop 1
+	v_permlane32_swap_b32_e32 v4, v5
+	v_add_f32_e32 v30, v31, v31
+	v_mfma_f32_32x32x16_bf16 v[8:23], v[40:43], v[4:7], v[8:23]
+	v_permlane32_swap_b32_e32 v50, v51
+	v_add_f32_e32 v30, v31, v31
+	v_add_f32_e32 v30, v31, v31
+	v_add_f32_e32 v30, v31, v31
+	v_add_f32_e32 v30, v31, v31
+	v_add_f32_e32 v30, v31, v31
+	v_add_f32_e32 v30, v31, v31
+	v_add_f32_e32 v30, v31, v31
+	v_add_f32_e32 v30, v31, v31
+	v_mfma_f32_32x32x16_bf16 v[8:23], v[50:53], v[44:47], v[8:23]
+	v_permlane32_swap_b32_e32 v8, v9
+	v_mfma_f32_32x32x16_bf16 v[8:23], v[60:63], v[64:67], v[8:23]
+	s_endpgm
+	.amdhsa_kernel _Z1sPf
+	.end_amdhsa_kernel
+"""
+
+
+def test_swap_to_matrix_operand_pairs_get_their_slots():
+    """the second rule (r05: profiles/r05/zz_soak_reproducibility.txt): >= N issue slots between a v_permlane32_swap and a matrix instruction that reads a swapped
+    register as its A or B operand; a swap eight instructions ahead, or one whose result is only the ACCUMULATOR operand, is left alone; off by default in the module"""
+    from ssdnerf_amd import asm_postpass as A
+    assert A.SWAP_MFMA_WAIT_STATES == 0 or A.SWAP_MFMA_WAIT_STATES == B.SWAP_MFMA_WAIT_STATES
+    saved = A.SWAP_MFMA_WAIT_STATES
+    try:
+        A.SWAP_MFMA_WAIT_STATES = 0
+        assert pad_trans_use(SWAP_LISTING, 4)[0] == SWAP_LISTING
+        A.SWAP_MFMA_WAIT_STATES = 8
+        out, st = pad_trans_use(SWAP_LISTING, 4)
+        lines = [l.strip() for l in out.split("\n")]
+        first = lines.index("v_mfma_f32_32x32x16_bf16 v[8:23], v[40:43], v[4:7], v[8:23]")
+        assert lines[first - 1] == "s_nop 6" and lines[first - 2] == "v_add_f32_e32 v30, v31, v31"          # swap, add (1 slot) -> 7 more
+        second = lines.index("v_mfma_f32_32x32x16_bf16 v[8:23], v[50:53], v[44:47], v[8:23]")
+        assert lines[second - 1] == "v_add_f32_e32 v30, v31, v31"                                            # eight instructions between: nothing to add
+        third = lines.index("v_mfma_f32_32x32x16_bf16 v[8:23], v[60:63], v[64:67], v[8:23]")
+        assert lines[third - 1] == "v_permlane32_swap_b32_e32 v8, v9"                                       # the accumulate operand is not this rule's business
+        assert st["swap_mfma_pairs_padded"] == 1
+        assert pad_trans_use(out, 4)[0] == out
+        assert [l for l in out.split("\n") if "s_nop 6" not in l] == SWAP_LISTING.split("\n")
+    finally:
+        A.SWAP_MFMA_WAIT_STATES = saved
+
+
 def test_real_listing_of_a_library_source_meets_the_invariant(tmp_path):
     src = os.path.join(B.CSRC, "raygen.hip")
     listing = tmp_path / "raygen.s"
@@ -77,6 +129,9 @@ def test_shipped_library_was_built_with_the_post_pass():
     assert shade["trans_instructions"] > 1000 and shade["closest_pair_after"] >= B.TRANS_USE_WAIT_STATES
     # the same rule re-checked on the linked code object by the independent scanner (asm_postpass.verify_code_object)
     assert shade["code_object_check"]["trans_instructions"] == shade["trans_instructions"] and shade["code_object_check"]["closest_pair"] >= B.TRANS_USE_WAIT_STATES
+    # the swap -> matrix-operand rule is on in the shipped build, and the shading kernel is where it applies
+    assert report["settings"]["swap_mfma_wait_states"] == B.SWAP_MFMA_WAIT_STATES >= 8 and shade["swap_mfma_pairs_padded"] > 0
+    assert all("swap_mfma_pairs_padded" not in v for k, v in report["sources"].items() if k != "shade_mfma.hip")
 
 
 HOLES = """

@@ -5,6 +5,8 @@ For the dose-response runs of the transcendental -> use hazard (tools/repro_chec
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 name, ws, flags = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
+if flags and flags[0].startswith("swap="):                       # NAME WAIT_STATES swap=N ...: the post-pass's second rule (asm_postpass.SWAP_MFMA_WAIT_STATES)
+    os.environ["SSDNERF_SWAP_MFMA_WAIT_STATES"] = flags.pop(0).split("=")[1]
 os.environ["SSDNERF_TRANS_USE_WAIT_STATES"] = str(ws)
 if ws == 0:
     os.environ["SSDNERF_NO_POSTPASS"] = "1"

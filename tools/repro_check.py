@@ -27,7 +27,10 @@ for it in range(n):
     diff = (cur[0] != ref[0]).any(-1) | (cur[1] != ref[1]) | (cur[2] != ref[2])
     bad.append(int(diff.sum()))
     if bad[-1]:
-        idx = diff.flatten().nonzero().flatten()[:8].tolist()
-        print(f"render {it}: {bad[-1]} rays differ, first at {idx}, counts {cur[2].flatten()[idx[:4]].tolist()} vs {ref[2].flatten()[idx[:4]].tolist()}")
-print(f"{n} renders, rays differing from render 0: {bad}")
+        where = diff.flatten().nonzero().flatten()
+        idx = where[:8].tolist()
+        d_img = float((cur[0] - ref[0]).abs().max()); d_dep = float((cur[1] - ref[1]).abs().max()); d_cnt = int((cur[2] != ref[2]).sum())
+        print(f"render {it}: {bad[-1]} rays differ (span of ray indices {int(where.max() - where.min()) + 1}), first at {idx}, counts {cur[2].flatten()[idx[:4]].tolist()} vs "
+              f"{ref[2].flatten()[idx[:4]].tolist()}; max |d image| {d_img:.3e}, max |d depth| {d_dep:.3e}, rays with another sample count {d_cnt}", flush=True)
+print(f"{n} renders, {sum(1 for b in bad if b)} differ from render 0" + (f": rays differing per render {bad}" if n <= 500 else f"; at renders {[i + 1 for i, b in enumerate(bad) if b]}"))
 print("samples", int(ref[2].sum()))
