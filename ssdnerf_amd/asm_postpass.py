@@ -319,12 +319,14 @@ def _mentions(operands: str) -> Set[int]:
     return regs
 
 
-def verify_code_object(path: str, wait_states: int, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump") -> Dict[str, int]:
+def verify_code_object(path: str, wait_states: int, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump", swap_mfma_wait_states: int = 0) -> Dict[str, int]:
     """Check the trans -> use rule on the instructions the device will execute: `llvm-objdump -d --symbolize-operands` of the linked code object.
     Deliberately NOT the listing parser: every instruction is (mnemonic, set of VGPRs it mentions anywhere); from each transcendental, every
     control-flow path (both sides of conditional branches, back-edges included) is followed for ``wait_states`` issue slots, and the first VALU
     instruction on a path that mentions a destination register of the transcendental must not be closer than that.  Mentions as a destination count
-    too (conservative: an overwrite this close would be flagged; none exists in the library).  Returns counts; raises RuntimeError on a violation."""
+    too (conservative: an overwrite this close would be flagged; none exists in the library).  ``swap_mfma_wait_states`` > 0 checks the second rule the
+    same way: from each `v_permlane32_swap` / `v_permlane16_swap`, the first MATRIX instruction on a path that mentions one of the two swapped registers
+    (any operand: conservative).  Returns counts; raises RuntimeError on a violation."""
     import subprocess
     text = subprocess.run([objdump, "-d", "--symbolize-operands", path], check=True, capture_output=True, text=True).stdout
     ins: List[Tuple[str, str]] = []
@@ -339,20 +341,15 @@ def verify_code_object(path: str, wait_states: int, objdump: str = "/opt/rocm/li
             continue
         parts = body.split(None, 1)
         ins.append((parts[0], parts[1] if len(parts) > 1 else ""))
-    n_trans = closest = 0
-    closest = 1 << 30
-    worst = None
-    for i, (op, operands) in enumerate(ins):
-        if not op.startswith(TRANS):
-            continue
-        n_trans += 1
-        first = operands.split(",")[0]
-        dst = _mentions(first)
+
+    def closest_reader(i: int, dst: Set[int], limit: int, reader_prefix: str):
+        """(slots, index) of the nearest instruction starting with `reader_prefix` that mentions a register of `dst`, over every path of `limit` slots from i + 1"""
+        best, at = 1 << 30, None
         stack = [(i + 1, 0, frozenset(dst))]
         seen = set()
         while stack:
             j, used, live = stack.pop()
-            while j < len(ins) and used < wait_states + 4 and live:           # (4 slots beyond the rule, so that the report shows the actual margin)
+            while j < len(ins) and used < limit and live:
                 if (j, used, live) in seen:
                     break
                 seen.add((j, used, live))
@@ -364,9 +361,9 @@ def verify_code_object(path: str, wait_states: int, objdump: str = "/opt/rocm/li
                 if o.startswith("v_"):
                     hit = _mentions(args) & live
                     if hit:
-                        if used < closest:
-                            closest, worst = used, (i, j)
-                        live = live - hit
+                        if o.startswith(reader_prefix) and used < best:
+                            best, at = used, j
+                        live = live - hit                            # (a VALU instruction that is not a reader re-defines or consumes the register: the nearest mention decides)
                 if o.startswith(("s_endpgm", "s_setpc")):
                     break
                 if o.startswith("s_branch"):
@@ -380,8 +377,31 @@ def verify_code_object(path: str, wait_states: int, objdump: str = "/opt/rocm/li
                         stack.append((labels[tgt], used + 1, live))
                 used += 1
                 j += 1
+        return best, at
+
+    n_trans = n_swaps = 0
+    closest = swap_closest = 1 << 30
+    worst = swap_worst = None
+    for i, (op, operands) in enumerate(ins):
+        if op.startswith(TRANS):
+            n_trans += 1
+            d, j = closest_reader(i, _mentions(operands.split(",")[0]), wait_states + 4, "v_")      # (4 slots beyond the rule, so that the report shows the actual margin)
+            if d < closest:
+                closest, worst = d, (i, j)
+        elif swap_mfma_wait_states > 0 and op.startswith(_SWAPS):
+            n_swaps += 1
+            d, j = closest_reader(i, _mentions(operands), swap_mfma_wait_states + 4, "v_mfma")
+            if d < swap_closest:
+                swap_closest, swap_worst = d, (i, j)
     if closest < wait_states:
         a, b = worst
         raise RuntimeError(f"{path}: `{ins[a][0]} {ins[a][1]}` is read {closest} issue slots later by `{ins[b][0]} {ins[b][1]}` in the linked code object "
                            f"(instructions {a} and {b}); the build requires {wait_states}")
-    return dict(trans_instructions=n_trans, closest_pair=None if closest == 1 << 30 else closest)
+    if swap_closest < swap_mfma_wait_states:
+        a, b = swap_worst
+        raise RuntimeError(f"{path}: `{ins[a][0]} {ins[a][1]}` is read {swap_closest} issue slots later by `{ins[b][0]} {ins[b][1]}` in the linked code object "
+                           f"(instructions {a} and {b}); the build requires {swap_mfma_wait_states} between a lane swap and a matrix instruction")
+    out = dict(trans_instructions=n_trans, closest_pair=None if closest == 1 << 30 else closest)
+    if swap_mfma_wait_states > 0:
+        out.update(swap_instructions=n_swaps, closest_swap_mfma_pair=None if swap_closest == 1 << 30 else swap_closest)
+    return out

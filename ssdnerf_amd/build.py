@@ -107,7 +107,7 @@ def _compile_with_postpass(src: str, obj: str, verbose: bool) -> dict:
     assemble_and_link(dev_s, dev_o, dev_out, verbose)
     # the same rule on what the device will execute, by a scanner that shares nothing with the listing parser (raises on a violation)
     try:
-        stats["code_object_check"] = verify_code_object(dev_out, TRANS_USE_WAIT_STATES, os.path.join(LLVM_BIN, "llvm-objdump"))
+        stats["code_object_check"] = verify_code_object(dev_out, TRANS_USE_WAIT_STATES, os.path.join(LLVM_BIN, "llvm-objdump"), SWAP_MFMA_WAIT_STATES)
     except RuntimeError as e:
         # the scanner also counts an OVERWRITE of a transcendental's destination as a mention (conservative); experimental side builds
         # (sensitivity probes with inline assembly) may ask for a warning instead -- never the library build
