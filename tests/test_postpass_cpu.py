@@ -131,6 +131,7 @@ def test_shipped_library_was_built_with_the_post_pass():
     assert shade["code_object_check"]["trans_instructions"] == shade["trans_instructions"] and shade["code_object_check"]["closest_pair"] >= B.TRANS_USE_WAIT_STATES
     # the swap -> matrix-operand rule is on in the shipped build, and the shading kernel is where it applies
     assert report["settings"]["swap_mfma_wait_states"] == B.SWAP_MFMA_WAIT_STATES >= 8 and shade["swap_mfma_pairs_padded"] > 0
+    assert shade["code_object_check"]["swap_instructions"] > 100 and shade["code_object_check"]["closest_swap_mfma_pair"] >= B.SWAP_MFMA_WAIT_STATES   # (linked code object)
     assert all("swap_mfma_pairs_padded" not in v for k, v in report["sources"].items() if k != "shade_mfma.hip")
 
 
