@@ -154,6 +154,10 @@ SITE_COUNT: Dict[str, int] = {}                 # sites seen per kernel by the l
 #: instruction's operand read in that kernel (one of them at 2).  0 = rule off.  Straight-line code only (a label clears the swap history).
 SWAP_MFMA_WAIT_STATES = 0
 _SWAPS = ("v_permlane32_swap", "v_permlane16_swap")
+#: Third rule (r06; build.VALU_MFMA_WAIT_STATES): the second rule for EVERY VALU producer -- issue slots between any VALU instruction (a matrix instruction is not
+#: one) that writes a VGPR and a matrix instruction that reads that VGPR as its A or B operand.  The toolchain's own distance for the pair is 2 wait states.  0 = off.
+#: Loads (LDS, global) are not VALU producers: their results are counted (`s_waitcnt`), not timed.
+VALU_MFMA_WAIT_STATES = 0
 
 
 def _walk(listing: str, wait_states: int, edit: bool):
@@ -261,18 +265,21 @@ def _walk(listing: str, wait_states: int, edit: bool):
                     need = max(need, need_inside)
                 site += 1
                 SITE_COUNT[kernel_name] = site
-        if SWAP_MFMA_WAIT_STATES > 0 and op.startswith("v_mfma"):
+        if (SWAP_MFMA_WAIT_STATES > 0 or VALU_MFMA_WAIT_STATES > 0) and op.startswith("v_mfma"):
             ops_ = _split(t.split(";")[0].split(None, 1)[1])
             pending = (_vregs(ops_[1]) | _vregs(ops_[2])) if len(ops_) >= 3 else set()
             d = 0
             for prev in reversed(run):
-                if d >= SWAP_MFMA_WAIT_STATES or not pending:
+                if d >= max(SWAP_MFMA_WAIT_STATES, VALU_MFMA_WAIT_STATES) or not pending:
                     break
                 hit = prev[1] & pending
                 if hit:
-                    if prev[0].startswith(_SWAPS):
+                    if prev[0].startswith(_SWAPS) and SWAP_MFMA_WAIT_STATES - d > 0:
                         need = max(need, SWAP_MFMA_WAIT_STATES - d)
                         stats["swap_mfma_pairs_padded"] = stats.get("swap_mfma_pairs_padded", 0) + 1
+                    if prev[0].startswith("v_") and not prev[0].startswith("v_mfma") and VALU_MFMA_WAIT_STATES - d > 0:
+                        need = max(need, VALU_MFMA_WAIT_STATES - d)
+                        stats["valu_mfma_pairs_padded"] = stats.get("valu_mfma_pairs_padded", 0) + 1
                     pending -= hit
                 d += prev[3]
         if need > 0 and edit:

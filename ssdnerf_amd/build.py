@@ -31,6 +31,7 @@ SOURCES = ["raymarching_ops.hip", "shencoder.hip", "decode.hip", "render_fused.h
 LLVM_BIN = os.environ.get("SSDNERF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 TRANS_USE_WAIT_STATES = int(os.environ.get("SSDNERF_TRANS_USE_WAIT_STATES", "4"))
 SWAP_MFMA_WAIT_STATES = int(os.environ.get("SSDNERF_SWAP_MFMA_WAIT_STATES", "8"))    # asm_postpass.SWAP_MFMA_WAIT_STATES (0 = rule off)
+VALU_MFMA_WAIT_STATES = int(os.environ.get("SSDNERF_VALU_MFMA_WAIT_STATES", "0"))    # asm_postpass.VALU_MFMA_WAIT_STATES (r06; 0 = rule off)
 HEADERS = ["common.h", "sh_basis.h", "decode_core.h", "decode_bwd_math.h", "gn_bwd_math.h", os.path.join("..", "..", "include", "ssdnerf_hip.h")]
 VALIDATED_HIP_VERSIONS = ("7.2.",)              # prefixes of `hipcc --version`'s "HIP version:" the post-pass + hazard analysis were validated on (r03 / r04)
 FLAGS = os.environ.get("SSDNERF_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-result"]
@@ -46,7 +47,8 @@ def _hipcc() -> str:
 def _settings() -> dict:
     """what, besides the sources, decides the bytes of the library: compared with the shipped report by needs_build()"""
     return {"wait_states": TRANS_USE_WAIT_STATES if os.environ.get("SSDNERF_NO_POSTPASS", "0") != "1" else None,
-            "extra_flags": os.environ.get("SSDNERF_EXTRA_FLAGS", ""), "swap_mfma_wait_states": SWAP_MFMA_WAIT_STATES}
+            "extra_flags": os.environ.get("SSDNERF_EXTRA_FLAGS", ""), "swap_mfma_wait_states": SWAP_MFMA_WAIT_STATES,
+            "valu_mfma_wait_states": VALU_MFMA_WAIT_STATES}
 
 
 def toolchain() -> dict:
@@ -97,6 +99,7 @@ def _compile_with_postpass(src: str, obj: str, verbose: bool) -> dict:
         listing = f.read()
     from . import asm_postpass
     asm_postpass.SWAP_MFMA_WAIT_STATES = SWAP_MFMA_WAIT_STATES
+    asm_postpass.VALU_MFMA_WAIT_STATES = VALU_MFMA_WAIT_STATES
     patched, stats = pad_trans_use(listing, TRANS_USE_WAIT_STATES)
     closest = closest_trans_use(patched)
     if closest < TRANS_USE_WAIT_STATES:                              # (an explicit raise: `python -O` drops asserts)

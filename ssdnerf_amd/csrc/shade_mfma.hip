@@ -133,6 +133,9 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 #ifndef SM_W_EARLY
 #define SM_W_EARLY 0                               // heads: the group's output-weight reads in front of its transcendentals instead of behind them
 #endif
+#ifndef SM_SWAP_F32
+#define SM_SWAP_F32 0                              // (r06) 1: the lane-half exchange on the fp32 features in front of the split instead of on the split terms behind it (see the split)
+#endif
 #ifndef SM_GATHER_FIRST
 #define SM_GATHER_FIRST 1                          // (r05) texel requests in front of the search arithmetic, blend behind it
 #endif
@@ -306,6 +309,11 @@ SSD_DEV float sm_skip(const FastMarchB& m, const RayGeom& r, const ProbeB& p, fl
 // wave's 14.3 k cycles per iteration).
 #ifndef SM_SEARCH_AHEAD
 #define SM_SEARCH_AHEAD 1
+#endif
+#ifndef SM_AHEAD_PROBES
+#define SM_AHEAD_PROBES 2                          // (r06) probes of the straight-line successor search: 2 = t1, then t2 behind one DDA skip (the r05 form); 1 = t1 only -- a sample whose successor
+                                                   // cell is empty parks at t1 and the march pass runs the skip it would have run here (same parameter sequence: bit-identical), ~90 VALU
+                                                   // instructions and two divergent stepping loops less per iteration against more parked rays (profiles/r06/c_*)
 #endif
 #ifndef SM_MARCH_BLOCKS
 #define SM_MARCH_BLOCKS 1                          // the march pass skips empty 4^3 / 2^3 blocks (r05 A/B below)
@@ -818,12 +826,18 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             uint32_t i1, i2;
             const float t1 = t + sdt;
             const ProbeB q1 = sm_probe_addr<DTG0>(c.m, r, t1, i1);
+#if SM_AHEAD_PROBES == 1
+            i2 = 0; sa_t2 = sa_t3 = t1;
+            sa_b1 = lin_bits[i1 >> 3];
+            sa_sh = i1 & 7u;
+#else
             sa_t2 = sm_skip<DTG0>(c.m, r, q1, sgx, sgy, sgz, t1);
             const ProbeB q2 = sm_probe_addr<DTG0>(c.m, r, sa_t2, i2);
             sa_t3 = sm_skip<DTG0>(c.m, r, q2, sgx, sgy, sgz, sa_t2);
             sa_b1 = lin_bits[i1 >> 3];
             sa_b2 = lin_bits[i2 >> 3];
             sa_sh = (i1 & 7u) | ((i2 & 7u) << 3);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) tap[pl].blend(pl, f);
@@ -894,6 +908,15 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #else
         uint32_t Z[3] = {0u, 0u, 0u};
 #endif
+#if SM_SWAP_F32
+        // (r06) the half exchange on the fp32 FEATURES, in front of the split: f[k] <-> f[8 + k] puts feature k (lane half 0) / 8 + k (half 1) of tile 0's samples into
+        // f[k] and of tile 1's into f[8 + k] -- the very values whose split terms the swaps below used to exchange, so T[.][0..7] hold the same bits -- with 8 swaps
+        // instead of 12, and, the point, with NO v_permlane32_swap result read by a matrix instruction: every swap is consumed by the split's VALU chain (and, sub,
+        // and, sub, perm), the matrix operands are written by v_perm_b32.  Features 16, 17 (one k-step for all six products, SM_K1_PACK) keep their swaps of split
+        // terms further down: their consumer is the LAST matrix instruction pair of a tile's layer 1, >= 20 matrix instructions behind them (profiles/r06/b_*).
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sm_swap(f[k], f[8 + k]);
+#endif
 #pragma unroll
         for (int p2 = 0; p2 < 9; ++p2) {
             uint32_t h0, m0, l0, h1, m1, l1;
@@ -901,6 +924,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             sm_split3(f[2 * p2 + 1], h1, m1, l1);
             T[0][p2] = sm_pack2(h0, h1); T[1][p2] = sm_pack2(m0, m1); T[2][p2] = sm_pack2(l0, l1);
         }
+#if !SM_SWAP_F32
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
 #pragma unroll
@@ -909,6 +933,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             sm_swap_u(T[tt][8], Z[tt]);
 #endif
         }
+#endif
 #if SM_K1_PACK
         // v_permlane32_swap(a, b): a = [a.lo ; b.lo], b = [a.hi ; b.hi] (lane halves).  With a = b = X: a = X of samples 0-31 in both halves (tile 0),
         // b = X of samples 32-63 (tile 1); with b = a constant: the constant lands in the upper half (k 8-15) of both tiles' operands
@@ -1121,9 +1146,14 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             const bool o1 = ((sa_b1 >> (sa_sh & 7u)) & 1u) != 0, o2 = ((sa_b2 >> (sa_sh >> 3)) & 1u) != 0;
             const bool look = go & !capped;
             const bool take1 = look & o1;
+#if SM_AHEAD_PROBES == 1
+            const bool take2 = false;
+            const bool park = look & !o1;                                          // one empty probe: park AT it (t1 < far_ holds: `go`); the march pass probes t1 again and skips from there
+#else
             const bool look2 = look & !o1 & (sa_t2 < far_);
             const bool take2 = look2 & o2;
             const bool park = look2 & !o2 & (sa_t3 < far_);                        // two empty probes: park at t3 (SM_SEARCH_PROBES == 2 in this form)
+#endif
             if (go & capped) { if (overflow_flag) atomicAdd(overflow_flag, 1); }
             t = take1 ? t1 : take2 ? sa_t2 : sa_t3;
             wait = (take1 | take2) ? 0u : park ? 2u : 1u;

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 name, ws, flags = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
 if flags and flags[0].startswith("swap="):                       # NAME WAIT_STATES swap=N ...: the post-pass's second rule (asm_postpass.SWAP_MFMA_WAIT_STATES)
     os.environ["SSDNERF_SWAP_MFMA_WAIT_STATES"] = flags.pop(0).split("=")[1]
+if flags and flags[0].startswith("valu="):                       # ... valu=N: the third rule (asm_postpass.VALU_MFMA_WAIT_STATES, r06)
+    os.environ["SSDNERF_VALU_MFMA_WAIT_STATES"] = flags.pop(0).split("=")[1]
 os.environ["SSDNERF_TRANS_USE_WAIT_STATES"] = str(ws)
 if ws == 0:
     os.environ["SSDNERF_NO_POSTPASS"] = "1"
