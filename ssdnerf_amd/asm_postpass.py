@@ -32,7 +32,8 @@ from __future__ import annotations
 import re
 from typing import Dict, List, Set, Tuple
 
-TRANS = ("v_exp_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_log_", "v_sin_", "v_cos_")
+import os as _os
+TRANS = ("v_exp_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_log_", "v_sin_", "v_cos_") + tuple(x for x in _os.environ.get("SSDNERF_POSTPASS_EXTRA_PRODUCERS", "").split(",") if x)
 _REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]|\bv\[(\d+)\]")
 ALL_VGPRS = frozenset(range(512))
 _LABEL = re.compile(r"^[A-Za-z_.$][\w.$]*:")
@@ -412,3 +413,123 @@ def verify_code_object(path: str, wait_states: int, objdump: str = "/opt/rocm/li
     if swap_mfma_wait_states > 0:
         out.update(swap_instructions=n_swaps, closest_swap_mfma_pair=None if swap_closest == 1 << 30 else swap_closest)
     return out
+
+
+# ---------------------------------------------------------------------------------------------- r06: packed fp32 instructions with cross-half operand selection
+#: Round 6 (profiles/r06/README.md).  The run-to-run differences of the shading kernel that need two waves per SIMD -- r02's "groups of 16
+#: neighbouring rays", r03's transcendental theory, r05's swap theory -- were traced, with per-ray hashes of every stage and an in-kernel re-evaluation
+#: (tools/trace_check.py, tools/blend_check.py), to ONE kind of instruction: a packed fp32 operation (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose `op_sel` / `op_sel_hi`
+#: bits make a half of the result read the OTHER half of a VGPR source pair (the compiler's way of broadcasting one weight to both halves).  On gfx950 with two waves on a
+#: SIMD the low half of such an instruction's result occasionally comes out, in lanes 48-63 only, as if the product term were absent.  The same arithmetic as plain
+#: v_mul / v_fma, or packed with the broadcast materialised in a register pair, never does.  The library therefore contains NO such instruction: the sources avoid them
+#: (explicit pairs or pinned plain instructions) and this scan, run by build.py on every listing and on the linked code object, fails the build if the compiler forms one.
+_PK_F32 = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")
+_SEL = re.compile(r"\b(op_sel|op_sel_hi):\[([01,]+)\]")
+
+
+def packed_cross_half(line: str):
+    """None, or (mnemonic, [source operand indices whose halves are crossed]) for one listing / disassembly line: a packed fp32 instruction that reads, for its low
+    result, the high register of a VGPR source pair (op_sel bit 1) or, for its high result, the low register (op_sel_hi bit 0)"""
+    text = line.split(";")[0].split("//")[0].strip()
+    parts = text.split(None, 1)
+    if len(parts) < 2 or not parts[0].startswith(_PK_F32):
+        return None
+    mods = dict((m.group(1), [int(x) for x in m.group(2).split(",")]) for m in _SEL.finditer(parts[1]))
+    body = _SEL.sub("", parts[1])
+    body = re.sub(r"\b(neg_lo|neg_hi):\[[01,]+\]|\bclamp\b", "", body)
+    ops = _split(body)
+    srcs = ops[1:]
+    n = len(srcs)
+    sel = mods.get("op_sel", [0] * n) + [0] * n
+    sel_hi = mods.get("op_sel_hi", [1] * n) + [1] * n
+    crossed = [i for i, o in enumerate(srcs) if _vregs(o) and (sel[i] == 1 or sel_hi[i] == 0)]
+    return (parts[0], crossed) if crossed else None
+
+
+def scan_packed_cross_half(text: str) -> Dict[str, int]:
+    """kernel / function name -> number of packed fp32 instructions with a crossed VGPR source, over a device listing (`hipcc -S`) or an `llvm-objdump -d` text"""
+    out: Dict[str, int] = {}
+    cur = "?"
+    for raw in text.split("\n"):
+        t = raw.strip()
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", t) or re.match(r"^([A-Za-z_$][\w$.]*):\s*(;.*)?$", t)
+        if m and not m.group(1).startswith((".L", "L")):
+            cur = m.group(1)
+            continue
+        if packed_cross_half(raw) is not None:
+            out[cur] = out.get(cur, 0) + 1
+    return out
+
+
+_PLAIN = {"v_pk_fma_f32": "v_fma_f32", "v_pk_mul_f32": "v_mul_f32_e64", "v_pk_add_f32": "v_add_f32_e64"}
+_PAIR = re.compile(r"^([vs])\[(\d+):(\d+)\]$")
+_BITS = re.compile(r"\b(op_sel|op_sel_hi|neg_lo|neg_hi):\[([01,]+)\]")
+
+
+def split_packed_cross_half(line: str):
+    """The two plain instructions that compute what a crossed packed fp32 instruction computes (see above), as listing lines; None if `line` is not such an
+    instruction.  D.lo = f(src_i[op_sel_i]), D.hi = f(src_i[op_sel_hi_i]) element-wise -- a packed fp32 operation is two independent IEEE operations, so the results are
+    bit-identical.  Raises ValueError for a form that cannot be split in place (destination overlapping a source of the other half both ways; a non-zero constant read
+    as a high half)."""
+    if packed_cross_half(line) is None:
+        return None
+    indent = line[: len(line) - len(line.lstrip())]
+    text = line.split(";")[0].strip()
+    op, rest = text.split(None, 1)
+    bits = dict((m.group(1), [int(x) for x in m.group(2).split(",")]) for m in _BITS.finditer(rest))
+    clamp = bool(re.search(r"\bclamp\b", rest))
+    body = re.sub(r"\bclamp\b", "", _BITS.sub("", rest))
+    ops = _split(body)
+    dst, srcs = ops[0], ops[1:]
+    n = len(srcs)
+    sel = (bits.get("op_sel", []) + [0] * n)[:n]
+    sel_hi = (bits.get("op_sel_hi", []) + [1] * n)[:n]
+    neg_lo = (bits.get("neg_lo", []) + [0] * n)[:n]
+    neg_hi = (bits.get("neg_hi", []) + [0] * n)[:n]
+    md = _PAIR.match(dst)
+    if not md or md.group(1) != "v":
+        raise ValueError(f"cannot split `{text}`: destination is not a VGPR pair")
+    d_lo, d_hi = int(md.group(2)), int(md.group(3))
+
+    def pick(o: str, which: int):
+        m = _PAIR.match(o)
+        if m:
+            return f"{m.group(1)}{int(m.group(2)) + which}", (m.group(1), int(m.group(2)) + which)
+        if which == 1 and o.strip() not in ("0", "0.0"):
+            raise ValueError(f"cannot split `{text}`: constant operand `{o}` read as a high half")
+        return o.strip(), None
+    lo, hi = [], []
+    for i, o in enumerate(srcs):
+        a, ra = pick(o, sel[i])
+        b, rb = pick(o, sel_hi[i])
+        lo.append((("-" if neg_lo[i] else "") + a, ra))
+        hi.append((("-" if neg_hi[i] else "") + b, rb))
+    plain = _PLAIN[next(p for p in _PK_F32 if op.startswith(p))]
+    tail = " clamp" if clamp else ""
+    lo_ins = f"{indent}{plain} v{d_lo}, " + ", ".join(t for t, _ in lo) + tail
+    hi_ins = f"{indent}{plain} v{d_hi}, " + ", ".join(t for t, _ in hi) + tail
+    lo_first_ok = all(r != ("v", d_lo) for _, r in hi)          # the high half must not read what the low half has just overwritten
+    hi_first_ok = all(r != ("v", d_hi) for _, r in lo)
+    if lo_first_ok:
+        return [lo_ins, hi_ins]
+    if hi_first_ok:
+        return [hi_ins, lo_ins]
+    # both halves read what the other writes: fine if they compute the same value (x * y into both halves of [x:y], x + y and y + x, ...) -- one operation and a copy
+    lt, ht = [t for t, _ in lo], [t for t, _ in hi]
+    same = (sorted(lt[:2]) == sorted(ht[:2]) and lt[2:] == ht[2:])          # (add, mul and the product of an fma commute: the IEEE result does not depend on the order)
+    if same:
+        return [lo_ins, f"{indent}v_mov_b32_e32 v{d_hi}, v{d_lo}"]
+    raise ValueError(f"cannot split `{text}` in place: each half's destination is a source of the other half")
+
+
+def unpack_cross_half(listing: str) -> Tuple[str, Dict[str, int]]:
+    """every crossed packed fp32 instruction of a device listing as two plain instructions; returns (listing, {'split': n})"""
+    out, n = [], 0
+    for raw in listing.split("\n"):
+        two = split_packed_cross_half(raw)
+        if two is None:
+            out.append(raw)
+        else:
+            out.extend(two)
+            n += 1
+    return "\n".join(out), {"packed_cross_half_split": n}

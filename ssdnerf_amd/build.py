@@ -31,6 +31,7 @@ SOURCES = ["raymarching_ops.hip", "shencoder.hip", "decode.hip", "render_fused.h
 LLVM_BIN = os.environ.get("SSDNERF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 TRANS_USE_WAIT_STATES = int(os.environ.get("SSDNERF_TRANS_USE_WAIT_STATES", "4"))
 SWAP_MFMA_WAIT_STATES = int(os.environ.get("SSDNERF_SWAP_MFMA_WAIT_STATES", "8"))    # asm_postpass.SWAP_MFMA_WAIT_STATES (0 = rule off)
+UNPACK_CROSS_HALF = os.environ.get("SSDNERF_KEEP_PACKED_CROSS_HALF", "0") != "1"      # r06 (asm_postpass.unpack_cross_half); =1 keeps the compiler's instructions (positive-control builds)
 VALU_MFMA_WAIT_STATES = int(os.environ.get("SSDNERF_VALU_MFMA_WAIT_STATES", "0"))    # asm_postpass.VALU_MFMA_WAIT_STATES (r06; 0 = rule off)
 HEADERS = ["common.h", "sh_basis.h", "decode_core.h", "decode_bwd_math.h", "gn_bwd_math.h", os.path.join("..", "..", "include", "ssdnerf_hip.h")]
 VALIDATED_HIP_VERSIONS = ("7.2.",)              # prefixes of `hipcc --version`'s "HIP version:" the post-pass + hazard analysis were validated on (r03 / r04)
@@ -48,7 +49,7 @@ def _settings() -> dict:
     """what, besides the sources, decides the bytes of the library: compared with the shipped report by needs_build()"""
     return {"wait_states": TRANS_USE_WAIT_STATES if os.environ.get("SSDNERF_NO_POSTPASS", "0") != "1" else None,
             "extra_flags": os.environ.get("SSDNERF_EXTRA_FLAGS", ""), "swap_mfma_wait_states": SWAP_MFMA_WAIT_STATES,
-            "valu_mfma_wait_states": VALU_MFMA_WAIT_STATES}
+            "valu_mfma_wait_states": VALU_MFMA_WAIT_STATES, "unpack_cross_half": UNPACK_CROSS_HALF}
 
 
 def toolchain() -> dict:
@@ -100,7 +101,11 @@ def _compile_with_postpass(src: str, obj: str, verbose: bool) -> dict:
     from . import asm_postpass
     asm_postpass.SWAP_MFMA_WAIT_STATES = SWAP_MFMA_WAIT_STATES
     asm_postpass.VALU_MFMA_WAIT_STATES = VALU_MFMA_WAIT_STATES
+    split_stats = {"packed_cross_half_split": None}
+    if UNPACK_CROSS_HALF:                                            # r06: no packed fp32 instruction whose halves read across a VGPR source pair (asm_postpass.py, the r06 block)
+        listing, split_stats = asm_postpass.unpack_cross_half(listing)
     patched, stats = pad_trans_use(listing, TRANS_USE_WAIT_STATES)
+    stats.update(split_stats)
     closest = closest_trans_use(patched)
     if closest < TRANS_USE_WAIT_STATES:                              # (an explicit raise: `python -O` drops asserts)
         raise RuntimeError(f"{src}: a transcendental -> use pair is still {closest} slots apart after the post-pass")
@@ -118,6 +123,12 @@ def _compile_with_postpass(src: str, obj: str, verbose: bool) -> dict:
             raise
         print(f"warning (SSDNERF_POSTPASS_VERIFY=warn): {e}", file=sys.stderr)
         stats["code_object_check"] = {"warning": str(e)}
+    if UNPACK_CROSS_HALF:                                            # ... and none in what the device will execute
+        dis = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", dev_out], check=True, capture_output=True, text=True).stdout
+        left = asm_postpass.scan_packed_cross_half(dis)
+        if left:
+            raise RuntimeError(f"{src}: packed fp32 instructions with a crossed VGPR source are left in the linked code object: {left}")
+        stats["code_object_check"]["packed_cross_half"] = 0
     _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
           "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={dev_out}", f"-output={fatbin}"], verbose)
     _run([_hipcc()] + FLAGS + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", src, "-o", obj], verbose)

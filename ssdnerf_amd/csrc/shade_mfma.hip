@@ -136,6 +136,21 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 #ifndef SM_SWAP_F32
 #define SM_SWAP_F32 0                              // (r06) 1: the lane-half exchange on the fp32 features in front of the split instead of on the split terms behind it (see the split)
 #endif
+#ifndef SM_BLEND_VARIANT
+#define SM_BLEND_VARIANT 0
+#endif
+#ifndef SM_BLEND_SCALAR
+#define SM_BLEND_SCALAR 0
+#endif
+#ifndef SM_KEEP_ADDR
+#define SM_KEEP_ADDR 0
+#endif
+#ifndef SM_GATHER_DRAIN
+#define SM_GATHER_DRAIN 0                          // (r06 experiments) bit 0: s_waitcnt vmcnt(0) in front of the texel requests; bit 1: ... behind them, in front of the blend
+#endif
+#ifndef SM_NO_BOUNDARY_COUNT
+#define SM_NO_BOUNDARY_COUNT 0
+#endif
 #ifndef SM_GATHER_FIRST
 #define SM_GATHER_FIRST 1                          // (r05) texel requests in front of the search arithmetic, blend behind it
 #endif
@@ -195,9 +210,59 @@ template <typename PT> struct SmPlaneTap {
         SmTexel<PT>::load6(planes, (row1 + x0) * TEXEL, t10);
         SmTexel<PT>::load6(planes, (row1 + x1) * TEXEL, t11);
         w00 = wx0 * wy0; w01 = wx1 * wy0; w10 = wx0 * wy1; w11 = wx1 * wy1;
+#if SM_KEEP_ADDR
+        o00 = (row0 + x0) * TEXEL; o01 = (row0 + x1) * TEXEL; o10 = (row1 + x0) * TEXEL; o11 = (row1 + x1) * TEXEL;
+#endif
     }
+#if SM_KEEP_ADDR
+    uint32_t o00, o01, o10, o11;
+    SSD_DEV void keep() const { asm volatile("" :: "v"(o00), "v"(o01), "v"(o10), "v"(o11)); }     // the offsets stay live: no load writes its data over its own address register
+#endif
     SSD_DEV void blend(int p, float f[18]) const {             // decode_core.h ssd_gather18's chain, on channel pairs
+#if SM_BLEND_SCALAR
+        // (r06 experiment) the same chain per channel as plain v_mul / v_fma (pinned: the SLP vectoriser would re-pack them): element-wise the same arithmetic
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float r = sm_plain_mul(t00[c], w00);
+            r = sm_plain_fma(t01[c], w01, r); r = sm_plain_fma(t10[c], w10, r); r = sm_plain_fma(t11[c], w11, r);
+            f[c * 3 + p] = r;
+        }
+        return;
+#endif
         typedef float ssd_f2 __attribute__((ext_vector_type(2)));
+#if SM_BLEND_VARIANT == 1
+        {   // (r06 experiment) packed, but the weights as explicit register pairs: no op_sel broadcast on the packed instructions
+            ssd_f2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
+            asm volatile("" : "+v"(W00), "+v"(W01), "+v"(W10), "+v"(W11));
+#pragma unroll
+            for (int c = 0; c < 6; c += 2) {
+                const ssd_f2 a00 = {t00[c], t00[c + 1]}, a01 = {t01[c], t01[c + 1]}, a10 = {t10[c], t10[c + 1]}, a11 = {t11[c], t11[c + 1]};
+                ssd_f2 r = a00 * W00;
+                r = __builtin_elementwise_fma(a01, W01, r); r = __builtin_elementwise_fma(a10, W10, r); r = __builtin_elementwise_fma(a11, W11, r);
+                f[c * 3 + p] = r.x; f[(c + 1) * 3 + p] = r.y;
+            }
+            return;
+        }
+#elif SM_BLEND_VARIANT == 2
+        {   // (r06 experiment) packed with op_sel, the three channel-pair chains advanced side by side: dependent packed instructions three slots apart
+            ssd_f2 r[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r[q] = ssd_f2{t00[2 * q], t00[2 * q + 1]} * ssd_f2{w00, w00};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r[q] = __builtin_elementwise_fma(ssd_f2{t01[2 * q], t01[2 * q + 1]}, ssd_f2{w01, w01}, r[q]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r[q] = __builtin_elementwise_fma(ssd_f2{t10[2 * q], t10[2 * q + 1]}, ssd_f2{w10, w10}, r[q]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r[q] = __builtin_elementwise_fma(ssd_f2{t11[2 * q], t11[2 * q + 1]}, ssd_f2{w11, w11}, r[q]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { f[2 * q * 3 + p] = r[q].x; f[(2 * q + 1) * 3 + p] = r[q].y; }
+            return;
+        }
+#endif
 #pragma unroll
         for (int c = 0; c < 6; c += 2) {
             const ssd_f2 a00 = {t00[c], t00[c + 1]}, a01 = {t01[c], t01[c + 1]}, a10 = {t10[c], t10[c + 1]}, a11 = {t11[c], t11[c + 1]};
@@ -248,6 +313,9 @@ struct ShadeCfg {
     const uint64_t* blocks64;   // [S][(H/4)^3] or null: the bitfield block-major, one u64 per 4^3 cells (k_bitfield_blocks64): the march pass skips empty blocks
     const uint32_t* order;      // [S][order_stride] or null: ticket i of a scene is slice order[i] of its queue (k_ticket_order, render_queue.hip)
     uint32_t order_stride;
+#ifdef SM_DEBUG_TRACE
+    uint32_t* dbg_trace;        // [S][N][8]: per-ray XOR hashes of what the kernel computed for the ray (tools/trace_check.py)
+#endif
 };
 
 struct ProbeB { float x, y, z, dt; int nx, ny, nz; bool occ; };
@@ -547,6 +615,21 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         weights_sum[gi] = ws_;
         if (sample_counts) sample_counts[gi] = (int32_t)cnt_;
     };
+    // SM_DEBUG_TRACE (r06, tools/trace_check.py): per ray, order-independent XOR hashes of 0 the march parameters t of its samples, 1 the gathered features, 2 the MLP
+    // outputs + step, 3 the SH operands read for it, 4 the ray constants at every (re)load into a lane, 5 the composited state behind every sample -- flushed with
+    // atomicXor whenever the ray leaves a lane.  Two renders of one scene must agree on every hash of every ray; the first kind that differs names the stage.
+#ifdef SM_DEBUG_TRACE
+    uint32_t th[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    auto th_mix = [](uint32_t x, uint32_t k) { uint32_t m = (x + k * 0x9E3779B9u) * 0x85EBCA6Bu; return m ^ (m >> 15); };
+    auto th_flush = [&](uint32_t rid) {
+        uint32_t* d = c.dbg_trace + (ray0 + (rid & id_mask)) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { if (th[q] != 0u) atomicXor(d + q, th[q]); th[q] = 0u; }
+    };
+#define SM_TH_FLUSH(rid) th_flush(rid)
+#else
+#define SM_TH_FLUSH(rid) do { } while (0)
+#endif
     auto set_signs = [&]() {
         sgx = ssd_fma(0.5f, ssd_sign1(r.dx), 0.5f); sgy = ssd_fma(0.5f, ssd_sign1(r.dy), 0.5f); sgz = ssd_fma(0.5f, ssd_sign1(r.dz), 0.5f);
     };
@@ -578,7 +661,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
       }
       if (event) {
         SM_SEC(0);
-        if (wait == 1) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; wait = 0; }      // the ONE store sequence of the loop body
+        if (wait == 1) { SM_TH_FLUSH((uint32_t)ray); write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; wait = 0; }      // the ONE store sequence of the loop body
         SM_SEC(4);
         // ---- park rays that need a long search (state -> LDS search pool) ----
         {
@@ -590,13 +673,14 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                     uint32_t* e = pool_search + ((sp_head + sp_count + rank) % SM_POOL) * 8;
                     *reinterpret_cast<uint4*>(e) = make_uint4((uint32_t)ray, __float_as_uint(t), __float_as_uint(ws), __float_as_uint(dep));
                     *reinterpret_cast<uint4*>(e + 4) = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cb), cnt);
+                    SM_TH_FLUSH((uint32_t)ray);
                     ray = -1;
                     wait = 0;
                 }
                 sp_count += min((uint32_t)__popcll(pm), room);
                 if (wait == 2) {   // pool full (cannot happen with the march-pass trigger below, kept as a guard): finish the search in the lane
                     for (;;) {
-                        if (!(t < far_)) { write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break; }
+                        if (!(t < far_)) { SM_TH_FLUSH((uint32_t)ray); write_out((uint32_t)ray, ws, dep, cr, cg, cb, cnt); ray = -1; break; }
                         const ProbeB p = sm_probe<DTG0>(c.m, lin_bits, r, t);
                         if (p.occ) { sx = p.x; sy = p.y; sz = p.z; sdt = p.dt; break; }
                         t = sm_skip<DTG0>(c.m, r, p, sgx, sgy, sgz, t);
@@ -696,6 +780,14 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             st_head += take; st_count -= take;
         }
         SM_SEC(7);
+#ifdef SM_DEBUG_TRACE
+        if (fresh) {
+            uint32_t hh = th_mix((uint32_t)ray, 1u) ^ th_mix(__float_as_uint(t), 2u) ^ th_mix(__float_as_uint(far_), 3u) ^ th_mix(__float_as_uint(r.ox), 4u) ^ th_mix(__float_as_uint(r.oy), 5u) ^
+                          th_mix(__float_as_uint(r.oz), 6u) ^ th_mix(__float_as_uint(r.dx), 7u) ^ th_mix(__float_as_uint(r.dy), 8u) ^ th_mix(__float_as_uint(r.dz), 9u) ^
+                          th_mix(__float_as_uint(r.rdx), 10u) ^ th_mix(__float_as_uint(r.rdy), 11u) ^ th_mix(__float_as_uint(r.rdz), 12u) ^ th_mix(__float_as_uint(ws), 13u) ^ th_mix(cnt, 14u);
+            th[4] ^= th_mix(hh, cnt);
+        }
+#endif
         if (fresh) { store_sh(); fresh = false; }               // (one copy of the SH evaluation + operand split for both refill sources)
         const uint64_t live = __ballot(ray >= 0);
         SM_SEC(8);
@@ -809,6 +901,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 
         // ================= shade: gather -> MFMA layers -> output layer -> composite =================
         float f[18];
+#ifdef SM_DEBUG_TRACE
+        uint32_t th_tex = 0u, th_w = 0u;
+#endif
 #if SM_SEARCH_AHEAD
         // the successor search of this sample, as far as it can go without the MLP: t1, t2, t3 and the two occupancy bytes (requested here, read after compositing)
         float sa_t2 = 0.f, sa_t3 = 0.f;
@@ -816,6 +911,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #if SM_GATHER_FIRST && SM_ADDR32
         // (r05) one block, in this order: the twelve texel requests, THEN the search arithmetic (two probe addresses, two DDA skips: ~100 VALU
         // instructions that need nothing from memory) under their latency, then the blend
+#if SM_GATHER_DRAIN & 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (r06 experiment) nothing older in flight when the texel requests start
+#endif
         if (on) {
             sm_sample_at<DTG0>(c.m, r, t, sx, sy, sz, sdt);
             SmPlaneTap<PT> tap[3];
@@ -839,8 +937,91 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             sa_sh = (i1 & 7u) | ((i2 & 7u) << 3);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+#if SM_GATHER_DRAIN & 2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (r06 experiment) every request back before the first texel is used (no counted partial waits)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#if SM_GATHER_DRAIN & 4
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // ... and 16 idle issue slots behind the wait
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#if SM_KEEP_ADDR
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) tap[pl].keep();
+#endif
+#ifdef SM_DEBUG_TRACE
+            th_tex = 0u; th_w = 0u;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    th_tex = (th_tex << 3 | th_tex >> 29) ^ __float_as_uint(tap[pl].t00[q]) ^ (__float_as_uint(tap[pl].t01[q]) * 3u) ^ (__float_as_uint(tap[pl].t10[q]) * 5u) ^ (__float_as_uint(tap[pl].t11[q]) * 7u);
+                th_w = (th_w << 5 | th_w >> 27) ^ __float_as_uint(tap[pl].w00) ^ (__float_as_uint(tap[pl].w01) * 3u) ^ (__float_as_uint(tap[pl].w10) * 5u) ^ (__float_as_uint(tap[pl].w11) * 7u);
+            }
+#endif
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) tap[pl].blend(pl, f);
+#if SM_KEEP_ADDR
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) tap[pl].keep();
+#endif
+#ifdef SM_DEBUG_BLEND2
+            {   // (r06) the blend a second time from the same registers (made opaque to the optimiser), and a third time as scalar FMAs: words 8 / 9 of scene 0's boundary line count
+                // lanes whose packed evaluations disagree / whose scalar evaluation disagrees with the first packed one; 10: lanes checked; 12..29: per feature
+                float f2[18], f3[18];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    SmPlaneTap<PT> q = tap[pl];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) asm volatile("" : "+v"(q.t00[e]), "+v"(q.t01[e]), "+v"(q.t10[e]), "+v"(q.t11[e]));
+                    asm volatile("" : "+v"(q.w00), "+v"(q.w01), "+v"(q.w10), "+v"(q.w11));
+                    q.blend(pl, f2);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        float rr = q.t00[e] * q.w00;
+                        rr = __builtin_fmaf(q.t01[e], q.w01, rr); rr = __builtin_fmaf(q.t10[e], q.w10, rr); rr = __builtin_fmaf(q.t11[e], q.w11, rr);
+                        asm volatile("" : "+v"(rr));
+                        f3[e * 3 + pl] = rr;
+                    }
+                }
+                uint32_t* d = queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 0);
+                bool b2 = false, b3 = false;
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    const bool x2 = __float_as_uint(f2[i]) != __float_as_uint(f[i]), x3 = __float_as_uint(f3[i]) != __float_as_uint(f[i]);
+                    b2 |= x2; b3 |= x3;
+                    if (x2 | x3) atomicAdd(d + 12 + i, 1u);
+                }
+                if ((b2 | b3) && c.S >= 8) {                                   // the first seven cases in full: words 8..27 of the boundary lines of scenes 1..7
+                    const uint32_t k = atomicAdd(d + 11, 1u);
+                    if (k < 7u) {
+                        int fi = 0;
+#pragma unroll
+                        for (int i = 17; i >= 0; --i) if (__float_as_uint(f2[i]) != __float_as_uint(f[i]) || __float_as_uint(f3[i]) != __float_as_uint(f[i])) fi = i;
+                        uint32_t* e = queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 1 + k) + 8;
+                        e[0] = (uint32_t)lane | (uint32_t)fi << 8 | (b2 ? 1u << 16 : 0u) | (b3 ? 1u << 17 : 0u);
+                        float fv = 0.f, f2v = 0.f, f3v = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 18; ++i) if (i == fi) { fv = f[i]; f2v = f2[i]; f3v = f3[i]; }
+                        e[1] = __float_as_uint(fv); e[2] = __float_as_uint(f2v); e[3] = __float_as_uint(f3v);
+                        const int pl = fi % 3, ch = fi / 3;
+#pragma unroll
+                        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                            for (int cc = 0; cc < 6; ++cc) if (pp == pl && cc == ch) {
+                                e[4] = __float_as_uint(tap[pp].t00[cc]); e[5] = __float_as_uint(tap[pp].t01[cc]); e[6] = __float_as_uint(tap[pp].t10[cc]); e[7] = __float_as_uint(tap[pp].t11[cc]);
+                                e[8] = __float_as_uint(tap[pp].w00); e[9] = __float_as_uint(tap[pp].w01); e[10] = __float_as_uint(tap[pp].w10); e[11] = __float_as_uint(tap[pp].w11);
+                                e[12] = __float_as_uint(tap[pp].t00[cc ^ 1]); e[13] = __float_as_uint(tap[pp].t01[cc ^ 1]);
+                            }
+                    }
+                }
+                if (b2) atomicAdd(d + 8, 1u);
+                if (b3) atomicAdd(d + 9, 1u);
+                if (lane == 0) atomicAdd(d + 10, 1u);
+                if (b2 | b3) atomicOr(d + 30 + (lane >> 5), 1u << (lane & 31));
+            }
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < 18; ++i) f[i] = 0.f;
@@ -899,9 +1080,42 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             asm volatile("" :: "v"(xd));
         }
 #endif
+#ifdef SM_DEBUG_TRACE
+        uint32_t th_f = 0u;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) th_f = (th_f << 3 | th_f >> 29) ^ __float_as_uint(f[i]);
+        uint32_t th_sh = 0u;
+#pragma unroll
+        for (int tt_ = 0; tt_ < 3; ++tt_) {
+            const uint4 q0 = sh_lds[tt_ * 128 + lane * 2], q1 = sh_lds[tt_ * 128 + lane * 2 + 1];
+            th_sh = (th_sh << 5 | th_sh >> 27) ^ q0.x ^ (q0.y * 3u) ^ (q0.z * 5u) ^ (q0.w * 7u) ^ (q1.x * 11u) ^ (q1.y * 13u) ^ (q1.z * 17u) ^ (q1.w * 19u);
+        }
+#endif
         // Split every feature into three bf16 terms, pack feature pairs, and trade halves so that T[t][0..3] is tile 0's k-step-0 operand
         // (features 0-15 of the samples of lanes 0-31) and T[t][4..7] tile 1's; T[t][8] / Z[t] carry features 16, 17 for k-step 1 (their other
         // k slots are the bias row and zeros).
+        // SM_DEBUG_DUAL (r06, tools/dual_check.py): the MLP of an iteration is evaluated TWICE by the same instructions on the same inputs (a loop that is not
+        // unrolled); per-lane hashes of six stages -- 0 matrix operands (split + lane-half exchange), 1 accumulators behind layer 1, 2 density pre-activations,
+        // 3 accumulators behind the direction term, 4 colour pre-activations, 5 the four outputs -- are compared between the two evaluations, and every lane
+        // whose hashes differ is counted per stage and per FIRST differing stage in spare counter words (scene 0's boundary line, words 8 ..).  Localises the
+        // run-to-run differences that need two waves per SIMD to a part of the MLP.
+#ifdef SM_DEBUG_DUAL
+        float dd_keep[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) dd_keep[i] = f[i];
+        uint32_t dd_first[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        float sigma = 0.f, sr = 0.f, sg = 0.f, sb_ = 0.f;
+#pragma unroll 1
+        for (int dd_rep = 0; dd_rep < 2; ++dd_rep) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) f[i] = dd_keep[i];
+        uint32_t dd_cur[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#define SM_DD(stage, bits) do { dd_cur[stage] = (dd_cur[stage] << 1 | dd_cur[stage] >> 31) ^ (uint32_t)(bits); } while (0)
+#define SM_DD_ACC(stage, nt) do { _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) SM_DD(stage, __float_as_uint(acc[nt][mt_][i_])); } } while (0)
+#else
+#define SM_DD(stage, bits) do { } while (0)
+#define SM_DD_ACC(stage, nt) do { } while (0)
+#endif
         uint32_t T[3][9];
 #if SM_K1_PACK
         uint32_t K1[2][4];                                                   // k-step 1 operands of tile 0 / tile 1 (see SM_K1_PACK)
@@ -941,6 +1155,15 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
         K1[0][1] = T[1][8]; K1[1][1] = T[1][8]; sm_swap_u(K1[0][1], K1[1][1]);
         K1[0][2] = T[2][8]; K1[1][2] = 0x3F803F80u; sm_swap_u(K1[0][2], K1[1][2]);     // (1.0, 1.0) x (b_hi, b_mid)
         K1[0][3] = T[0][8]; K1[1][3] = 0x00003F80u; sm_swap_u(K1[0][3], K1[1][3]);     // (1.0, 0)   x (b_lo, 0)
+#endif
+#if defined(SM_DEBUG_DUAL) && SM_K1_PACK
+#pragma unroll
+        for (int tt_ = 0; tt_ < 3; ++tt_) {
+#pragma unroll
+            for (int k_ = 0; k_ < 8; ++k_) SM_DD(0, T[tt_][k_]);
+        }
+#pragma unroll
+        for (int k_ = 0; k_ < 4; ++k_) { SM_DD(0, K1[0][k_]); SM_DD(0, K1[1][k_]); }
 #endif
         const uint32_t bias_pair = half == 0 ? 0x00003F80u : 0u;          // {bf16(1.0), 0}: the bias row of layer 1's k-step 1 (k = 18), lane half 0 only
         constexpr int TI[6] = {2, 1, 0, 1, 0, 0}, TJ[6] = {0, 1, 2, 0, 1, 0};   // products (weight term i) x (input term j), i + j <= 2, smallest first
@@ -1061,6 +1284,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #pragma unroll
         for (int g = 0; g < 6; ++g) layer1(0, g);
         SM_SEC_MLP(11);
+        SM_DD_ACC(1, 0);
         // ---- B: layer 1 of tile 1 || density head of tile 0;  C: direction term of tile 0 || density head of tile 1;  D: direction term of tile 1 || colour head of tile 0
         sm_static_for<6>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -1078,6 +1302,8 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             else if (g & 1) dir_term(nt, 3 + g / 2);                         // products (1,0), (0,1), (0,0) behind the groups 1, 3, 5
         };
         SM_SEC_MLP(12);
+        SM_DD_ACC(1, 1);
+        SM_DD(2, __float_as_uint(ps_[0].x)); SM_DD(2, __float_as_uint(ps_[0].y));
         load_sh(0);
         sm_static_for<6>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -1086,6 +1312,8 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             __builtin_amdgcn_sched_barrier(0);
         });
         SM_SEC_MLP(13);
+        SM_DD_ACC(3, 0);
+        SM_DD(2, __float_as_uint(ps_[1].x)); SM_DD(2, __float_as_uint(ps_[1].y));
         load_sh(1);
         sm_static_for<6>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -1094,6 +1322,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             __builtin_amdgcn_sched_barrier(0);
         });
         SM_SEC_MLP(14);
+        SM_DD_ACC(3, 1);
+        SM_DD(4, __float_as_uint(pr_[0].x)); SM_DD(4, __float_as_uint(pr_[0].y)); SM_DD(4, __float_as_uint(pg_[0].x)); SM_DD(4, __float_as_uint(pg_[0].y));
+        SM_DD(4, __float_as_uint(pb_[0].x)); SM_DD(4, __float_as_uint(pb_[0].y));
 #ifdef SM_X_MFMA
         {   // sensitivity probe: SM_X_MFMA extra matrix instructions on their own accumulators, beside the last head (which has none of its own)
             floatx16 xa0, xa1;
@@ -1114,14 +1345,42 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             __builtin_amdgcn_sched_barrier(0);
         });
         SM_SEC_MLP(15);
+        SM_DD(4, __float_as_uint(pr_[1].x)); SM_DD(4, __float_as_uint(pr_[1].y)); SM_DD(4, __float_as_uint(pg_[1].x)); SM_DD(4, __float_as_uint(pg_[1].y));
+        SM_DD(4, __float_as_uint(pb_[1].x)); SM_DD(4, __float_as_uint(pb_[1].y));
         ps0 = ps_[0].x + ps_[0].y; ps1 = ps_[1].x + ps_[1].y; pr0 = pr_[0].x + pr_[0].y; pr1 = pr_[1].x + pr_[1].y;
         pg0 = pg_[0].x + pg_[0].y; pg1 = pg_[1].x + pg_[1].y; pb0 = pb_[0].x + pb_[0].y; pb1 = pb_[1].x + pb_[1].y;
         // cross-half reduction: after the swap, (x0 + x1) on lane l is the total for sample l
         sm_swap(ps0, ps1); sm_swap(pr0, pr1); sm_swap(pg0, pg1); sm_swap(pb0, pb1);
+#ifdef SM_DEBUG_DUAL
+        sigma = ssd_exp(ps0 + ps1 + b_sigma);
+        sr = ssd_fma(ssd_sigmoid(pr0 + pr1 + bc0), sat_k, -c.sat);
+        sg = ssd_fma(ssd_sigmoid(pg0 + pg1 + bc1), sat_k, -c.sat);
+        sb_ = ssd_fma(ssd_sigmoid(pb0 + pb1 + bc2), sat_k, -c.sat);
+        SM_DD(5, __float_as_uint(sigma)); SM_DD(5, __float_as_uint(sr)); SM_DD(5, __float_as_uint(sg)); SM_DD(5, __float_as_uint(sb_));
+        if (dd_rep == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) dd_first[q] = dd_cur[q];
+        } else {
+            uint32_t dd_mask = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) dd_mask |= (dd_cur[q] != dd_first[q] ? 1u : 0u) << q;
+            if (dd_mask != 0) {                                                  // words 8..13: lanes per differing stage; 14: lanes; 16..21: lanes per FIRST differing stage; 22: lanes that were shading
+                uint32_t* d = queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) if (dd_mask >> q & 1u) atomicAdd(d + 8 + q, 1u);
+                atomicAdd(d + 14, 1u);
+                atomicAdd(d + 16 + (__builtin_ctz(dd_mask)), 1u);
+                if (on) atomicAdd(d + 22, 1u);
+                atomicOr(d + 24 + (lane >> 5), 1u << (lane & 31));              // words 24, 25: which lanes ever differed
+            }
+        }
+        }   // dd_rep
+#else
         const float sigma = ssd_exp(ps0 + ps1 + b_sigma);
         const float sr = ssd_fma(ssd_sigmoid(pr0 + pr1 + bc0), sat_k, -c.sat);
         const float sg = ssd_fma(ssd_sigmoid(pg0 + pg1 + bc1), sat_k, -c.sat);
         const float sb_ = ssd_fma(ssd_sigmoid(pb0 + pb1 + bc2), sat_k, -c.sat);
+#endif
 
         SM_SEC(2);
         if (on) {
@@ -1130,12 +1389,25 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
             const float w = alpha * Tr;
             // diagnostic: termination tests that land within float noise of the threshold (the only rays whose sample count may differ from
             // the reference's, whose exp is CUDA's __expf: DESIGN.md "arithmetic contract"); a few % of the hitting rays, once each
+#if !SM_NO_BOUNDARY_COUNT
             if (fabsf(Tr - c.T_thresh) < 2e-6f) atomicAdd(queue_count + ssd_counter(SSD_CNT_BOUNDARY, c.S, scene), 1u);
+#endif
+#ifdef SM_DEBUG_TRACE
+            th[0] ^= th_mix(__float_as_uint(t), cnt);
+            th[1] ^= th_mix(th_f, cnt);
+            th[2] ^= th_mix(__float_as_uint(sigma) ^ (__float_as_uint(sr) * 3u) ^ (__float_as_uint(sg) * 5u) ^ (__float_as_uint(sb_) * 7u) ^ (__float_as_uint(sdt) * 11u), cnt);
+            th[3] ^= th_mix(th_sh, cnt);
+            th[6] ^= th_mix(th_tex, cnt);
+            th[7] ^= th_mix(th_w, cnt);
+#endif
             ws += w;
             dep = ssd_fma(w, t, dep);
             cr = ssd_fma(w, sr, cr);
             cg = ssd_fma(w, sg, cg);
             cb = ssd_fma(w, sb_, cb);
+#ifdef SM_DEBUG_TRACE
+            th[5] ^= th_mix(__float_as_uint(ws) ^ (__float_as_uint(dep) * 3u) ^ (__float_as_uint(cr) * 5u) ^ (__float_as_uint(cg) * 7u) ^ (__float_as_uint(cb) * 11u), cnt);
+#endif
             ++cnt;
 #if SM_SEARCH_AHEAD
             // the loop's tests in the loop's order -- far, cap, probe 1, far, probe 2, far, park -- as predicates and selects (the if / else-if chain
@@ -1246,6 +1518,13 @@ static int sm_shade(const void* planes, int planes_dtype, uint32_t Hp, uint32_t 
     c.blocks64 = (grid_size >= 16 && getenv("SSDNERF_NO_COARSE") == nullptr) ? w.blocks64 : nullptr;      // (what rq_first_hit built: same condition)
     c.order = ticket_order ? w.order : nullptr;
     c.order_stride = w.order_stride;
+#ifdef SM_DEBUG_TRACE
+    {
+        const char* tp = getenv("SSDNERF_DEBUG_TRACE_PTR");                 // a zeroed device buffer of S * N * 8 words (tools/trace_check.py)
+        SSD_REQUIRE(tp != nullptr, "render_shade_queue_mfma: a SM_DEBUG_TRACE build needs SSDNERF_DEBUG_TRACE_PTR");
+        c.dbg_trace = reinterpret_cast<uint32_t*>(strtoull(tp, nullptr, 0));
+    }
+#endif
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;

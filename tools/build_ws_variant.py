@@ -9,6 +9,9 @@ if flags and flags[0].startswith("swap="):                       # NAME WAIT_STA
     os.environ["SSDNERF_SWAP_MFMA_WAIT_STATES"] = flags.pop(0).split("=")[1]
 if flags and flags[0].startswith("valu="):                       # ... valu=N: the third rule (asm_postpass.VALU_MFMA_WAIT_STATES, r06)
     os.environ["SSDNERF_VALU_MFMA_WAIT_STATES"] = flags.pop(0).split("=")[1]
+if flags and flags[0] == "keepcross":                            # ... keepcross: leave the compiler's packed fp32 instructions with crossed halves alone (r06 positive controls)
+    flags.pop(0)
+    os.environ["SSDNERF_KEEP_PACKED_CROSS_HALF"] = "1"
 os.environ["SSDNERF_TRANS_USE_WAIT_STATES"] = str(ws)
 if ws == 0:
     os.environ["SSDNERF_NO_POSTPASS"] = "1"
