@@ -1,6 +1,15 @@
-"""Assembly post-pass of the library build: at least N issue slots (build.TRANS_USE_WAIT_STATES, 4) between a transcendental VALU instruction and the
-instruction that reads its result -- and (r05, ``SWAP_MFMA_WAIT_STATES`` below) at least 8 between a `v_permlane32_swap` and a matrix instruction that
-reads one of the swapped registers as an operand.
+"""Assembly post-pass of the library build.
+
+ROUND 6 -- what the pass is FOR now (the block at the end of this file: ``unpack_cross_half``, ``scan_packed_cross_half``): every packed fp32 instruction whose
+op_sel / op_sel_hi bits read across the halves of a VGPR source pair is split into two plain instructions, and the build fails if one is left in a linked code
+object.  That instruction kind is what made the fused render differ from run to run with two waves on a SIMD (rounds 2 - 5); the per-ray trace hashes and the
+in-kernel re-evaluation that found it are tools/trace_check.py and tools/blend_check.py.
+
+The rest of this docstring and the walk below are the two PADDING rules of rounds 3 and 5, kept for experiments and OFF in the default build (build.py): at least
+N issue slots (``wait_states``) between a transcendental VALU instruction and the instruction that reads its result, and (``SWAP_MFMA_WAIT_STATES``) between a
+`v_permlane32_swap` and a matrix instruction that reads one of the swapped registers.  Both were adopted on dose-response evidence that round 6 explains as timing
+side effects -- padding moves the two waves of a SIMD against each other -- of the packed instructions above: with those split, every arrangement that failed at
+some padding is clean at the toolchain's own distances (profiles/r06/e_loud_arrangements_split.txt).
 
 Why (round 3, profiles/r03/hazard.txt): on gfx950 the quarter-rate instructions (v_exp / v_rcp / v_rsq / v_sqrt / v_log / v_sin / v_cos: 16 lanes per
 pass) hand their result to a following VALU instruction through a software-managed hazard; ROCm 7.2's hazard recogniser (VALUTransUseHazard) pads it
@@ -533,3 +542,38 @@ def unpack_cross_half(listing: str) -> Tuple[str, Dict[str, int]]:
             out.extend(two)
             n += 1
     return "\n".join(out), {"packed_cross_half_split": n}
+
+
+def device_code_objects(path: str, arch: str = "gfx950") -> List[bytes]:
+    """the device code objects embedded in a host object / shared library built by hipcc: every clang offload bundle (`__CLANG_OFFLOAD_BUNDLE__`) in the file, the
+    entries whose target triple names `arch`"""
+    import struct
+    data = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out: List[bytes] = []
+    at = data.find(magic)
+    while at >= 0:
+        n = struct.unpack_from("<Q", data, at + len(magic))[0]
+        p = at + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24: p + 24 + tl].decode("ascii", "replace")
+            p += 24 + tl
+            if arch in triple and size > 0:
+                out.append(data[at + off: at + off + size])
+        at = data.find(magic, at + len(magic))
+    return out
+
+
+def disassemble_library(path: str, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump", arch: str = "gfx950") -> str:
+    """`llvm-objdump -d` of every device code object embedded in `path`, concatenated"""
+    import subprocess
+    import tempfile
+    text = ""
+    with tempfile.TemporaryDirectory() as td:
+        for i, blob in enumerate(device_code_objects(path, arch)):
+            f = f"{td}/co{i}.out"
+            with open(f, "wb") as fh:
+                fh.write(blob)
+            text += subprocess.run([objdump, "-d", f], check=True, capture_output=True, text=True).stdout
+    return text

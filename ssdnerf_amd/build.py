@@ -4,12 +4,16 @@
 where the sources call ``__builtin_fmaf``, so integer outputs (sample counts, alive flags) are
 reproducible bit for bit against the CPU oracle.
 
-Every source goes  hipcc -S (device listing) -> ``asm_postpass.pad_trans_use`` (FOUR issue slots, ``TRANS_USE_WAIT_STATES``, behind every
-transcendental instruction before its result is read: the toolchain pads that hazard to one, which is not always enough on gfx950 with two waves
-on a SIMD -- see asm_postpass.py and profiles/r03/hazard.txt; r05: and EIGHT, ``SWAP_MFMA_WAIT_STATES``, between a `v_permlane32_swap` and a matrix
-instruction that reads a swapped register as its A / B operand -- profiles/r05/zz_soak_reproducibility.txt) -> assembler -> lld -> ``asm_postpass.verify_code_object`` (the rule re-checked on
-the LINKED code object with an independent scanner) -> offload bundle -> host object that embeds it.  ``SSDNERF_NO_POSTPASS=1`` builds the
-compiler's own code (A/B runs only).  ``lib/postpass_report.json`` records what the pass did per source, the settings, and the toolchain.
+Every source goes  hipcc -S (device listing) -> ``asm_postpass.unpack_cross_half`` -> assembler -> lld -> checks on the LINKED code object -> offload bundle ->
+host object that embeds it.  The post-pass has ONE job since round 6: every packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose op_sel /
+op_sel_hi bits read ACROSS the halves of a VGPR source pair is replaced by the two plain instructions that compute the same two IEEE results.  On gfx950, with
+two waves on a SIMD, such an instruction occasionally loses the product term of its low half in lanes 48-63: the cause of the run-to-run differences of the
+fused render that rounds 2 - 5 chased as a transcendental -> use and a swap -> MFMA hazard (asm_postpass.py, the r06 block; DESIGN.md section 5.5;
+profiles/r06/README.md).  The build FAILS if one such instruction is left in a linked code object.  The two padding rules of r03 / r05 (issue slots behind a
+transcendental, between a lane swap and a matrix instruction) are still in asm_postpass.py for experiments and are OFF by default (``SSDNERF_TRANS_USE_WAIT_STATES=1``
+is the toolchain's own distance, ``SSDNERF_SWAP_MFMA_WAIT_STATES=0``): with the crossed instructions gone, the compiler's own code is clean in every arrangement that
+used to fail and over 10^5 renders (profiles/r06/g_*, e_*).  ``SSDNERF_KEEP_PACKED_CROSS_HALF=1`` keeps the compiler's instructions (positive-control builds only);
+``SSDNERF_NO_POSTPASS=1`` builds with plain `hipcc -c`.  ``lib/postpass_report.json`` records what the pass did per source, the settings, and the toolchain.
 
 The pass parses the device listing syntax of ROCm 7.2 and re-states `hipcc -c`'s internal device steps, so it is PINNED to the toolchains it was
 validated on (``VALIDATED_HIP_VERSIONS``): another `hipcc --version` fails the build loudly (``SSDNERF_ALLOW_UNVALIDATED_TOOLCHAIN=1`` overrides
@@ -29,8 +33,8 @@ LIB_DIR = os.environ.get("SSDNERF_LIB_DIR") or os.path.join(HERE, "lib")     # S
 LIB_PATH = os.path.join(LIB_DIR, "libssdnerf_hip.so")
 SOURCES = ["raymarching_ops.hip", "shencoder.hip", "decode.hip", "render_fused.hip", "render_queue.hip", "shade_mfma.hip", "ddim.hip", "groupnorm.hip", "conv_igemm.hip", "attention.hip", "raygen.hip", "marching_cubes.hip"]
 LLVM_BIN = os.environ.get("SSDNERF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
-TRANS_USE_WAIT_STATES = int(os.environ.get("SSDNERF_TRANS_USE_WAIT_STATES", "4"))
-SWAP_MFMA_WAIT_STATES = int(os.environ.get("SSDNERF_SWAP_MFMA_WAIT_STATES", "8"))    # asm_postpass.SWAP_MFMA_WAIT_STATES (0 = rule off)
+TRANS_USE_WAIT_STATES = int(os.environ.get("SSDNERF_TRANS_USE_WAIT_STATES", "1"))     # 1 = the toolchain's own distance: the r03 rule is off (r06)
+SWAP_MFMA_WAIT_STATES = int(os.environ.get("SSDNERF_SWAP_MFMA_WAIT_STATES", "0"))    # asm_postpass.SWAP_MFMA_WAIT_STATES (0 = rule off: the default since r06)
 UNPACK_CROSS_HALF = os.environ.get("SSDNERF_KEEP_PACKED_CROSS_HALF", "0") != "1"      # r06 (asm_postpass.unpack_cross_half); =1 keeps the compiler's instructions (positive-control builds)
 VALU_MFMA_WAIT_STATES = int(os.environ.get("SSDNERF_VALU_MFMA_WAIT_STATES", "0"))    # asm_postpass.VALU_MFMA_WAIT_STATES (r06; 0 = rule off)
 HEADERS = ["common.h", "sh_basis.h", "decode_core.h", "decode_bwd_math.h", "gn_bwd_math.h", os.path.join("..", "..", "include", "ssdnerf_hip.h")]

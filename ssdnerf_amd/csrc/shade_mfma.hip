@@ -134,7 +134,8 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 #define SM_W_EARLY 0                               // heads: the group's output-weight reads in front of its transcendentals instead of behind them
 #endif
 #ifndef SM_SWAP_F32
-#define SM_SWAP_F32 0                              // (r06) 1: the lane-half exchange on the fp32 features in front of the split instead of on the split terms behind it (see the split)
+#define SM_SWAP_F32 1                              // (r06) 1: the lane-half exchange on the fp32 features in front of the split (8 swaps) instead of on the split terms behind it (12):
+                                                   // bit-identical, shade kernel 4.75 -> 4.72 ms (profiles/r06/f_ab_split_vs_packed.txt)
 #endif
 #ifndef SM_BLEND_VARIANT
 #define SM_BLEND_VARIANT 0
@@ -161,15 +162,17 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 #define SM_EVENT_MIN 4                             // r05 A/B (bench scene, shade kernel, with SM_SEARCH_AHEAD and the one-round gather): 1: 5.06, 3: 4.94-4.97, 4: 4.94-4.96, 5: 4.97, 6: 5.01 ms
 #endif
 
-// Run-to-run reproducibility (r02 symptom, r03 cause).  r02: with two waves per SIMD a render repeated on the same inputs differed on groups of
-// EXACTLY 16 neighbouring rays -- one quarter-wave, one sample each, up to 6e-3 in rgb / depth, ~30 rays of 4 M per launch -- and a scheduling
-// barrier in front of every MFMA group made it go away; it was taken for a VALU -> MFMA operand hazard.  r03 (profiles/r03/hazard.txt): the
-// barriers only MOVED code.  The pair is  v_exp_f32 / v_rcp_f32 (quarter rate: 16 lanes per pass) -> the packed op that reads the result  in the
-// SiLUs below: the toolchain pads that hazard (VALUTransUseHazard) to one wait state, and with two waves on a SIMD the consumer occasionally
-// reads the register before the last 16-lane pass is written.  Evidence: any 4-byte shift of the instruction stream in front of those pairs hid
-// the failure, a 64-byte shift did not; lengthening only the compiler's own `s_nop 0` behind transcendentals to `s_nop 1` IN PLACE (identical code
-// layout) gave 0 differing renders of 200 at every placement, 40 of 40 without.  The fix is therefore not here but in the build: asm_postpass.py
-// gives every transcendental -> use pair of the library four wait states, and the r02 barriers are gone.
+// Run-to-run reproducibility (r02 symptom; r06 cause).  With two waves per SIMD a render repeated on the same inputs differed on groups of neighbouring rays -- up to 16,
+// one quarter-wave: lanes 48-63 -- by 1e-8 .. 5e-2, about one render in 3 000 in the shipped arrangement and hundreds to 250 000 rays per render in arrangements of the
+// SiLU heads that differ from it only in grouping.  r02 blamed a VALU -> MFMA operand hazard, r03 the transcendental -> use pair (and padded it at build level), r05 the
+// v_permlane32_swap -> MFMA pair (padded too); every "fix" was a change of timing.  r06 followed the error with per-ray hashes of every stage (SM_DEBUG_TRACE below,
+// tools/trace_check.py): march parameters, texels, bilinear weights and the MLP (evaluated twice per sample, SM_DEBUG_DUAL) always agree between runs -- the FEATURES do
+// not: the bilinear blend's packed chain  v_pk_mul_f32 r, a00, w op_sel_hi:[1,0] ; v_pk_fma_f32 r, a01, w, r op_sel:[0,1,0] ; ...  occasionally returns, in the low
+// half of lanes 48-63, the chain WITHOUT one product term (SM_DEBUG_BLEND2, tools/blend_check.py: the same registers blended again, packed and plain).  The trigger is the
+// packed fp32 instruction whose op_sel / op_sel_hi read across the halves of a VGPR pair (the compiler's broadcast of one weight): the same chain with the broadcast in a
+// register pair (SM_BLEND_VARIANT 1) or as plain v_mul / v_fma (SM_BLEND_SCALAR) never fails, in any arrangement.  The fix is in the build, for the whole library:
+// asm_postpass.unpack_cross_half splits every such instruction into two plain ones and the build refuses a code object that still holds one.  The r03 / r05 padding
+// rules are off.  Stand-alone probes of the instruction (tools/ubench/pk_cross_hazard.hip, pk_cross_gather.hip) are clean: the failure needs this kernel around it.
 
 // SM_ADDR32 (r05): the gather of decode_core.h with the texel address as ONE 32-bit byte offset from the scene's (wave-uniform) plane base, so that
 // the loads take the base from SGPRs (saddr form) instead of a 64-bit add per corner; element-wise the same arithmetic, bit-identical features.
@@ -1124,10 +1127,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
 #endif
 #if SM_SWAP_F32
         // (r06) the half exchange on the fp32 FEATURES, in front of the split: f[k] <-> f[8 + k] puts feature k (lane half 0) / 8 + k (half 1) of tile 0's samples into
-        // f[k] and of tile 1's into f[8 + k] -- the very values whose split terms the swaps below used to exchange, so T[.][0..7] hold the same bits -- with 8 swaps
-        // instead of 12, and, the point, with NO v_permlane32_swap result read by a matrix instruction: every swap is consumed by the split's VALU chain (and, sub,
-        // and, sub, perm), the matrix operands are written by v_perm_b32.  Features 16, 17 (one k-step for all six products, SM_K1_PACK) keep their swaps of split
-        // terms further down: their consumer is the LAST matrix instruction pair of a tile's layer 1, >= 20 matrix instructions behind them (profiles/r06/b_*).
+        // f[k] and of tile 1's into f[8 + k] -- the very values whose split terms the swaps further down used to exchange, so T[.][0..7] hold the same bits -- with 8
+        // swaps instead of 12 (written while the swap -> MFMA pair was the suspect of the reproducibility hunt, kept because it is 0.7 % faster).  Features 16, 17 (one
+        // k-step for all six products, SM_K1_PACK) keep their swaps of split terms.
 #pragma unroll
         for (int k = 0; k < 8; ++k) sm_swap(f[k], f[8 + k]);
 #endif

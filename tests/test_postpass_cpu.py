@@ -1,11 +1,15 @@
-"""The build's assembly post-pass (ssdnerf_amd/asm_postpass.py): every transcendental -> use pair gets the required issue slots, the compiler's own
-pad is lengthened in place where there is one, nothing else moves, and the pass is idempotent.  Checked on a hand-written listing and on the
-compiler's real listing of one library source (hipcc cross-compiles without a GPU)."""
+"""The build's assembly post-pass (ssdnerf_amd/asm_postpass.py).  Round 6: packed fp32 instructions whose halves read across a VGPR source pair are split into
+two plain instructions (the instruction kind behind the run-to-run differences of rounds 2 - 5) and none may be left in the shipped library.  The padding rules of
+rounds 3 / 5 (transcendental -> use, swap -> matrix operand) are off in the build and still tested here as functions: every pair gets the required issue slots, the
+compiler's own pad is lengthened in place where there is one, nothing else moves, the pass is idempotent.  Hand-written listings and the compiler's real listing of
+library sources (hipcc cross-compiles without a GPU)."""
 import os
 import subprocess
 
 from ssdnerf_amd import build as B
 from ssdnerf_amd.asm_postpass import closest_trans_use, pad_trans_use
+
+WS = 4          # the r03 rule's distance, as a function argument (the build's default is the toolchain's own: WS == 1)
 
 LISTING = """
 	.text
@@ -87,7 +91,6 @@ def test_swap_to_matrix_operand_pairs_get_their_slots():
     """the second rule (r05: profiles/r05/zz_soak_reproducibility.txt): >= N issue slots between a v_permlane32_swap and a matrix instruction that reads a swapped
     register as its A or B operand; a swap eight instructions ahead, or one whose result is only the ACCUMULATOR operand, is left alone; off by default in the module"""
     from ssdnerf_amd import asm_postpass as A
-    assert A.SWAP_MFMA_WAIT_STATES == 0 or A.SWAP_MFMA_WAIT_STATES == B.SWAP_MFMA_WAIT_STATES
     saved = A.SWAP_MFMA_WAIT_STATES
     try:
         A.SWAP_MFMA_WAIT_STATES = 0
@@ -114,25 +117,124 @@ def test_real_listing_of_a_library_source_meets_the_invariant(tmp_path):
     subprocess.check_call([B._hipcc()] + B.FLAGS + ["-S", "--cuda-device-only", src, "-o", str(listing)], stderr=subprocess.DEVNULL)
     text = listing.read_text()
     assert closest_trans_use(text) <= 1                      # the toolchain pads this hazard to one wait state (or leaves trans -> trans pairs adjacent)
-    out, st = pad_trans_use(text, B.TRANS_USE_WAIT_STATES)
+    out, st = pad_trans_use(text, WS)
     assert st["trans_instructions"] > 0 and st["pairs_closer_than_required"] > 0
-    assert closest_trans_use(out) >= B.TRANS_USE_WAIT_STATES
+    assert closest_trans_use(out) >= WS
     assert [l for l in out.split("\n") if "s_nop" not in l] == [l for l in text.split("\n") if "s_nop" not in l]
 
 
 def test_shipped_library_was_built_with_the_post_pass():
     import json
     report = json.load(open(os.path.join(B.LIB_DIR, "postpass_report.json")))
-    assert report["wait_states"] == B.TRANS_USE_WAIT_STATES >= 2 and report["toolchain"]["validated"] is True
-    assert set(report["sources"]) == set(B.SOURCES)
+    assert report["toolchain"]["validated"] is True and set(report["sources"]) == set(B.SOURCES)
+    assert report["settings"]["unpack_cross_half"] is True                      # r06: the one rule of the build
     shade = report["sources"]["shade_mfma.hip"]
-    assert shade["trans_instructions"] > 1000 and shade["closest_pair_after"] >= B.TRANS_USE_WAIT_STATES
-    # the same rule re-checked on the linked code object by the independent scanner (asm_postpass.verify_code_object)
-    assert shade["code_object_check"]["trans_instructions"] == shade["trans_instructions"] and shade["code_object_check"]["closest_pair"] >= B.TRANS_USE_WAIT_STATES
-    # the swap -> matrix-operand rule is on in the shipped build, and the shading kernel is where it applies
-    assert report["settings"]["swap_mfma_wait_states"] == B.SWAP_MFMA_WAIT_STATES >= 8 and shade["swap_mfma_pairs_padded"] > 0
-    assert shade["code_object_check"]["swap_instructions"] > 100 and shade["code_object_check"]["closest_swap_mfma_pair"] >= B.SWAP_MFMA_WAIT_STATES   # (linked code object)
-    assert all("swap_mfma_pairs_padded" not in v for k, v in report["sources"].items() if k != "shade_mfma.hip")
+    assert shade["packed_cross_half_split"] > 500 and shade["code_object_check"]["packed_cross_half"] == 0
+    assert sum(v["packed_cross_half_split"] for v in report["sources"].values()) > 2000
+    assert all(v["code_object_check"]["packed_cross_half"] == 0 for v in report["sources"].values())
+    # the padding rules of r03 / r05 are off: the toolchain's own distance behind transcendentals, no swap -> matrix-operand rule
+    assert report["settings"]["wait_states"] == B.TRANS_USE_WAIT_STATES == 1 and report["settings"]["swap_mfma_wait_states"] == B.SWAP_MFMA_WAIT_STATES == 0
+    assert shade["trans_instructions"] > 1000 and shade["pairs_closer_than_required"] == 0
+
+
+def test_no_crossed_packed_instruction_in_the_shipped_library():
+    """the linked device code of lib/libssdnerf_hip.so, disassembled here: no v_pk_{fma,mul,add}_f32 reads across the halves of a VGPR source pair"""
+    from ssdnerf_amd.asm_postpass import device_code_objects, disassemble_library, scan_packed_cross_half
+    assert len(device_code_objects(B.LIB_PATH)) == len(B.SOURCES)                   # one code object per source
+    text = disassemble_library(B.LIB_PATH, os.path.join(B.LLVM_BIN, "llvm-objdump"))
+    assert text.count("v_mfma_f32_32x32x16_bf16") > 100, "the disassembly does not show the library's device code"
+    assert "v_pk_fma_f32" in text                                                    # (uncrossed packed instructions stay)
+    assert scan_packed_cross_half(text) == {}
+
+
+PACKED = """
+	v_pk_fma_f32 v[0:1], v[4:5], v[186:187], v[0:1] op_sel:[0,1,0]
+	v_pk_mul_f32 v[0:1], v[0:1], v[186:187] op_sel_hi:[1,0]
+	v_pk_add_f32 v[4:5], v[0:1], s[80:81] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]
+	v_pk_mul_f32 v[186:187], v[186:187], v[2:3] op_sel_hi:[0,1]
+	v_pk_mul_f32 v[46:47], v[46:47], v[46:47] op_sel:[0,1] op_sel_hi:[0,1]
+	v_pk_add_f32 v[136:137], v[136:137], 1.0 op_sel_hi:[1,0]
+	v_pk_fma_f32 v[144:145], v[144:145], v[182:183], 0 op_sel_hi:[1,1,0]
+	v_pk_fma_f32 v[8:9], v[2:3], v[4:5], v[6:7] clamp
+	v_pk_mov_b32 v[56:57], v[56:57], v[58:59] op_sel:[1,0]
+"""
+
+
+def test_crossed_packed_instructions_are_split_into_the_same_arithmetic():
+    """``unpack_cross_half`` on hand-written lines: crossed VGPR sources are split, constants and uncrossed instructions stay; and the two plain instructions compute,
+    on random register contents, exactly what the packed instruction's definition says (D.lo = f(src_i[op_sel_i]), D.hi = f(src_i[op_sel_hi_i]))"""
+    import re
+    import numpy as np
+    from ssdnerf_amd.asm_postpass import packed_cross_half, scan_packed_cross_half, split_packed_cross_half, unpack_cross_half
+    lines = [l for l in PACKED.split("\n") if l.strip()]
+    crossed = [packed_cross_half(l) is not None for l in lines]
+    assert crossed == [True, True, True, True, True, False, False, False, False]
+    out, st = unpack_cross_half(PACKED)
+    assert st["packed_cross_half_split"] == 5 and scan_packed_cross_half(out) == {}
+    assert all(l in out for l, c in zip(lines, crossed) if not c)                    # untouched
+    rng = np.random.default_rng(0)
+
+    def run_plain(ins, v, s):
+        op, rest = ins.strip().split(None, 1)
+        clamp = rest.endswith(" clamp")
+        ops = [o.strip() for o in rest.replace(" clamp", "").split(",")]
+        def val(o):
+            neg = o.startswith("-"); o = o.lstrip("-")
+            x = v[int(o[1:])] if o[0] == "v" else s[int(o[1:])] if o[0] == "s" else np.float32(float(o))
+            return -x if neg else x
+        if op == "v_mov_b32_e32":
+            r = val(ops[1])
+        else:
+            a = [val(o) for o in ops[1:]]
+            r = {"v_fma_f32": lambda: np.float32(np.float64(a[0]) * np.float64(a[1]) + np.float64(a[2])), "v_mul_f32_e64": lambda: np.float32(a[0] * a[1]),
+                 "v_add_f32_e64": lambda: np.float32(a[0] + a[1])}[op]()
+        v[int(ops[0][1:])] = np.clip(r, 0, 1).astype(np.float32) if clamp else r
+
+    def run_packed(ins, v, s):
+        op, rest = ins.strip().split(None, 1)
+        bits = {m.group(1): [int(x) for x in m.group(2).split(",")] for m in re.finditer(r"(op_sel|op_sel_hi|neg_lo|neg_hi):\[([01,]+)\]", rest)}
+        ops = [o.strip() for o in re.sub(r"(op_sel|op_sel_hi|neg_lo|neg_hi):\[[01,]+\]", "", rest).split(", ")]
+        ops = [o.strip().rstrip(",") for o in ops if o.strip()]
+        d = int(re.match(r"v\[(\d+):", ops[0]).group(1))
+        n = len(ops) - 1
+        res = []
+        for half, key, dflt in ((0, "op_sel", 0), (1, "op_sel_hi", 1)):
+            a = []
+            for i, o in enumerate(ops[1:]):
+                sel = (bits.get(key, []) + [dflt] * n)[i]
+                neg = (bits.get("neg_lo" if half == 0 else "neg_hi", []) + [0] * n)[i]
+                m = re.match(r"([vs])\[(\d+):", o)
+                x = (v if m.group(1) == "v" else s)[int(m.group(2)) + sel]
+                a.append(-x if neg else x)
+            res.append({"v_pk_fma_f32": lambda: np.float32(np.float64(a[0]) * np.float64(a[1]) + np.float64(a[2])), "v_pk_mul_f32": lambda: np.float32(a[0] * a[1]),
+                        "v_pk_add_f32": lambda: np.float32(a[0] + a[1])}[op]())
+        v[d], v[d + 1] = res
+    for l in [x for x, c in zip(lines, crossed) if c]:
+        for _ in range(20):
+            v0 = rng.standard_normal(256).astype(np.float32); s0 = rng.standard_normal(104).astype(np.float32)
+            v1, v2 = v0.copy(), v0.copy()
+            run_packed(l, v1, s0)
+            for ins in split_packed_cross_half(l):
+                run_plain(ins, v2, s0)
+            assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)), l
+
+
+def test_real_listings_split_completely(tmp_path):
+    """the compiler's listing of a source that is full of crossed packed instructions (the triplane decode): all of them split, the result assembles and links"""
+    from ssdnerf_amd.asm_postpass import scan_packed_cross_half, unpack_cross_half
+    src = os.path.join(B.CSRC, "raymarching_ops.hip")
+    listing = tmp_path / "r.s"
+    subprocess.check_call([B._hipcc()] + B.FLAGS + ["-S", "--cuda-device-only", src, "-o", str(listing)], stderr=subprocess.DEVNULL)
+    text = listing.read_text()
+    before = scan_packed_cross_half(text)
+    assert sum(before.values()) > 5
+    out, st = unpack_cross_half(text)
+    assert st["packed_cross_half_split"] == sum(before.values()) and scan_packed_cross_half(out) == {}
+    fixed = tmp_path / "fixed.s"
+    fixed.write_text(out)
+    B.assemble_and_link(str(fixed), str(tmp_path / "f.o"), str(tmp_path / "f.out"))
+    dis = subprocess.run([os.path.join(B.LLVM_BIN, "llvm-objdump"), "-d", str(tmp_path / "f.out")], check=True, capture_output=True, text=True).stdout
+    assert scan_packed_cross_half(dis) == {}
 
 
 HOLES = """
@@ -190,13 +292,13 @@ def test_linked_code_object_is_verified_independently(tmp_path):
     src = os.path.join(B.CSRC, "raygen.hip")
     raw_s, fixed_s = tmp_path / "raw.s", tmp_path / "fixed.s"
     subprocess.check_call([B._hipcc()] + B.FLAGS + ["-S", "--cuda-device-only", src, "-o", str(raw_s)], stderr=subprocess.DEVNULL)
-    fixed_s.write_text(pad_trans_use(raw_s.read_text(), B.TRANS_USE_WAIT_STATES)[0])
+    fixed_s.write_text(pad_trans_use(raw_s.read_text(), WS)[0])
     outs = {}
     for name, path in (("raw", raw_s), ("fixed", fixed_s)):
         obj, out = tmp_path / f"{name}.o", tmp_path / f"{name}.out"
         B.assemble_and_link(str(path), str(obj), str(out))
         outs[name] = str(out)
     with pytest.raises(RuntimeError, match="issue slots later"):
-        verify_code_object(outs["raw"], B.TRANS_USE_WAIT_STATES)
-    rep = verify_code_object(outs["fixed"], B.TRANS_USE_WAIT_STATES)
-    assert rep["trans_instructions"] > 0 and (rep["closest_pair"] is None or rep["closest_pair"] >= B.TRANS_USE_WAIT_STATES)
+        verify_code_object(outs["raw"], WS)
+    rep = verify_code_object(outs["fixed"], WS)
+    assert rep["trans_instructions"] > 0 and (rep["closest_pair"] is None or rep["closest_pair"] >= WS)
