@@ -158,3 +158,59 @@ def test_eight_rank_scene_parallel_evaluation(n_scenes):
     assert all(r[3] for r in res)
     want = 20.0 + (n_scenes - 1) / 2
     assert all(abs(r[4] - want) < 1e-3 for r in res), ([r[4] for r in res], want)
+
+
+# ---------------------------------------------------------------------------------------------- the second axis: views of one scene over the ranks (#scenes < #GPUs)
+def test_render_shard_plan_covers_every_view_once():
+    from ssdnerf_amd.parallel import plan_render_shards
+    for scenes, views, world in [(1, 251, 8), (3, 251, 8), (8, 251, 8), (11, 10, 8), (2, 250, 8), (1, 5, 8), (7, 251, 2), (5, 3, 8)]:
+        plan = plan_render_shards(scenes, views, world)
+        assert len(plan) == world
+        cover = np.zeros((scenes, views), dtype=int)
+        for a, b, c, d in plan:
+            cover[a:b, c:d] += 1
+        assert (cover == 1).all(), (scenes, views, world, plan)
+    # one scene on the node of north_star: 251 views -> 31 / 32 per rank, contiguous
+    assert plan_render_shards(1, 251, 8) == [(0, 1, 0, 31), (0, 1, 31, 63), (0, 1, 63, 94), (0, 1, 94, 126), (0, 1, 126, 157), (0, 1, 157, 188), (0, 1, 188, 220), (0, 1, 220, 251)]
+    # scenes >= ranks: the reference's scene partition, all views
+    assert plan_render_shards(704, 251, 8)[3] == (264, 352, 0, 251)
+
+
+def _worker_views(rank, world, port, scenes, views, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssdnerf_amd import parallel
+
+    def render(a, b, c, d):                                                    # view v of scene s: every pixel (s * 16 + v) % 251, plus a pixel that names the rank
+        out = torch.zeros(b - a, d - c, 2, 2, 3, dtype=torch.uint8)
+        for i, s in enumerate(range(a, b)):
+            for j, v in enumerate(range(c, d)):
+                out[i, j] = (s * 16 + v) % 251
+        return out
+    full = parallel.render_sharded(render, scenes, views)
+    want = torch.tensor([[(s * 16 + v) % 251 for v in range(views)] for s in range(scenes)], dtype=torch.uint8)
+    ok = tuple(full.shape) == (scenes, views, 2, 2, 3) and bool((full == want[:, :, None, None, None]).all())
+    q.put((rank, ok, parallel.plan_render_shards(scenes, views, world)[rank]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenes,views", [(1, 251), (3, 10), (8, 4)])
+def test_eight_rank_view_split_render(scenes, views):
+    """One scene's 251 views over the 8 ranks of the node (31 / 32 views each), three scenes over 8 ranks (3 + 2 + 3 ranks), and the scene-parallel case through the
+    same entry point: every rank ends up with every view of every scene."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_views, args=(r, world, port, scenes, views, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    if scenes == 1:
+        assert [r[2][3] - r[2][2] for r in res] == [31, 32, 31, 32, 31, 31, 32, 31]
