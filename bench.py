@@ -64,6 +64,7 @@ def parse_args():
                     "timed region: no overflow-flag read per batch); A/B only")
     ap.add_argument("--sync-overflow-check", action="store_true", help="read every render's overflow flag before the next render is queued (the r04 timed "
                     "step) instead of nerf.render's deferred check (flag copied asynchronously, examined behind the next render's launches)")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not launch the next step's stage A beside this step's shading kernel (nerf.render's next_batch, r06): the r05 step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-nccl", action="store_true", help="with --gpus 1: take the N > 1 code path with a ONE-rank RCCL process group (backend 'nccl', "
                     "world_size 1) -- RCCL initialisation, the asynchronous all-gather on RCCL's stream, graph captures beside RCCL's watchdog thread -- a "
@@ -168,7 +169,8 @@ def main():
         ``render_packed`` plus what the product path does around them: the ONE overflow-flag read per batch (a host sync) that decides whether the batch
         has to be redone through the stepwise path, and the uint8 views"""
         image, depth, image_u8 = nerf.render(dec, code_, bits_, hw, hw, intr, poses, grid_size=64, bg_color=1.0, cfg={}, planes=planes_,
-                                              rays=rays, return_u8=True, defer_overflow_check=not args.sync_overflow_check)
+                                              rays=rays, return_u8=True, defer_overflow_check=not args.sync_overflow_check,
+                                              next_batch=None if args.no_prefetch else (bits_, intr, poses))     # (r06) the next step's stage A beside this step's shading kernel
         return {"image": image.reshape(ns, nv * hw * hw, 3), "depth": depth.reshape(ns, nv * hw * hw), "image_u8": image_u8}
 
     # N > 1: every rank ends up with every rank's quantised views (RCCL all-gather over xGMI).  The collective of step i runs on RCCL's
@@ -264,6 +266,18 @@ def main():
 
     first_hit_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in kernel_events]))
     shade_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in kernel_events]))
+    # (r06) with next_batch, stage A of step i+1 runs on a second stream beside the shading kernel of step i: the events of the timed region then bracket the shading
+    # kernel WITH that company (what `roofline` must report: the kernel's launches of the timed region) and no longer stage A.  A short untimed loop without the
+    # prefetch gives both stages alone, on this box, in this process
+    alone = None
+    prefetching = not (args.no_prefetch or args.packed_loop or rays is not None)
+    if prefetching:
+        args.no_prefetch = True
+        _, ev_alone, _ = timed(planes, bits, 3, 10, code_dev)
+        args.no_prefetch = False
+        alone = dict(first_hit_ms=float(np.mean([e[0].elapsed_time(e[1]) for e in ev_alone])), shade_ms=float(np.mean([e[1].elapsed_time(e[2]) for e in ev_alone])))
+        first_hit_ms = alone["first_hit_ms"]
+        log(f"stages alone (no prefetch): first_hit {alone['first_hit_ms']:.3f} ms, shade {alone['shade_ms']:.3f} ms; shade in the timed region {shade_ms:.3f} ms")
     # dominant kernel = k_shade_mfma (gather + MLP + composite).  Its algorithmic bytes: 288 B per sample it shades plus,
     # per hitting ray, 8 B queue entry + 20 B outputs (+ 24 B ray when ray arrays are read).
     n_hit = stats["n_hit"]
@@ -304,17 +318,22 @@ def main():
                                  ("nerf.render (BaseNeRF.render on cached planes: two launches + the overflow-flag read per batch + uint8 views)" if args.sync_overflow_check else
                                   "nerf.render(defer_overflow_check=True) + nerf.finish_render after the last step (BaseNeRF.render on cached planes: two launches + uint8 "
                                   "views per batch; every batch's overflow flag is copied to pinned host memory asynchronously and examined behind the NEXT batch's "
-                                  "launches -- a raised flag redoes that batch into its own output tensors; --sync-overflow-check restores the r04 read before the next launch)"),
+                                  "launches -- a raised flag redoes that batch into its own output tensors; --sync-overflow-check restores the r04 read before the next launch)") +
+                                 ("" if args.no_prefetch or args.packed_loop else "; next_batch: stage A of the next step is launched on a second stream beside this step's shading kernel (r06; --no-prefetch: the r05 step)"),
                    "collective": "all_gather(uint8 views), overlapped with the next step's render" if multi else "none"},
         "views_per_s": rays_per_s / (hw * hw), "samples_per_s": n_samples_all / (elapsed / args.steps),
         "mean_samples_per_ray": n_samples / n_rays, "rays_at_step_cap": stats["overflow"],
         "roofline": {"bound": "hbm", "kernel": "k_shade_mfma", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,
                      "launch_ms": shade_ms, "launches_per_step": 1,
+                     "launch_ms_alone": None if alone is None else alone["shade_ms"],
+                     "frac_alone": None if alone is None else algo_bytes / (alone["shade_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "company": None if alone is None else "the timed region's launches share the chip with stage A of the NEXT step (second stream, nerf.render's next_batch): launch_ms / "
+                                                           "frac are measured with that company; launch_ms_alone / frac_alone in a short loop without it (--no-prefetch times that loop)",
                      "note": f"algorithmic = {bytes_per_sample} B/sample + {bytes_per_hit_ray} B per hitting ray; planes (1.5 MiB/scene) are L2-resident, so real HBM "
                              "traffic is far below this (PMC numbers in DESIGN.md / profiles/)",
                      "other_kernels": {"first_hit (k_ray_cull + k_survivor_march)": {
-                         "launch_ms": first_hit_ms, "algorithmic_bytes_per_launch": first_hit_bytes,
+                         "launch_ms": first_hit_ms, "hidden_beside_the_previous_steps_shading_kernel": prefetching, "algorithmic_bytes_per_launch": first_hit_bytes,
                          "achieved_GBs": first_hit_bytes / (first_hit_ms * 1e-3) / 1e9}}},
         "hit_rays_per_step_per_gpu": n_hit,
         "per_rank": None if per_rank is None else {

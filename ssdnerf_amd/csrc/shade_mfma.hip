@@ -131,7 +131,9 @@ template <int N, class F> SSD_DEV void sm_static_for(F&& f) { sm_static_for_impl
 // the bookkeeping as ONE event when SM_EVENT_MIN lanes are waiting (or nothing is left to shade).  Per-ray arithmetic and its order are
 // untouched -- every output is bit-identical for any value; 1 = an event in every iteration (the r01-r04 behaviour).
 #ifndef SM_W_EARLY
-#define SM_W_EARLY 0                               // heads: the group's output-weight reads in front of its transcendentals instead of behind them
+#define SM_W_EARLY 1                               // heads: the group's output-weight reads in front of its transcendentals instead of behind them: their LDS latency runs under the
+                                                   // v_exp burst (shade kernel 4.73 -> 4.65 ms, profiles/r06/h_ab_heads.txt; r05 had measured the same gain and could not ship it: this is
+                                                   // one of the arrangements in which the crossed packed instructions of the blend failed loudly -- see "Run-to-run reproducibility" below)
 #endif
 #ifndef SM_SWAP_F32
 #define SM_SWAP_F32 1                              // (r06) 1: the lane-half exchange on the fp32 features in front of the split (8 swaps) instead of on the split terms behind it (12):

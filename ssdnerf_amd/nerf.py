@@ -54,8 +54,14 @@ def get_cam_rays(c2w: torch.Tensor, intrinsics: torch.Tensor, h: int, w: int) ->
 def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch.Tensor, h: int, w: int, intrinsics: torch.Tensor,
            poses: torch.Tensor, grid_size: int = 64, bg_color: float = 1.0, cfg: Optional[Dict] = None,
            planes: Optional[torch.Tensor] = None, rays: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, return_u8: bool = False,
-           defer_overflow_check: bool = False):
+           defer_overflow_check: bool = False, next_batch: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
     """``BaseNeRF.render``: (S,V) views of S scenes -> image (S,V,h,w,3) blended with ``bg_color``, depth (S,V,h,w).
+
+    ``next_batch`` (extra, r06; streaming loops over cached scenes -- evaluation, bench.py): ``(density_bitfield, intrinsics, poses)`` of the NEXT ``render`` call on this
+    decoder.  Stage A of that render (cull + survivor march: it needs the bitfield and the cameras, not the planes) is launched now, on a second stream and into its own
+    workspace and output tensors, and runs beside THIS render's shading kernel (``TriPlaneDecoder.render_packed(prefetch=...)``); the next call recognises its inputs
+    -- the same tensors, unchanged -- and launches only its shading kernel.  Those inputs must be complete on the current stream at this call; a next call with other
+    inputs renders normally; ``finish_render`` after the last call of a loop forgets a stage nobody will use.  Only the uncond form (``dt_gamma_scale`` 0) takes it.
 
     ``defer_overflow_check`` (extra, r05): the one host read per call -- did a ray reach the ``max_steps`` cap, so that the batch has to be redone through the
     stepwise path? -- normally sits between this call's launches and the next call's (a host sync: ~0.12 ms per 6 ms render, and the GPU idles while the
@@ -86,8 +92,13 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
     overflow = []                                                     # device flags of the fused launches: ONE host read after the last chunk
     if planes is not None and rays is None and not chunked and os.environ.get("SSDNERF_RENDER_ARRAYS", "0") != "1":   # (=1: debugging aid, materialise the rays)
         # the whole batch in one fused launch pair, rays generated in the kernels from (poses, intrinsics): no (S,V,h,w,3) arrays at all
+        prefetch = None
+        if next_batch is not None:                                    # (density_bitfield, intrinsics, poses) of the NEXT render call: its stage A runs beside this one's shading kernel
+            n_bits, n_intr, n_poses = next_batch
+            if dt_gamma_scale == 0 and tuple(n_poses.shape[:2]) == (s, v):
+                prefetch = dict(cams=(n_poses, n_intr.expand(s, v, 4), h, w), density_bitfield=n_bits)
         out = decoder.render_packed(planes, None, None, density_bitfield, grid_size, dt_gamma, 1e-4, bg_color=bg_color,
-                                    check_overflow=False, cams=(poses, intrinsics.expand(s, v, 4), h, w), want_u8=return_u8)
+                                    check_overflow=False, cams=(poses, intrinsics.expand(s, v, 4), h, w), want_u8=return_u8, prefetch=prefetch)
         overflow.append(decoder.last_render_stats["overflow"])
         image, depth = out["image"], out["depth"]
         image_u8 = out.get("image_u8")
@@ -176,7 +187,9 @@ def _settle_deferred(decoder) -> bool:
 
 
 def finish_render(decoder) -> bool:
-    """settle the last ``render(..., defer_overflow_check=True)`` on this decoder (see there).  Returns True if that batch had to be redone."""
+    """settle the last ``render(..., defer_overflow_check=True)`` on this decoder (see there) and forget a stage A that ``next_batch`` launched ahead for a render
+    that will not come.  Returns True if that batch had to be redone."""
+    decoder.drop_prefetch()
     return _settle_deferred(decoder)
 
 

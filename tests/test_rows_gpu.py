@@ -375,3 +375,54 @@ def test_fused_render_is_reproducible_bit_for_bit(variant, n_scenes, n_views, re
         again = render()
         for a, b, name in zip(ref, again, ("sample_counts", "image", "depth", "image_u8")):
             assert torch.equal(a, b), (name, int((a != b).sum()))
+
+
+# ---------------------------------------------------------------------------------------------- r06: stage A of the next render beside this render's shading kernel
+def test_prefetched_stage_a_renders_the_same_bits():
+    """``nerf.render(next_batch=...)``: stage A of the NEXT render is launched on a second stream, into its own workspace and outputs, beside the current render's shading
+    kernel.  A streaming loop over two alternating batches (other cameras, other bitfield) must give, for every call, the bits of a plain render of that batch; a call
+    whose inputs are NOT the announced ones must render normally; ``finish_render`` forgets a stage nobody uses."""
+    from ssdnerf_amd import nerf, synthetic as S
+    from ssdnerf_amd.decoders import pack_triplanes
+    from ssdnerf_amd.density import get_density
+    dec = _decoder()
+    g = torch.Generator().manual_seed(7)
+    jit = [torch.rand(64 ** 3, 3, generator=g).cuda() for _ in range(8)]
+    ns, nv = 2, 24
+    codes = [torch.stack([S.make_triplane(sd, "object") for sd in seeds]).cuda() for seeds in ((2021, 2022), (2023, 2024))]
+    bits = [get_density(dec, c, 64, density_thresh=0.1, density_step=8, jitters=jit)[1] for c in codes]
+    planes = [pack_triplanes(c) for c in codes]
+    all_poses = S.spiral_poses(251).cuda()
+    poses = [all_poses[:nv][None].expand(ns, -1, -1, -1).contiguous(), all_poses[100:100 + nv][None].expand(ns, -1, -1, -1).contiguous()]
+    intr = S.cars_intrinsics(128, 128).cuda()[None, None].expand(ns, nv, -1).contiguous()
+
+    def plain(b):
+        im, dp, u8 = nerf.render(dec, codes[b], bits[b], 128, 128, intr, poses[b], grid_size=64, bg_color=1.0, cfg={}, planes=planes[b], return_u8=True)
+        return im.clone(), dp.clone(), u8.clone()
+    want = [plain(0), plain(1)]
+    assert not torch.equal(want[0][0], want[1][0])
+    got = []
+    order = [0, 1, 0, 0, 1, 1, 0]
+    for i, b in enumerate(order):
+        nb = order[i + 1] if i + 1 < len(order) else 0
+        im, dp, u8 = nerf.render(dec, codes[b], bits[b], 128, 128, intr, poses[b], grid_size=64, bg_color=1.0, cfg={}, planes=planes[b], return_u8=True,
+                                 defer_overflow_check=True, next_batch=(bits[nb], intr, poses[nb]))
+        got.append((b, im, dp, u8))
+        if i in (0, 3):
+            assert getattr(dec, "_prefetched", None) is not None                      # a stage A is in flight for the next call
+    nerf.finish_render(dec)
+    assert getattr(dec, "_prefetched", None) is None
+    for b, im, dp, u8 in got:
+        assert torch.equal(im, want[b][0]) and torch.equal(dp, want[b][1]) and torch.equal(u8, want[b][2]), b
+    # an announced batch that does not come: the call renders its own inputs
+    nerf.render(dec, codes[0], bits[0], 128, 128, intr, poses[0], grid_size=64, bg_color=1.0, cfg={}, planes=planes[0], next_batch=(bits[1], intr, poses[1]))
+    im, dp = nerf.render(dec, codes[0], bits[0], 128, 128, intr, poses[0], grid_size=64, bg_color=1.0, cfg={}, planes=planes[0])
+    assert torch.equal(im, want[0][0]) and torch.equal(dp, want[0][1])
+    # ... and a bitfield changed IN PLACE between the announcement and the call is noticed (tensor version)
+    nerf.render(dec, codes[0], bits[0], 128, 128, intr, poses[0], grid_size=64, bg_color=1.0, cfg={}, planes=planes[0], next_batch=(bits[0], intr, poses[0]))
+    saved = bits[0].clone()
+    bits[0].copy_(bits[1])
+    im2, _ = nerf.render(dec, codes[0], bits[0], 128, 128, intr, poses[0], grid_size=64, bg_color=1.0, cfg={}, planes=planes[0])
+    bits[0].copy_(saved)
+    im3, _ = nerf.render(dec, codes[0], bits[1], 128, 128, intr, poses[0], grid_size=64, bg_color=1.0, cfg={}, planes=planes[0])
+    assert torch.equal(im2, im3)

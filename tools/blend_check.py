@@ -20,7 +20,7 @@ need = C.lib().ssdnerf_render_queue_workspace(ns, nv * hw * hw, 64)
 tot = torch.zeros(32, dtype=torch.int64); ref = None; ndiff = 0
 for it in range(n):
     out = dec.render_packed(planes, None, None, bits, 64, [0.0] * ns, 1e-4, bg_color=1.0, want_counts=True, cams=(poses, intr, hw, hw))
-    wsp = dec._workspace(need, dev)
+    wsp = dec._workspace(need, dev, tag="render0")
     tot += wsp[:4 * ns * 128].view(torch.int32).view(4, ns, 32)[3, 0].clone().cpu().to(torch.int64)
     cur = (out["image"].clone(), out["depth"].clone())
     if ref is None: ref = cur
