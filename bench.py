@@ -251,6 +251,17 @@ def main():
     stats = stat_pass(planes, bits)
     log(f"stat pass done: {stats['n_samples']} samples, overflow {stats['overflow']}, boundary tests {stats['boundary']}")
     code_dev = code_cpu.to(dev)                              # (only read if a batch must be redone through the stepwise path)
+    # (r06) with next_batch, stage A of step i+1 runs on a second stream beside the shading kernel of step i: the events of the timed region then bracket the shading
+    # kernel WITH that company (what `roofline` must report: the kernel's launches of the timed region) and no longer stage A.  A short untimed loop without the
+    # prefetch, AHEAD of the timed region (whose launches stay the last ones of the process: tools/prof_render.sh), gives both stages alone, on this box, in this process
+    alone = None
+    prefetching = not (args.no_prefetch or args.packed_loop or rays is not None)
+    if prefetching:
+        args.no_prefetch = True
+        _, ev_alone, _ = timed(planes, bits, 5, 10, code_dev)
+        args.no_prefetch = False
+        alone = dict(first_hit_ms=float(np.mean([e[0].elapsed_time(e[1]) for e in ev_alone])), shade_ms=float(np.mean([e[1].elapsed_time(e[2]) for e in ev_alone])))
+        log(f"stages alone (no prefetch): first_hit {alone['first_hit_ms']:.3f} ms, shade {alone['shade_ms']:.3f} ms")
     elapsed, kernel_events, out = timed(planes, bits, args.warmup, args.steps, code_dev)
     per_rank = pending.get("per_rank")
     n_samples = stats["n_samples"]
@@ -264,20 +275,8 @@ def main():
     log(f"timed region done: {ms_per_step:.2f} ms/step")
     rays_per_s = world * n_rays / (elapsed / args.steps)
 
-    first_hit_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in kernel_events]))
+    first_hit_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in kernel_events])) if alone is None else alone["first_hit_ms"]
     shade_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in kernel_events]))
-    # (r06) with next_batch, stage A of step i+1 runs on a second stream beside the shading kernel of step i: the events of the timed region then bracket the shading
-    # kernel WITH that company (what `roofline` must report: the kernel's launches of the timed region) and no longer stage A.  A short untimed loop without the
-    # prefetch gives both stages alone, on this box, in this process
-    alone = None
-    prefetching = not (args.no_prefetch or args.packed_loop or rays is not None)
-    if prefetching:
-        args.no_prefetch = True
-        _, ev_alone, _ = timed(planes, bits, 3, 10, code_dev)
-        args.no_prefetch = False
-        alone = dict(first_hit_ms=float(np.mean([e[0].elapsed_time(e[1]) for e in ev_alone])), shade_ms=float(np.mean([e[1].elapsed_time(e[2]) for e in ev_alone])))
-        first_hit_ms = alone["first_hit_ms"]
-        log(f"stages alone (no prefetch): first_hit {alone['first_hit_ms']:.3f} ms, shade {alone['shade_ms']:.3f} ms; shade in the timed region {shade_ms:.3f} ms")
     # dominant kernel = k_shade_mfma (gather + MLP + composite).  Its algorithmic bytes: 288 B per sample it shades plus,
     # per hitting ray, 8 B queue entry + 20 B outputs (+ 24 B ray when ray arrays are read).
     n_hit = stats["n_hit"]

@@ -236,9 +236,10 @@ int ssdnerf_render_shade_queue_mfma(const void* planes, int planes_dtype, uint32
  * NULL: the image ALSO quantised the way eval_and_viz does before views are gathered and written (base_nerf.py:551-553: clamp to [0,1], x 255,
  * round half to even -- ssdnerf_quantize_u8's arithmetic), stored by the same kernels that store the float image (both calls must get it). */
 /* Flag for the `grid_size` argument of the two ssdnerf_render_first_hit* entry points (OR it in; the grid size proper is the low 16 bits).
- * SSDNERF_FIRST_HIT_SMALL_BLOCKS (r06): the cull kernel in blocks of 512 rays (9 KB of LDS) instead of 2048 (21 KB), so that stage A of the NEXT render can run on a
+ * SSDNERF_FIRST_HIT_SMALL_BLOCKS (r06): the cull kernel in blocks of 256 rays (3.6 KB of LDS) instead of 2048 (21 KB), so that stage A of the NEXT render can run on a
  * second stream BESIDE the shading kernel of the current one, whose two workgroups hold 148 of a CU's 160 KB of LDS: with its own workspace and output tensors the call
- * is independent of the render in flight (the host layer's `next_batch`, ssdnerf_amd/nerf.py).  Same outputs bit for bit; 2 % slower when nothing runs beside it. */
+ * is independent of the render in flight (the host layer's `next_batch`, ssdnerf_amd/nerf.py).  Same outputs bit for bit; slower when nothing runs beside it.
+ * Grids finer than 64^3 (coarse bitfield above 512 B) take the default form. */
 #define SSDNERF_FIRST_HIT_SMALL_BLOCKS 0x10000u
 int ssdnerf_render_first_hit_cams(const uint8_t* bitfield, uint32_t grid_size, const float* c2w, const float* intrinsics, uint32_t S,
                                   uint32_t V, uint32_t h, uint32_t w, float bound, float min_near, float dt_gamma,

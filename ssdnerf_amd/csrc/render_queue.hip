@@ -281,8 +281,10 @@ struct CullGrid { uint32_t group; uint32_t views_cap; uint32_t zr_cap; int32_t t
 #endif                                         // blocks were 2 441 blocks on 2 048 slots, a second mostly empty round.  Stage A 0.797 -> 0.711 ms; 16 / 4 / 2 chunks 0.93 / 0.76 / 0.76;
                                                // blocks of 128 / 64 threads 0.85 / 1.11 (profiles/r05/z_march_block_granularity_ab.txt)
 static constexpr unsigned RQ_CHUNKS_DEFAULT = RQ_CULL_CHUNKS;   // 256-ray chunks per block of k_ray_cull: the block stages its list in LDS and reserves global slots ONCE
-static constexpr unsigned RQ_CHUNKS_SMALL = 2;                  // ... with SSDNERF_FIRST_HIT_SMALL_BLOCKS (r06): 9 KB of LDS instead of 21 KB per block, so that the kernel finds room on a CU
-                                                                // whose LDS the shading kernel of the PREVIOUS render holds (2 x 74 KB of 160): profiles/r06/i_pipeline_probe.txt
+static constexpr unsigned RQ_CHUNKS_SMALL = 1;                  // ... with SSDNERF_FIRST_HIT_SMALL_BLOCKS (r06): 256-ray blocks with 3.6 KB of LDS (the coarse bitfield of a 64^3 grid is 512 B) instead
+static constexpr unsigned RQ_COARSE_SMALL = 512;                // of 2048 rays and 21 KB, so that THREE blocks find room on a CU whose LDS the shading kernel of the previous render holds (2 x 74 KB
+                                                                // of 160) -- with 9 KB (two chunks, 4 KB for the coarse bits) only one did and the kernel took the whole 4.4 ms of the shading
+                                                                // kernel beside it, leaving k_survivor_march exposed behind it (profiles/r06/i_pipeline_*.txt)
 static constexpr unsigned RQ_MCHUNKS = RQ_MARCH_CHUNKS;      // ... and of k_survivor_march
 #ifndef RQ_MARCH_TPB
 #define RQ_MARCH_TPB 256
@@ -310,7 +312,7 @@ SSD_DEV void rq_flush(const T* list, const uint32_t* list_count, uint32_t* slot 
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) global_list[base + i] = list[i];
 }
 
-template <unsigned RQ_CHUNKS>
+template <unsigned RQ_CHUNKS, unsigned RQ_COARSE_LDS>
 __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, CullGrid cg, const uint8_t* __restrict__ coarse_bits,
                                                       float* __restrict__ image, float* __restrict__ depth, float* __restrict__ weights_sum,
                                                       int32_t* __restrict__ sample_counts, uint2* __restrict__ survivors,
@@ -326,7 +328,7 @@ __global__ void __launch_bounds__(RQ_TPB) k_ray_cull(QueueCfg c, RaySrc src, Cul
     const bool tiled = view_cull && (src.w & 7u) == 0 && ((src.hw / src.w) & 7u) == 0;
     const bool pow2 = src.w_shift >= 3 && cg.tile_w_shift >= 0 && cg.tile_h_shift >= 0;          // power-of-two view and tile sizes: shifts instead of divisions
     // this scene's coarse bitfield -> LDS ((H/4)^3 bits; 512 B for H = 64)
-    __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_MAX_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t coarse_lds[RQ_COARSE_LDS];
     __shared__ uint2 list[RQ_CHUNKS * RQ_TPB];
     __shared__ uint32_t list_count, slot;
     const uint32_t Hc = c.m.H >> RQ_COARSE_LOG2B, log2Hc = c.m.log2H - RQ_COARSE_LOG2B, coarse_bytes = (Hc * Hc * Hc) >> 3;
@@ -847,7 +849,7 @@ static int rq_ray_src(RaySrc& src, const char* who, const float* rays_o, const f
 static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySrc& src, uint32_t S, uint32_t N, float bound, float min_near,
                         float dt_gamma, const float* dt_gammas, uint32_t max_steps, float bg_color, float* image, float* depth, float* weights_sum,
                         int32_t* sample_counts, uint8_t* image_u8, void* workspace, size_t workspace_bytes, void* stream) {
-    const bool small_blocks = (grid_size & SSDNERF_FIRST_HIT_SMALL_BLOCKS) != 0;             // flags ride in the upper half of `grid_size` (include/ssdnerf_hip.h)
+    bool small_blocks = (grid_size & SSDNERF_FIRST_HIT_SMALL_BLOCKS) != 0;                   // flags ride in the upper half of `grid_size` (include/ssdnerf_hip.h)
     grid_size &= 0xffffu;
     SSD_REQUIRE(bitfield && image && depth && weights_sum && workspace, "render_first_hit: null pointer");
     if (workspace_bytes < ssdnerf_render_queue_workspace(S, N, grid_size))
@@ -881,6 +883,7 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
         if (th && !(th & (th - 1))) cg.tile_h_shift = __builtin_ctz(th);
     }
     dim3 grid;
+    small_blocks = small_blocks && (!coarse_ok || (hc * hc * hc / 8) <= RQ_COARSE_SMALL);      // (a finer grid's coarse bits do not fit the small form: the default form then)
     const unsigned chunks = small_blocks ? RQ_CHUNKS_SMALL : RQ_CHUNKS_DEFAULT;
     if (src.c2w != nullptr) { cg.group = src.hw; grid = dim3(ssd_blocks(src.hw, RQ_TPB * chunks), src.V, S); }      // one view per blockIdx.y: camera loads are scalar
     else { cg.group = N; grid = dim3(ssd_blocks(N, RQ_TPB * chunks), 1, S); }
@@ -888,10 +891,10 @@ static int rq_first_hit(const uint8_t* bitfield, uint32_t grid_size, const RaySr
     if (view_cull)
         hipLaunchKernelGGL(k_view_masks, dim3(src.V, S), dim3(RQ_TPB), 0, s, c.m, src, cg.views_cap, cg.zr_cap, w.coarse, w.view_masks, w.view_zr);
     if (small_blocks)
-        hipLaunchKernelGGL(k_ray_cull<RQ_CHUNKS_SMALL>, grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
+        hipLaunchKernelGGL((k_ray_cull<RQ_CHUNKS_SMALL, RQ_COARSE_SMALL>), grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
                            w.survivors, w.counters, view_cull ? w.view_masks : (const uint32_t*)nullptr, w.view_zr);
     else
-        hipLaunchKernelGGL(k_ray_cull<RQ_CHUNKS_DEFAULT>, grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
+        hipLaunchKernelGGL((k_ray_cull<RQ_CHUNKS_DEFAULT, RQ_COARSE_MAX_BYTES>), grid, dim3(RQ_TPB), 0, s, c, src, cg, coarse_ok ? w.coarse : (const uint8_t*)nullptr, image, depth, weights_sum, sample_counts,
                            w.survivors, w.counters, view_cull ? w.view_masks : (const uint32_t*)nullptr, w.view_zr);
     const char* to_env = getenv("SSDNERF_TICKET_ORDER");            // =0: the two-class queue of r02 - r04 (A/B runs, the bit-identity test); read per call,
     const bool ticket_order = !(to_env && to_env[0] == '0');        // and the same way by the shading launch (shade_mfma.hip, sm_shade)

@@ -34,6 +34,17 @@ with open(sys.argv[1], "w") as out:
         last = durs[-20:]
         out.write(f"{k[:70]:70s} {len(durs):6d} {sum(durs) / len(durs):11.1f} {sum(last) / len(last):14.1f} {min(durs):9.1f} {max(last):14.1f}\n")
 print(open(sys.argv[1]).read()[:2400])
+# (r06) the timeline of the last three timed steps: which kernels overlap (stage A of step i+1 runs on a second stream beside the shading kernel of step i), and the gaps
+rows = sorted((s, s + int(dur * 1e3), k) for k, v in d.items() for s, dur in v)
+shade = [r for r in rows if "k_shade_mfma" in r[2]]
+if len(shade) >= 4:
+    t0 = shade[-4][1]
+    with open(sys.argv[1].replace("_launch_avg.txt", "_timeline.txt"), "w") as out:
+        out.write("start_us    end_us      dur_us   kernel   (last three timed steps; 0 = the end of the shading kernel of the step before them)\n")
+        for s, e, k in rows:
+            if s >= shade[-4][0]:
+                out.write(f"{(s - t0) / 1e3:10.1f} {(e - t0) / 1e3:10.1f} {(e - s) / 1e3:9.1f}   {k[:60]}\n")
+    print(open(sys.argv[1].replace("_launch_avg.txt", "_timeline.txt")).read()[:3000])
 PY
 : > $OUT/${TAG}_pmc.txt
 pmc() { # name, counters...
