@@ -67,7 +67,7 @@ static uint32_t* cv_fold_tickets(const ConvArgs& a, void* splitk_ws, size_t spli
     // OFF unless SSDNERF_CONV_FOLD=1 (r05, measured on the cars UNet at 8 scenes: fp32 step 8.13 -> 8.87 ms, bf16 4.24 -> 4.50 ms WITH the fold): the finishing
     // kernel spreads a layer's epilogue over the whole chip, the fold leaves it to the one block per tile that arrives last -- 64 uncached loads per lane in series
     // with that tile's tail -- and these layers are latency-bound already.  Kept as an opt-in; results equal the finishing pass's (tests/test_unet_fast_gpu.py run with it).
-    static const bool on = getenv("SSDNERF_CONV_FOLD") != nullptr;
+    static const bool on = [] { const char* e = getenv("SSDNERF_CONV_FOLD"); return e != nullptr && e[0] != '\0' && e[0] != '0'; }();      // (=0 and empty mean off)
     if (!on || a.splits <= 1 || splitk_ws == nullptr || (void*)a.splitk_ws != splitk_ws) return nullptr;
     if (splitk_ws_bytes < (size_t)a.M * a.Cout * 4 + CV_TICKET_BYTES || (size_t)a.m_tiles * a.n_tiles * 4 > CV_TICKET_BYTES) return nullptr;
     if (want_stats && (a.Ho * a.Wo) % bm != 0) return nullptr;

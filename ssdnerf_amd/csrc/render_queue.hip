@@ -655,7 +655,8 @@ __global__ void __launch_bounds__(1024) k_ticket_order(uint32_t S, const uint8_t
         uint32_t run = 0;
         for (int b = 0; b < 64; ++b) { cursor[b] = run; run += hist[b]; }
         counters[ssd_counter(SSD_CNT_HITS, S, scene)] = count;
-    }
+        if (scene == 0) counters[ssd_counter(SSD_CNT_TICKETS, S, 0) + 1] = 1u;      // "this workspace holds an order table" (r05 advisor): the shading kernel looks HERE, not at its own
+    }                                                                              // launch's view of SSDNERF_TICKET_ORDER, before it indexes the table
     __syncthreads();
     for (uint32_t sl = threadIdx.x; sl < n_slices; sl += blockDim.x) order[(uint64_t)scene * order_stride + atomicAdd(&cursor[bucket_of(sl)], 1u)] = sl;
 }

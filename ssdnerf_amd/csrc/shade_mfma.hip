@@ -501,6 +501,9 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
     // planes stay in that XCD's L2, and move on to the next scene when theirs has no slices left (work stealing: a wrong
     // placement guess only costs L2 misses).  Counters (hits per scene, slice tickets): common.h, ssd_counter. ----
     const uint32_t start_scene = (blockIdx.x & 7u) % c.S;
+    // the order table is used only if stage A says it built one for THIS workspace (word 1 of scene 0's ticket line, k_ticket_order): the two launches read the
+    // SSDNERF_TICKET_ORDER switch separately, and an order pointer into a table nobody wrote would send tickets to arbitrary slices (r05 advisor)
+    const bool use_order = c.order != nullptr && queue_count[ssd_counter(SSD_CNT_TICKETS, c.S, 0) + 1] != 0u;
     const PT* planes_base = planes;
     const uint8_t* bits_base = lin_bits;
     const uint2* queue_base = queue;
@@ -736,7 +739,7 @@ __global__ void __launch_bounds__(SM_TPB, SmGeo::WPS) k_shade_mfma(ShadeCfg c, R
                     if (lane == 0) sl = atomicAdd(queue_count + ssd_counter(SSD_CNT_TICKETS, c.S, scene), 1u);
                     sl = __builtin_amdgcn_readfirstlane(sl);
                     if (sl < n_slices) {
-                        if (c.order != nullptr) sl = c.order[(uint64_t)scene * c.order_stride + sl];
+                        if (use_order) sl = c.order[(uint64_t)scene * c.order_stride + sl];
                         next = sl * SM_SLICE; end = min(next + SM_SLICE, count);
                     }
                     else scene_done = true;

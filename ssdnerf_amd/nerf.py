@@ -68,7 +68,9 @@ def render(decoder: TriPlaneDecoder, code: torch.Tensor, density_bitfield: torch
     next call's Python runs).  With the flag set, the device flag is copied to pinned host memory asynchronously and examined when the NEXT ``render`` on this
     decoder has queued its own launches (or in ``finish_render(decoder)``): by then the copy has long landed, nothing waits.  If the flag was raised, the
     batch is redone THEN, into the SAME output tensors.  Contract: the tensors returned by a deferred call are final once the next ``render`` /
-    ``finish_render`` on the decoder has returned -- a caller that streams batches (evaluation loops, bench.py) calls ``finish_render`` after the last one.
+    ``finish_render`` on the decoder has returned -- a caller that streams batches (evaluation loops, bench.py) calls ``finish_render`` after the last one -- and
+    until then the call's INPUTS (code, bitfield, poses, intrinsics, rays) must not be modified in place: a redo reads them again (they and the outputs stay
+    referenced by the decoder until the check has run).
 
     ``planes`` / ``rays`` let callers that render the same scenes or cameras repeatedly keep the packed planes /
     ray arrays resident instead of rebuilding them (they are pure functions of ``code`` / ``poses, intrinsics``).

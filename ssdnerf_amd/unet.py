@@ -688,6 +688,8 @@ class _GraphedGrad:
                 outer.fwd.replay()
                 outer.serial += 1
                 ctx.serial = outer.pending = outer.serial
+                import weakref
+                outer._ctx = weakref.ref(ctx)                      # (r05 advisor) the autograd NODE of this forward: alive exactly as long as a backward can still come
                 return outer.y.detach()
 
             @staticmethod
@@ -705,8 +707,16 @@ class _GraphedGrad:
         self._replay = _Replay
 
     def busy(self) -> bool:
-        """a forward has been replayed whose backward has not run: another forward now would overwrite its activations"""
-        return self.pending != 0
+        """a forward has been replayed whose backward has not run AND can still come: another forward now would overwrite its activations.  Liveness is the autograd
+        node's own (a weak reference to the Function's ctx, per captured signature): an output tensor may die while its graph lives on in a consumer's node, and the
+        output of another signature's forward says nothing about this one (r05 advisor)."""
+        if self.pending == 0:
+            return False
+        ref = getattr(self, "_ctx", None)
+        if ref is not None and ref() is None:                      # the graph was dropped without a backward
+            self.pending = 0
+            return False
+        return True
 
     def release(self) -> None:
         """forget a pending backward (its autograd graph was dropped without being run)"""
@@ -967,18 +977,11 @@ class DenoisingUnetMod(nn.Module):
         if label is None and concat_cond is None and not return_noise:
             graphed = self._grad_graph_call(x_t, t)
             if graphed is not None and graphed.busy():
-                # a forward whose backward is still outstanding (two forwards before their backwards; or the caller dropped the last graph without
-                # running it): the eager path keeps its own activations per call.  A dropped graph is recognised by its output having died.
-                ref = self.__dict__.get("_grad_graph_last_out")
-                if ref is not None and ref() is None:
-                    graphed.release()
-                else:
-                    graphed = None
+                # a forward whose backward is still outstanding (two forwards before their backwards): the eager path keeps its own activations per call.
+                # (A graph the caller dropped without running it is recognised inside busy(): its autograd node has died.)
+                graphed = None
             if graphed is not None:
-                out = graphed(x_t, t).clone()                        # (the graph's output buffer is overwritten by the next replay)
-                import weakref
-                self.__dict__["_grad_graph_last_out"] = weakref.ref(out)
-                return out
+                return graphed(x_t, t).clone()                       # (the graph's output buffer is overwritten by the next replay)
         return self._forward_eager(x_t, t, label, concat_cond)
 
     def _forward_eager(self, x_t, t, label=None, concat_cond=None):
