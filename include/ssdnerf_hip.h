@@ -195,7 +195,8 @@ int ssdnerf_render_rays_fused_batch(const void* planes, int planes_dtype, uint32
  *                 are finished too, the others are appended to a per-scene hit queue inside `workspace`;
  *   shade_queue : persistent waves shade the queued rays (gather + MLP + composite + onward march).
  * Both take the SAME workspace (ssdnerf_render_queue_workspace(S, N, grid_size) bytes, caller-owned) and must be issued
- * in this order on one stream.  Results are bit-identical to ssdnerf_render_rays_fused_batch.
+ * in this order on one stream.  Results are bit-identical to ssdnerf_render_rays_fused_batch, and from run to run (soaked over 10^5 renders of 33 M rays since r06:
+ * the build removes the one instruction kind that made rounds 1 - 5 differ about once in 3 000 renders -- ssdnerf_amd/asm_postpass.py).
  * r05: first_hit also leaves, per hit-queue entry, a bound of the ray's remaining march steps and -- k_ticket_order -- the order in which the
  * MFMA shading kernel takes the queue's 64-entry slices (longest first; + 1.06 B per ray of workspace).  The order never enters a ray's result.
  * Environment SSDNERF_TICKET_ORDER=0 (read per call, by both stages) restores the two-class queue of earlier rounds. */
