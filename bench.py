@@ -296,9 +296,15 @@ def main():
         if (w["scenes"], w["views"], w["size"], w["variant"], w["plane_dtype"]) == (ns, nv, hw, args.variant, args.plane_dtype) and tj["kernel"].startswith("k_shade_mfma") \
                 and w.get("ray_source", "arrays") == ("arrays" if args.ray_arrays else "cameras") \
                 and int(tj.get("dir_products", 3)) == int(dec.shade_dir_products):
-            traffic = tj["hbm_bytes_per_launch"]
             traffic_source = {k: tj.get(k) for k in ("source", "profiled_commit", "kernel", "rocprof_launch_ms_avg_timed_steps", "rocprof_launches_averaged",
-                                                     "hip_event_launch_ms_same_run", "method")}
+                                                     "hip_event_launch_ms_same_run", "method", "render_build_id")}
+            from ssdnerf_amd.build import render_build_id
+            mine = render_build_id()
+            if tj.get("render_build_id") == mine:                    # (r06) the session profiled a library built from THESE render sources with THESE settings
+                traffic = tj["hbm_bytes_per_launch"]
+            else:
+                traffic_source["refused"] = (f"the profiling session's library ({tj.get('render_build_id')}) is not the one timed here ({mine}): "
+                                             "traffic is null until tools/prof_render.sh has been run on this build")
     except Exception:
         pass
     result = {

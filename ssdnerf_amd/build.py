@@ -66,6 +66,22 @@ def toolchain() -> dict:
     return {"hip_version": hip, "clang": clang, "validated": bool(hip) and hip.startswith(VALIDATED_HIP_VERSIONS)}
 
 
+def render_build_id() -> dict:
+    """what decides the render kernels of the library that is loaded: a hash over the render path's sources and the post-pass, and the build settings of the shipped
+    report.  tools/make_traffic_json.py stores it with a profiling session; bench.py quotes a session's HBM traffic only if it matches the library it times."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ["shade_mfma.hip", "render_queue.hip", "common.h", "decode_core.h", "sh_basis.h"]:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "asm_postpass.py"), "rb").read())
+    try:
+        with open(os.path.join(LIB_DIR, "postpass_report.json")) as f:
+            settings = json.load(f).get("settings")
+    except Exception:                                                # noqa: BLE001
+        settings = None
+    return {"render_csrc_sha16": h.hexdigest()[:16], "build_settings": settings}
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

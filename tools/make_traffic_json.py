@@ -7,6 +7,7 @@ import json
 import os
 import re
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 out, tag = sys.argv[1], sys.argv[2]
 
@@ -41,6 +42,7 @@ tj = {"workload": {"scenes": cfg["scenes_per_gpu"], "views": cfg["views_per_scen
                 "averaged); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); launch average = rocprofv3 --kernel-trace over the "
                 "20 timed launches of `bench.py --warmup 10 --steps 20`, HIP events of the same run beside it",
       "profiled_commit": os.environ.get("SSDNERF_PROFILED_COMMIT"),
+      "render_build_id": __import__("ssdnerf_amd.build", fromlist=["render_build_id"]).render_build_id(),      # (r06) bench.py quotes the traffic only for a library built from these sources + settings
       "source": f"profiles/{os.environ.get('SSDNERF_PROFILE_ROUND', 'r05')}/{tag}_pmc.txt, {tag}_launch_avg.txt, {tag}_bench_under_rocprof.json"}
 json.dump(tj, open(f"{out}/traffic_latest.json", "w"), indent=1)
 # ... and installed where bench.py reads it (on the GPU box that copy is scratch: run this tool again on the merged gpurun_out/prof_<tag>/ and commit)
