@@ -577,3 +577,22 @@ def disassemble_library(path: str, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-o
                 fh.write(blob)
             text += subprocess.run([objdump, "-d", f], check=True, capture_output=True, text=True).stdout
     return text
+
+
+if __name__ == "__main__":
+    # python -m ssdnerf_amd.asm_postpass scan FILE...   -- count packed fp32 instructions with crossed VGPR halves per kernel: FILE is a device listing (`hipcc -S
+    # --cuda-device-only`), an `llvm-objdump -d` text, or a host object / shared library built by hipcc (its embedded gfx950 code objects are disassembled)
+    import sys
+    if len(sys.argv) >= 3 and sys.argv[1] == "scan":
+        total = 0
+        for path in sys.argv[2:]:
+            with open(path, "rb") as fh:
+                head = fh.read(4)
+            text = disassemble_library(path) if head == b"\x7fELF" else open(path).read()
+            found = scan_packed_cross_half(text)
+            total += sum(found.values())
+            print(f"{path}: {sum(found.values())} packed fp32 instructions read across the halves of a VGPR source pair" + ("" if not found else ":"))
+            for k, v in sorted(found.items(), key=lambda kv: -kv[1])[:20]:
+                print(f"    {v:6d}  {k}")
+        sys.exit(1 if total else 0)
+    print(__doc__)

@@ -338,3 +338,24 @@ def test_pre_split_convolution_planning_is_host_logic():
     rc = lib.ssdnerf_split_f32_nhwc(buf, buf, ctypes.c_uint64(4), u32(32), ctypes.c_uint64(0), None)                       # in place
     assert rc == -1 and b"split_f32_nhwc" in lib.ssdnerf_last_error()
     assert lib.ssdnerf_split_f32_nhwc(None, None, ctypes.c_uint64(0), u32(32), ctypes.c_uint64(0), None) == 0                # empty: a no-op
+
+
+def test_traffic_figure_is_bound_to_the_render_build():
+    """bench.py quotes profiles/traffic_latest.json's HBM bytes only for a library built from the render sources and settings the profiling session ran on
+    (``build.render_build_id``): the committed session must match the tree, and a changed source must be noticed"""
+    import json
+    import os
+    from ssdnerf_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tj = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))
+    mine = B.render_build_id()
+    assert set(mine) == {"render_csrc_sha16", "build_settings"} and len(mine["render_csrc_sha16"]) == 16
+    assert tj["render_build_id"] == mine, "the render sources or build settings changed since tools/prof_render.sh last ran: rerun it (tools/r06_final.sh) and commit profiles/"
+    saved = B.CSRC
+    try:
+        B.CSRC = os.path.join(root, "tests", "host")                      # (other files under the same names would hash differently; a missing one raises)
+        import pytest
+        with pytest.raises(FileNotFoundError):
+            B.render_build_id()
+    finally:
+        B.CSRC = saved
