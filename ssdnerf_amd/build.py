@@ -67,19 +67,22 @@ def toolchain() -> dict:
 
 
 def render_build_id() -> dict:
-    """what decides the render kernels of the library that is loaded: a hash over the render path's sources and the post-pass, and the build settings of the shipped
-    report.  tools/make_traffic_json.py stores it with a profiling session; bench.py quotes a session's HBM traffic only if it matches the library it times."""
+    """what decides the render kernels of the library that is loaded: a hash over the render path's sources, and the build settings and the post-pass's effect on those sources from the
+    shipped report.  tools/make_traffic_json.py stores it with a profiling session; bench.py quotes a session's HBM traffic only if it matches the library it times."""
     import hashlib
     h = hashlib.sha256()
     for f in ["shade_mfma.hip", "render_queue.hip", "common.h", "decode_core.h", "sh_basis.h"]:
         h.update(open(os.path.join(CSRC, f), "rb").read())
-    h.update(open(os.path.join(HERE, "asm_postpass.py"), "rb").read())
     try:
         with open(os.path.join(LIB_DIR, "postpass_report.json")) as f:
-            settings = json.load(f).get("settings")
+            rep = json.load(f)
+        settings = rep.get("settings")
+        # what the post-pass DID to the two render sources (not the text of asm_postpass.py: a comment there changes no instruction)
+        effect = {k: {kk: rep["sources"][k].get(kk) for kk in ("packed_cross_half_split", "pairs_closer_than_required", "trans_instructions")}
+                  for k in ("shade_mfma.hip", "render_queue.hip") if k in rep.get("sources", {})}
     except Exception:                                                # noqa: BLE001
-        settings = None
-    return {"render_csrc_sha16": h.hexdigest()[:16], "build_settings": settings}
+        settings, effect = None, None
+    return {"render_csrc_sha16": h.hexdigest()[:16], "build_settings": settings, "postpass_effect": effect}
 
 
 def needs_build() -> bool:

@@ -349,7 +349,7 @@ def test_traffic_figure_is_bound_to_the_render_build():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tj = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))
     mine = B.render_build_id()
-    assert set(mine) == {"render_csrc_sha16", "build_settings"} and len(mine["render_csrc_sha16"]) == 16
+    assert set(mine) == {"render_csrc_sha16", "build_settings", "postpass_effect"} and len(mine["render_csrc_sha16"]) == 16
     assert tj["render_build_id"] == mine, "the render sources or build settings changed since tools/prof_render.sh last ran: rerun it (tools/r06_final.sh) and commit profiles/"
     saved = B.CSRC
     try:
