@@ -8,18 +8,21 @@ from ssdnerf_amd import synthetic as S
 from ssdnerf_amd.decoders import TriPlaneDecoder, pack_triplanes
 from ssdnerf_amd.density import get_density
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+# (r06) the other forms of the shading kernel: REPRO_VARIANT=uniform (fog scene: every ray shades, long rays), REPRO_PLANES=float16 (config 5's scene cache), REPRO_DT_GAMMA=<float>
+# (cone angle > 0: the MODE 1 form of the recons renders), REPRO_VIEWS=<n>; SSDNERF_SHADE_GENERIC=1 selects the generic form (MODE 0)
+VARIANT, PLANES, DTG, NV = os.environ.get("REPRO_VARIANT", "object"), os.environ.get("REPRO_PLANES", "float32"), float(os.environ.get("REPRO_DT_GAMMA", "0")), int(os.environ.get("REPRO_VIEWS", "251"))
 dev = torch.device("cuda")
-dec = TriPlaneDecoder(base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], dir_layers=[16, 64], max_steps=256)
+dec = TriPlaneDecoder(base_layers=[18, 64], density_layers=[64, 1], color_layers=[64, 3], dir_layers=[16, 64], max_steps=256, plane_dtype=PLANES)
 dec.load_state_dict(S.make_decoder_params(2021), strict=False); dec = dec.to(dev).eval()
 g = torch.Generator().manual_seed(7); jit = [torch.rand(64 ** 3, 3, generator=g).to(dev) for _ in range(8)]
-ns, nv, hw = 8, 251, 128
+ns, nv, hw = 8, NV, 128
 poses = S.spiral_poses(nv).to(dev)[None].expand(ns, -1, -1, -1).contiguous(); intr = S.cars_intrinsics(hw, hw).to(dev)[None, None].expand(ns, nv, -1).contiguous()
-code = torch.stack([S.make_triplane(2021 + s, "object") for s in range(ns)]).to(dev)
+code = torch.stack([S.make_triplane(2021 + s, VARIANT) for s in range(ns)]).to(dev)
 _, bits = get_density(dec, code, 64, density_thresh=0.1, density_step=8, jitters=jit)
 planes = pack_triplanes(code, dec.plane_dtype)
 ref, bad = None, []
 for it in range(n):
-    out = dec.render_packed(planes, None, None, bits, 64, [0.0] * ns, 1e-4, bg_color=1.0, want_counts=True, cams=(poses, intr, hw, hw))
+    out = dec.render_packed(planes, None, None, bits, 64, [DTG] * ns, 1e-4, bg_color=1.0, want_counts=True, check_overflow=False, cams=(poses, intr, hw, hw))
     cur = (out["image"].clone(), out["depth"].clone(), dec.last_render_stats["sample_counts"].clone())
     if ref is None:
         ref = cur
