@@ -22,8 +22,13 @@ _, bits = get_density(dec, code, 64, density_thresh=0.1, density_step=8, jitters
 planes = pack_triplanes(code, dec.plane_dtype)
 ref, bad = None, []
 for it in range(n):
-    out = dec.render_packed(planes, None, None, bits, 64, [DTG] * ns, 1e-4, bg_color=1.0, want_counts=True, check_overflow=False, cams=(poses, intr, hw, hw))
-    cur = (out["image"].clone(), out["depth"].clone(), dec.last_render_stats["sample_counts"].clone())
+    if os.environ.get("REPRO_PREFETCH", "0") == "1":              # the streaming form: stage A of the next render beside this render's shading kernel (no per-ray counts on that path)
+        out = dec.render_packed(planes, None, None, bits, 64, [DTG] * ns, 1e-4, bg_color=1.0, check_overflow=False, cams=(poses, intr, hw, hw), want_u8=True,
+                                prefetch=dict(cams=(poses, intr, hw, hw), density_bitfield=bits))
+        cur = (out["image"].clone(), out["depth"].clone(), out["image_u8"].view(torch.uint8).reshape(ns, -1, 3).sum(-1, dtype=torch.int32).clone())
+    else:
+        out = dec.render_packed(planes, None, None, bits, 64, [DTG] * ns, 1e-4, bg_color=1.0, want_counts=True, check_overflow=False, cams=(poses, intr, hw, hw))
+        cur = (out["image"].clone(), out["depth"].clone(), dec.last_render_stats["sample_counts"].clone())
     if ref is None:
         ref = cur
         continue
