@@ -313,11 +313,13 @@ int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint32_t C1, int
 /* d/dx of ssdnerf_group_norm_nhwc (single source x, no pre_bias) for frozen gamma / beta and a scale/shift that does not depend on x --
  * the gradient rendering guidance and the fine-tuning prior push through every norm of the UNet (what autograd assembles from
  * native_group_norm_backward, silu_backward and the scale/shift mul/add; modules.py:51-110).  x, dy, dx:
- * [B][HW][C] of `dtype`; fwd_sums: the forward's workspace (sum, sum of squares per sample and group); bwd_workspace: another
- * ssdnerf_group_norm_workspace(B, G) bytes, zero-filled by the call unless bwd_workspace_is_zero.  Two passes, nothing else saved.
+ * [B][HW][C] of `dtype`; fwd_sums: the forward's workspace (sum, sum of squares per sample and group); bwd_workspace:
+ * ssdnerf_group_norm_backward_workspace(B, G) bytes (r06: several copies of the sums, so that the statistics pass's atomics do not queue on one
+ * address), zero-filled by the call unless bwd_workspace_is_zero.  Two passes, nothing else saved.
  * act: bit 0 = the forward applied SiLU; bit 1 (r04, fp32, C % 32 == 0): write dx PRE-SPLIT (the layout of ssdnerf_group_norm_nhwc's act | 2) for the
  * backward-data convolution that consumes it (ssdnerf_conv2d_nhwc_f32x2_presplit on the transposed weights).
  * Arithmetic: csrc/gn_bwd_math.h (plain C, also built by gcc for tests/test_groupnorm_backward_cpu.py). */
+size_t ssdnerf_group_norm_backward_workspace(uint32_t B, uint32_t G);
 int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
                                      const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride,
                                      float eps, int act, const void* fwd_sums, void* bwd_workspace, int bwd_workspace_is_zero,

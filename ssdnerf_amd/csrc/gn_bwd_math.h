@@ -24,15 +24,11 @@
 #define SSDG_RCP(x) (1.0f / (x))
 #endif
 
-// per-(sample, channel) coefficients from the forward's fp64 sums; mirrors k_gn_apply's fold (pre_bias = 0)
-SSDG_FN void ssdg_coeffs(double sum, double sumsq, double inv_n, float eps, float gamma, float beta, int has_ss, float scale, float shift,
-                         float* A, float* O, float* k, float* mean_f, float* rstd_f) {
-    const double mean = sum * inv_n;
-    double var = sumsq * inv_n - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+// per-(sample, channel) coefficients from the group's (mean, rstd) as floats (r06: the kernels compute those once per block and group)
+SSDG_FN void ssdg_coeffs_from(float mean, float rstd, float gamma, float beta, int has_ss, float scale, float shift,
+                              float* A, float* O, float* k, float* mean_f, float* rstd_f) {
     float a = rstd * gamma;
-    float o = fmaf(-(float)mean, a, beta);
+    float o = fmaf(-mean, a, beta);
     float kk = gamma;
     if (has_ss) {
         const float sc = 1.0f + scale;
@@ -40,7 +36,17 @@ SSDG_FN void ssdg_coeffs(double sum, double sumsq, double inv_n, float eps, floa
         o = fmaf(o, sc, shift);
         kk *= sc;
     }
-    *A = a; *O = o; *k = kk; *mean_f = (float)mean; *rstd_f = rstd;
+    *A = a; *O = o; *k = kk; *mean_f = mean; *rstd_f = rstd;
+}
+
+// per-(sample, channel) coefficients from the forward's fp64 sums; mirrors k_gn_apply's fold (pre_bias = 0)
+SSDG_FN void ssdg_coeffs(double sum, double sumsq, double inv_n, float eps, float gamma, float beta, int has_ss, float scale, float shift,
+                         float* A, float* O, float* k, float* mean_f, float* rstd_f) {
+    const double mean = sum * inv_n;
+    double var = sumsq * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    ssdg_coeffs_from((float)mean, rstd, gamma, beta, has_ss, scale, shift, A, O, k, mean_f, rstd_f);
 }
 
 // p = dL/dxhat contribution of one element, and its xhat

@@ -29,6 +29,8 @@ template <> struct GnVec<GN_F32> {
         const float4 v = reinterpret_cast<const float4*>(p)[idx];
         f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
     }
+    __device__ static uint4 raw(const void* p, size_t idx) { return reinterpret_cast<const uint4*>(p)[idx]; }       // the 16 bytes as they are (r06: loads issued ahead of their use)
+    __device__ static void cvt(const uint4& v, float* f) { f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w); }
     __device__ static void store(void* p, size_t idx, const float* f) { reinterpret_cast<float4*>(p)[idx] = make_float4(f[0], f[1], f[2], f[3]); }
     __device__ static float round(float x) { return x; }               // value as it reads back from storage
     // PRE-SPLIT store (r04): the four fp32 values leave as their bf16 pair split -- hi = truncation to bf16, lo = truncation of the exact remainder,
@@ -57,6 +59,15 @@ template <> struct GnVec<GN_BF16> {
             f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
+    __device__ static uint4 raw(const void* p, size_t idx) { return reinterpret_cast<const uint4*>(p)[idx]; }
+    __device__ static void cvt(const uint4& v, float* f) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
     // fp32 -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32, one instruction per PAIR (r03; the integer form -- add, shift, and, add,
     // shift per element plus the pack -- was a third of k_gn_apply's VALU work, which at bf16 is what bounds that kernel, not HBM)
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -75,6 +86,13 @@ template <> struct GnVec<GN_F16> {
     __device__ static void load(const void* p, size_t idx, float* f) {
         union { uint4 u; _Float16 h[8]; } v;
         v.u = reinterpret_cast<const uint4*>(p)[idx];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v.h[i];
+    }
+    __device__ static uint4 raw(const void* p, size_t idx) { return reinterpret_cast<const uint4*>(p)[idx]; }
+    __device__ static void cvt(const uint4& r, float* f) {
+        union { uint4 u; _Float16 h[8]; } v;
+        v.u = r;
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = (float)v.h[i];
     }
@@ -300,18 +318,58 @@ __global__ __launch_bounds__(GN_TPB) void k_bias_residual(const void* __restrict
 //   k_gn_bwd_apply : dx = rstd * (p - mean(p) - xhat * mean(p * xhat))
 // = 4 reads + 1 write of the activation for what eager autograd does with ~10 kernels (native_group_norm_backward, silu_backward,
 // the scale/shift mul/add pair, and an NHWC <-> NCHW copy on either side).
-template <int DT, int V>
-__device__ __forceinline__ void gn_bwd_coeffs(uint32_t b, uint32_t cv, uint32_t HW, uint32_t C, uint32_t G, const double* __restrict__ fsums,
-                                              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale_shift,
-                                              uint32_t ss_stride, float eps, float* A, float* O, float* K, float* M, float* R) {
+// r06: a group's mean / rstd (an fp64 square root and division) are computed once per block, by one thread per group, into LDS; until then every thread
+// derived them for each of its V channels.  Same expressions in the same precisions (ssdg_coeffs): bit-identical results.
+__device__ __forceinline__ void gn_bwd_group_table(uint32_t b, uint32_t HW, uint32_t C, uint32_t G, const double* __restrict__ fsums, float eps,
+                                                   float* __restrict__ g_mean, float* __restrict__ g_rstd) {
+    const double inv_n = 1.0 / ((double)HW * (double)(C / G));
+    for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
+        const double mean = fsums[((size_t)b * G + g) * 2 + 0] * inv_n;
+        double var = fsums[((size_t)b * G + g) * 2 + 1] * inv_n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        g_mean[g] = (float)mean;
+        g_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+#ifndef GN_BWD_UNROLL
+#define GN_BWD_UNROLL 4
+#endif
+#ifndef GN_BWD_REPLICAS
+#define GN_BWD_REPLICAS 8
+#endif
+// ... and a channel's coefficients (A, O, k) once per block by ONE thread per channel into LDS -- consecutive threads, consecutive channels: coalesced loads of
+// gamma / beta / scale / shift.  Each thread used to load them for its own V channels: 4 V scalar loads whose 64 lanes stride by V floats (bf16: 32 loads of 16
+// cache lines each), which made the bf16 passes of the mid-size tensors twice as slow as the fp32 ones (tools/bench_gn_bwd.py: 32 x 32 x 256: 18.5 against 9 us).
+// tab: [3][C] (A, O, k); g_mean / g_rstd: the group table.  Callers synchronise behind it.
+__device__ __forceinline__ void gn_bwd_channel_table(uint32_t b, uint32_t C, uint32_t G, const float* __restrict__ g_mean, const float* __restrict__ g_rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale_shift,
+                                                     uint32_t ss_stride, float* __restrict__ tab) {
     const uint32_t cpg = C / G;
-    const double inv_n = 1.0 / ((double)HW * (double)cpg);
+    for (uint32_t c = threadIdx.x; c < C; c += GN_TPB) {
+        const uint32_t g = c / cpg;
+        float A, O, K, M, R;
+        ssdg_coeffs_from(g_mean[g], g_rstd[g], gamma[c], beta[c], scale_shift != nullptr,
+                         scale_shift ? scale_shift[(size_t)b * ss_stride + c] : 0.f, scale_shift ? scale_shift[(size_t)b * ss_stride + C + c] : 0.f, &A, &O, &K, &M, &R);
+        tab[c] = A; tab[C + c] = O; tab[2 * C + c] = K;
+    }
+}
+template <int V>
+__device__ __forceinline__ void gn_bwd_coeffs(uint32_t cv, uint32_t C, uint32_t G, const float* __restrict__ g_mean, const float* __restrict__ g_rstd,
+                                              const float* __restrict__ tab, float* A, float* O, float* K, float* M, float* R) {
+    const uint32_t cpg = C / G;
+#pragma unroll
+    for (int i = 0; i < V; i += 4) {                                           // (V is 4 or 8; cv * V + i is a multiple of 4: 16-byte LDS reads)
+        const float4 a = *reinterpret_cast<const float4*>(tab + cv * V + i), o = *reinterpret_cast<const float4*>(tab + C + cv * V + i),
+                     k = *reinterpret_cast<const float4*>(tab + 2 * C + cv * V + i);
+        A[i] = a.x; A[i + 1] = a.y; A[i + 2] = a.z; A[i + 3] = a.w;
+        O[i] = o.x; O[i + 1] = o.y; O[i + 2] = o.z; O[i + 3] = o.w;
+        K[i] = k.x; K[i + 1] = k.y; K[i + 2] = k.z; K[i + 3] = k.w;
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const uint32_t c = cv * V + i, g = c / cpg;
-        ssdg_coeffs(fsums[((size_t)b * G + g) * 2 + 0], fsums[((size_t)b * G + g) * 2 + 1], inv_n, eps, gamma[c], beta[c], scale_shift != nullptr,
-                    scale_shift ? scale_shift[(size_t)b * ss_stride + c] : 0.f, scale_shift ? scale_shift[(size_t)b * ss_stride + C + c] : 0.f,
-                    &A[i], &O[i], &K[i], &M[i], &R[i]);
+        const uint32_t g = (cv * V + i) / cpg;
+        M[i] = g_mean[g]; R[i] = g_rstd[g];
     }
 }
 
@@ -325,22 +383,49 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_stats(const void* __restrict_
     const uint32_t tpr = C / V, rif = GN_TPB / tpr;
     const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
     const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
+    // r06: a block's life was a chain of exposed latencies -- coefficients (global loads), then one 16-byte load pair per row trip, each trip waiting for
+    // its own -- over 32 rows, and the passes ran at 1.3 - 1.7 TB/s (bf16: SLOWER than fp32 on the same tensor, tools/bench_gn_bwd.py).  Now a trip is
+    // GN_BWD_UNROLL rows whose loads are all issued before the first is used, the first trip's loads go out ahead of the coefficient prologue, and the host
+    // hands a block enough rows for several trips where the tensor has them and one trip where it is small (gn_bwd_rows).
+    constexpr int UR = GN_BWD_UNROLL;
+    const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+    uint4 rx[UR], rd[UR];
+    auto issue = [&](uint32_t r0) {
+#pragma unroll
+        for (int k = 0; k < UR; ++k)
+            if (r0 + k * rif < rows_per_block) {
+                rx[k] = GnVec<DT>::raw(x, base + (size_t)(r0 + k * rif) * tpr);
+                rd[k] = GnVec<DT>::raw(dy, base + (size_t)(r0 + k * rif) * tpr);
+            }
+    };
+    if (lane_row < rif) issue(lane_row);
+    extern __shared__ __attribute__((aligned(16))) float ctab[];             // dynamic: [3][C] A, O, k per channel (16-byte reads) | [2][G] mean, rstd per group
+    float* const gtab = ctab + 3 * C;
+    gn_bwd_group_table(b, HW, C, G, fsums, eps, gtab, gtab + G);
+    __syncthreads();
+    gn_bwd_channel_table(b, C, G, gtab, gtab + G, gamma, beta, scale_shift, ss_stride, ctab);
+    __syncthreads();
+    float A[V], O[V], K[V], M[V], R[V];
+    if (lane_row < rif) gn_bwd_coeffs<V>(cv, C, G, gtab, gtab + G, ctab, A, O, K, M, R);
     if (lane_row < rif) {
-        float A[V], O[V], K[V], M[V], R[V], s[V], q[V];
-        gn_bwd_coeffs<DT, V>(b, cv, HW, C, G, fsums, gamma, beta, scale_shift, ss_stride, eps, A, O, K, M, R);
+        float s[V], q[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; }
-        const size_t base = ((size_t)b * HW + row0) * tpr + cv;
-        for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
-            float f[V], d[V];
-            GnVec<DT>::load(x, base + (size_t)r * tpr, f);
-            GnVec<DT>::load(dy, base + (size_t)r * tpr, d);
+        for (uint32_t r0 = lane_row; r0 < rows_per_block; r0 += rif * UR) {
+            if (r0 != lane_row) issue(r0);
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                float p, xh;
-                ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act & 1, &p, &xh);
-                s[i] += p;
-                q[i] = __builtin_fmaf(p, xh, q[i]);
+            for (int k = 0; k < UR; ++k) {
+                if (r0 + k * rif >= rows_per_block) break;
+                float f[V], d[V];
+                GnVec<DT>::cvt(rx[k], f);
+                GnVec<DT>::cvt(rd[k], d);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float p, xh;
+                    ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act & 1, &p, &xh);
+                    s[i] += p;
+                    q[i] = __builtin_fmaf(p, xh, q[i]);
+                }
             }
         }
 #pragma unroll
@@ -357,8 +442,11 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_stats(const void* __restrict_
     for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
         double ds = 0.0, dq = 0.0;
         for (uint32_t i = 0; i < cpg; ++i) { ds += (double)part_s[g * cpg + i]; dq += (double)part_q[g * cpg + i]; }
-        atomicAdd(&bsums[((size_t)b * G + g) * 2 + 0], ds);
-        atomicAdd(&bsums[((size_t)b * G + g) * 2 + 1], dq);
+        // r06: GN_BWD_REPLICAS copies of the sums, a block adds to copy (blockIdx.x mod replicas): device-scope fp64 atomics on ONE address are performed one after
+        // the other at the memory side (~0.15 us each, measured: 1024 blocks per launch on 512 addresses cost 20 us); k_gn_bwd_apply adds the copies up
+        double* rep = bsums + (size_t)(blockIdx.x % GN_BWD_REPLICAS) * gridDim.y * G * 2;
+        atomicAdd(&rep[((size_t)b * G + g) * 2 + 0], ds);
+        atomicAdd(&rep[((size_t)b * G + g) * 2 + 1], dq);
     }
 }
 
@@ -371,32 +459,66 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict_
     const uint32_t tpr = C / V, rif = GN_TPB / tpr;
     const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
     const uint32_t b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
+    extern __shared__ __attribute__((aligned(16))) float ctab[];             // dynamic: [3][C] A, O, k per channel (16-byte reads) | [4][G] mean, rstd, mean(p), mean(p * xhat) per group
+    float* const gtab = ctab + 3 * C;
+    const uint32_t cpg = C / G;
+    constexpr int UR = GN_BWD_UNROLL;
+    const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+    uint4 rx[UR], rd[UR];
+    auto issue = [&](uint32_t r0) {
+#pragma unroll
+        for (int k = 0; k < UR; ++k)
+            if (r0 + k * rif < rows_per_block) {
+                rx[k] = GnVec<DT>::raw(x, base + (size_t)(r0 + k * rif) * tpr);
+                rd[k] = GnVec<DT>::raw(dy, base + (size_t)(r0 + k * rif) * tpr);
+            }
+    };
+    if (lane_row < rif) issue(lane_row);                                     // (ahead of the prologue's own loads, as in k_gn_bwd_stats)
+    gn_bwd_group_table(b, HW, C, G, fsums, eps, gtab, gtab + G);
+    {
+        const double inv_n = 1.0 / ((double)HW * (double)cpg);
+        for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (uint32_t r = 0; r < GN_BWD_REPLICAS; ++r) {                    // (fixed order: the same sums in every block)
+                const double2 v = *reinterpret_cast<const double2*>(bsums + ((size_t)r * gridDim.y * G + (size_t)b * G + g) * 2);
+                s0 += v.x; s1 += v.y;
+            }
+            gtab[2 * G + g] = (float)(s0 * inv_n);
+            gtab[3 * G + g] = (float)(s1 * inv_n);
+        }
+    }
+    __syncthreads();
+    gn_bwd_channel_table(b, C, G, gtab, gtab + G, gamma, beta, scale_shift, ss_stride, ctab);
+    __syncthreads();
     if (lane_row >= rif) return;
     float A[V], O[V], K[V], M[V], R[V], m1[V], m2[V];
-    gn_bwd_coeffs<DT, V>(b, cv, HW, C, G, fsums, gamma, beta, scale_shift, ss_stride, eps, A, O, K, M, R);
-    const uint32_t cpg = C / G;
-    const double inv_n = 1.0 / ((double)HW * (double)cpg);
+    gn_bwd_coeffs<V>(cv, C, G, gtab, gtab + G, ctab, A, O, K, M, R);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const uint32_t g = (cv * V + i) / cpg;
-        m1[i] = (float)(bsums[((size_t)b * G + g) * 2 + 0] * inv_n);
-        m2[i] = (float)(bsums[((size_t)b * G + g) * 2 + 1] * inv_n);
+        m1[i] = gtab[2 * G + g];
+        m2[i] = gtab[3 * G + g];
     }
-    const size_t base = ((size_t)b * HW + row0) * tpr + cv;
-    for (uint32_t r = lane_row; r < rows_per_block; r += rif) {
-        float f[V], d[V];
-        GnVec<DT>::load(x, base + (size_t)r * tpr, f);
-        GnVec<DT>::load(dy, base + (size_t)r * tpr, d);
+    for (uint32_t r0 = lane_row; r0 < rows_per_block; r0 += rif * UR) {
+        if (r0 != lane_row) issue(r0);
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float p, xh;
-            ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act & 1, &p, &xh);
-            f[i] = ssdg_dx(p, xh, R[i], m1[i], m2[i]);
+        for (int k = 0; k < UR; ++k) {
+            if (r0 + k * rif >= rows_per_block) break;
+            float f[V], d[V];
+            GnVec<DT>::cvt(rx[k], f);
+            GnVec<DT>::cvt(rd[k], d);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float p, xh;
+                ssdg_elem(f[i], d[i], A[i], O[i], K[i], M[i], R[i], act & 1, &p, &xh);
+                f[i] = ssdg_dx(p, xh, R[i], m1[i], m2[i]);
+            }
+            if constexpr (DT == GN_F32) {
+                if (act & 2) { GnVec<DT>::store_split(dx, base + (size_t)(r0 + k * rif) * tpr, f); continue; }   // (host: C % 32 == 0) dx PRE-SPLIT for the backward convolution
+            }
+            GnVec<DT>::store(dx, base + (size_t)(r0 + k * rif) * tpr, f);
         }
-        if constexpr (DT == GN_F32) {
-            if (act & 2) { GnVec<DT>::store_split(dx, base + (size_t)r * tpr, f); continue; }       // (host: C % 32 == 0) dx PRE-SPLIT for the backward convolution
-        }
-        GnVec<DT>::store(dx, base + (size_t)r * tpr, f);
     }
 }
 
@@ -427,13 +549,13 @@ __global__ __launch_bounds__(256) void k_split_f32(const float* __restrict__ x, 
 #define GN_FWD_APPLY_ROWS 16
 #endif
 #ifndef GN_BWD_STATS_BLOCKS
-#define GN_BWD_STATS_BLOCKS 2048
+#define GN_BWD_STATS_BLOCKS 1024
 #endif
-#ifndef GN_BWD_STATS_ROWS
-#define GN_BWD_STATS_ROWS 32
+#ifndef GN_BWD_MIN_TRIPS
+#define GN_BWD_MIN_TRIPS 1
 #endif
 #ifndef GN_BWD_APPLY_BLOCKS
-#define GN_BWD_APPLY_BLOCKS 2048
+#define GN_BWD_APPLY_BLOCKS 1024
 #endif
 uint32_t gn_rows_per_block(uint32_t B, uint32_t HW, uint32_t min_blocks, uint32_t min_rows) {
     uint32_t rows = HW;                                 // largest power-of-two split of HW that still leaves >= min_blocks blocks
@@ -444,6 +566,7 @@ uint32_t gn_rows_per_block(uint32_t B, uint32_t HW, uint32_t min_blocks, uint32_
 }  // namespace
 
 extern "C" size_t ssdnerf_group_norm_workspace(uint32_t B, uint32_t G) { return (size_t)B * G * 2 * sizeof(double); }
+extern "C" size_t ssdnerf_group_norm_backward_workspace(uint32_t B, uint32_t G) { return (size_t)GN_BWD_REPLICAS * B * G * 2 * sizeof(double); }
 
 extern "C" int ssdnerf_group_norm_nhwc(const void* x, const void* x2, uint32_t C1, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* pre_bias, const float* gamma,
                                        const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act, void* workspace,
@@ -503,7 +626,7 @@ extern "C" int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint3
 }
 
 // d/dx of ssdnerf_group_norm_nhwc (single source, no pre_bias) given dy; `fwd_sums` is the forward's workspace (per sample and group:
-// sum, sum of squares of x), `bwd_workspace` another ssdnerf_group_norm_workspace(B, G) bytes, zero-filled here unless
+// sum, sum of squares of x), `bwd_workspace` ssdnerf_group_norm_backward_workspace(B, G) bytes (r06: replicated sums), zero-filled here unless
 // `bwd_workspace_is_zero` (stream capture: let the caller zero it with a kernel).
 extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* gamma,
                                                 const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act,
@@ -517,14 +640,17 @@ extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, i
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc_backward: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
     SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc_backward: the pre-split dx (act & 2) needs fp32 and C % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t rows_s = gn_rows_per_block(B, HW, GN_BWD_STATS_BLOCKS, GN_BWD_STATS_ROWS), rows_a = gn_rows_per_block(B, HW, GN_BWD_APPLY_BLOCKS, 16);
+    // r06: rows per block from the thread layout -- at least one row per row group (C / V threads share a row, 256 / (C / V) rows are in flight), so that the
+    // small tensors (8 x 8, 16 x 16: 64 - 256 rows per sample) spread over 100+ blocks instead of 16 blocks walking 8 trips each
+    const uint32_t rif = GN_TPB / (C / V) ? GN_TPB / (C / V) : 1;
+    const uint32_t rows_s = gn_rows_per_block(B, HW, GN_BWD_STATS_BLOCKS, rif * GN_BWD_MIN_TRIPS), rows_a = gn_rows_per_block(B, HW, GN_BWD_APPLY_BLOCKS, rif * GN_BWD_MIN_TRIPS);
     const dim3 grid_s(HW / rows_s, B), grid_a(HW / rows_a, B), block(GN_TPB);
-    if (!bwd_workspace_is_zero && hipMemsetAsync(bwd_workspace, 0, ssdnerf_group_norm_workspace(B, G), st) != hipSuccess)
+    if (!bwd_workspace_is_zero && hipMemsetAsync(bwd_workspace, 0, ssdnerf_group_norm_backward_workspace(B, G), st) != hipSuccess)
         return ssdnerf_fail(SSDNERF_E_LAUNCH, "group_norm_nhwc_backward: memset failed");
 #define SSD_GNB_LAUNCH(DT)                                                                                                                              \
-    hipLaunchKernelGGL(k_gn_bwd_stats<DT>, grid_s, block, 0, st, x, dy, HW, C, G, rows_s, (const double*)fwd_sums, gamma, beta, scale_shift, scale_shift_stride, \
+    hipLaunchKernelGGL(k_gn_bwd_stats<DT>, grid_s, block, ((size_t)2 * G + 3 * C) * 4, st, x, dy, HW, C, G, rows_s, (const double*)fwd_sums, gamma, beta, scale_shift, scale_shift_stride, \
                        eps, act, (double*)bwd_workspace);                                                                                              \
-    hipLaunchKernelGGL(k_gn_bwd_apply<DT>, grid_a, block, 0, st, x, dy, HW, C, G, rows_a, (const double*)fwd_sums, (const double*)bwd_workspace, gamma, beta,   \
+    hipLaunchKernelGGL(k_gn_bwd_apply<DT>, grid_a, block, ((size_t)4 * G + 3 * C) * 4, st, x, dy, HW, C, G, rows_a, (const double*)fwd_sums, (const double*)bwd_workspace, gamma, beta,   \
                        scale_shift, scale_shift_stride, eps, act, dx);
     if (dtype == GN_F32) { SSD_GNB_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_GNB_LAUNCH(GN_F16) } else { SSD_GNB_LAUNCH(GN_BF16) }
 #undef SSD_GNB_LAUNCH

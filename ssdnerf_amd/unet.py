@@ -148,6 +148,90 @@ class _ConvGeneralFn(torch.autograd.Function):
         return (gx if cin8 == conv.in_channels else gx[:, :conv.in_channels]), None
 
 
+def _bf16_weights_of(weight4, bias, transposed, cache):
+    """bf16 operand of a frozen (Cout, Cin, k, k) weight for ``conv2d_nhwc_bf16``: channel counts zero-padded to multiples of 8, channels_last;
+    ``transposed`` = the backward-data form (spatially flipped, in / out swapped).  + the padded fp32 bias (forward form).  Rebuilt when the weights change."""
+    w = weight4
+    key = (w._version, w.data_ptr(), str(w.device), None if bias is None else bias._version)
+    if cache.get("key") != key:
+        cache.clear()
+        cache["key"] = key
+    slot = ("bf16", transposed)
+    if slot not in cache:
+        cout8, cin8 = -(-w.size(0) // 8) * 8, -(-w.size(1) // 8) * 8
+        wp = w.detach()
+        if (cout8, cin8) != (w.size(0), w.size(1)):
+            wp = torch.zeros((cout8, cin8) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+            wp[:w.size(0), :w.size(1)] = w.detach()
+        wt = wp.flip(2, 3).transpose(0, 1) if transposed else wp
+        b = None
+        if bias is not None and not transposed:
+            b = torch.zeros(cout8, dtype=torch.float32, device=w.device)
+            b[:w.size(0)] = bias.detach().float()
+        cache[slot] = (wt.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), b)
+    return cache[slot]
+
+
+def _runs_fusable_bf16(B, hw_out, conv) -> bool:
+    """``_runs_fusable`` for the bf16 kernel (the rule of unet_fast.FastUnet._can_fuse_stats, bf16 branch)"""
+    from . import _cabi as C
+    cout, cin, k = conv.out_channels, conv.in_channels, conv.kernel_size[0]
+    if cout % 8 != 0 or cin % 8 != 0 or hw_out > 128 * 256:
+        return False
+    plan = C.lib().ssdnerf_conv2d_nhwc_bf16_plan(C.u32(B * hw_out), C.u32(cin), C.u32(cout), C.u32(k), 0, 1, 0)
+    if plan >> 8 != 1:
+        return True
+    return hw_out % (256 if (plan & 0xff) == 4 else 128 if (plan & 0xff) == 1 else 64) == 0
+
+
+class _ConvBf16Fn(torch.autograd.Function):
+    """r06, the NATIVE bf16 gradient path (config 5: ``autocast_dtype='bfloat16'``; reference lib/models/autodecoders/diffusion_nerf.py:301-304 runs the guided
+    UNet forward + backward under autocast): y = conv2d(x, W) + b (+ residual) for bf16 channel-last activations and FROZEN weights, differentiable w.r.t. x and
+    the residual -- every layer of the cars UNet: 1 x 1 / 3 x 3, stride 1 or 2, channel counts padded to multiples of 8 (18 -> 128 stem, 128 -> 18 head).
+    Forward and backward-data are the inference executor's bf16 implicit-GEMM kernels (``ssdnerf_conv2d_nhwc_bf16``: bf16 operands, fp32 accumulation, bf16
+    result -- the arithmetic of the reference's autocast convolutions); d/dx of a stride-2 layer is the stride-1 convolution of the zero-inserted dy
+    (``_ConvGeneralFn``).  ``box['runs']``: the output's GroupNorm sums per run of 4 channels from the epilogue, as in ``_ConvF32x2Fn``."""
+
+    @staticmethod
+    def forward(ctx, x, conv, residual=None, box=None):
+        from . import unet_fast as UF
+        w, bias = conv._bf16_weights(False)
+        cout8, cin8 = int(w.size(0)), int(w.size(1))
+        stride = conv.stride[0] if isinstance(conv.stride, tuple) else int(conv.stride)
+        ctx.conv, ctx.in_shape, ctx.stride = conv, tuple(x.shape), stride
+        ctx.has_residual = residual is not None
+        xc = _pad_channels(x, cin8)
+        runs = None
+        if box is not None:
+            hw_out = (x.size(2) // stride) * (x.size(3) // stride)
+            if cout8 == conv.out_channels and _runs_fusable_bf16(x.size(0), hw_out, conv):
+                n = x.size(0) * (cout8 // 4) * 2
+                arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
+                runs = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
+            box["runs"] = runs
+        y = UF.conv2d_nhwc_bf16(xc, w, bias, None if residual is None else residual.contiguous(memory_format=torch.channels_last), stride=stride, gn_sums=runs,
+                                gn_groups=cout8 // 4 if runs is not None else 0, splitk_ws=UF.shared_splitk_ws(x.device))
+        return y if cout8 == conv.out_channels else y[:, :conv.out_channels]
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import unet_fast as UF
+        conv = ctx.conv
+        g_res = gy if ctx.has_residual and ctx.needs_input_grad[2] else None
+        if not ctx.needs_input_grad[0]:
+            return None, None, g_res, None
+        w, _ = conv._bf16_weights(True)                              # (cin8, cout8, k, k): dy's channels in, x's channels out
+        cin8, cout8 = int(w.size(0)), int(w.size(1))
+        B, _, H, W = ctx.in_shape
+        if ctx.stride == 2:
+            z = torch.zeros((B, cout8, H, W), dtype=gy.dtype, device=gy.device).contiguous(memory_format=torch.channels_last)
+            z[:, :gy.size(1), ::2, ::2] = gy
+        else:
+            z = _pad_channels(gy, cout8)
+        gx = UF.conv2d_nhwc_bf16(z, w, splitk_ws=UF.shared_splitk_ws(gy.device))
+        return (gx if cin8 == conv.in_channels else gx[:, :conv.in_channels]), None, g_res, None
+
+
 class _Conv2d(nn.Conv2d):
     """``nn.Conv2d`` (same parameters and state-dict keys) that routes input-gradient-only fp32 GPU calls through ``_ConvF32x2Fn``."""
 
@@ -182,6 +266,18 @@ class _Conv2d(nn.Conv2d):
                 bias[:w.size(0)] = self.bias.detach()
             cache[transposed] = split_bf16x2_adjacent(wt.contiguous()) + (bias,)
         return cache[transposed]
+
+    def _eligible_bf16(self, x):
+        """what ``_ConvBf16Fn`` takes: bf16 activations of the native bf16 gradient path (``DenoisingUnetMod.forward`` casts and switches autocast off)"""
+        k = self.kernel_size[0]
+        return (self.grad_conv and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad and not self.weight.requires_grad and _device_ok(x)
+                and not torch.is_autocast_enabled(x.device.type) and x.dim() == 4 and self.groups == 1
+                and self.kernel_size in ((1, 1), (3, 3)) and self.dilation == (1, 1) and self.padding == (k // 2, k // 2) and self.padding_mode == "zeros"
+                and (self.stride == (1, 1) or (self.stride == (2, 2) and k == 3 and x.size(2) % 2 == 0 and x.size(3) % 2 == 0))
+                and (self.bias is None or not self.bias.requires_grad))
+
+    def _bf16_weights(self, transposed):
+        return _bf16_weights_of(self.weight, self.bias, transposed, self.__dict__.setdefault("_bf16_cache", {}))
 
     #: SSDNERF_UNET_GRAD_CONV=0 keeps MIOpen for the differentiable path
     grad_conv = os.environ.get("SSDNERF_UNET_GRAD_CONV", "1") != "0"
@@ -239,6 +335,10 @@ class _Conv2d(nn.Conv2d):
         if self._eligible_general(x):
             y = _ConvGeneralFn.apply(x, self)
             return y if residual is None else y + residual
+        if x.dtype == torch.bfloat16 and self._eligible_bf16(x):
+            fuse = self.fuse_epilogues and self.out_channels % 8 == 0
+            y = _ConvBf16Fn.apply(x, self, residual if fuse else None, box if fuse else None)
+            return y if residual is None or fuse else y + residual
         if x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
             _Conv2d.library_calls += 1
         y = super().forward(x)
@@ -264,6 +364,11 @@ class _Pointwise:
         m = self.m
         return (m.groups == 1 and m.kernel_size == (1,) and m.stride == (1,) and m.in_channels % 8 == 0 and m.out_channels % 8 == 0
                 and not m.weight.requires_grad and (m.bias is None or not m.bias.requires_grad))
+
+    stride = (1, 1)
+
+    def _bf16_weights(self, transposed):
+        return _bf16_weights_of(self.m.weight[:, :, :, None], self.m.bias, transposed, self.__dict__.setdefault("_bf16_cache", {}))
 
     def _split_pair(self, transposed):
         from .unet_fast import split_bf16x2_adjacent
@@ -370,7 +475,7 @@ class _GroupNormActFn(torch.autograd.Function):
         from . import unet_fast as UF
         xc, sums = ctx.saved_tensors
         norm = ctx.norm
-        ws = ctx.arena.take(xc.size(0) * norm.num_groups * 2) if ctx.arena is not None else None
+        ws = ctx.arena.take(UF.group_norm_backward_workspace_doubles(xc.size(0), norm.num_groups)) if ctx.arena is not None else None
         dx = UF.group_norm_nhwc_backward(xc, dy.contiguous(memory_format=torch.channels_last), norm.num_groups, norm.weight.detach(), norm.bias.detach(),
                                          ctx.ss, norm.eps, ctx.act, sums, workspace=ws, split_out=ctx.grad_split)
         return dx, None, None, None, None, None, None
@@ -395,7 +500,8 @@ GRAD_ATT = os.environ.get("SSDNERF_UNET_GRAD_ATT", "1") != "0"
 
 
 def _gn_act_eligible(x, norm, scale_shift=None):
-    return (GRAD_GN and torch.is_grad_enabled() and x.requires_grad and x.dim() == 4 and _device_ok(x) and x.dtype == torch.float32
+    return (GRAD_GN and torch.is_grad_enabled() and x.requires_grad and x.dim() == 4 and _device_ok(x)
+            and (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and norm.num_channels % 8 == 0))      # (bf16: the native bf16 gradient path, r06)
             and not torch.is_autocast_enabled(x.device.type) and isinstance(norm, nn.GroupNorm) and norm.affine
             and not norm.weight.requires_grad and not norm.bias.requires_grad and norm.num_channels % 4 == 0 and norm.num_channels <= 1024
             and (scale_shift is None or not scale_shift.requires_grad))
@@ -569,6 +675,16 @@ class MultiHeadAttentionMod(nn.Module):
         if GRAD_ATT_POINTWISE and _Conv2d.grad_conv and _Conv2d.fuse_epilogues and pw[0].ok() and pw[1].ok():
             # r04: the two projections on the fp32-class 1x1 convolution kernel of the residual blocks (the inference executor's choice) instead of the
             # library's fp32 GEMMs: `proj(a) + x` and the statistics of the sum for the next block's norm come out of ONE epilogue
+            if x.dtype == torch.bfloat16:
+                # r06, native bf16 gradient path: the projections on the bf16 kernel; softmax(QK^T)V stays on the fp32-class kernels (forward with the rows'
+                # log-sum-exp + backward; the reference's softmax is fp32 under autocast as well) between two casts of the (B, T, 3C) / (B, T, C) tensors
+                qkv = _ConvBf16Fn.apply(xn, pw[0], None, None).permute(0, 2, 3, 1).reshape(b, t, 3 * c).float()
+                a = (_AttentionF32Fn.apply(qkv, heads) if attention_kernel_ok(qkv, heads) else self._sdpa(qkv, b, t, heads, ch)).to(torch.bfloat16)
+                box = {}
+                out = _ConvBf16Fn.apply(a.view(b, h, w, c).permute(0, 3, 1, 2), pw[1], xc, box)
+                if box.get("runs") is not None:
+                    out._ssd_runs = box["runs"]
+                return out
             qkv = _ConvF32x2Fn.apply(xn, pw[0], None, None).permute(0, 2, 3, 1).reshape(b, t, 3 * c)          # channel = head*3ch + {q,k,v}*ch + i
             a = _AttentionF32Fn.apply(qkv, heads) if attention_kernel_ok(qkv, heads) else self._sdpa(qkv, b, t, heads, ch)
             box = {}
@@ -903,6 +1019,38 @@ class DenoisingUnetMod(nn.Module):
     #: profiles/r04).  SSDNERF_UNET_GRAD_AUTOCAST=1 keeps the eager autocast modules (the reference's arithmetic for that config).
     grad_path_fp32_under_autocast = os.environ.get("SSDNERF_UNET_GRAD_AUTOCAST", "0") != "1"
 
+    #: r06: ... and with ``autocast_dtype='bfloat16'`` the same calls run NATIVELY in bf16 (SSDNERF_UNET_GRAD_BF16=0: the fp32-class kernels again): bf16
+    #: channel-last activations and gradients end to end -- ``_ConvBf16Fn`` (the executor's bf16 implicit-GEMM kernels, forward and backward-data),
+    #: the fused GroupNorm forward / backward in their bf16 instantiations, attention on the fp32-class kernels between two casts -- which is the
+    #: arithmetic the reference asks for there (autocast: bf16 convolutions / GEMMs with fp32 accumulation, fp32 norm statistics and softmax), at a third of the
+    #: matrix instructions and half the bytes of the fp32-class path.
+    grad_path_bf16_native = os.environ.get("SSDNERF_UNET_GRAD_BF16", "1") != "0"
+
+    def _bf16_grad_path_ok(self) -> bool:
+        """every layer of this UNet has a kernel on the native bf16 gradient path (checked once per module tree; the cars / chairs configs do)"""
+        ok = self.__dict__.get("_bf16_grad_ok")
+        if ok is None:
+            ok = _Conv2d.grad_conv and _Conv2d.fuse_epilogues and GRAD_GN and GRAD_ATT and GRAD_ATT_POINTWISE and self.concat_cond_channels == 0
+            for m in self.modules():
+                if isinstance(m, _Conv2d):
+                    k = m.kernel_size[0]
+                    ok = ok and m.groups == 1 and m.kernel_size in ((1, 1), (3, 3)) and m.dilation == (1, 1) and m.padding == (k // 2, k // 2) \
+                        and m.padding_mode == "zeros" and (m.stride == (1, 1) or (m.stride == (2, 2) and k == 3))
+                elif isinstance(m, nn.GroupNorm):
+                    ok = ok and m.affine and m.num_channels % 8 == 0 and m.num_channels <= 1024
+                elif isinstance(m, MultiHeadAttentionMod):
+                    ok = ok and m.groups == 1 and m.qkv.in_channels % 8 == 0
+                elif isinstance(m, NormWithEmbedding):
+                    ok = ok and m.use_scale_shift
+                elif isinstance(m, DenoisingResBlockMod):
+                    ok = ok and isinstance(m.conv_1[1], nn.SiLU) and isinstance(m.conv_2[0], nn.SiLU)
+                elif isinstance(m, (nn.AvgPool2d, nn.Conv2d)) and not isinstance(m, _Conv2d):
+                    ok = False
+                elif isinstance(m, _NormActConv):
+                    ok = ok and isinstance(m.activate, nn.SiLU)
+            self.__dict__["_bf16_grad_ok"] = bool(ok)
+        return bool(ok)
+
     #: r04: input-gradient calls with frozen weights (rendering-guided DDIM steps, the prior loss of fine-tuning) replay a CAPTURED forward and a captured
     #: backward (two hipGraphs over static buffers, ``_GraphedGrad``) once a signature has been seen ``grad_graph_after`` times: the
     #: eager gradient path is ~600 launches and ~250 autograd nodes per call, ~25 ms of host time beside ~25 ms of kernels (profiles/r04).  Same kernels in
@@ -913,7 +1061,7 @@ class DenoisingUnetMod(nn.Module):
 
     def _grad_graph_call(self, x_t, t):
         """The captured forward + backward for this call's signature, or None (not eligible, not yet seen often enough, capture failed)."""
-        if not (self.grad_graph and x_t.is_cuda and x_t.dtype == torch.float32 and x_t.requires_grad and torch.is_grad_enabled() and not self.training
+        if not (self.grad_graph and x_t.is_cuda and x_t.dtype in (torch.float32, torch.bfloat16) and x_t.requires_grad and torch.is_grad_enabled() and not self.training
                 and torch.is_tensor(t) and t.is_cuda and not t.requires_grad and not torch.is_autocast_enabled("cuda")
                 and not torch.cuda.is_current_stream_capturing()):
             return None
@@ -925,7 +1073,7 @@ class DenoisingUnetMod(nn.Module):
             if p.requires_grad:
                 return None                                          # (a weight gradient is asked for: the eager path)
             versions += p._version + (p.data_ptr() & 0xffffffff)
-        key = (tuple(x_t.shape), tuple(t.shape), t.dtype, x_t.device.index)
+        key = (tuple(x_t.shape), tuple(t.shape), t.dtype, x_t.device.index, x_t.dtype)
         graphs = self.__dict__.setdefault("_grad_graphs", {})
         entry = graphs.get(key)
         if entry is None or entry["versions"] != versions:
@@ -962,7 +1110,7 @@ class DenoisingUnetMod(nn.Module):
 
     def grad_graph_info(self):
         """[{signature, captured, capture_s, failed}] of the gradient path's captured graphs (bench / tests)"""
-        return [dict(x_shape=list(k[0]), captured=e["fn"] is not None, capture_s=e.get("capture_s"), failed=e["failed"])
+        return [dict(x_shape=list(k[0]), dtype=str(k[4]), captured=e["fn"] is not None, capture_s=e.get("capture_s"), failed=e["failed"])
                 for k, e in self.__dict__.get("_grad_graphs", {}).items()]
 
     def forward(self, x_t, t, label=None, concat_cond=None, return_noise=False):
@@ -972,7 +1120,11 @@ class DenoisingUnetMod(nn.Module):
                 return self._fast_executor(dtype)(x_t.float(), t)
         if (self.grad_path_fp32_under_autocast and x_t.is_cuda and torch.is_grad_enabled() and x_t.requires_grad and torch.is_autocast_enabled("cuda")
                 and self._all_weights_frozen()):
+            native = (self.grad_path_bf16_native and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not self.training and label is None
+                      and concat_cond is None and not return_noise and self._bf16_grad_path_ok())
             with torch.autocast("cuda", enabled=False):
+                if native:                                           # (the casts are autograd nodes: the caller's fp32 leaf receives an fp32 gradient)
+                    return self.forward(x_t.to(torch.bfloat16), t).float()
                 return self.forward(x_t.float(), t, label, None if concat_cond is None else concat_cond.float(), return_noise)
         if label is None and concat_cond is None and not return_noise:
             graphed = self._grad_graph_call(x_t, t)
@@ -996,8 +1148,9 @@ class DenoisingUnetMod(nn.Module):
             n_gn = self.__dict__.get("_n_group_norms") or sum(m.num_groups for m in self.modules() if isinstance(m, nn.GroupNorm))
             n_runs = self.__dict__.get("_n_conv_runs") or sum(m.out_channels // 2 for m in self.modules() if isinstance(m, _Conv2d))
             self.__dict__["_n_group_norms"], self.__dict__["_n_conv_runs"] = n_gn, n_runs
-            # forward + backward sums of every norm, and the run-level sums (Cout / 4 runs x 2) the convolutions' epilogues leave for them
-            _ZeroArena.current = _ZeroArena(x_t.size(0) * (4 * n_gn + n_runs), x_t.device)
+            # forward + backward sums of every norm (the backward's in several copies), and the run-level sums (Cout / 4 runs x 2) the convolutions' epilogues leave
+            from . import unet_fast as UF
+            _ZeroArena.current = _ZeroArena(x_t.size(0) * (2 * n_gn + n_runs) + UF.group_norm_backward_workspace_doubles(x_t.size(0), n_gn), x_t.device)
         try:
             return self._forward_blocks(x_t, embedding, concat_cond)
         finally:

@@ -92,6 +92,11 @@ def group_norm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: tor
     return y
 
 
+def group_norm_backward_workspace_doubles(B: int, groups: int) -> int:
+    """doubles of zeroed workspace one ``group_norm_nhwc_backward`` call takes (r06: the statistics pass adds to several copies of the sums)"""
+    return int(C.lib().ssdnerf_group_norm_backward_workspace(C.u32(B), C.u32(groups))) // 8
+
+
 def group_norm_nhwc_backward(x: torch.Tensor, dy: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, scale_shift: Optional[torch.Tensor],
                              eps: float, act: bool, fwd_sums: torch.Tensor, workspace: Optional[torch.Tensor] = None, split_out: bool = False) -> torch.Tensor:
     """d/dx of ``group_norm_nhwc`` (single source, no pre_bias) for frozen gamma / beta / scale_shift (csrc/groupnorm.hip, k_gn_bwd_*).
@@ -106,7 +111,10 @@ def group_norm_nhwc_backward(x: torch.Tensor, dy: torch.Tensor, groups: int, gam
         assert scale_shift.dtype == torch.float32 and scale_shift.shape == (B, 2 * Cc) and scale_shift.stride(1) == 1
         ss_stride = scale_shift.stride(0)
     dx = torch.empty_like(x)
-    ws = workspace if workspace is not None else torch.zeros(B * groups * 2, dtype=torch.float64, device=x.device)   # (all zero on entry)
+    need = group_norm_backward_workspace_doubles(B, groups)
+    ws = workspace if workspace is not None else torch.zeros(need, dtype=torch.float64, device=x.device)   # (all zero on entry)
+    if ws.numel() < need or ws.dtype != torch.float64:
+        raise RuntimeError(f"group_norm_nhwc_backward: the workspace must hold {need} zeroed doubles (group_norm_backward_workspace_doubles)")
     C.check(C.lib().ssdnerf_group_norm_nhwc_backward(C.ptr(x), C.ptr(dy), _GN_DTYPE[x.dtype], C.u32(B), C.u32(H * W), C.u32(Cc), C.u32(groups), C.ptr(gamma),
                                                       C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)) | (2 if split_out else 0), C.ptr(fwd_sums), C.ptr(ws), 1,
                                                       C.ptr(dx), C.stream()), "group_norm_nhwc_backward")
