@@ -317,7 +317,8 @@ int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint32_t C1, int
  * ssdnerf_group_norm_backward_workspace(B, G) bytes (r06: several copies of the sums, so that the statistics pass's atomics do not queue on one
  * address), zero-filled by the call unless bwd_workspace_is_zero.  Two passes, nothing else saved.
  * act: bit 0 = the forward applied SiLU; bit 1 (r04, fp32, C % 32 == 0): write dx PRE-SPLIT (the layout of ssdnerf_group_norm_nhwc's act | 2) for the
- * backward-data convolution that consumes it (ssdnerf_conv2d_nhwc_f32x2_presplit on the transposed weights).
+ * backward-data convolution that consumes it (ssdnerf_conv2d_nhwc_f32x2_presplit on the transposed weights); bit 2 (r06, (C / G) % 4 == 0): fwd_sums holds the
+ * forward's statistics per RUN of 4 channels, [B][C / 4][2] -- what ssdnerf_group_norm_nhwc_runs read -- instead of per group.
  * Arithmetic: csrc/gn_bwd_math.h (plain C, also built by gcc for tests/test_groupnorm_backward_cpu.py). */
 size_t ssdnerf_group_norm_backward_workspace(uint32_t B, uint32_t G);
 int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,

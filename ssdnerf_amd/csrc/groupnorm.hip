@@ -320,12 +320,24 @@ __global__ __launch_bounds__(GN_TPB) void k_bias_residual(const void* __restrict
 // the scale/shift mul/add pair, and an NHWC <-> NCHW copy on either side).
 // r06: a group's mean / rstd (an fp64 square root and division) are computed once per block, by one thread per group, into LDS; until then every thread
 // derived them for each of its V channels.  Same expressions in the same precisions (ssdg_coeffs): bit-identical results.
-__device__ __forceinline__ void gn_bwd_group_table(uint32_t b, uint32_t HW, uint32_t C, uint32_t G, const double* __restrict__ fsums, float eps,
+__device__ __forceinline__ void gn_bwd_group_table(uint32_t b, uint32_t HW, uint32_t C, uint32_t G, const double* __restrict__ fsums, float eps, int act,
                                                    float* __restrict__ g_mean, float* __restrict__ g_rstd) {
-    const double inv_n = 1.0 / ((double)HW * (double)(C / G));
+    const uint32_t cpg = C / G;
+    const double inv_n = 1.0 / ((double)HW * (double)cpg);
     for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
-        const double mean = fsums[((size_t)b * G + g) * 2 + 0] * inv_n;
-        double var = fsums[((size_t)b * G + g) * 2 + 1] * inv_n - mean * mean;
+        double gs, gq;
+        if (act & 4) {                                                        // (r06) fsums per RUN of 4 channels, [B][C / 4][2], as the convolutions' epilogues leave them
+            gs = 0.0; gq = 0.0;
+            const uint32_t rpg = cpg / 4;
+            for (uint32_t r = 0; r < rpg; ++r) {
+                const double2 v = *reinterpret_cast<const double2*>(fsums + ((size_t)b * (C / 4) + g * rpg + r) * 2);
+                gs += v.x; gq += v.y;
+            }
+        } else {
+            gs = fsums[((size_t)b * G + g) * 2 + 0]; gq = fsums[((size_t)b * G + g) * 2 + 1];
+        }
+        const double mean = gs * inv_n;
+        double var = gq * inv_n - mean * mean;
         var = var > 0.0 ? var : 0.0;
         g_mean[g] = (float)mean;
         g_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_stats(const void* __restrict_
     if (lane_row < rif) issue(lane_row);
     extern __shared__ __attribute__((aligned(16))) float ctab[];             // dynamic: [3][C] A, O, k per channel (16-byte reads) | [2][G] mean, rstd per group
     float* const gtab = ctab + 3 * C;
-    gn_bwd_group_table(b, HW, C, G, fsums, eps, gtab, gtab + G);
+    gn_bwd_group_table(b, HW, C, G, fsums, eps, act, gtab, gtab + G);
     __syncthreads();
     gn_bwd_channel_table(b, C, G, gtab, gtab + G, gamma, beta, scale_shift, ss_stride, ctab);
     __syncthreads();
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict_
             }
     };
     if (lane_row < rif) issue(lane_row);                                     // (ahead of the prologue's own loads, as in k_gn_bwd_stats)
-    gn_bwd_group_table(b, HW, C, G, fsums, eps, gtab, gtab + G);
+    gn_bwd_group_table(b, HW, C, G, fsums, eps, act, gtab, gtab + G);
     {
         const double inv_n = 1.0 / ((double)HW * (double)cpg);
         for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
@@ -639,6 +651,7 @@ extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, i
     SSD_REQUIRE(!scale_shift || scale_shift_stride >= 2 * C, "group_norm_nhwc_backward: scale_shift_stride must be >= 2*C");
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc_backward: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
     SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc_backward: the pre-split dx (act & 2) needs fp32 and C % 32 == 0");
+    SSD_REQUIRE(!(act & 4) || (C / G) % 4 == 0, "group_norm_nhwc_backward: run-level forward sums (act & 4) need groups of a multiple of 4 channels");
     hipStream_t st = (hipStream_t)stream;
     // r06: rows per block from the thread layout -- at least one row per row group (C / V threads share a row, 256 / (C / V) rows are in flight), so that the
     // small tensors (8 x 8, 16 x 16: 64 - 256 rows per sample) spread over 100+ blocks instead of 16 blocks walking 8 trips each

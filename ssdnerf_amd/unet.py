@@ -193,24 +193,26 @@ class _ConvBf16Fn(torch.autograd.Function):
     (``_ConvGeneralFn``).  ``box['runs']``: the output's GroupNorm sums per run of 4 channels from the epilogue, as in ``_ConvF32x2Fn``."""
 
     @staticmethod
-    def forward(ctx, x, conv, residual=None, box=None):
+    def forward(ctx, x, conv, residual=None, box=None, upsample=False):
+        """``upsample``: convolve the nearest-neighbour 2x upsampling of x without building it (the kernel's index map; DenoisingUpsampleMod); its gradient is the
+        2 x 2 sum-pooling of the backward convolution's result"""
         from . import unet_fast as UF
         w, bias = conv._bf16_weights(False)
         cout8, cin8 = int(w.size(0)), int(w.size(1))
         stride = conv.stride[0] if isinstance(conv.stride, tuple) else int(conv.stride)
-        ctx.conv, ctx.in_shape, ctx.stride = conv, tuple(x.shape), stride
+        ctx.conv, ctx.in_shape, ctx.stride, ctx.upsample = conv, tuple(x.shape), stride, bool(upsample)
         ctx.has_residual = residual is not None
         xc = _pad_channels(x, cin8)
         runs = None
         if box is not None:
-            hw_out = (x.size(2) // stride) * (x.size(3) // stride)
+            hw_out = (x.size(2) // stride) * (x.size(3) // stride) * (4 if upsample else 1)
             if cout8 == conv.out_channels and _runs_fusable_bf16(x.size(0), hw_out, conv):
                 n = x.size(0) * (cout8 // 4) * 2
                 arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
                 runs = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
             box["runs"] = runs
-        y = UF.conv2d_nhwc_bf16(xc, w, bias, None if residual is None else residual.contiguous(memory_format=torch.channels_last), stride=stride, gn_sums=runs,
-                                gn_groups=cout8 // 4 if runs is not None else 0, splitk_ws=UF.shared_splitk_ws(x.device))
+        y = UF.conv2d_nhwc_bf16(xc, w, bias, None if residual is None else residual.contiguous(memory_format=torch.channels_last), stride=stride, upsample=bool(upsample),
+                                gn_sums=runs, gn_groups=cout8 // 4 if runs is not None else 0, splitk_ws=UF.shared_splitk_ws(x.device))
         return y if cout8 == conv.out_channels else y[:, :conv.out_channels]
 
     @staticmethod
@@ -219,7 +221,7 @@ class _ConvBf16Fn(torch.autograd.Function):
         conv = ctx.conv
         g_res = gy if ctx.has_residual and ctx.needs_input_grad[2] else None
         if not ctx.needs_input_grad[0]:
-            return None, None, g_res, None
+            return None, None, g_res, None, None
         w, _ = conv._bf16_weights(True)                              # (cin8, cout8, k, k): dy's channels in, x's channels out
         cin8, cout8 = int(w.size(0)), int(w.size(1))
         B, _, H, W = ctx.in_shape
@@ -229,7 +231,9 @@ class _ConvBf16Fn(torch.autograd.Function):
         else:
             z = _pad_channels(gy, cout8)
         gx = UF.conv2d_nhwc_bf16(z, w, splitk_ws=UF.shared_splitk_ws(gy.device))
-        return (gx if cin8 == conv.in_channels else gx[:, :conv.in_channels]), None, g_res, None
+        if ctx.upsample:                                             # d/dx of the nearest 2x upsampling: every input pixel collects its 2 x 2 copies (x 4 is exact in bf16)
+            gx = F.avg_pool2d(gx, 2).mul_(4.0)
+        return (gx if cin8 == conv.in_channels else gx[:, :conv.in_channels]), None, g_res, None, None
 
 
 class _Conv2d(nn.Conv2d):
@@ -452,11 +456,13 @@ class _GroupNormActFn(torch.autograd.Function):
         xc = x.contiguous(memory_format=torch.channels_last)
         arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
         ctx.arena = arena
+        ctx.sums_are_runs = False
         ss = None if scale_shift is None else scale_shift.detach().float().contiguous()
         B, Cc, G = x.size(0), x.size(1), norm.num_groups
         if runs is not None and (Cc // G) % 4 == 0 and runs.numel() == B * (Cc // 4) * 2:
             y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, None, runs=(runs, None), split_out=split_out)
-            sums = runs.view(B, G, Cc // (4 * G), 2).sum(dim=2).reshape(-1)                  # per-group sums for the backward (a few hundred doubles)
+            sums = runs                                                  # (r06) the backward adds a group's runs up itself (act & 4): no reduction kernel per norm
+            ctx.sums_are_runs = True
         else:
             n = B * G * 2
             sums = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
@@ -477,7 +483,7 @@ class _GroupNormActFn(torch.autograd.Function):
         norm = ctx.norm
         ws = ctx.arena.take(UF.group_norm_backward_workspace_doubles(xc.size(0), norm.num_groups)) if ctx.arena is not None else None
         dx = UF.group_norm_nhwc_backward(xc, dy.contiguous(memory_format=torch.channels_last), norm.num_groups, norm.weight.detach(), norm.bias.detach(),
-                                         ctx.ss, norm.eps, ctx.act, sums, workspace=ws, split_out=ctx.grad_split)
+                                         ctx.ss, norm.eps, ctx.act, sums, workspace=ws, split_out=ctx.grad_split, sums_are_runs=ctx.sums_are_runs)
         return dx, None, None, None, None, None, None
 
 
@@ -739,6 +745,12 @@ class DenoisingUpsampleMod(nn.Module):
             self.conv = _Conv2d(in_channels, in_channels, 3, 1, 1, groups=groups)
 
     def forward(self, x):
+        if self.with_conv and x.dtype == torch.bfloat16 and self.conv._eligible_bf16(x) and self.conv.fuse_epilogues and self.conv.out_channels % 8 == 0:
+            box = {}                                                 # (r06, native bf16 gradient path) the upsampling is the convolution kernel's index map
+            out = _ConvBf16Fn.apply(x, self.conv, None, box, True)
+            if box.get("runs") is not None:
+                out._ssd_runs = box["runs"]
+            return out
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         if not self.with_conv:
             return x

@@ -98,10 +98,12 @@ def group_norm_backward_workspace_doubles(B: int, groups: int) -> int:
 
 
 def group_norm_nhwc_backward(x: torch.Tensor, dy: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, scale_shift: Optional[torch.Tensor],
-                             eps: float, act: bool, fwd_sums: torch.Tensor, workspace: Optional[torch.Tensor] = None, split_out: bool = False) -> torch.Tensor:
+                             eps: float, act: bool, fwd_sums: torch.Tensor, workspace: Optional[torch.Tensor] = None, split_out: bool = False,
+                             sums_are_runs: bool = False) -> torch.Tensor:
     """d/dx of ``group_norm_nhwc`` (single source, no pre_bias) for frozen gamma / beta / scale_shift (csrc/groupnorm.hip, k_gn_bwd_*).
     ``x``, ``dy``: (B, C, H, W) channels_last, same dtype; ``fwd_sums``: the forward's workspace (fp64, B * groups * 2).  ``split_out`` (fp32,
-    C % 32 == 0): dx is written PRE-SPLIT for the backward-data convolution that consumes it (``conv2d_nhwc_f32x2_presplit``)."""
+    C % 32 == 0): dx is written PRE-SPLIT for the backward-data convolution that consumes it (``conv2d_nhwc_f32x2_presplit``).  ``sums_are_runs``: ``fwd_sums`` is the
+    run-level statistics tensor (B, C / 4, 2) that ``group_norm_nhwc(runs=...)`` read (no reduction to groups on the host side)."""
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or dy.shape != x.shape or dy.dtype != x.dtype \
             or not dy.is_contiguous(memory_format=torch.channels_last):
         raise RuntimeError("group_norm_nhwc_backward: x and dy must be channels_last 4-D tensors of the same shape and dtype")
@@ -116,7 +118,7 @@ def group_norm_nhwc_backward(x: torch.Tensor, dy: torch.Tensor, groups: int, gam
     if ws.numel() < need or ws.dtype != torch.float64:
         raise RuntimeError(f"group_norm_nhwc_backward: the workspace must hold {need} zeroed doubles (group_norm_backward_workspace_doubles)")
     C.check(C.lib().ssdnerf_group_norm_nhwc_backward(C.ptr(x), C.ptr(dy), _GN_DTYPE[x.dtype], C.u32(B), C.u32(H * W), C.u32(Cc), C.u32(groups), C.ptr(gamma),
-                                                      C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)) | (2 if split_out else 0), C.ptr(fwd_sums), C.ptr(ws), 1,
+                                                      C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps), int(bool(act)) | (2 if split_out else 0) | (4 if sums_are_runs else 0), C.ptr(fwd_sums), C.ptr(ws), 1,
                                                       C.ptr(dx), C.stream()), "group_norm_nhwc_backward")
     return dx
 

@@ -220,7 +220,7 @@ def test_tiled_triplane_unet_shapes_module_oracle_and_executor():
     assert torch.allclose(got, want, atol=2e-4, rtol=2e-4), (got - want).abs().max()
 
 
-def _gn_backward_standin(x, dy, groups, gamma, beta, scale_shift, eps, act, fwd_sums, workspace=None, split_out=False):
+def _gn_backward_standin(x, dy, groups, gamma, beta, scale_shift, eps, act, fwd_sums, workspace=None, split_out=False, sums_are_runs=False):
     assert not split_out                                            # (the pre-split dx exists on the GPU only)
     assert x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last) and fwd_sums.dtype == torch.float64
     with torch.enable_grad():
