@@ -321,6 +321,15 @@ int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint32_t C1, int
  * forward's statistics per RUN of 4 channels, [B][C / 4][2] -- what ssdnerf_group_norm_nhwc_runs read -- instead of per group.
  * Arithmetic: csrc/gn_bwd_math.h (plain C, also built by gcc for tests/test_groupnorm_backward_cpu.py). */
 size_t ssdnerf_group_norm_backward_workspace(uint32_t B, uint32_t G);
+
+/* r06: the same for a norm over the channel concatenation [x | x2] (C1 channels from x) that ssdnerf_group_norm_nhwc normalised without building it -- the skip
+ * connections of the UNet's decoder half (denoising.py:209-213 `torch.cat([h, hs.pop()], dim=1)`): the gradient leaves as two dense tensors, dx [B][HW][C1] and dx2
+ * [B][HW][C - C1] (autograd's cat hands back channel slices of one tensor, which every consumer copied dense first).  x2 == NULL: the single-source call above.
+ * fwd_sums2 (act & 4 only): x2's run-level statistics, fwd_sums then holds x's.  No pre-split dx (act & 2) for two sources. */
+int ssdnerf_group_norm_nhwc_backward_cat(const void* x, const void* x2, uint32_t C1, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
+                                         const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act,
+                                         const void* fwd_sums, const void* fwd_sums2, void* bwd_workspace, int bwd_workspace_is_zero, void* dx, void* dx2,
+                                         void* stream);
 int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
                                      const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride,
                                      float eps, int act, const void* fwd_sums, void* bwd_workspace, int bwd_workspace_is_zero,

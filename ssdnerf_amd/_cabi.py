@@ -28,7 +28,7 @@ EXPORTS = [
     "ssdnerf_point_decode_backward",
     "ssdnerf_render_rays_fused", "ssdnerf_render_rays_fused_batch", "ssdnerf_render_queue_workspace", "ssdnerf_render_first_hit",
     "ssdnerf_render_shade_queue", "ssdnerf_render_shade_queue_mfma", "ssdnerf_render_first_hit_cams", "ssdnerf_render_shade_queue_mfma_cams", "ssdnerf_density_grid_update", "ssdnerf_packbits_dev_thresh", "ssdnerf_ddim_step_v",
-    "ssdnerf_group_norm_workspace", "ssdnerf_group_norm_backward_workspace", "ssdnerf_group_norm_nhwc", "ssdnerf_group_norm_nhwc_runs", "ssdnerf_group_norm_nhwc_backward", "ssdnerf_bias_residual_nhwc",
+    "ssdnerf_group_norm_workspace", "ssdnerf_group_norm_backward_workspace", "ssdnerf_group_norm_nhwc", "ssdnerf_group_norm_nhwc_runs", "ssdnerf_group_norm_nhwc_backward", "ssdnerf_group_norm_nhwc_backward_cat", "ssdnerf_bias_residual_nhwc",
     "ssdnerf_conv2d_nhwc_bf16_supported", "ssdnerf_conv2d_nhwc_bf16_plan", "ssdnerf_conv2d_nhwc_bf16", "ssdnerf_conv2d_nhwc_f32x2", "ssdnerf_conv2d_nhwc_f32x2_plan", "ssdnerf_attention_qkv_bf16", "ssdnerf_attention_qkv_f32", "ssdnerf_attention_qkv_f32_lse", "ssdnerf_attention_qkv_f32_backward", "ssdnerf_cam_rays", "ssdnerf_quantize_u8",
     "ssdnerf_marching_cubes_count", "ssdnerf_marching_cubes_emit", "ssdnerf_conv2d_nhwc_f32x2_presplit_supported", "ssdnerf_conv2d_nhwc_f32x2_presplit", "ssdnerf_split_f32_nhwc",
 ]

@@ -321,16 +321,16 @@ __global__ __launch_bounds__(GN_TPB) void k_bias_residual(const void* __restrict
 // r06: a group's mean / rstd (an fp64 square root and division) are computed once per block, by one thread per group, into LDS; until then every thread
 // derived them for each of its V channels.  Same expressions in the same precisions (ssdg_coeffs): bit-identical results.
 __device__ __forceinline__ void gn_bwd_group_table(uint32_t b, uint32_t HW, uint32_t C, uint32_t G, const double* __restrict__ fsums, float eps, int act,
-                                                   float* __restrict__ g_mean, float* __restrict__ g_rstd) {
+                                                   float* __restrict__ g_mean, float* __restrict__ g_rstd, const double* __restrict__ fsums2 = nullptr, uint32_t C1 = 0) {
     const uint32_t cpg = C / G;
     const double inv_n = 1.0 / ((double)HW * (double)cpg);
     for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
         double gs, gq;
         if (act & 4) {                                                        // (r06) fsums per RUN of 4 channels, [B][C / 4][2], as the convolutions' epilogues leave them
             gs = 0.0; gq = 0.0;
-            const uint32_t rpg = cpg / 4;
-            for (uint32_t r = 0; r < rpg; ++r) {
-                const double2 v = *reinterpret_cast<const double2*>(fsums + ((size_t)b * (C / 4) + g * rpg + r) * 2);
+            const uint32_t rpg = cpg / 4, R1 = fsums2 ? C1 / 4 : C / 4, R2 = C / 4 - R1;          // (two sources: the runs of x, then the runs of x2, as k_gn_apply<RUNS>)
+            for (uint32_t r = g * rpg; r < (g + 1) * rpg; ++r) {
+                const double2 v = *reinterpret_cast<const double2*>(r < R1 ? fsums + ((size_t)b * R1 + r) * 2 : fsums2 + ((size_t)b * R2 + (r - R1)) * 2);
                 gs += v.x; gq += v.y;
             }
         } else {
@@ -389,7 +389,7 @@ template <int DT>
 __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_stats(const void* __restrict__ x, const void* __restrict__ dy, uint32_t HW, uint32_t C, uint32_t G,
                                                           uint32_t rows_per_block, const double* __restrict__ fsums, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ scale_shift, uint32_t ss_stride, float eps,
-                                                          int act, double* __restrict__ bsums) {
+                                                          int act, double* __restrict__ bsums, const void* __restrict__ x2, uint32_t C1, const double* __restrict__ fsums2) {
     constexpr int V = GnVec<DT>::V;
     __shared__ float part_s[GN_TPB * V], part_q[GN_TPB * V];
     const uint32_t tpr = C / V, rif = GN_TPB / tpr;
@@ -401,19 +401,25 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_stats(const void* __restrict_
     // hands a block enough rows for several trips where the tensor has them and one trip where it is small (gn_bwd_rows).
     constexpr int UR = GN_BWD_UNROLL;
     const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+    // (r06) x may be the never-materialised concatenation [x | x2] (C1 channels from x): a thread's channel vector lies in one of the two
+    const uint32_t tpr1 = (x2 ? C1 : C) / V;
+    const bool second = cv >= tpr1;
+    const void* const xs = second ? x2 : x;
+    const uint32_t stpr = second ? tpr - tpr1 : tpr1;
+    const size_t sbase = ((size_t)b * HW + row0) * stpr + (second ? cv - tpr1 : cv);
     uint4 rx[UR], rd[UR];
     auto issue = [&](uint32_t r0) {
 #pragma unroll
         for (int k = 0; k < UR; ++k)
             if (r0 + k * rif < rows_per_block) {
-                rx[k] = GnVec<DT>::raw(x, base + (size_t)(r0 + k * rif) * tpr);
+                rx[k] = GnVec<DT>::raw(xs, sbase + (size_t)(r0 + k * rif) * stpr);
                 rd[k] = GnVec<DT>::raw(dy, base + (size_t)(r0 + k * rif) * tpr);
             }
     };
     if (lane_row < rif) issue(lane_row);
     extern __shared__ __attribute__((aligned(16))) float ctab[];             // dynamic: [3][C] A, O, k per channel (16-byte reads) | [2][G] mean, rstd per group
     float* const gtab = ctab + 3 * C;
-    gn_bwd_group_table(b, HW, C, G, fsums, eps, act, gtab, gtab + G);
+    gn_bwd_group_table(b, HW, C, G, fsums, eps, act, gtab, gtab + G, fsums2, C1);
     __syncthreads();
     gn_bwd_channel_table(b, C, G, gtab, gtab + G, gamma, beta, scale_shift, ss_stride, ctab);
     __syncthreads();
@@ -466,7 +472,8 @@ template <int DT>
 __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict__ x, const void* __restrict__ dy, uint32_t HW, uint32_t C, uint32_t G,
                                                           uint32_t rows_per_block, const double* __restrict__ fsums, const double* __restrict__ bsums,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale_shift,
-                                                          uint32_t ss_stride, float eps, int act, void* __restrict__ dx) {
+                                                          uint32_t ss_stride, float eps, int act, void* __restrict__ dx, const void* __restrict__ x2, uint32_t C1,
+                                                          const double* __restrict__ fsums2, void* __restrict__ dx2) {
     constexpr int V = GnVec<DT>::V;
     const uint32_t tpr = C / V, rif = GN_TPB / tpr;
     const uint32_t lane_row = threadIdx.x / tpr, cv = threadIdx.x % tpr;
@@ -476,17 +483,23 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict_
     const uint32_t cpg = C / G;
     constexpr int UR = GN_BWD_UNROLL;
     const size_t base = ((size_t)b * HW + row0) * tpr + cv;
+    const uint32_t tpr1 = (x2 ? C1 : C) / V;                                  // (r06) two sources / two gradients: see k_gn_bwd_stats
+    const bool second = cv >= tpr1;
+    const void* const xs = second ? x2 : x;
+    void* const dxs = second ? dx2 : dx;
+    const uint32_t stpr = second ? tpr - tpr1 : tpr1;
+    const size_t sbase = ((size_t)b * HW + row0) * stpr + (second ? cv - tpr1 : cv);
     uint4 rx[UR], rd[UR];
     auto issue = [&](uint32_t r0) {
 #pragma unroll
         for (int k = 0; k < UR; ++k)
             if (r0 + k * rif < rows_per_block) {
-                rx[k] = GnVec<DT>::raw(x, base + (size_t)(r0 + k * rif) * tpr);
+                rx[k] = GnVec<DT>::raw(xs, sbase + (size_t)(r0 + k * rif) * stpr);
                 rd[k] = GnVec<DT>::raw(dy, base + (size_t)(r0 + k * rif) * tpr);
             }
     };
     if (lane_row < rif) issue(lane_row);                                     // (ahead of the prologue's own loads, as in k_gn_bwd_stats)
-    gn_bwd_group_table(b, HW, C, G, fsums, eps, act, gtab, gtab + G);
+    gn_bwd_group_table(b, HW, C, G, fsums, eps, act, gtab, gtab + G, fsums2, C1);
     {
         const double inv_n = 1.0 / ((double)HW * (double)cpg);
         for (uint32_t g = threadIdx.x; g < G; g += GN_TPB) {
@@ -527,9 +540,9 @@ __global__ __launch_bounds__(GN_TPB) void k_gn_bwd_apply(const void* __restrict_
                 f[i] = ssdg_dx(p, xh, R[i], m1[i], m2[i]);
             }
             if constexpr (DT == GN_F32) {
-                if (act & 2) { GnVec<DT>::store_split(dx, base + (size_t)(r0 + k * rif) * tpr, f); continue; }   // (host: C % 32 == 0) dx PRE-SPLIT for the backward convolution
+                if (act & 2) { GnVec<DT>::store_split(dx, base + (size_t)(r0 + k * rif) * tpr, f); continue; }      // (host: single source only)   // (host: C % 32 == 0) dx PRE-SPLIT for the backward convolution
             }
-            GnVec<DT>::store(dx, base + (size_t)(r0 + k * rif) * tpr, f);
+            GnVec<DT>::store(dxs, sbase + (size_t)(r0 + k * rif) * stpr, f);
         }
     }
 }
@@ -637,12 +650,16 @@ extern "C" int ssdnerf_group_norm_nhwc_runs(const void* x, const void* x2, uint3
     return SSDNERF_OK;
 }
 
-// d/dx of ssdnerf_group_norm_nhwc (single source, no pre_bias) given dy; `fwd_sums` is the forward's workspace (per sample and group:
+// d/dx of ssdnerf_group_norm_nhwc (no pre_bias) given dy; `fwd_sums` is the forward's workspace (per sample and group:
 // sum, sum of squares of x), `bwd_workspace` ssdnerf_group_norm_backward_workspace(B, G) bytes (r06: replicated sums), zero-filled here unless
 // `bwd_workspace_is_zero` (stream capture: let the caller zero it with a kernel).
-extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* gamma,
-                                                const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act,
-                                                const void* fwd_sums, void* bwd_workspace, int bwd_workspace_is_zero, void* dx, void* stream) {
+// _cat (r06): x is the channel concatenation [x | x2] (C1 channels from x) that the forward never built, and the gradient leaves as TWO dense tensors, dx
+// [B][HW][C1] and dx2 [B][HW][C - C1] -- the skip connections of the UNet's decoder half: autograd's torch.cat returned channel SLICES of one tensor, which every
+// consumer copied dense first.  fwd_sums2 (act & 4 only): the run-level statistics of x2 (fwd_sums: those of x).
+extern "C" int ssdnerf_group_norm_nhwc_backward_cat(const void* x, const void* x2, uint32_t C1, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G,
+                                                    const float* gamma, const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act,
+                                                    const void* fwd_sums, const void* fwd_sums2, void* bwd_workspace, int bwd_workspace_is_zero, void* dx, void* dx2,
+                                                    void* stream) {
     if (B == 0 || HW == 0 || C == 0) return SSDNERF_OK;
     SSD_REQUIRE(x && dy && dx && gamma && beta && fwd_sums && bwd_workspace, "group_norm_nhwc_backward: null pointer");
     SSD_REQUIRE(dtype == GN_F32 || dtype == GN_F16 || dtype == GN_BF16, "group_norm_nhwc_backward: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
@@ -652,6 +669,13 @@ extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, i
     SSD_REQUIRE(C % V == 0 && C / V <= GN_TPB && C <= GN_MAX_C, "group_norm_nhwc_backward: channel count must be a multiple of the 16-byte vector and <= 1024 (f32) / 2048 (16-bit)");
     SSD_REQUIRE(!(act & 2) || (dtype == GN_F32 && C % 32 == 0), "group_norm_nhwc_backward: the pre-split dx (act & 2) needs fp32 and C % 32 == 0");
     SSD_REQUIRE(!(act & 4) || (C / G) % 4 == 0, "group_norm_nhwc_backward: run-level forward sums (act & 4) need groups of a multiple of 4 channels");
+    if (x2) {
+        SSD_REQUIRE(dx2 && C1 > 0 && C1 < C && C1 % V == 0, "group_norm_nhwc_backward_cat: needs dx2 and 0 < C1 < C, C1 a multiple of the 16-byte vector");
+        SSD_REQUIRE(!(act & 2), "group_norm_nhwc_backward_cat: no pre-split dx for two sources");
+        SSD_REQUIRE(!(act & 4) || (fwd_sums2 && C1 % 4 == 0), "group_norm_nhwc_backward_cat: run-level sums need fwd_sums2 and C1 % 4 == 0");
+    } else {
+        C1 = C; fwd_sums2 = nullptr; dx2 = nullptr;
+    }
     hipStream_t st = (hipStream_t)stream;
     // r06: rows per block from the thread layout -- at least one row per row group (C / V threads share a row, 256 / (C / V) rows are in flight), so that the
     // small tensors (8 x 8, 16 x 16: 64 - 256 rows per sample) spread over 100+ blocks instead of 16 blocks walking 8 trips each
@@ -662,13 +686,20 @@ extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, i
         return ssdnerf_fail(SSDNERF_E_LAUNCH, "group_norm_nhwc_backward: memset failed");
 #define SSD_GNB_LAUNCH(DT)                                                                                                                              \
     hipLaunchKernelGGL(k_gn_bwd_stats<DT>, grid_s, block, ((size_t)2 * G + 3 * C) * 4, st, x, dy, HW, C, G, rows_s, (const double*)fwd_sums, gamma, beta, scale_shift, scale_shift_stride, \
-                       eps, act, (double*)bwd_workspace);                                                                                              \
+                       eps, act, (double*)bwd_workspace, x2, C1, (const double*)fwd_sums2);                                                            \
     hipLaunchKernelGGL(k_gn_bwd_apply<DT>, grid_a, block, ((size_t)4 * G + 3 * C) * 4, st, x, dy, HW, C, G, rows_a, (const double*)fwd_sums, (const double*)bwd_workspace, gamma, beta,   \
-                       scale_shift, scale_shift_stride, eps, act, dx);
+                       scale_shift, scale_shift_stride, eps, act, dx, x2, C1, (const double*)fwd_sums2, dx2);
     if (dtype == GN_F32) { SSD_GNB_LAUNCH(GN_F32) } else if (dtype == GN_F16) { SSD_GNB_LAUNCH(GN_F16) } else { SSD_GNB_LAUNCH(GN_BF16) }
 #undef SSD_GNB_LAUNCH
     SSD_CHECK_LAUNCH("group_norm_nhwc_backward");
     return SSDNERF_OK;
+}
+
+extern "C" int ssdnerf_group_norm_nhwc_backward(const void* x, const void* dy, int dtype, uint32_t B, uint32_t HW, uint32_t C, uint32_t G, const float* gamma,
+                                                const float* beta, const float* scale_shift, uint32_t scale_shift_stride, float eps, int act,
+                                                const void* fwd_sums, void* bwd_workspace, int bwd_workspace_is_zero, void* dx, void* stream) {
+    return ssdnerf_group_norm_nhwc_backward_cat(x, nullptr, C, dy, dtype, B, HW, C, G, gamma, beta, scale_shift, scale_shift_stride, eps, act, fwd_sums, nullptr, bwd_workspace,
+                                                bwd_workspace_is_zero, dx, nullptr, stream);
 }
 
 extern "C" int ssdnerf_bias_residual_nhwc(const void* x, int dtype, uint32_t B, uint32_t HW, uint32_t C, const float* bias, const void* residual, void* y,

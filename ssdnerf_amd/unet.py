@@ -283,6 +283,26 @@ class _Conv2d(nn.Conv2d):
     def _bf16_weights(self, transposed):
         return _bf16_weights_of(self.weight, self.bias, transposed, self.__dict__.setdefault("_bf16_cache", {}))
 
+    def _bf16_weights_cat(self, c1):
+        """the backward-data operand in two halves, input channels [0, c1) and [c1, Cin): one backward convolution per source of a concatenated input"""
+        wt, _ = self._bf16_weights(True)                             # (Cin, Cout, k, k); also refreshes the cache's key
+        cache = self.__dict__["_bf16_cache"]
+        slot = ("bf16_cat", c1)
+        if slot not in cache:
+            cache[slot] = (wt[:c1].contiguous(memory_format=torch.channels_last), wt[c1:].contiguous(memory_format=torch.channels_last))
+        return cache[slot]
+
+    def _split_pair_cat(self, c1):
+        """``_split_pair(True)`` in two halves (see ``_bf16_weights_cat``), each an adjacent (hi, lo) pair of its own"""
+        from .unet_fast import split_bf16x2_adjacent
+        self._split_pair(True)                                       # (refreshes the cache's key)
+        cache = self.__dict__["_f32x2_cache"]
+        slot = ("cat", c1)
+        if slot not in cache:
+            wt = self.weight.detach().flip(2, 3).transpose(0, 1)
+            cache[slot] = (split_bf16x2_adjacent(wt[:c1].contiguous()), split_bf16x2_adjacent(wt[c1:].contiguous()))
+        return cache[slot]
+
     #: SSDNERF_UNET_GRAD_CONV=0 keeps MIOpen for the differentiable path
     grad_conv = os.environ.get("SSDNERF_UNET_GRAD_CONV", "1") != "0"
 
@@ -487,6 +507,78 @@ class _GroupNormActFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
+class _Pair(tuple):
+    """(h, skip): the channel concatenation ``torch.cat([h, skip], dim=1)`` of the UNet's decoder half (denoising.py:209-213) that is NOT built -- the residual block
+    that receives it reads both tensors (``_CatNormShortcutFn``) where it has kernels for that, and builds the concatenation where it does not."""
+
+    def cat(self):
+        h, skip = self
+        out = torch.cat([h, skip], dim=1)
+        ra, rb = _runs_of(h), _runs_of(skip)
+        if ra is not None and rb is not None:                        # (B, C/4, 2) each: the concatenation's runs are the two lists, one behind the other
+            B = h.size(0)
+            out._ssd_runs = torch.cat([ra.view(B, -1, 2), rb.view(B, -1, 2)], dim=1).reshape(-1)
+        return out
+
+
+class _CatNormShortcutFn(torch.autograd.Function):
+    """r06.  The two readers of a decoder block's input [h | skip] in ONE autograd node: n = silu(GroupNorm([h | skip])) and s = shortcut([h | skip]), both kernels
+    reading the two tensors in place (``x2``).  Until r06 the gradient path built the concatenation (one copy of both tensors per block), and autograd's cat
+    handed its gradient back as two channel SLICES of one tensor, which the producers' backward functions copied dense again.  Here the backward writes two dense
+    gradients: the norm's (``ssdnerf_group_norm_nhwc_backward_cat``: dx, dx2) and, added to them in the epilogue (``residual``) of two backward convolutions over
+    the two halves of the transposed weights, the shortcut's.  fp32-class and bf16 kernels alike; same arithmetic as the separate functions."""
+
+    @staticmethod
+    def forward(ctx, h, skip, norm, conv, runs_h, runs_skip, split_out):
+        from . import unet_fast as UF
+        hc, sc = h.contiguous(memory_format=torch.channels_last), skip.contiguous(memory_format=torch.channels_last)
+        B, C1, C2, G = h.size(0), h.size(1), skip.size(1), norm.num_groups
+        Cc = C1 + C2
+        arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == h.device else None
+        ctx.arena, ctx.norm, ctx.conv = arena, norm, conv
+        use_runs = runs_h is not None and runs_skip is not None and (Cc // G) % 4 == 0 and runs_h.numel() == B * (C1 // 4) * 2 and runs_skip.numel() == B * (C2 // 4) * 2
+        if use_runs:
+            n = UF.group_norm_nhwc(hc, G, norm.weight.detach(), norm.bias.detach(), None, norm.eps, True, None, x2=sc, runs=(runs_h, runs_skip), split_out=split_out)
+            sums = (runs_h, runs_skip)
+        else:
+            ws = arena.take(B * G * 2) if arena is not None else torch.zeros(B * G * 2, dtype=torch.float64, device=h.device)
+            n = UF.group_norm_nhwc(hc, G, norm.weight.detach(), norm.bias.detach(), None, norm.eps, True, ws, workspace_is_zero=True, x2=sc, split_out=split_out)
+            sums = (ws,)
+        ctx.use_runs = use_runs
+        if h.dtype == torch.bfloat16:
+            w, bias = conv._bf16_weights(False)
+            s = UF.conv2d_nhwc_bf16(hc, w, bias, x2=sc, splitk_ws=UF.shared_splitk_ws(h.device))
+        else:
+            hi, lo = conv._split_pair(False)
+            s = UF.conv2d_nhwc_f32x2(hc, hi, lo, bias=conv.bias, x2=sc, splitk_ws=UF.shared_splitk_ws(h.device))
+        ctx.save_for_backward(hc, sc, *sums)
+        return n, s
+
+    @staticmethod
+    def backward(ctx, dn, ds):
+        from . import unet_fast as UF
+        hc, sc, *sums = ctx.saved_tensors
+        norm, conv = ctx.norm, ctx.conv
+        B, C1, G = hc.size(0), hc.size(1), norm.num_groups
+        ws = ctx.arena.take(UF.group_norm_backward_workspace_doubles(B, G)) if ctx.arena is not None else None
+        dx1, dx2 = UF.group_norm_nhwc_backward_cat(hc, sc, dn.contiguous(memory_format=torch.channels_last), G, norm.weight.detach(), norm.bias.detach(), None, norm.eps,
+                                                   True, sums[0], sums[1] if ctx.use_runs else None, workspace=ws)
+        dsc = ds.contiguous(memory_format=torch.channels_last)
+        if hc.dtype == torch.bfloat16:
+            w1, w2 = conv._bf16_weights_cat(C1)
+            g1 = UF.conv2d_nhwc_bf16(dsc, w1, residual=dx1, splitk_ws=UF.shared_splitk_ws(hc.device))
+            g2 = UF.conv2d_nhwc_bf16(dsc, w2, residual=dx2, splitk_ws=UF.shared_splitk_ws(hc.device))
+        else:
+            (hi1, lo1), (hi2, lo2) = conv._split_pair_cat(C1)
+            g1 = UF.conv2d_nhwc_f32x2(dsc, hi1, lo1, residual=dx1, splitk_ws=UF.shared_splitk_ws(hc.device))
+            g2 = UF.conv2d_nhwc_f32x2(dsc, hi2, lo2, residual=dx2, splitk_ws=UF.shared_splitk_ws(hc.device))
+        return g1, g2, None, None, None, None, None
+
+
+#: SSDNERF_UNET_GRAD_CAT=0: the decoder half's concatenations are built again (A/B runs)
+GRAD_CAT_FUSED = os.environ.get("SSDNERF_UNET_GRAD_CAT", "1") != "0"
+
+
 def _tag_presplit(y, on: bool):
     if on:
         y._ssd_presplit = True
@@ -620,7 +712,35 @@ class DenoisingResBlockMod(nn.Module):
         nn.init.constant_(self.conv_2[-1].weight, 0.0)          # mmgen zeroes the last conv of every residual branch
         nn.init.constant_(self.conv_2[-1].bias, 0.0)
 
+    def _cat_fused_ok(self, pair) -> bool:
+        """the block can read its input [h | skip] from the two tensors (``_CatNormShortcutFn``)"""
+        h, skip = pair
+        sc = self.shortcut if self.learnable_shortcut else None
+        return bool(GRAD_CAT_FUSED and sc is not None and h.dtype == skip.dtype and h.shape[0] == skip.shape[0] and h.shape[2:] == skip.shape[2:]
+                    and h.size(1) % 8 == 0 and skip.size(1) % 8 == 0 and skip.requires_grad and _gn_act_eligible(h, self.conv_1[0])
+                    and isinstance(self.conv_1[1], nn.SiLU) and isinstance(self.conv_2[0], nn.SiLU) and not (self.training and len(self.conv_2) > 2)
+                    and _Conv2d.fuse_epilogues and sc.stride == (1, 1) and sc.in_channels == h.size(1) + skip.size(1)
+                    and (sc._eligible(h) if h.dtype == torch.float32 else sc._eligible_bf16(h) and sc.out_channels % 8 == 0))
+
     def forward(self, x, y):
+        if isinstance(x, _Pair):
+            if not self._cat_fused_ok(x):
+                x = x.cat()
+            else:
+                from . import unet_fast as UF
+                h_in, skip = x
+                c1 = self.conv_1[-1]
+                cc = h_in.size(1) + skip.size(1)
+                ps1 = bool(h_in.dtype == torch.float32 and c1.fuse_epilogues and UF._Conv.PRESPLIT and c1.kernel_size == (3, 3) and c1._eligible(h_in)
+                           and UF.presplit_supported(UF._like(h_in, cc), c1.out_channels, 3, True))
+                n, s = _CatNormShortcutFn.apply(h_in, skip, self.conv_1[0], self.shortcut, _runs_of(h_in), _runs_of(skip), ps1)
+                box1, box2, gflag = {}, {}, {}
+                h = c1(_tag_presplit(n, ps1), None, box1, gflag)
+                h, activated = self.norm_with_embedding(h, y, fuse_silu=True, runs=box1.get("runs"), split_for=self.conv_2[-1], gflag=gflag)
+                out = self.conv_2[-1](h if activated else self.conv_2[0](h), s, box2)
+                if box2.get("runs") is not None:
+                    out._ssd_runs = box2["runs"]
+                return out
         s = self.shortcut(x) if self.learnable_shortcut else x
         if _gn_act_eligible(x, self.conv_1[0]) and isinstance(self.conv_1[1], nn.SiLU) and isinstance(self.conv_2[0], nn.SiLU) \
                 and not (self.training and len(self.conv_2) > 2):
@@ -1177,11 +1297,9 @@ class DenoisingUnetMod(nn.Module):
             hs.append(h)
         h = self.mid_blocks(h, embedding)
         for block in self.out_blocks:
-            skip = hs.pop()
-            cat = torch.cat([h, skip], dim=1)
-            ra, rb = _runs_of(h), _runs_of(skip)
-            if ra is not None and rb is not None:                # (B, C/4, 2) each: the concatenation's runs are the two lists, one behind the other
-                B = h.size(0)
-                cat._ssd_runs = torch.cat([ra.view(B, -1, 2), rb.view(B, -1, 2)], dim=1).reshape(-1)
-            h = block(cat, embedding)
+            pair = _Pair((h, hs.pop()))
+            # r06: a block whose first layer is a residual block that can read the two tensors in place gets the pair; everything else the concatenation
+            first = block[0] if isinstance(block, nn.Sequential) and len(block) > 0 else None
+            fused = isinstance(first, DenoisingResBlockMod) and h.is_cuda and torch.is_grad_enabled() and h.requires_grad and first._cat_fused_ok(pair)
+            h = block(pair if fused else pair.cat(), embedding)
         return self.out(h)

@@ -123,6 +123,33 @@ def group_norm_nhwc_backward(x: torch.Tensor, dy: torch.Tensor, groups: int, gam
     return dx
 
 
+def group_norm_nhwc_backward_cat(x: torch.Tensor, x2: torch.Tensor, dy: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor,
+                                 scale_shift: Optional[torch.Tensor], eps: float, act: bool, fwd_sums: torch.Tensor, fwd_sums2: Optional[torch.Tensor] = None,
+                                 workspace: Optional[torch.Tensor] = None):
+    """``group_norm_nhwc_backward`` for a norm over the never-built concatenation [x | x2] (``group_norm_nhwc(x, ..., x2=x2)``): returns (dx, dx2), two dense
+    channels_last tensors.  ``fwd_sums2``: x2's run-level statistics (then ``fwd_sums`` is x's, both (B, C_i / 4, 2)); None: ``fwd_sums`` holds per-group sums."""
+    ok = lambda t: t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+    if not (ok(x) and ok(x2) and ok(dy)) or x.dtype != x2.dtype or x.dtype != dy.dtype or x.shape[0] != x2.shape[0] or x.shape[2:] != x2.shape[2:] \
+            or dy.shape != (x.size(0), x.size(1) + x2.size(1), x.size(2), x.size(3)):
+        raise RuntimeError("group_norm_nhwc_backward_cat: x, x2 and dy must be channels_last 4-D tensors of one dtype, dy over the concatenated channels")
+    B, C1, H, W = x.shape
+    Cc = C1 + x2.size(1)
+    ss_stride = 0
+    if scale_shift is not None:
+        assert scale_shift.dtype == torch.float32 and scale_shift.shape == (B, 2 * Cc) and scale_shift.stride(1) == 1
+        ss_stride = scale_shift.stride(0)
+    dx, dx2 = torch.empty_like(x), torch.empty_like(x2)
+    need = group_norm_backward_workspace_doubles(B, groups)
+    ws = workspace if workspace is not None else torch.zeros(need, dtype=torch.float64, device=x.device)
+    if ws.numel() < need or ws.dtype != torch.float64:
+        raise RuntimeError(f"group_norm_nhwc_backward_cat: the workspace must hold {need} zeroed doubles")
+    C.check(C.lib().ssdnerf_group_norm_nhwc_backward_cat(C.ptr(x), C.ptr(x2), C.u32(C1), C.ptr(dy), _GN_DTYPE[x.dtype], C.u32(B), C.u32(H * W), C.u32(Cc), C.u32(groups),
+                                                          C.ptr(gamma), C.ptr(beta), C.ptr(scale_shift), C.u32(ss_stride), C.f32(eps),
+                                                          int(bool(act)) | (4 if fwd_sums2 is not None else 0), C.ptr(fwd_sums), C.ptr(fwd_sums2), C.ptr(ws), 1, C.ptr(dx), C.ptr(dx2),
+                                                          C.stream()), "group_norm_nhwc_backward_cat")
+    return dx, dx2
+
+
 def bias_residual_nhwc(x: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor], gn_sums: Optional[torch.Tensor] = None,
                        gn_groups: int = 0) -> torch.Tensor:
     """In place ``x += bias[c] + residual`` for a channels_last (B, C, H, W) or contiguous (B, T, C) tensor (fp32 bias, residual of x's

@@ -809,6 +809,82 @@ def test_group_norm_backward_kernel_matches_autograd(C, G, HW, scale_shift, act)
     assert float((got - want).abs().max()) <= 5e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C1,C2,G,HW,use_runs", [(256, 128, 32, (16, 16), True), (512, 512, 32, (8, 8), False), (128, 128, 32, (32, 32), True), (64, 192, 32, (16, 16), False),
+                                                 (128, 256, 32, (64, 64), True), (40, 24, 8, (12, 20), False)])
+def test_group_norm_backward_over_two_sources_matches_the_concatenated_call(dtype, C1, C2, G, HW, use_runs):
+    """r06: ``ssdnerf_group_norm_nhwc_backward_cat`` -- the norm over [x | x2] read in place, its gradient written as two dense tensors, the forward's statistics
+    per group or per run of 4 channels of the two tensors -- against the single-source call on the built concatenation: the same arithmetic on the same values (the
+    block sums reach the fp64 accumulators in another order: a last-bit difference of the group means is allowed for)."""
+    from ssdnerf_amd import unet_fast as UF
+    g = torch.Generator().manual_seed(C1 + C2)
+    B, (H, W) = 3, HW
+    C = C1 + C2
+    mk = lambda c: (torch.randn(B, c, H, W, generator=g) * 1.3 + 0.2).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    x1, x2 = mk(C1), mk(C2)
+    dy = torch.randn(B, C, H, W, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    gamma, beta = torch.randn(C, generator=g).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=torch.channels_last)
+    sums = torch.zeros(B * G * 2, dtype=torch.float64, device="cuda")
+    UF.group_norm_nhwc(xc, G, gamma, beta, None, 1e-5, True, sums, workspace_is_zero=True)
+    want = UF.group_norm_nhwc_backward(xc, dy, G, gamma, beta, None, 1e-5, True, sums)
+    if use_runs:
+        runs = lambda t: torch.stack([t.double().sum((2, 3)).view(B, -1, 4).sum(2), t.double().square().sum((2, 3)).view(B, -1, 4).sum(2)], dim=-1).reshape(-1).contiguous()
+        y_cat = UF.group_norm_nhwc(x1, G, gamma, beta, None, 1e-5, True, None, x2=x2, runs=(runs(x1), runs(x2)))
+        got1, got2 = UF.group_norm_nhwc_backward_cat(x1, x2, dy, G, gamma, beta, None, 1e-5, True, runs(x1), runs(x2))
+    else:
+        y_cat = UF.group_norm_nhwc(x1, G, gamma, beta, None, 1e-5, True, torch.zeros_like(sums), workspace_is_zero=True, x2=x2)
+        got1, got2 = UF.group_norm_nhwc_backward_cat(x1, x2, dy, G, gamma, beta, None, 1e-5, True, sums)
+    assert got1.shape == x1.shape and got2.shape == x2.shape and got1.is_contiguous(memory_format=torch.channels_last) and got2.is_contiguous(memory_format=torch.channels_last)
+    tol = (2e-6 if dtype == torch.float32 else 8e-3) * float(want.float().abs().max())
+    assert float((got1.float() - want[:, :C1].float()).abs().max()) <= tol and float((got2.float() - want[:, C1:].float()).abs().max()) <= tol
+    frac = float(((got1 != want[:, :C1]).sum() + (got2 != want[:, C1:]).sum()) / want.numel())
+    print(f"two-source GroupNorm backward: max diff {float((got1.float() - want[:, :C1].float()).abs().max()):.2e} of {float(want.float().abs().max()):.2e}, {frac:.2e} of the elements differ")
+    if not use_runs:                                                          # (run-level statistics are other fp64 sums than the workspace's: a group's mean may round the other way)
+        assert frac <= 2e-3, frac                                             # all but a last-bit flip here and there are the same bits
+    assert y_cat.shape == xc.shape
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_decoder_concatenations_read_in_place_match_the_built_ones(mode, monkeypatch):
+    """r06: the decoder half's `torch.cat([h, skip])` is not built on the input-gradient path -- ``unet._CatNormShortcutFn`` reads the two tensors in the first
+    norm and the shortcut of the block and returns two dense gradients.  Against the same network with the concatenations built (SSDNERF_UNET_GRAD_CAT=0's path):
+    fp32-class to rounding; bf16 to the run-to-run spread of that path (both are compared with the fp32-class result)."""
+    from ssdnerf_amd import unet as U
+    net = _unet(seed=6)
+    net.requires_grad_(False)
+    net.grad_graph = False
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(3, 18, 32, 32, generator=g).cuda()
+    t = torch.tensor([600, 40, 999]).cuda()
+    probe = torch.randn(3, 18, 32, 32, generator=g).cuda()
+    calls = []
+    real = U._CatNormShortcutFn.apply
+    monkeypatch.setattr(U._CatNormShortcutFn, "apply", staticmethod(lambda *a: (calls.append(1), real(*a))[1]))
+
+    def call(autocast, fused):
+        monkeypatch.setattr(U, "GRAD_CAT_FUSED", fused)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            y = net(x, t)
+        (gx,) = torch.autograd.grad((y.float() * probe).sum(), x)
+        return y.detach().float(), gx
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    y0, g0 = call(False, False)
+    assert not calls
+    y1, g1 = call(False, True)
+    n_up = len(net.out_blocks)
+    assert len(calls) == n_up, (len(calls), n_up)                              # every decoder block read its two inputs in place
+    if mode == "fp32":
+        assert rel(y1, y0) <= 2e-5 and rel(g1, g0) <= 2e-5, (rel(y1, y0), rel(g1, g0))
+        return
+    y2, g2 = call(True, False)
+    y3, g3 = call(True, True)
+    assert len(calls) == 2 * n_up
+    print(f"bf16 path vs fp32-class: concatenations built y {rel(y2, y0):.2e} gx {rel(g2, g0):.2e}; read in place y {rel(y3, y0):.2e} gx {rel(g3, g0):.2e}")
+    assert rel(y3, y0) <= 1.5 * rel(y2, y0) + 1e-4 and rel(g3, g0) <= 1.5 * rel(g2, g0) + 1e-4
+
+
 def test_input_gradient_norms_fused_on_the_gpu():
     """The input-gradient path (default): fused channel-last GroupNorm(+scale-shift)+SiLU forward and input gradient and channel-last attention
     blocks inside the module graph, against the eager library path."""
