@@ -312,8 +312,13 @@ __global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_bin(const uint32_t* __re
                 // (a clamped border corner, x1 == x0, carries weight 0 in every sample of the run: its sum is +-0 and adding it changes nothing)
                 if (lx < DB_TILE && ly < DB_TILE) {
                     float* t = acc + (ly * DB_TILE + lx) * 6;
+#ifdef DB_EXP_NO_ATOMICS                                                         // (measurement only: racy plain adds -- what the pass costs without the LDS atomics)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) t[c] += v[q][c];
+#else
 #pragma unroll
                     for (int c = 0; c < 6; ++c) atomicAdd(t + c, v[q][c]);
+#endif
                 }
             }
         }
@@ -348,7 +353,9 @@ __global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_bin(const uint32_t* __re
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 1
         while (cnt >= 64) {
+#ifndef DB_EXP_SCAN_ONLY                                                          // (measurement only: the key scan and the lists alone)
             add_listed(64);
+#endif
             head = (head + 64) % DB_LIST;
             cnt -= 64;
         }
@@ -359,6 +366,184 @@ __global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_bin(const uint32_t* __re
         for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
     }
     add_listed(cnt);
+    __syncthreads();
+    float* out = partial + (((uint64_t)k * S + scene) * 3 + p) * Hp * Wp * 6;
+    for (uint32_t e = threadIdx.x; e < DB_TILE_FLOATS; e += DEC_TPB) {
+        const uint32_t ly = e / (DB_TILE * 6), r = e % (DB_TILE * 6);
+        const uint32_t y = ty0 + ly, xc = tx0 * 6 + r;
+        if (y < Hp && xc < Wp * 6) out[(uint64_t)y * Wp * 6 + xc] = acc[e];
+    }
+}
+
+// r06: the same reduction WITHOUT floating-point LDS atomics.  tools/r06_decode_bwd_split.sh: of k_decode_bwd_bin's 2.7 ms (7 M uniform samples; 1.9 ms ray-ordered)
+// 0.64 ms are the key scan, the lists, the contributions and the tile stores -- the rest is `ds_add_f32`, which the LDS retires at ~2.4 cycles PER LANE (a 64-lane
+// instruction ~150 cycles; plain 4-byte reads and writes run at 32 lanes per cycle).  So the additions become plain read-modify-writes, made safe by OWNERSHIP:
+//   * the tile's four 16 x 16 quadrants belong to the block's four waves -- no two waves ever touch the same texel.  The waves still share the key scan (each scans a quarter
+//     of a step's 1024 keys) and hand the samples over through four per-quadrant rings in LDS (a sample whose 2 x 2 footprint crosses a quadrant border is listed in each
+//     quadrant it touches; every consumer adds only the corners inside its own); one barrier behind a step's listing, one behind its draining (rings of 1152: fewer than 64
+//     left over + at most 1024 new);
+//   * inside a wave, lanes that target the same texel are serialised by a one-word election per round: every pending lane writes its id to owner[texel], reads it back, the
+//     one that finds itself there adds its six values (three 8-byte reads and writes) and retires; LDS instructions of a wave execute in order, so a later round reads what an
+//     earlier round wrote.  Equal-texel RUNS of neighbouring lanes (march order: whole rays on one texel of the plane a view looks down on) are summed in registers first,
+//     as before (DPP row scans), so an election sees at most one lane per run.
+// Same products, same per-run sums; the order of the additions into a texel differs (it was arbitrary before as well).
+static constexpr uint32_t DBQ_CAP = 1152;
+__global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_bin_owned(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counters, uint32_t S,
+                                                                   uint32_t total, uint32_t Hp, uint32_t Wp, uint32_t K, uint32_t tiles_x,
+                                                                   const uint32_t* __restrict__ keys, const float2* __restrict__ pos,
+                                                                   const float* __restrict__ gfeat, float* __restrict__ partial) {
+    static_assert(DB_TILE == 32 && DEC_TPB == 256, "four waves, four 16 x 16 quadrants");
+    __shared__ __attribute__((aligned(16))) float acc[DB_TILE_FLOATS];
+    __shared__ uint32_t qlist[4][DBQ_CAP];
+    __shared__ uint32_t owner[4][256];
+    __shared__ uint32_t qtail[4];
+    const uint32_t tile = blockIdx.x, p = blockIdx.y / K, k = blockIdx.y % K, scene = blockIdx.z;
+    const uint32_t tx0 = (tile % tiles_x) * DB_TILE, ty0 = (tile / tiles_x) * DB_TILE;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t e = threadIdx.x; e < DB_TILE_FLOATS; e += DEC_TPB) acc[e] = 0.0f;
+    if (threadIdx.x < 4) qtail[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t o0 = offsets[scene], o1 = o0 + counters[scene * DB_COUNTER_STRIDE];
+    const uint32_t chunk = (((o1 - o0) + K - 1) / K + DEC_TPB - 1) / DEC_TPB * DEC_TPB;
+    const uint32_t k0 = min(o1, o0 + k * chunk), k1 = min(o1, k0 + chunk);
+    const uint32_t* kp = keys + (uint64_t)p * total;
+    const float2* pp = pos + (uint64_t)p * total;
+    const float* gp = gfeat + (uint64_t)p * total * 6;
+    uint32_t* const list = qlist[wave];
+    uint32_t* const own = owner[wave];
+    const uint32_t qx0 = (uint32_t)(wave & 1) * 16u, qy0 = (uint32_t)(wave >> 1) * 16u;       // this wave's quadrant inside the tile
+    uint32_t head = 0;                                                                          // items of this quadrant's ring consumed so far
+    auto add_listed = [&](uint32_t n) {
+        const bool on = (uint32_t)lane < n;
+        uint32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        float v[4][6];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[q][c] = 0.0f;
+        uint32_t key = 0xffffffffu;
+        if (on) {
+            const uint32_t j = list[(head + lane) % DBQ_CAP];
+            const float2 xy = pp[j];
+            float wx0, wx1, wy0, wy1;
+            ssdb_corners(xy.x, Wp, &x0, &x1, &wx0, &wx1);
+            ssdb_corners(xy.y, Hp, &y0, &y1, &wy0, &wy1);
+            key = (y0 << 16) | x0;
+            const float2* src = reinterpret_cast<const float2*>(gp + (uint64_t)j * 6);
+            const float2 g01 = src[0], g23 = src[1], g45 = src[2];
+            const float gv[6] = {g01.x, g01.y, g23.x, g23.y, g45.x, g45.y};
+            const float w[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[q][c] = gv[c] * w[q];
+        }
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true);          // row_shr:1
+        const uint64_t heads = __ballot((lane & 15) == 0 || key != prev);                                           // first lane of every run (per 16-lane row)
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int d = 1 << step;
+            const bool same = (lane & 15) >= d && ((heads >> (lane - d + 1)) & ((1ull << d) - 1ull)) == 0;
+            const float take = same ? 1.0f : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float up = __int_as_float(step == 0 ? __builtin_amdgcn_update_dpp(0, __float_as_int(v[q][c]), 0x111, 0xf, 0xf, true)
+                                                    : step == 1 ? __builtin_amdgcn_update_dpp(0, __float_as_int(v[q][c]), 0x112, 0xf, 0xf, true)
+                                                    : step == 2 ? __builtin_amdgcn_update_dpp(0, __float_as_int(v[q][c]), 0x114, 0xf, 0xf, true)
+                                                                : __builtin_amdgcn_update_dpp(0, __float_as_int(v[q][c]), 0x118, 0xf, 0xf, true));
+                    v[q][c] = __builtin_fmaf(up, take, v[q][c]);
+                }
+        }
+        const bool tail = on && ((lane & 15) == 15 || (uint32_t)lane + 1 == n || ((heads >> (lane + 1)) & 1ull));
+        const uint32_t cx[4] = {x0, x1, x0, x1}, cy[4] = {y0, y0, y1, y1};
+        // (corner by corner: ONE election over all four corners per round -- fewer dependent LDS round trips -- was measured slower, 2.38 against 2.25 ms: 256 (lane, corner)
+        // pairs on the quadrant's 256 texels collide far more often than 64 lanes do)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // (a clamped border corner, x1 == x0, carries weight 0 in every sample of the run: its sum is +-0 and adding it changes nothing)
+            const uint32_t lx = cx[q] - tx0 - qx0, ly = cy[q] - ty0 - qy0;                      // inside this wave's quadrant iff both < 16 (unsigned)
+            bool pending = tail && lx < 16u && ly < 16u;
+            const uint32_t tex = (ly & 15u) * 16u + (lx & 15u);
+            float2* const t2 = reinterpret_cast<float2*>(acc + (((ly & 15u) + qy0) * DB_TILE + (lx & 15u) + qx0) * 6);
+            while (__ballot(pending) != 0ull) {
+                if (pending) own[tex] = (uint32_t)lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t who = own[tex];                                                // (the election's answer and the texel's values in ONE round trip: every
+                float2 a = t2[0], b = t2[1], c = t2[2];                                       //  address is inside the wave's own arrays, so the reads are unconditional)
+                const bool win = pending && who == (uint32_t)lane;
+                if (win) {
+                    a.x += v[q][0]; a.y += v[q][1]; b.x += v[q][2]; b.y += v[q][3]; c.x += v[q][4]; c.y += v[q][5];
+                    t2[0] = a; t2[1] = b; t2[2] = c;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                pending = pending && !win;
+            }
+        }
+    };
+    constexpr uint32_t STEP = 4 * 64;
+    auto load_keys = [&](uint32_t base, uint32_t (&kk)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = base + 64 * j + lane;
+            kk[j] = i < k1 ? kp[i] : 0xffffffffu;
+        }
+    };
+    uint32_t cur[4], nxt[4];
+    load_keys(k0 + wave * STEP, cur);
+    for (uint32_t it = k0; it < k1; it += (DEC_TPB / 64) * STEP) {                              // (block-uniform trip count: the barriers below)
+        const uint32_t base = it + wave * STEP;
+        load_keys(base + (DEC_TPB / 64) * STEP, nxt);
+        // the footprint {x0, x0 + 1} touches quadrant column 0 (tile columns 0 - 15) iff x0 - tx0 in [-1, 15], column 1 iff in [15, 31]; rows alike.
+        // All sixteen (key slot, quadrant) masks first, then ONE LDS atomic per quadrant and step (lanes 0 - 3, one instruction): a returning atomic per non-empty
+        // mask was up to sixteen dependent LDS round trips per step on uniformly scattered samples (0.8 ms of the launch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ux = (cur[j] & 0xffffu) + 1u - tx0, uy = (cur[j] >> 16) + 1u - ty0;
+            const bool hx[2] = {ux <= 16u, ux - 16u <= 16u}, hy[2] = {uy <= 16u, uy - 16u <= 16u};
+            if (__ballot((hx[0] || hx[1]) && (hy[0] || hy[1])) == 0ull) continue;            // (march-ordered samples: most key slots of most blocks end here)
+            // the four quadrant masks of this key slot, then ONE LDS atomic instruction (lanes 0 - 3) for their ring positions: a returning atomic per non-empty mask
+            // was up to sixteen dependent LDS round trips per step on uniformly scattered samples
+            uint64_t hm[4];
+            uint32_t nq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hm[q] = __ballot(hx[q & 1] && hy[q >> 1]);
+                nq[q] = (uint32_t)__popcll(hm[q]);
+            }
+            const uint32_t mine = lane == 0 ? nq[0] : lane == 1 ? nq[1] : lane == 2 ? nq[2] : nq[3];
+            uint32_t first = 0;
+            if (lane < 4 && mine != 0u) first = atomicAdd(&qtail[lane], mine);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (hm[q] == 0ull) continue;
+                const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)first, q);
+                if (hx[q & 1] && hy[q >> 1]) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm[q], 0u));
+                    qlist[q][(at + rank) % DBQ_CAP] = base + 64 * j + lane;
+                }
+            }
+        }
+        __syncthreads();                                                                      // this step's samples are listed
+        const uint32_t tail_now = *reinterpret_cast<volatile uint32_t*>(&qtail[wave]);
+#pragma unroll 1
+        while (tail_now - head >= 64u) {
+#ifndef DB_EXP_SCAN_ONLY
+            add_listed(64);
+#endif
+            head += 64u;
+        }
+        __syncthreads();                                                                      // every ring is below 64 before the next step's (at most 1024) items arrive
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+    add_listed(*reinterpret_cast<volatile uint32_t*>(&qtail[wave]) - head);
     __syncthreads();
     float* out = partial + (((uint64_t)k * S + scene) * 3 + p) * Hp * Wp * 6;
     for (uint32_t e = threadIdx.x; e < DB_TILE_FLOATS; e += DEC_TPB) {
@@ -414,8 +599,13 @@ extern "C" int ssdnerf_point_decode_backward(const void* planes, int planes_dtyp
 #undef SSD_LAUNCH_FEAT
     SSD_CHECK_LAUNCH("point_decode_backward (features)");
     const uint32_t tiles_x = (Wp + DB_TILE - 1) / DB_TILE, tiles_y = (Hp + DB_TILE - 1) / DB_TILE;
-    hipLaunchKernelGGL(k_decode_bwd_bin, dim3(tiles_x * tiles_y, 3 * w.K, S), b, 0, s, offsets, w.counters, S, total, Hp, Wp, w.K, tiles_x, w.keys, w.pos,
-                       w.gfeat, w.partial);
+    static const bool lds_atomics = [] { const char* e = getenv("SSDNERF_DECODE_BWD_ATOMICS"); return e != nullptr && e[0] != '\0' && e[0] != '0'; }();   // the r02 - r05 kernel (A/B runs)
+    if (lds_atomics)
+        hipLaunchKernelGGL(k_decode_bwd_bin, dim3(tiles_x * tiles_y, 3 * w.K, S), b, 0, s, offsets, w.counters, S, total, Hp, Wp, w.K, tiles_x, w.keys, w.pos,
+                           w.gfeat, w.partial);
+    else
+        hipLaunchKernelGGL(k_decode_bwd_bin_owned, dim3(tiles_x * tiles_y, 3 * w.K, S), b, 0, s, offsets, w.counters, S, total, Hp, Wp, w.K, tiles_x, w.keys, w.pos,
+                           w.gfeat, w.partial);
     SSD_CHECK_LAUNCH("point_decode_backward (binned reduction)");
     hipLaunchKernelGGL(k_decode_bwd_sum, dim3(ssd_blocks(n_texels, DEC_TPB)), b, 0, s, w.partial, w.K, n_texels, Hp * Wp, grad_code);
     SSD_CHECK_LAUNCH("point_decode_backward (sum)");

@@ -45,5 +45,11 @@ e0.record()
 for _ in range(a.iters):
     (gcode,) = torch.autograd.grad(loss, code, retain_graph=True)
 e1.record(); torch.cuda.synchronize()
-print(json.dumps({"scenes": a.scenes, "samples_total": n, "ray_like": a.ray_like, "cone": a.cone, "ms_per_backward": e0.elapsed_time(e1) / a.iters,
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for _ in range(3):
+        torch.autograd.grad(loss, code, retain_graph=True)
+    torch.cuda.synchronize()
+kern = {e.key.split("(")[0].replace("void ", "")[:40]: round(e.self_device_time_total / e.count * 1e-3, 3) for e in prof.key_averages() if "k_decode_bwd" in e.key}
+print(json.dumps({"kernels_ms": kern, "scenes": a.scenes, "samples_total": n, "ray_like": a.ray_like, "cone": a.cone, "ms_per_backward": e0.elapsed_time(e1) / a.iters,
                   "grad_abs_sum": float(gcode.abs().sum()), "lib": os.environ.get("SSDNERF_HIP_LIB", "in-tree")}))
