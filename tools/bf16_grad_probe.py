@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--aten", action="store_true", help="with --profile: the aten:: elementwise operators of one call by input shape (copies, casts, accumulations), both arithmetic classes")
     ap.add_argument("--kernels", default="", help="with --profile: print only the kernels whose name contains one of these comma-separated strings, for both arithmetic classes")
     args = ap.parse_args()
     import ssdnerf_amd  # noqa: F401
@@ -71,6 +72,17 @@ def main():
     print("graphs:", net.grad_graph_info())
     if args.profile:
         from torch.profiler import profile, ProfilerActivity
+        if args.aten:
+            for name in ("fp32_class", "bf16_native"):
+                with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True) as prof:
+                    call(*arms[name], graph=False)
+                    torch.cuda.synchronize()
+                rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.self_device_time_total > 0]
+                tot = sum(e.self_device_time_total for e in rows)
+                print(f"== {name}: aten operators with device time, one call: {tot * 1e-3:.3f} ms")
+                for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:40]:
+                    print(f"  {e.key:28s} x{e.count:3d} {e.self_device_time_total * 1e-3:7.3f} ms  {str(e.input_shapes)[:150]}")
+            return
         want = [k for k in args.kernels.split(",") if k]
         for name in (("fp32_class", "bf16_native") if want else ("bf16_native",)):
             with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
