@@ -31,12 +31,12 @@ def _device_ok(x: torch.Tensor) -> bool:
     return x.is_cuda
 
 
-def _runs_fusable(x: torch.Tensor, conv) -> bool:
+def _runs_fusable(x: torch.Tensor, conv, upsample: bool = False) -> bool:
     """whether the fp32-class convolution kernel can leave the GroupNorm sums of its OUTPUT, per run of 4 channels, in its epilogue (the rule of
     unet_fast.FastUnet._can_fuse_stats: every output tile inside one sample, or a split-K layer whose finishing pass takes them)"""
     from . import _cabi as C
     cout, cin, k = conv.out_channels, conv.in_channels, conv.kernel_size[0]
-    hw = x.size(2) * x.size(3)
+    hw = x.size(2) * x.size(3) * (4 if upsample else 1)
     if cout % 4 != 0 or hw > 128 * 256:
         return False
     plan = C.lib().ssdnerf_conv2d_nhwc_f32x2_plan(C.u32(x.size(0) * hw), C.u32(cin), C.u32(cout), C.u32(k), 0, 0)
@@ -54,8 +54,9 @@ class _ConvF32x2Fn(torch.autograd.Function):
     then needs no statistics pass (``_GroupNormActFn``)."""
 
     @staticmethod
-    def forward(ctx, x, conv, residual=None, box=None, presplit=False, gflag=None):
-        """``gflag`` (a dict shared with the ``_GroupNormActFn`` that reads this convolution's output, and with nobody else): if that norm's backward
+    def forward(ctx, x, conv, residual=None, box=None, presplit=False, gflag=None, upsample=False):
+        """``upsample`` (r06): convolve the nearest-neighbour 2x upsampling of x without building it (the kernel's index map); the gradient is the 2 x 2 sum-pooling of
+        the backward convolution's result.  ``gflag`` (a dict shared with the ``_GroupNormActFn`` that reads this convolution's output, and with nobody else): if that norm's backward
         writes its dx PRE-SPLIT it sets gflag['split'] in ITS forward, and this function's backward then multiplies the pre-split gradient
         (``conv2d_nhwc_f32x2_presplit`` on the transposed weights) -- both sides read one decision, taken once."""
         from . import unet_fast as UF
@@ -63,6 +64,8 @@ class _ConvF32x2Fn(torch.autograd.Function):
         ctx.conv = conv
         ctx.gflag = gflag
         ctx.has_residual = residual is not None
+        ctx.upsample = bool(upsample)
+        assert not (upsample and presplit)
         xc = x.contiguous(memory_format=torch.channels_last)
         if presplit:                                                # x is what the norm in front wrote pre-split for the two-group kernel (see _GroupNormActFn)
             runs = None
@@ -74,23 +77,30 @@ class _ConvF32x2Fn(torch.autograd.Function):
             return UF.conv2d_nhwc_f32x2_presplit(xc, hi, lo, conv.bias, None if residual is None else residual.contiguous(memory_format=torch.channels_last),
                                                  runs, conv.out_channels // 4 if runs is not None else 0, splitk_ws=UF.shared_splitk_ws(x.device))
         runs = None
-        if box is not None and _runs_fusable(xc, conv):
+        if box is not None and _runs_fusable(xc, conv, upsample):
             n = xc.size(0) * (conv.out_channels // 4) * 2
             arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
             runs = arena.take(n) if arena is not None else torch.zeros(n, dtype=torch.float64, device=x.device)
         if box is not None:
             box["runs"] = runs
         return UF.conv2d_nhwc_f32x2(xc, hi, lo, bias=conv.bias, residual=None if residual is None else residual.contiguous(memory_format=torch.channels_last),
-                                    gn_sums=runs, gn_groups=conv.out_channels // 4 if runs is not None else 0, splitk_ws=UF.shared_splitk_ws(x.device))
+                                    upsample=bool(upsample), gn_sums=runs, gn_groups=conv.out_channels // 4 if runs is not None else 0, splitk_ws=UF.shared_splitk_ws(x.device))
 
     @staticmethod
     def backward(ctx, gy):
+        gx, g_res = _ConvF32x2Fn._backward(ctx, gy)
+        if ctx.upsample and gx is not None:                          # every input pixel collects its 2 x 2 copies
+            gx = F.avg_pool2d(gx, 2).mul_(4.0)
+        return gx, None, g_res, None, None, None, None
+
+    @staticmethod
+    def _backward(ctx, gy):
         from . import unet_fast as UF
         hi, lo = ctx.conv._split_pair(True)
         if ctx.gflag is not None and ctx.gflag.get("split"):        # gy is the pre-split dx of the norm behind this convolution (no residual here: _Conv2d.forward)
             gyc = gy.contiguous(memory_format=torch.channels_last)
             gx = UF.conv2d_nhwc_f32x2_presplit(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
-            return gx, None, None, None, None, None
+            return gx, None
         conv = ctx.conv
         # a LARGE layer (the two-group row kernel's) whose dy no norm produced -- the accumulated gradient in front of a block's second convolution, or the
         # channel slice autograd returns for one input of a concatenation --: one split pass (two passes over dy, reading a slice IN PLACE) + the pre-split
@@ -98,10 +108,10 @@ class _ConvF32x2Fn(torch.autograd.Function):
         pstride = UF.nhwc_pixel_stride(gy) if getattr(conv, "grad_split_dy", False) and gy.dtype == torch.float32 and gy.size(1) % 32 == 0 else 0
         if pstride > 0 and pstride % 4 == 0 and gy.data_ptr() % 16 == 0 and UF.presplit_supported(gy, conv.in_channels, conv.kernel_size[0]) == 1:
             gx = UF.conv2d_nhwc_f32x2_presplit(UF.split_f32_nhwc(gy), hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
-            return gx, None, (gy if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None, None
+            return gx, (gy if ctx.has_residual and ctx.needs_input_grad[2] else None)
         gyc = gy.contiguous(memory_format=torch.channels_last)
         gx = UF.conv2d_nhwc_f32x2(gyc, hi, lo, splitk_ws=UF.shared_splitk_ws(gy.device)) if ctx.needs_input_grad[0] else None
-        return gx, None, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None), None, None, None
+        return gx, (gyc if ctx.has_residual and ctx.needs_input_grad[2] else None)
 
 
 def _pad_channels(t: torch.Tensor, c: int) -> torch.Tensor:
@@ -477,7 +487,13 @@ class _GroupNormActFn(torch.autograd.Function):
         arena = _ZeroArena.current if _ZeroArena.current is not None and _ZeroArena.current.buf.device == x.device else None
         ctx.arena = arena
         ctx.sums_are_runs = False
-        ss = None if scale_shift is None else scale_shift.detach().float().contiguous()
+        ss = None
+        if scale_shift is not None:                                  # (a row slice of the batched projections: the kernels take its row stride, no dense copy per norm)
+            ss = scale_shift.detach()
+            if ss.dtype != torch.float32:
+                ss = ss.float()
+            if ss.dim() != 2 or ss.stride(1) != 1:
+                ss = ss.contiguous()
         B, Cc, G = x.size(0), x.size(1), norm.num_groups
         if runs is not None and (Cc // G) % 4 == 0 and runs.numel() == B * (Cc // 4) * 2:
             y = UF.group_norm_nhwc(xc, G, norm.weight.detach(), norm.bias.detach(), ss, norm.eps, act, None, runs=(runs, None), split_out=split_out)
@@ -868,6 +884,12 @@ class DenoisingUpsampleMod(nn.Module):
         if self.with_conv and x.dtype == torch.bfloat16 and self.conv._eligible_bf16(x) and self.conv.fuse_epilogues and self.conv.out_channels % 8 == 0:
             box = {}                                                 # (r06, native bf16 gradient path) the upsampling is the convolution kernel's index map
             out = _ConvBf16Fn.apply(x, self.conv, None, box, True)
+            if box.get("runs") is not None:
+                out._ssd_runs = box["runs"]
+            return out
+        if self.with_conv and x.dtype == torch.float32 and self.conv._eligible(x) and self.conv.fuse_epilogues and x.is_cuda:
+            box = {}                                                 # (r06) ... and of the fp32-class kernel
+            out = _ConvF32x2Fn.apply(x, self.conv, None, box, False, None, True)
             if box.get("runs") is not None:
                 out._ssd_runs = box["runs"]
             return out
