@@ -369,8 +369,8 @@ def test_coarse_pretest_other_grid_sizes(decoder, scene, grid, monkeypatch):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
-@pytest.mark.parametrize("ns,plane_hw", [([70001, 40320], (128, 128)), ([200000, 0, 130001], (128, 128)), ([30011, 50000], (40, 72))],
-                         ids=["two-scenes", "split-sample-ranges-and-an-empty-scene", "ragged-tiles-non-square"])
+@pytest.mark.parametrize("ns,plane_hw", [([70001, 40320], (128, 128)), ([200000, 0, 130001], (128, 128)), ([30011, 50000], (40, 72)), ([66000, 3000, 64000], (128, 128))],
+                         ids=["two-scenes", "split-sample-ranges-and-an-empty-scene", "ragged-tiles-non-square", "same-texel-collisions"])
 def test_fused_decode_backward_matches_autograd_through_the_eager_decode(ns, plane_hw):
     """d loss / d code of ``point_decode`` with the decoder frozen: fused kernels (ssdnerf_point_decode + _backward: per-sample feature gradient,
     binned LDS reduction over 32 x 32-texel tiles, NCHW sum) vs PyTorch autograd through grid_sample + nn.Linear on the same GPU.  Ragged
@@ -390,6 +390,14 @@ def test_fused_decode_backward_matches_autograd_through_the_eager_decode(ns, pla
     else:
         code = (torch.randn(len(ns), 3, 6, *plane_hw, generator=g) * 0.5).cuda()
     xyzs = [(torch.rand(n, 3, generator=g) * 2.3 - 1.15).cuda() for n in ns]
+    if ns == [66000, 3000, 64000]:
+        # r06 (the reduction's in-wave elections and run sums): 1000 points repeated 66 times in a row (runs that straddle 16-lane rows and waves), every sample of a
+        # scene on ONE point, and axis-parallel rays whose samples share a texel on one plane and walk across quadrant and tile borders on the other two
+        xyzs[0] = xyzs[0][:1000].repeat_interleave(66, dim=0)
+        xyzs[1] = xyzs[1][:1].expand(3000, 3).contiguous()
+        o = (torch.rand(500, 1, 3, generator=g) * 2 - 1).cuda()
+        t = torch.linspace(-1.0, 1.0, 128).cuda()[None, :, None] * torch.tensor([0.0, 0.0, 1.0]).cuda()
+        xyzs[2] = (o * torch.tensor([1.0, 1.0, 0.0]).cuda() + t).reshape(-1, 3).contiguous()
     dirs = [torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda() for n in ns]
     gs = (torch.randn(sum(ns), generator=g) * 0.1).cuda()
     gc = torch.randn(sum(ns), 3, generator=g).cuda()
