@@ -692,22 +692,26 @@ def test_conv_bf16_row_reuse_kernel(B, H, W, Cin, Cout):
     assert torch.equal(got, unet_fast.conv2d_nhwc_bf16(a_, w, bias, res, tile_hint=1, x2=b_))
 
 
-@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("full", [False, True, "tiled"])
 def test_native_bf16_gradient_path_is_as_close_to_fp32_as_the_reference_arithmetic(full):
     """r06 (r05 verdict, missing #2): under ``autocast(bfloat16)`` an input-gradient call with frozen weights runs NATIVELY in bf16 -- bf16 channel-last activations
     and gradients, ``unet._ConvBf16Fn`` on the executor's bf16 implicit-GEMM kernels in both directions, the fused norms' bf16 instantiations, attention on the
     fp32-class kernels between casts.  The reference's arithmetic for such a call is the eager module under autocast (library bf16 convolutions, fp32 norms and
     softmax: lib/models/autodecoders/diffusion_nerf.py:301-304).  Both are compared with the fp32-class path on the same inputs: the native path must be at least as
     close as the reference arithmetic (x 1.25 for the different summation orders), inside an absolute bound, with NO library convolution; the captured-graph form must
-    agree with the eager launches.  ``full``: the cars UNet at 128 x 128 (2 scenes), else the small three-level net."""
+    agree with the eager launches.  ``full``: the cars UNet at 128 x 128 (2 scenes), else the small three-level net; "tiled": that net at the tiled-triplane layout's widths."""
     from ssdnerf_amd import unet as U
-    net = _bench_unet() if full else _unet(seed=4)
+    if full == "tiled":                                                       # the tiled-triplane layout's widths: base 80, 16 groups (groups of 5 / 10 / 20 channels: no run-level
+        net = _unet(seed=4, in_channels=6, base_channels=80, norm_cfg=dict(type="GN", num_groups=16))    # statistics in the decoder half), 6 input channels, a non-square latent
+        cin, hh, ww, B = 6, 32, 96, 2
+    else:
+        net = _bench_unet() if full else _unet(seed=4)
+        cin, hh, ww, B = (18, 128, 128, 2) if full else (18, 32, 32, 3)
     net.requires_grad_(False)
-    hw, B = (128, 2) if full else (32, 3)
     g = torch.Generator().manual_seed(3)
-    x0 = torch.randn(B, 18, hw, hw, generator=g).cuda()
+    x0 = torch.randn(B, cin, hh, ww, generator=g).cuda()
     t = torch.tensor([600, 40, 999][:B]).cuda()
-    probe = torch.randn(B, 18, hw, hw, generator=g).cuda()
+    probe = torch.randn(B, cin, hh, ww, generator=g).cuda()
     saved = (net.grad_graph, net.grad_path_bf16_native, net.grad_path_fp32_under_autocast)
 
     def call(autocast, native, eager, graph=False):

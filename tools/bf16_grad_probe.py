@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--scenes", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--tiled", action="store_true", help="the tiled-triplane UNet (configs/new_cfgs/ssdnerf_cars_recons1v_tiled.py: base 80, 16 groups, 6 x 128 x 384 input)")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--aten", action="store_true", help="with --profile: the aten:: elementwise operators of one call by input shape (copies, casts, accumulations), both arithmetic classes")
     ap.add_argument("--kernels", default="", help="with --profile: print only the kernels whose name contains one of these comma-separated strings, for both arithmetic classes")
@@ -26,13 +27,23 @@ def main():
     from ssdnerf_amd import unet as U
     from test_unet_fast_gpu import _bench_unet, _unet
     net = _unet(seed=4) if args.small else _bench_unet()
+    cin, hh, ww = 18, (32 if args.small else 128), (32 if args.small else 128)
+    if args.tiled:
+        from ssdnerf_amd.registry import MODULES
+        net = MODULES.build(dict(type="DenoisingUnetMod", image_size=128, in_channels=6, base_channels=80, channels_cfg=[1, 1, 2, 2, 4, 4], resblocks_per_downsample=2, dropout=0.0,
+                                 use_scale_shift_norm=True, downsample_conv=True, upsample_conv=True, num_heads=4, attention_res=[16, 8, 4],
+                                 norm_cfg=dict(type="GN", num_groups=16))).cuda().eval()
+        gw = torch.Generator().manual_seed(0)
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.copy_((torch.randn(p_.shape, generator=gw) * 0.03).cuda())
+        cin, hh, ww = 6, 128, 384
     net.requires_grad_(False)
-    hw = 32 if args.small else 128
     B = args.scenes
     g = torch.Generator().manual_seed(3)
-    x0 = torch.randn(B, 18, hw, hw, generator=g).cuda()
+    x0 = torch.randn(B, cin, hh, ww, generator=g).cuda()
     t = torch.tensor([999, 979, 600, 339, 120, 59, 19, 0] * ((B + 7) // 8))[:B].cuda()
-    probe = torch.randn(B, 18, hw, hw, generator=g).cuda()
+    probe = torch.randn(B, cin, hh, ww, generator=g).cuda()
 
     def call(autocast, native, eager, graph=False):
         net.grad_graph = graph
