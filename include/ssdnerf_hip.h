@@ -158,7 +158,10 @@ int ssdnerf_march_rays_train_batch_write(const float* rays_o, const float* rays_
  * with dirs: density head only) -> grad_code (S,3,6,Hp,Wp) fp32, the code's own NCHW layout, OVERWRITTEN (no zero-fill needed).
  * Nothing is saved by the forward; the hidden units are recomputed.  Samples with an all-zero upstream gradient are skipped.  The
  * scatter is a binned reduction in LDS (no global atomics); additions inside a 32x32-texel tile are unordered, so results are
- * reproducible to fp32 rounding.  workspace: ssdnerf_point_decode_backward_workspace bytes (108 B per sample + the per-split tile images). */
+ * reproducible to fp32 rounding.  workspace: ssdnerf_point_decode_backward_workspace bytes (108 B per sample + the per-split tile images).
+ * planes_dtype | SSDNERF_DECODE_BWD_FEAT_MFMA (r06, opt-in, colour + density gradients only): the per-sample feature gradients through three matrix-core products per
+ * 64 samples (bf16-pair operands, fp32 accumulation: the arithmetic class of the UNet's fp32-class kernels) instead of fp32 fused multiply-adds on the vector ALUs. */
+#define SSDNERF_DECODE_BWD_FEAT_MFMA 0x100
 size_t ssdnerf_point_decode_backward_workspace(uint32_t S, uint32_t total, uint32_t Hp, uint32_t Wp);
 int ssdnerf_point_decode_backward(const void* planes, int planes_dtype, uint32_t S, uint32_t Hp, uint32_t Wp, const float* mlp_params,
                                   const float* xyzs, const float* dirs, const uint32_t* offsets, uint32_t total,

@@ -221,7 +221,12 @@ __global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_feat(const PT* __restric
     float f[18], gf[18], sh[16];
     ssd_gather18<PT>(planes + scene * plane_stride, g, x, y, z, f);
     if (COLOR) shb::eval<4, false>(dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2], sh, nullptr, nullptr, nullptr);
+#ifdef DB_EXP_NO_MLP                                                             // (measurement only: everything of the kernel but the MLP)
+#pragma unroll
+    for (int k = 0; k < 18; ++k) gf[k] = f[k] * gs + (COLOR ? sh[k & 15] * gc[k % 3] : 0.0f);
+#else
     ssdb_mlp_backward(P, f, COLOR ? sh : f, sat, gs, gc, COLOR ? 1 : 0, gf);
+#endif
     const float us[3] = {x, x, y}, vs[3] = {y, z, z};
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -232,6 +237,278 @@ __global__ void __launch_bounds__(DEC_TPB) k_decode_bwd_feat(const PT* __restric
         dst[0] = make_float2(gf[0 + p], gf[3 + p]);
         dst[1] = make_float2(gf[6 + p], gf[9 + p]);
         dst[2] = make_float2(gf[12 + p], gf[15 + p]);
+    }
+}
+
+// ================================================================================================================================
+// r06: k_decode_bwd_feat on the matrix cores (colour + density heads; the density-only form keeps the kernel above).
+// The per-lane form computes every hidden unit twice (registers) with 6 300 fused multiply-adds and 512 transcendentals per sample on the vector ALUs -- 1.6 ms for 7 M
+// samples, the larger half of the decode backward once the reduction lost its LDS atomics.  Here a wave takes 64 samples through three small matrix products
+//   H  [64 hidden x 64 samples] = W1 [64 x 19] F [19 x 64]      (features + a bias row)            24 MFMA 32x32x16 (bf16 pair split: hi hi + hi lo + lo hi)
+//   D  [64 x 64]                = Wd [64 x 16] SH [16 x 64]                                       12
+//   GF [18 x 64]                = W1^T [18 x 64] dPRE [64 x 64]                                    24
+// and everything between them stays in the products' C layout (a lane holds one sample column -- two, one per 32-sample tile -- and 16 of a row tile's 32 hidden
+// units): silu, the two heads' partial dot products (their other half sits in lane ^ 32: one v_permlane32_swap per value), silu' stored over H and D, the combination
+// dPRE = dsa w_sigma silu'(h) + (dz . Wc) silu'(u), whose registers ARE the B operand of the third product (the k order of W1^T's fragments is permuted to the C layout's
+// row order).  Hidden units once, 256 transcendentals per sample.  Persistent blocks (the weights' fragments are built once per block into LDS).
+// Arithmetic class: fp32 accumulation of bf16-pair products (>= 16 significand bits per factor), as the UNet's fp32-class kernels; the reduction downstream is unchanged.
+typedef __bf16 db_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float db_f32x16 __attribute__((ext_vector_type(16)));
+typedef float db_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 db_b2 __attribute__((ext_vector_type(2)));
+SSD_DEV uint32_t db_cvt2(float even, float odd) {                            // {bf16(even), bf16(odd)}, round to nearest even: v_cvt_pk_bf16_f32
+    const db_b2 r = __builtin_convertvector(db_f2{even, odd}, db_b2);
+    return *reinterpret_cast<const uint32_t*>(&r);
+}
+// two values -> their packed hi terms and packed lo terms (x ~= hi + lo to 2^-17: both roundings to nearest)
+SSD_DEV void db_split_pair(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = db_cvt2(x0, x1);
+    lo = db_cvt2(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+SSD_DEV db_bf16x8 db_op(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint4 u = make_uint4(a, b, c, d);
+    return *reinterpret_cast<const db_bf16x8*>(&u);
+}
+// v_permlane32_swap(a, b): lanes 32..63 of a trade places with lanes 0..31 of b
+SSD_DEV void db_swap(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+// 8 fp32 values -> the hi and lo operand vectors
+SSD_DEV void db_operands(const float* v, db_bf16x8& hi, db_bf16x8& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) db_split_pair(v[2 * i], v[2 * i + 1], h[i], l[i]);
+    hi = db_op(h[0], h[1], h[2], h[3]);
+    lo = db_op(l[0], l[1], l[2], l[3]);
+}
+SSD_DEV db_f32x16 db_mfma3(const db_bf16x8& a_hi, const db_bf16x8& a_lo, const db_bf16x8& b_hi, const db_bf16x8& b_lo, db_f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
+}
+// LDS fragment tables (uint4 = one lane's 8 bf16 of an A operand), built once per block
+struct DbFrags {
+    uint4 a1[2][2][2][64];     // layer 1: [row tile][k step][hi | lo][lane]; k step 0 = features 0 - 15, k step 1 = {16, 17, bias, 0 ...}
+    uint4 ad[2][2][64];        // direction layer: [row tile][hi | lo][lane]
+    uint4 at[4][2][64];        // W1^T: [k step = (row tile, half)][hi | lo][lane]; rows = features (18 used), k = hidden units in the C layout's order
+    float4 head[64];           // {w_sigma, w_c0, w_c1, w_c2} per hidden unit
+    float bd[64];
+};
+template <typename PT>
+__global__ void __launch_bounds__(DEC_TPB, 2) k_decode_bwd_feat_mfma(const PT* __restrict__ planes, PlaneGeom g, uint64_t plane_stride, const float* __restrict__ P,
+                                                                   const float* __restrict__ xyzs, const float* __restrict__ dirs,
+                                                                   const uint32_t* __restrict__ offsets, uint32_t S, uint32_t total, float sat,
+                                                                   const float* __restrict__ g_sigmas, const float* __restrict__ g_rgbs,
+                                                                   uint32_t* __restrict__ counters, uint32_t* __restrict__ keys, float2* __restrict__ pos,
+                                                                   float* __restrict__ gfeat) {
+    __shared__ DbFrags fr;
+    __shared__ uint32_t wave_count[DEC_TPB / 64];
+    __shared__ uint32_t block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t hf = (uint32_t)lane >> 5, ln = (uint32_t)lane & 31u;
+    // ---- the weights' operand fragments
+    auto put = [&](uint4* hi_dst, uint4* lo_dst, const float (&v)[8]) {
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) db_split_pair(v[2 * i], v[2 * i + 1], h[i], l[i]);
+        *hi_dst = make_uint4(h[0], h[1], h[2], h[3]);
+        *lo_dst = make_uint4(l[0], l[1], l[2], l[3]);
+    };
+    for (uint32_t e = threadIdx.x; e < 2 * 2 * 64 + 2 * 64 + 4 * 64; e += DEC_TPB) {
+        float v[8];
+        if (e < 256) {                                                        // layer 1: (mt, ks, lane)
+            const uint32_t mt = e >> 7, ks = (e >> 6) & 1u, l = e & 63u, i = 32u * mt + (l & 31u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t k = 16u * ks + 8u * (l >> 5) + (uint32_t)j;
+                v[j] = k <= 18u ? P[i * 24u + k] : 0.0f;                      // (k == 18: the bias, multiplied by the 1.0 row of the features)
+            }
+            put(&fr.a1[mt][ks][0][l], &fr.a1[mt][ks][1][l], v);
+        } else if (e < 384) {                                                 // direction layer: (mt, lane)
+            const uint32_t q = e - 256u, mt = q >> 6, l = q & 63u, i = 32u * mt + (l & 31u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = P[SSDB_OFF_WD + i * 16u + 8u * (l >> 5) + (uint32_t)j];
+            put(&fr.ad[mt][0][l], &fr.ad[mt][1][l], v);
+        } else {                                                              // W1^T: (k step s = 2 mt + e2, lane); row = feature l % 32
+            const uint32_t q = e - 384u, s4 = q >> 6, l = q & 63u, k = l & 31u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t i = 32u * (s4 >> 1) + 16u * (s4 & 1u) + (uint32_t)(j < 4 ? j : j + 4) + 4u * (l >> 5);      // the C layout's row of slot j in this lane half
+                v[j] = k < 18u ? P[i * 24u + k] : 0.0f;
+            }
+            put(&fr.at[s4][0][l], &fr.at[s4][1][l], v);
+        }
+    }
+    if (threadIdx.x < 64) {
+        const float* rec = P + threadIdx.x * 24u;
+        fr.head[threadIdx.x] = make_float4(rec[19], rec[20], rec[21], rec[22]);
+        fr.bd[threadIdx.x] = P[SSDB_OFF_BD + threadIdx.x];
+    }
+    __syncthreads();
+    const float b_sigma = P[SSDB_OFF_TAIL + 0], b_c0 = P[SSDB_OFF_TAIL + 1], b_c1 = P[SSDB_OFF_TAIL + 2], b_c2 = P[SSDB_OFF_TAIL + 3];
+    const uint4* a1 = &fr.a1[0][0][0][0];
+    for (uint32_t first = blockIdx.x * DEC_TPB; first < total; first += gridDim.x * DEC_TPB) {       // (block-uniform trip count)
+        const uint32_t i = first + threadIdx.x;
+        float gs = 0.0f, gc[3] = {0.0f, 0.0f, 0.0f};
+        if (i < total) {
+            gs = g_sigmas ? g_sigmas[i] : 0.0f;
+            gc[0] = g_rgbs[3ull * i]; gc[1] = g_rgbs[3ull * i + 1]; gc[2] = g_rgbs[3ull * i + 2];
+        }
+        const bool active = gs != 0.0f || gc[0] != 0.0f || gc[1] != 0.0f || gc[2] != 0.0f;
+        // ---- compacted slot of this sample within its scene (as k_decode_bwd_feat)
+        const uint32_t scene_first = db_scene_of(offsets, S, first), scene_last = db_scene_of(offsets, S, min(first + DEC_TPB, total) - 1u);
+        uint32_t scene = scene_first, slot = 0;
+        const uint64_t am = __ballot(active);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+        if (scene_first == scene_last) {
+            if (lane == 0) wave_count[wave] = (uint32_t)__popcll(am);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t n = 0;
+                for (uint32_t w = 0; w < DEC_TPB / 64; ++w) n += wave_count[w];
+                block_base = n ? atomicAdd(counters + scene * DB_COUNTER_STRIDE, n) : 0u;
+            }
+            __syncthreads();
+            slot = block_base + rank;
+            for (int w = 0; w < wave; ++w) slot += wave_count[w];
+            __syncthreads();                                                  // (wave_count / block_base are reused by the next trip)
+        } else {
+            scene = i < total ? db_scene_of(offsets, S, i) : scene_last;
+            uint64_t todo = am;
+            while (todo != 0) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t s0 = __builtin_amdgcn_readlane(scene, leader);
+                const uint64_t m = __ballot(active && scene == s0);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(counters + s0 * DB_COUNTER_STRIDE, (uint32_t)__popcll(m));
+                base = __builtin_amdgcn_readlane(base, leader);
+                if (active && scene == s0) slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                todo &= ~m;
+            }
+        }
+        if (am == 0ull) continue;                                             // (wave-uniform: nothing of this wave's 64 samples carries a gradient)
+        float x = 0.f, y = 0.f, z = 0.f, f[18], sh[16];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) f[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sh[k] = 0.0f;
+        if (active) {
+            x = xyzs[3ull * i]; y = xyzs[3ull * i + 1]; z = xyzs[3ull * i + 2];
+            ssd_gather18<PT>(planes + scene * plane_stride, g, x, y, z, f);
+            shb::eval<4, false>(dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2], sh, nullptr, nullptr, nullptr);
+        }
+        // ---- B operands.  After f[k] <-> f[8 + k] a lane holds, for tile 0 (samples 0 - 31) in f[0..7] and for tile 1 (samples 32 - 63) in f[8..15], the features
+        // 8 hf .. 8 hf + 7 of the tile's column lane % 32: exactly its k slots of the k step
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { db_swap(f[k], f[8 + k]); db_swap(sh[k], sh[8 + k]); }
+        float a16 = f[16], b16 = f[16], a17 = f[17], b17 = f[17];            // swap(a = b = X): a = X of samples 0 - 31 in both halves, b = X of samples 32 - 63
+        db_swap(a16, b16); db_swap(a17, b17);
+        float gsa = gs, gsb = gs, g0a = gc[0], g0b = gc[0], g1a = gc[1], g1b = gc[1], g2a = gc[2], g2b = gc[2];      // ... and the upstream gradients of the tiles' columns
+        db_swap(gsa, gsb); db_swap(g0a, g0b); db_swap(g1a, g1b); db_swap(g2a, g2b);
+        // ---- one 32-sample tile at a time (the two tiles are independent up to the last exchange; together their accumulators do not fit two waves per SIMD)
+        auto tile = [&](const float* fv, const float* sv, float v16, float v17, float ugs, float ug0, float ug1, float ug2) -> db_f32x16 {
+            db_bf16x8 bfh, bfl, bsh, bsl, bkh, bkl;                          // features 0 - 15, SH, and the k step {f16, f17, 1, 0 ...}
+            db_operands(fv, bfh, bfl);
+            db_operands(sv, bsh, bsl);
+            {
+                const float one = hf == 0u ? 1.0f : 0.0f;                     // the k step's slots 0 - 7 belong to lane half 0: half 1 multiplies zeros
+                const float tk[8] = {hf == 0u ? v16 : 0.f, hf == 0u ? v17 : 0.f, one, 0.f, 0.f, 0.f, 0.f, 0.f};
+                db_operands(tk, bkh, bkl);
+            }
+            // H = W1 F + b1, D = Wd SH   (C layout: register r of lane l = hidden unit 32 mt + 8 (r / 4) + 4 hf + r % 4 of the tile's sample l % 32)
+            db_f32x16 H[2], Dd[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { H[mt][r] = 0.0f; Dd[mt][r] = 0.0f; }
+                const db_bf16x8 w0h = *reinterpret_cast<const db_bf16x8*>(&fr.a1[mt][0][0][lane]), w0l = *reinterpret_cast<const db_bf16x8*>(&fr.a1[mt][0][1][lane]);
+                const db_bf16x8 w1h = *reinterpret_cast<const db_bf16x8*>(&fr.a1[mt][1][0][lane]), w1l = *reinterpret_cast<const db_bf16x8*>(&fr.a1[mt][1][1][lane]);
+                const db_bf16x8 wdh = *reinterpret_cast<const db_bf16x8*>(&fr.ad[mt][0][lane]), wdl = *reinterpret_cast<const db_bf16x8*>(&fr.ad[mt][1][lane]);
+                H[mt] = db_mfma3(w1h, w1l, bkh, bkl, H[mt]);
+                H[mt] = db_mfma3(w0h, w0l, bfh, bfl, H[mt]);
+                Dd[mt] = db_mfma3(wdh, wdl, bsh, bsl, Dd[mt]);
+            }
+            // pass 1: the heads' partial dot products over this lane's 32 hidden units; silu'(h) over H, silu'(u) over D
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t iu = 32u * mt + 8u * (r >> 2) + 4u * hf + (r & 3);
+                    const float4 hw = fr.head[iu];
+                    const float h = H[mt][r], u = h + (Dd[mt][r] + fr.bd[iu]);
+                    const float sg = ssdb_sigmoid(h), su = ssdb_sigmoid(u);
+                    part[0] = fmaf(hw.x, h * sg, part[0]);
+                    const float c = u * su;
+                    part[1] = fmaf(hw.y, c, part[1]); part[2] = fmaf(hw.z, c, part[2]); part[3] = fmaf(hw.w, c, part[3]);
+                    H[mt][r] = sg * fmaf(h, 1.0f - sg, 1.0f);
+                    Dd[mt][r] = su * fmaf(u, 1.0f - su, 1.0f);
+                }
+            // the other 32 hidden units of the column sit in lane ^ 32: swap(a = b = v) leaves the lower half's values in a and the upper half's in b, in every lane
+            float tot[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { float a = part[q], b = part[q]; db_swap(a, b); tot[q] = a + b; }
+            const float sa = tot[0] + b_sigma, z0 = tot[1] + b_c0, z1 = tot[2] + b_c1, z2 = tot[3] + b_c2;
+            const float e = SSDB_EXP2(sa * 1.4426950408889634f);
+            const float dsa = ugs * fminf(1e6f, fmaxf(e, 1e-6f));
+            const float kk = fmaf(sat, 2.0f, 1.0f);
+            const float s0 = ssdb_sigmoid(z0), s1 = ssdb_sigmoid(z1), s2 = ssdb_sigmoid(z2);
+            const float dz0 = ug0 * kk * (s0 * (1.0f - s0)), dz1 = ug1 * kk * (s1 * (1.0f - s1)), dz2 = ug2 * kk * (s2 * (1.0f - s2));
+            // pass 2 and GF = W1^T dPRE: the registers of H are the B operand (k step (mt, e2) = registers 8 e2 .. 8 e2 + 7)
+            db_f32x16 G;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G[r] = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t iu = 32u * mt + 8u * (r >> 2) + 4u * hf + (r & 3);
+                    const float4 hw = fr.head[iu];
+                    const float dc = fmaf(dz2, hw.w, fmaf(dz1, hw.z, dz0 * hw.y));
+                    H[mt][r] = fmaf(dc, Dd[mt][r], dsa * hw.x * H[mt][r]);
+                }
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    float v8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v8[j] = H[mt][8 * e2 + j];
+                    db_bf16x8 bh, bl;
+                    db_operands(v8, bh, bl);
+                    const db_bf16x8 ah = *reinterpret_cast<const db_bf16x8*>(&fr.at[2 * mt + e2][0][lane]), al = *reinterpret_cast<const db_bf16x8*>(&fr.at[2 * mt + e2][1][lane]);
+                    G = db_mfma3(ah, al, bh, bl, G);
+                }
+            }
+            return G;
+        };
+        db_f32x16 G[2];
+        G[0] = tile(f, sh, a16, a17, gsa, g0a, g1a, g2a);
+        __builtin_amdgcn_sched_barrier(0);
+        G[1] = tile(f + 8, sh + 8, b16, b17, gsb, g0b, g1b, g2b);
+        // ---- back to one sample per lane: register r holds feature 8 (r / 4) + 4 hf + r % 4 of the tiles' columns; swap(a = G[0][r], b = G[1][r]) leaves in a the
+        // hf = 0 rows and in b the hf = 1 rows of the lane's OWN sample (tile 0 for lanes 0 - 31, tile 1 for lanes 32 - 63)
+        float gf[18];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            float a = G[0][r], b = G[1][r];
+            db_swap(a, b);
+            const int k0 = 8 * (r >> 2) + (r & 3);
+            if (k0 < 18) gf[k0] = a;
+            if (k0 + 4 < 18 && r < 8) gf[k0 + 4] = b;
+        }
+        if (!active) continue;
+        const uint64_t j = (uint64_t)offsets[scene] + slot;
+        const float us[3] = {x, x, y}, vs[3] = {y, z, z};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const float ix = ssdb_unnormalise(us[p], g.Wp), iy = ssdb_unnormalise(vs[p], g.Hp);
+            keys[(uint64_t)p * total + j] = ((uint32_t)floorf(iy) << 16) | (uint32_t)floorf(ix);
+            pos[(uint64_t)p * total + j] = make_float2(ix, iy);
+            float2* dst = reinterpret_cast<float2*>(gfeat + ((uint64_t)p * total + j) * 6);
+            dst[0] = make_float2(gf[0 + p], gf[3 + p]);
+            dst[1] = make_float2(gf[6 + p], gf[9 + p]);
+            dst[2] = make_float2(gf[12 + p], gf[15 + p]);
+        }
     }
 }
 
@@ -584,6 +861,8 @@ extern "C" int ssdnerf_point_decode_backward(const void* planes, int planes_dtyp
     SSD_REQUIRE(planes && mlp_params && xyzs && offsets && workspace, "point_decode_backward: null pointer");
     SSD_REQUIRE((grad_rgbs == nullptr) == (dirs == nullptr), "point_decode_backward: grad_rgbs and dirs must both be given or both be NULL");
     SSD_REQUIRE(grad_sigmas || grad_rgbs, "point_decode_backward: no upstream gradient given");
+    const bool feat_mfma = (planes_dtype & SSDNERF_DECODE_BWD_FEAT_MFMA) != 0;       // (r06, opt-in) the per-sample feature gradients on the matrix cores
+    planes_dtype &= 0xff;
     SSD_REQUIRE(planes_dtype == 0 || planes_dtype == 1, "point_decode_backward: unsupported plane dtype");
     const DecodeBwdWs w = db_workspace(workspace, S, total, Hp, Wp);
     if (workspace_bytes < w.bytes) return ssdnerf_fail(SSDNERF_E_WORKSPACE, "point_decode_backward: workspace too small");
@@ -594,7 +873,22 @@ extern "C" int ssdnerf_point_decode_backward(const void* planes, int planes_dtyp
     const bool color = grad_rgbs != nullptr;
 #define SSD_LAUNCH_FEAT(PT, COL) hipLaunchKernelGGL((k_decode_bwd_feat<PT, COL>), gr, b, 0, s, (const PT*)planes, g, plane_stride, mlp_params, xyzs, dirs, offsets, S, \
                                                     total, sigmoid_saturation, grad_sigmas, grad_rgbs, w.counters, w.keys, w.pos, w.gfeat)
-    if (planes_dtype == 0) { if (color) SSD_LAUNCH_FEAT(float, true); else SSD_LAUNCH_FEAT(float, false); }
+    if (feat_mfma && color) {                                                // (r06) the matrix-core form: persistent blocks, two per CU
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        const uint32_t want = ssd_blocks(total, DEC_TPB), cap = (uint32_t)n_cu * 2u;
+        dim3 gm(want < cap ? want : cap);
+        if (planes_dtype == 0)
+            hipLaunchKernelGGL((k_decode_bwd_feat_mfma<float>), gm, b, 0, s, (const float*)planes, g, plane_stride, mlp_params, xyzs, dirs, offsets, S, total,
+                               sigmoid_saturation, grad_sigmas, grad_rgbs, w.counters, w.keys, w.pos, w.gfeat);
+        else
+            hipLaunchKernelGGL((k_decode_bwd_feat_mfma<__half>), gm, b, 0, s, (const __half*)planes, g, plane_stride, mlp_params, xyzs, dirs, offsets, S, total,
+                               sigmoid_saturation, grad_sigmas, grad_rgbs, w.counters, w.keys, w.pos, w.gfeat);
+    } else if (planes_dtype == 0) { if (color) SSD_LAUNCH_FEAT(float, true); else SSD_LAUNCH_FEAT(float, false); }
     else { if (color) SSD_LAUNCH_FEAT(__half, true); else SSD_LAUNCH_FEAT(__half, false); }
 #undef SSD_LAUNCH_FEAT
     SSD_CHECK_LAUNCH("point_decode_backward (features)");

@@ -115,7 +115,8 @@ class _PointDecodeFn(torch.autograd.Function):
         ws_bytes = int(C.lib().ssdnerf_point_decode_backward_workspace(C.u32(s_), C.u32(total), C.u32(hp), C.u32(wp)))
         ws = decoder._workspace(max(ws_bytes, 1), dev, "decode_bwd")                       # the decoder's cached scratch (grown on demand), not a fresh tensor per backward
         C.check(C.lib().ssdnerf_point_decode_backward(
-            C.ptr(planes), C.dtype_code(planes), C.u32(s_), C.u32(hp), C.u32(wp), C.ptr(decoder.packed_params()), C.ptr(xyzs), C.ptr(dirs),
+            C.ptr(planes), C.dtype_code(planes) | (0x100 if getattr(decoder, "decode_bwd_feat_mfma", False) else 0), C.u32(s_), C.u32(hp), C.u32(wp),
+            C.ptr(decoder.packed_params()), C.ptr(xyzs), C.ptr(dirs),
             C.ptr(offsets), C.u32(total), C.f32(decoder.sigmoid_saturation), C.ptr(g_sigmas), C.ptr(g_rgbs), C.ptr(grad_code), C.ptr(ws),
             C.ctypes.c_size_t(ws_bytes), C.stream()), "point_decode_backward")
         return grad_code.to(dtype), None, None, None
@@ -428,6 +429,10 @@ class TriPlaneDecoder(VolumeRenderer):
 
     #: SSDNERF_DECODE_GRAD=0 sends the code-gradient decode through PyTorch autograd (grid_sample + nn.Linear) instead of the fused kernels
     fused_code_grad = os.environ.get("SSDNERF_DECODE_GRAD", "1") != "0"
+    #: r06, opt-in (SSDNERF_DECODE_BWD_FEAT_MFMA=1): the decode backward's per-sample feature gradients on the matrix cores (csrc/decode.hip: k_decode_bwd_feat_mfma; bf16-pair
+    #: products instead of fp32 FMAs).  Measured: 1.55 -> 1.27 ms on 7 M march-ordered samples, 1.60 -> 1.56 ms on uniformly scattered ones (the gather and the compaction are
+    #: 0.4 - 0.6 ms of either), guided step -0.1 ms: not worth a lower arithmetic class by default.
+    decode_bwd_feat_mfma = os.environ.get("SSDNERF_DECODE_BWD_FEAT_MFMA", "0") == "1"
 
     def _point_decode_hip(self, xyzs, dirs, code, density_only, planes=None):
         if planes is None:

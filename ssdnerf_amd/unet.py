@@ -577,8 +577,13 @@ class _CatNormShortcutFn(torch.autograd.Function):
         norm, conv = ctx.norm, ctx.conv
         B, C1, G = hc.size(0), hc.size(1), norm.num_groups
         ws = ctx.arena.take(UF.group_norm_backward_workspace_doubles(B, G)) if ctx.arena is not None else None
-        dx1, dx2 = UF.group_norm_nhwc_backward_cat(hc, sc, dn.contiguous(memory_format=torch.channels_last), G, norm.weight.detach(), norm.bias.detach(), None, norm.eps,
-                                                   True, sums[0], sums[1] if ctx.use_runs else None, workspace=ws)
+        if dn is None:                                               # (an output nobody differentiated through: its share of the gradient is zero)
+            dx1, dx2 = torch.zeros_like(hc), torch.zeros_like(sc)
+        else:
+            dx1, dx2 = UF.group_norm_nhwc_backward_cat(hc, sc, dn.contiguous(memory_format=torch.channels_last), G, norm.weight.detach(), norm.bias.detach(), None, norm.eps,
+                                                       True, sums[0], sums[1] if ctx.use_runs else None, workspace=ws)
+        if ds is None:
+            return dx1, dx2, None, None, None, None, None
         dsc = ds.contiguous(memory_format=torch.channels_last)
         if hc.dtype == torch.bfloat16:
             w1, w2 = conv._bf16_weights_cat(C1)
@@ -1182,9 +1187,11 @@ class DenoisingUnetMod(nn.Module):
 
     def _bf16_grad_path_ok(self) -> bool:
         """every layer of this UNet has a kernel on the native bf16 gradient path (checked once per module tree; the cars / chairs configs do)"""
+        if not (_Conv2d.grad_conv and _Conv2d.fuse_epilogues and GRAD_GN and GRAD_ATT and GRAD_ATT_POINTWISE):      # (the A/B switches, read on every call: tests flip them)
+            return False
         ok = self.__dict__.get("_bf16_grad_ok")
         if ok is None:
-            ok = _Conv2d.grad_conv and _Conv2d.fuse_epilogues and GRAD_GN and GRAD_ATT and GRAD_ATT_POINTWISE and self.concat_cond_channels == 0
+            ok = self.concat_cond_channels == 0
             for m in self.modules():
                 if isinstance(m, _Conv2d):
                     k = m.kernel_size[0]

@@ -413,12 +413,16 @@ def test_fused_decode_backward_matches_autograd_through_the_eager_decode(ns, pla
     try:
         s1, r1, n1, g1 = run(True)
         s0, r0, n0, g0 = run(False)
+        dec.decode_bwd_feat_mfma = True                                        # r06, opt-in: the feature gradients on the matrix cores (bf16-pair products)
+        _, _, _, g2 = run(True)
     finally:
         dec.fused_code_grad = True
+        dec.decode_bwd_feat_mfma = False
     assert n1 == n0 == ns
     assert float(((s1 - s0).abs() / s0.abs().clamp(min=1e-3)).max()) <= 2e-5 and float((r1 - r0).abs().max()) <= 2e-6
     scale = float(g0.abs().max())
     assert scale > 0 and float((g1 - g0).abs().max()) <= 2e-4 * scale, (float((g1 - g0).abs().max()), scale)
+    assert float((g2 - g0).abs().max()) <= 2e-4 * scale and float((g2 - g1).abs().max()) > 0, (float((g2 - g0).abs().max()), scale)      # (same bound; another kernel did run)
     # decoder parameters that need a gradient keep the autograd path
     dec.requires_grad_(True)
     c = code.clone().requires_grad_(True)
