@@ -12,6 +12,10 @@ Compute: no-grad GPU calls run through ``unet_fast.FastUnet`` (hand-written MFMA
 hipGraph replay).  Calls that need a gradient w.r.t. the INPUT with frozen weights (rendering guidance, the diffusion prior of
 ``val_optim``) keep the eager module graph, but their 64-channel-aligned stride-1 convolutions go through ``_ConvF32x2Fn``: forward
 and backward-data on the same fp32-class matrix-core kernel (csrc/conv_igemm.hip) instead of MIOpen.  Everything else is PyTorch-ROCm.
+
+r04 - r06: every layer of that path has its own kernel by now (``_ConvGeneralFn`` for stride 2 / stem / head, ``_GroupNormActFn``, ``_AttentionF32Fn``,
+``_CatNormShortcutFn`` for the decoder half's never-built concatenations), the whole forward + backward replays as two captured graphs (``_GraphedGrad``),
+and under ``autocast(bfloat16)`` the same calls run natively in bf16 (``_ConvBf16Fn``, ``DenoisingUnetMod.grad_path_bf16_native``).
 """
 from __future__ import annotations
 
