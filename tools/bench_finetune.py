@@ -16,6 +16,7 @@ ap.add_argument("--scenes", type=int, default=8); ap.add_argument("--guide-steps
 ap.add_argument("--extra-scene-step", type=int, default=3); ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
 ap.add_argument("--full-batch", action="store_true", help="also time (and with --cprofile: profile the host side of) ONE whole val_step: 75 guided steps + 25 x (1 + 4) + 250 views")
 ap.add_argument("--cprofile", action="store_true", help="cProfile of the timed fine-tuning call (host side: top functions by own time)")
+ap.add_argument("--aten", action="store_true", help="with --profile: the aten:: operators with device time by input shape (copies, fills, accumulations outside the custom kernels)")
 ap.add_argument("--profile", action="store_true", help="instead of timing: torch.profiler tables (top kernels by device time) of one guided step and one outer iteration")
 a = ap.parse_args()
 cfg = dict(type="DiffusionNeRF", code_size=(3, 6, 128, 128), code_reshape=(18, 128, 128), code_activation=dict(type="TanhCode", scale=2), grid_size=64,
@@ -68,9 +69,15 @@ if a.profile:
                                                                  density_bitfield=bits.clone()))
     for name, fn in runs.items():
         timed(fn)                                                             # warm-up
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=a.aten) as prof:
             _, dt = timed(fn)
         print(f"==== {name}: {dt * 1e3:.1f} ms wall (includes one-off setup: rays, optimizer, grids)")
+        if a.aten:
+            rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.self_device_time_total > 0]
+            print(f"aten operators with device time: {sum(e.self_device_time_total for e in rows) * 1e-3:.3f} ms")
+            for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:45]:
+                print(f"  {e.key:30s} x{e.count:3d} {e.self_device_time_total * 1e-3:7.3f} ms  {str(e.input_shapes)[:140]}")
+            continue
         print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=70))
     sys.exit(0)
 
